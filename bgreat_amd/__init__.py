@@ -1,0 +1,269 @@
+"""bgreat_amd -- ctypes view of the C-ABI in include/bgreat_gpu.h (lib/libbgreat_gpu.so).
+
+The product is the shared library + the `bgreat` CLI (C++/HIP).  This module only lets Python (tests,
+bench.py, __graft_entry__) call the same entry points; it contains no algorithm and no CPU fallback: if
+the library is missing it raises, and mapping calls fail when there is no HIP device.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbgreat_gpu.so")
+CLI_PATH = os.path.join(_HERE, "bin", "bgreat")
+
+MODE_GREEDY, MODE_EXHAUSTIVE = 0, 1
+ST_NOANCHOR, ST_FAILED, ST_ALIGNED, ST_MASK, ST_RC = 0, 1, 2, 3, 4
+
+# every symbol include/bgreat_gpu.h declares (checked by tests/test_cabi.py)
+SYMBOLS = [
+    "bgr_last_error", "bgr_device_count", "bgr_graph_build", "bgr_graph_build_from_fasta", "bgr_graph_blob",
+    "bgr_graph_from_blob", "bgr_graph_info", "bgr_graph_destroy", "bgr_graph_upload", "bgr_graph_device_blob",
+    "bgr_graph_adopt_device_blob", "bgr_aligner_create", "bgr_aligner_destroy", "bgr_align_batch", "bgr_align_device",
+    "bgr_aligner_sync", "bgr_aligner_device_results", "bgr_aligner_fetch", "bgr_aligner_counters",
+    "bgr_aligner_reset_counters", "bgr_aligner_kernel_time", "bgr_aligner_reset_kernel_time", "bgr_aligner_launch_info",
+    "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
+    "bgr_write_records",
+]
+
+
+class BgrError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("max_mismatch", C.c_uint32), ("effort", C.c_uint32), ("partial", C.c_uint32)]
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("n_levels", C.c_uint32), ("n_unitigs", C.c_uint64), ("n_keys", C.c_uint64),
+                ("n_left_keys", C.c_uint64), ("n_right_keys", C.c_uint64), ("n_fallback", C.c_uint64),
+                ("total_bases", C.c_uint64), ("blob_bytes", C.c_uint64), ("mphf_bytes", C.c_uint64),
+                ("max_unitig_len", C.c_uint64), ("has_exceptions", C.c_uint32), ("reserved", C.c_uint32),
+                ("gamma", C.c_double)]
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile lib/libbgreat_gpu.so and bin/bgreat for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BgrError("libbgreat_gpu.so is not built (%s); run `make -C bgreat_amd` -- there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.bgr_last_error.restype = C.c_char_p
+    L.bgr_device_count.restype = i32
+    L.bgr_graph_build.argtypes = [u32, u64, vp, vp, C.c_double, C.POINTER(vp)]
+    L.bgr_graph_build_from_fasta.argtypes = [C.c_char_p, u32, C.c_double, C.POINTER(vp)]
+    L.bgr_graph_blob.restype = vp
+    L.bgr_graph_blob.argtypes = [vp, C.POINTER(u64)]
+    L.bgr_graph_from_blob.argtypes = [vp, u64, C.POINTER(vp)]
+    L.bgr_graph_info.argtypes = [vp, C.POINTER(GraphInfo)]
+    L.bgr_graph_destroy.argtypes = [vp]
+    L.bgr_graph_destroy.restype = None
+    L.bgr_graph_upload.argtypes = [vp, i32]
+    L.bgr_graph_device_blob.restype = vp
+    L.bgr_graph_device_blob.argtypes = [vp, i32]
+    L.bgr_graph_adopt_device_blob.argtypes = [i32, vp, u64, C.POINTER(vp)]
+    L.bgr_aligner_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.bgr_aligner_destroy.argtypes = [vp]
+    L.bgr_aligner_destroy.restype = None
+    L.bgr_align_batch.argtypes = [vp, C.POINTER(Params), vp, vp, u64, vp, u64, vp, vp]
+    L.bgr_align_device.argtypes = [vp, C.POINTER(Params), vp, vp, u64, u64, u32]
+    L.bgr_aligner_sync.argtypes = [vp]
+    L.bgr_aligner_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.bgr_aligner_fetch.argtypes = [vp, u64, vp, u64, vp, vp]
+    L.bgr_aligner_counters.argtypes = [vp, vp]
+    L.bgr_aligner_reset_counters.argtypes = [vp]
+    L.bgr_aligner_kernel_time.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double)]
+    L.bgr_aligner_reset_kernel_time.argtypes = [vp]
+    L.bgr_aligner_launch_info.argtypes = [vp, vp]
+    L.bgr_aligner_configure.argtypes = [vp, u32, u32, u32]
+    L.bgr_readset_load.argtypes = [C.c_char_p, i32, u32, C.POINTER(vp)]
+    L.bgr_readset_count.restype = u64
+    L.bgr_readset_count.argtypes = [vp]
+    L.bgr_readset_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.bgr_readset_destroy.argtypes = [vp]
+    L.bgr_readset_destroy.restype = None
+    L.bgr_write_records.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise BgrError("bgreat_gpu error %d: %s" % (rc, lib().bgr_last_error().decode("utf-8", "replace")))
+
+
+def device_count():
+    return lib().bgr_device_count()
+
+
+def _as_u8(a):
+    if isinstance(a, (bytes, bytearray)):
+        a = np.frombuffer(a, dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Graph:
+    """The immutable index (Aligner::indexUnitigs, aligner.cpp:407-547)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def build(cls, k, seqs, offsets, gamma=0.0):
+        seqs = _as_u8(seqs)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().bgr_graph_build(k, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, gamma, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_fasta(cls, path, k, gamma=0.0):
+        h = C.c_void_p()
+        _check(lib().bgr_graph_build_from_fasta(path.encode(), k, gamma, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_blob(cls, blob):
+        blob = _as_u8(blob)
+        h = C.c_void_p()
+        _check(lib().bgr_graph_from_blob(blob.ctypes.data, blob.size, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def adopt_device_blob(cls, device, dev_ptr, nbytes):
+        h = C.c_void_p()
+        _check(lib().bgr_graph_adopt_device_blob(device, dev_ptr, nbytes, C.byref(h)))
+        return cls(h)
+
+    def blob(self):
+        n = C.c_uint64()
+        p = lib().bgr_graph_blob(self.h, C.byref(n))
+        if not p:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,))
+
+    def info(self):
+        gi = GraphInfo()
+        _check(lib().bgr_graph_info(self.h, C.byref(gi)))
+        return {f[0]: getattr(gi, f[0]) for f in GraphInfo._fields_ if f[0] != "reserved"}
+
+    def upload(self, device=0):
+        _check(lib().bgr_graph_upload(self.h, device))
+
+    def device_blob(self, device=0):
+        return lib().bgr_graph_device_blob(self.h, device)
+
+    def close(self):
+        if self.h:
+            lib().bgr_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Aligner:
+    """Batch form of alignReadGreedy / alignReadExhaustive on one GPU."""
+
+    def __init__(self, graph, device=0):
+        self.graph = graph
+        self.h = C.c_void_p()
+        _check(lib().bgr_aligner_create(graph.h, device, C.byref(self.h)))
+
+    def configure(self, waves_per_block=0, blocks_per_cu=0, lds_mphf=0):
+        _check(lib().bgr_aligner_configure(self.h, waves_per_block, blocks_per_cu, lds_mphf))
+
+    def align(self, reads, offsets, m=2, effort=2, mode=MODE_GREEDY, partial=False):
+        """-> (paths int32[], path_offsets uint64[n+1], status uint8[n]) in input order."""
+        reads = _as_u8(reads)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        cap = int(offsets[-1] - offsets[0]) + 8 * n + 8
+        paths = np.empty(cap, dtype=np.int32)
+        poffs = np.empty(n + 1, dtype=np.uint64)
+        status = np.empty(max(n, 1), dtype=np.uint8)
+        p = Params(mode, m, effort, int(partial))
+        _check(lib().bgr_align_batch(self.h, C.byref(p), reads.ctypes.data, offsets.ctypes.data, n, paths.ctypes.data, cap,
+                                     poffs.ctypes.data, status.ctypes.data))
+        return paths[: int(poffs[n])].copy(), poffs, status[:n]
+
+    def align_device(self, d_reads_ptr, d_offsets_ptr, n, total_bases, max_len, m=2, effort=2, mode=MODE_GREEDY, partial=False):
+        p = Params(mode, m, effort, int(partial))
+        _check(lib().bgr_align_device(self.h, C.byref(p), d_reads_ptr, d_offsets_ptr, n, total_bases, max_len))
+
+    def fetch(self, n, cap):
+        paths = np.empty(cap, dtype=np.int32)
+        poffs = np.empty(n + 1, dtype=np.uint64)
+        status = np.empty(max(n, 1), dtype=np.uint8)
+        _check(lib().bgr_aligner_fetch(self.h, n, paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
+        return paths[: int(poffs[n])].copy(), poffs, status[:n]
+
+    def sync(self):
+        _check(lib().bgr_aligner_sync(self.h))
+
+    def counters(self):
+        out = np.zeros(5, dtype=np.uint64)
+        _check(lib().bgr_aligner_counters(self.h, out.ctypes.data))
+        return dict(zip(["reads", "no_overlap", "aligned", "not_aligned", "overlaps"], (int(x) for x in out)))
+
+    def reset_counters(self):
+        _check(lib().bgr_aligner_reset_counters(self.h))
+
+    def kernel_time(self):
+        n, ms = C.c_uint64(), C.c_double()
+        _check(lib().bgr_aligner_kernel_time(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def reset_kernel_time(self):
+        _check(lib().bgr_aligner_reset_kernel_time(self.h))
+
+    def launch_info(self):
+        out = np.zeros(4, dtype=np.uint32)
+        _check(lib().bgr_aligner_launch_info(self.h, out.ctypes.data))
+        return {"blocks": int(out[0]), "threads": int(out[1]), "lds_bytes": int(out[2]), "mphf_in_lds": bool(out[3])}
+
+    def close(self):
+        if self.h:
+            lib().bgr_aligner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_reads(path, k, fastq=False):
+    """getReads (aligner.cpp:46-117) over a whole file -> (reads u8[], read_offs u64[n+1], headers u8[], header_offs u64[n+1])."""
+    h = C.c_void_p()
+    _check(lib().bgr_readset_load(path.encode(), int(fastq), k, C.byref(h)))
+    try:
+        n = lib().bgr_readset_count(h)
+        r, ro, hd, ho = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().bgr_readset_view(h, C.byref(r), C.byref(ro), C.byref(hd), C.byref(ho)))
+        roffs = np.ctypeslib.as_array(C.cast(ro, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        hoffs = np.ctypeslib.as_array(C.cast(ho, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        reads = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint8)), shape=(max(int(roffs[n]), 1),))[: int(roffs[n])].copy() if n else np.zeros(0, np.uint8)
+        heads = np.ctypeslib.as_array(C.cast(hd, C.POINTER(C.c_uint8)), shape=(max(int(hoffs[n]), 1),))[: int(hoffs[n])].copy() if n else np.zeros(0, np.uint8)
+        return reads, roffs, heads, hoffs
+    finally:
+        lib().bgr_readset_destroy(h)

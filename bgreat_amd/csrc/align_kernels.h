@@ -1,0 +1,52 @@
+// align_kernels.h -- launch interface between the C-ABI (capi.hip) and the gfx950 kernels (align_kernels.hip).
+#ifndef BGREAT_AMD_ALIGN_KERNELS_H
+#define BGREAT_AMD_ALIGN_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "graph_layout.h"
+
+namespace bgr {
+
+struct BatchIO {
+    const uint8_t* reads;        // concatenated ASCII reads
+    const uint64_t* read_offs;   // n+1
+    uint32_t n_reads;
+    uint32_t words_per_read;     // u64 words of each packed per-wave LDS array (max_read_len/32 + 2)
+    uint32_t path_cap;           // ints of the per-wave LDS path buffer
+    uint32_t arena_cap;          // ints
+    uint8_t* status;             // n
+    uint32_t* path_off;          // n
+    uint32_t* path_len;          // n
+    int32_t* arena;
+    uint32_t* cursor;            // [0] ints used, [1] overflow flag
+    unsigned long long* counters;  // readNumber, noOverlapRead, alignedRead, notAligned, overlaps
+};
+
+struct KernelParams {
+    uint32_t max_mismatch, effort, partial, mode;
+};
+
+struct LaunchCfg {
+    uint32_t waves_per_block;  // 1..16
+    uint32_t blocks;           // grid
+    uint32_t lds_bytes;        // dynamic LDS
+    uint32_t stage_mphf;       // 1: copy the MPHF cascade into LDS at block start
+};
+
+// Per-wave LDS bytes for a batch whose longest read has max_len bases.
+inline uint32_t lds_bytes_per_wave(uint32_t max_len, uint32_t* words, uint32_t* path_cap) {
+    uint32_t w = max_len / 32 + 2;
+    uint32_t pc = max_len + 8;
+    pc = (pc + 1) & ~1u;
+    if (words) *words = w;
+    if (path_cap) *path_cap = pc;
+    return 4 * 8 * w + 4 * pc;
+}
+
+hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);
+
+}  // namespace bgr
+
+#endif

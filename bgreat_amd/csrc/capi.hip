@@ -1,0 +1,511 @@
+// capi.hip -- implementation of the C-ABI declared in include/bgreat_gpu.h.  Thin: argument checks, HIP memory
+// and stream management, launch geometry; the algorithm lives in graph_build.cpp (index) and
+// align_kernels.hip (mapping).  There is no CPU mapping path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bgreat_gpu.h"
+#include "align_kernels.h"
+#include "fastx.h"
+#include "graph_build.h"
+
+namespace {
+
+thread_local std::string tl_err;
+int fail(int code, const std::string& msg) { tl_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(BGR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+const double kDefaultGamma = 1.0;
+const int kTimerRing = 256;
+
+}  // namespace
+
+struct bgr_graph {
+    bgr::HostGraph host;  // empty when adopted from a device blob
+    BgrBlobHeader header;
+    struct Dev { void* ptr; bool owned; };
+    std::map<int, Dev> dev;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct bgr_aligner {
+    bgr_graph* graph = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    BgrDeviceGraph dg;
+    DevBuf in_reads, in_offs, status, path_off, path_len, arena, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    uint64_t last_n = 0;
+    uint32_t last_launch[4] = {0, 0, 0, 0};
+    uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
+    int num_cus = 0;
+    size_t lds_per_cu = 0;
+    hipEvent_t ev_start[kTimerRing], ev_stop[kTimerRing];
+    int ev_used = 0;
+    uint64_t t_launches = 0;
+    double t_ms = 0;
+    std::vector<uint8_t> h_status;
+    std::vector<uint32_t> h_off, h_len;
+    std::vector<int32_t> h_arena;
+};
+
+namespace {
+
+int drain_timers(bgr_aligner* a) {
+    if (a->ev_used == 0) return BGR_OK;
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    for (int i = 0; i < a->ev_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, a->ev_start[i], a->ev_stop[i]));
+        a->t_ms += ms;
+        ++a->t_launches;
+    }
+    a->ev_used = 0;
+    return BGR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bgr_last_error(void) { return tl_err.c_str(); }
+
+int bgr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- index ------------------------------------------------------------------------------------------
+int bgr_graph_build(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, bgr_graph** out) {
+    if (!out || (n_unitigs && (!seqs || !offsets))) return fail(BGR_E_ARG, "bgr_graph_build: null argument");
+    bgr_graph* g = new bgr_graph();
+    std::string err;
+    uint64_t zero[1] = {0};
+    if (!bgr::build_graph(k, n_unitigs, seqs, n_unitigs ? offsets : zero, gamma > 0 ? gamma : kDefaultGamma, g->host, err)) {
+        delete g;
+        return fail(BGR_E_ARG, err);
+    }
+    g->header = *g->host.header();
+    *out = g;
+    return BGR_OK;
+}
+
+int bgr_graph_build_from_fasta(const char* path, uint32_t k, double gamma, bgr_graph** out) {
+    if (!path || !out) return fail(BGR_E_ARG, "bgr_graph_build_from_fasta: null argument");
+    std::vector<char> seqs;
+    std::vector<uint64_t> offs;
+    std::string err;
+    if (!bgr::read_unitig_fasta(path, k, seqs, offs, err)) return fail(BGR_E_IO, err);
+    return bgr_graph_build(k, offs.size() - 1, seqs.data(), offs.data(), gamma, out);
+}
+
+const void* bgr_graph_blob(const bgr_graph* g, uint64_t* bytes) {
+    if (!g || g->host.blob.empty()) { if (bytes) *bytes = 0; return nullptr; }
+    if (bytes) *bytes = g->header.blob_bytes;
+    return g->host.blob.data();
+}
+
+int bgr_graph_from_blob(const void* blob, uint64_t bytes, bgr_graph** out) {
+    if (!blob || !out) return fail(BGR_E_ARG, "bgr_graph_from_blob: null argument");
+    std::string err;
+    if (!bgr::validate_blob(blob, bytes, err)) return fail(BGR_E_ARG, err);
+    bgr_graph* g = new bgr_graph();
+    g->host.blob.assign((bytes + 7) / 8, 0);
+    memcpy(g->host.blob.data(), blob, bytes);
+    g->header = *g->host.header();
+    *out = g;
+    return BGR_OK;
+}
+
+int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* o) {
+    if (!g || !o) return fail(BGR_E_ARG, "bgr_graph_info: null argument");
+    const BgrBlobHeader& h = g->header;
+    memset(o, 0, sizeof(*o));
+    o->k = h.k; o->n_levels = h.n_levels; o->n_unitigs = h.n_unitigs; o->n_keys = h.n_keys;
+    o->n_left_keys = h.n_left_keys; o->n_right_keys = h.n_right_keys; o->n_fallback = h.n_fallback;
+    o->total_bases = h.total_bases; o->blob_bytes = h.blob_bytes; o->mphf_bytes = h.n_units * 16;
+    o->max_unitig_len = h.max_unitig_len; o->has_exceptions = h.has_exc; o->gamma = h.gamma;
+    return BGR_OK;
+}
+
+void bgr_graph_destroy(bgr_graph* g) {
+    if (!g) return;
+    for (auto& kv : g->dev) {
+        if (kv.second.owned && kv.second.ptr) {
+            if (hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second.ptr);
+        }
+    }
+    delete g;
+}
+
+int bgr_graph_upload(bgr_graph* g, int device) {
+    if (!g) return fail(BGR_E_ARG, "bgr_graph_upload: null graph");
+    if (g->dev.count(device)) return BGR_OK;
+    if (g->host.blob.empty()) return fail(BGR_E_ARG, "bgr_graph_upload: graph has no host blob (adopted graphs live on one device)");
+    HIP_TRY(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, g->header.blob_bytes));
+    hipError_t e = hipMemcpy(p, g->host.blob.data(), g->header.blob_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(p); return fail(BGR_E_HIP, std::string("blob H2D: ") + hipGetErrorString(e)); }
+    g->dev[device] = {p, true};
+    return BGR_OK;
+}
+
+const void* bgr_graph_device_blob(const bgr_graph* g, int device) {
+    if (!g) return nullptr;
+    auto it = g->dev.find(device);
+    return it == g->dev.end() ? nullptr : it->second.ptr;
+}
+
+int bgr_graph_adopt_device_blob(int device, const void* dev_blob, uint64_t bytes, bgr_graph** out) {
+    if (!dev_blob || !out || bytes < sizeof(BgrBlobHeader)) return fail(BGR_E_ARG, "bgr_graph_adopt_device_blob: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    bgr_graph* g = new bgr_graph();
+    hipError_t e = hipMemcpy(&g->header, dev_blob, sizeof(BgrBlobHeader), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { delete g; return fail(BGR_E_HIP, std::string("header D2H: ") + hipGetErrorString(e)); }
+    if (g->header.magic != BGR_MAGIC || g->header.version != 1 || g->header.blob_bytes != bytes || g->header.n_levels > BGR_MAX_LEVELS) {
+        delete g;
+        return fail(BGR_E_ARG, "bgr_graph_adopt_device_blob: not a graph blob of that size");
+    }
+    g->dev[device] = {const_cast<void*>(dev_blob), false};
+    *out = g;
+    return BGR_OK;
+}
+
+// ---- mapping ----------------------------------------------------------------------------------------
+int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out) {
+    if (!g || !out) return fail(BGR_E_ARG, "bgr_aligner_create: null argument");
+    int nd = 0;
+    hipError_t e0 = hipGetDeviceCount(&nd);
+    if (e0 != hipSuccess || nd == 0) return fail(BGR_E_HIP, "no HIP device available (this library has no CPU mapping path)");
+    if (device < 0 || device >= nd) return fail(BGR_E_ARG, "bgr_aligner_create: device index out of range");
+    int rc = bgr_graph_upload(g, device);
+    if (rc != BGR_OK) return rc;
+    HIP_TRY(hipSetDevice(device));
+    bgr_aligner* a = new bgr_aligner();
+    a->graph = g;
+    a->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete a; return fail(BGR_E_HIP, hipGetErrorString(e)); }
+    a->num_cus = prop.multiProcessorCount;
+    a->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+    e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete a; return fail(BGR_E_HIP, hipGetErrorString(e)); }
+    for (int i = 0; i < kTimerRing; ++i) {
+        if (hipEventCreate(&a->ev_start[i]) != hipSuccess || hipEventCreate(&a->ev_stop[i]) != hipSuccess) {
+            delete a;
+            return fail(BGR_E_HIP, "hipEventCreate failed");
+        }
+    }
+    bgr::resolve_device_graph(&g->header, g->dev[device].ptr, a->dg);
+    e = a->small.ensure(256);
+    if (e == hipSuccess) e = hipMemset(a->small.p, 0, 256);
+    if (e != hipSuccess) { delete a; return fail(BGR_E_HIP, hipGetErrorString(e)); }
+    *out = a;
+    return BGR_OK;
+}
+
+void bgr_aligner_destroy(bgr_aligner* a) {
+    if (!a) return;
+    if (hipSetDevice(a->device) == hipSuccess) {
+        if (a->stream) (void)hipStreamSynchronize(a->stream);
+        a->in_reads.release(); a->in_offs.release(); a->status.release(); a->path_off.release();
+        a->path_len.release(); a->arena.release(); a->small.release();
+        for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
+        if (a->stream) (void)hipStreamDestroy(a->stream);
+    }
+    delete a;
+}
+
+int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blocks_per_cu, uint32_t lds_mphf) {
+    if (!a || waves_per_block > 16 || lds_mphf > 2) return fail(BGR_E_ARG, "bgr_aligner_configure: bad argument");
+    a->cfg_waves = waves_per_block;
+    a->cfg_blocks_per_cu = blocks_per_cu;
+    a->cfg_lds_mphf = lds_mphf;
+    return BGR_OK;
+}
+
+int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
+                     uint64_t total_bases, uint32_t max_read_len) {
+    if (!a || !p) return fail(BGR_E_ARG, "bgr_align_device: null argument");
+    if (p->mode > BGR_MODE_EXHAUSTIVE) return fail(BGR_E_ARG, "bgr_align_device: unknown mode");
+    a->last_n = n_reads;
+    if (n_reads == 0) return BGR_OK;
+    if (!d_reads || !d_read_offsets) return fail(BGR_E_ARG, "bgr_align_device: null device buffer");
+    if (n_reads >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: more than 2^32-2 reads in one batch");
+    // every path int consumes at least one read base; +8 per read covers offsets and short reads
+    uint64_t arena_cap = total_bases + 8 * n_reads;
+    if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (bases + 8*reads must stay below 2^32); split it");
+    HIP_TRY(hipSetDevice(a->device));
+    if (a->ev_used == kTimerRing) { int rc = drain_timers(a); if (rc != BGR_OK) return rc; }
+    HIP_TRY(a->status.ensure(n_reads));
+    HIP_TRY(a->path_off.ensure(n_reads * 4));
+    HIP_TRY(a->path_len.ensure(n_reads * 4));
+    HIP_TRY(a->arena.ensure(arena_cap * 4));
+
+    // ---- launch geometry -----------------------------------------------------------------------
+    uint32_t words = 0, path_cap = 0;
+    const uint32_t per_wave = bgr::lds_bytes_per_wave(max_read_len, &words, &path_cap);
+    const size_t lds_cu = a->lds_per_cu;
+    const uint32_t mphf_bytes = a->dg.units_bytes_lo;
+    bgr::LaunchCfg cfg;
+    bool stage = false;
+    if (a->cfg_lds_mphf != 1) {
+        // stage the cascade in LDS when it leaves room for a useful number of waves in the workgroup
+        uint32_t min_waves = a->cfg_lds_mphf == 2 ? 1 : 8;
+        if ((uint64_t)mphf_bytes + 16 + (uint64_t)min_waves * per_wave <= lds_cu && a->graph->header.n_units * 16 < 0xFFFFFFFFull) stage = true;
+    }
+    uint32_t waves;
+    if (stage) {
+        uint32_t fit = (uint32_t)((lds_cu - mphf_bytes - 16) / per_wave);
+        waves = std::min<uint32_t>(16, fit);
+        if (a->cfg_waves) waves = std::min(waves, a->cfg_waves);
+        cfg.lds_bytes = ((mphf_bytes + 7) / 8) * 8 + waves * per_wave;
+        uint32_t bpc = std::max<uint32_t>(1, (uint32_t)(lds_cu / cfg.lds_bytes));
+        if (a->cfg_blocks_per_cu) bpc = std::min(bpc, a->cfg_blocks_per_cu);
+        bpc = std::min<uint32_t>(bpc, std::max<uint32_t>(1, 32 / waves));
+        cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
+    } else {
+        waves = a->cfg_waves ? a->cfg_waves : 4;
+        uint32_t fit = (uint32_t)(lds_cu / per_wave);
+        if (fit == 0) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
+        waves = std::min(waves, fit);
+        cfg.lds_bytes = waves * per_wave;
+        uint32_t bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, 32 / waves);
+        bpc = std::min<uint32_t>(bpc, std::max<uint32_t>(1, (uint32_t)(lds_cu / cfg.lds_bytes)));
+        cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
+    }
+    if (waves == 0) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging");
+    cfg.waves_per_block = waves;
+    cfg.stage_mphf = stage ? 1 : 0;
+    a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf;
+
+    bgr::BatchIO io;
+    io.reads = static_cast<const uint8_t*>(d_reads);
+    io.read_offs = static_cast<const uint64_t*>(d_read_offsets);
+    io.n_reads = (uint32_t)n_reads;
+    io.words_per_read = words;
+    io.path_cap = path_cap;
+    io.arena_cap = (uint32_t)arena_cap;
+    io.status = static_cast<uint8_t*>(a->status.p);
+    io.path_off = static_cast<uint32_t*>(a->path_off.p);
+    io.path_len = static_cast<uint32_t*>(a->path_len.p);
+    io.arena = static_cast<int32_t*>(a->arena.p);
+    io.cursor = static_cast<uint32_t*>(a->small.p);
+    io.counters = reinterpret_cast<unsigned long long*>(static_cast<char*>(a->small.p) + 64);
+    bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode};
+
+    HIP_TRY(hipMemsetAsync(a->small.p, 0, 8, a->stream));
+    HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
+    hipError_t e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(a->ev_stop[a->ev_used], a->stream));
+    ++a->ev_used;
+    return BGR_OK;
+}
+
+int bgr_aligner_sync(bgr_aligner* a) {
+    if (!a) return fail(BGR_E_ARG, "bgr_aligner_sync: null aligner");
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    return BGR_OK;
+}
+
+int bgr_aligner_device_results(bgr_aligner* a, void** d_status, void** d_path_off, void** d_path_len, void** d_arena, void** d_cursor) {
+    if (!a) return fail(BGR_E_ARG, "bgr_aligner_device_results: null aligner");
+    if (d_status) *d_status = a->status.p;
+    if (d_path_off) *d_path_off = a->path_off.p;
+    if (d_path_len) *d_path_len = a->path_len.p;
+    if (d_arena) *d_arena = a->arena.p;
+    if (d_cursor) *d_cursor = a->small.p;
+    return BGR_OK;
+}
+
+int bgr_aligner_fetch(bgr_aligner* a, uint64_t n, int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
+    if (!a || !path_offsets || !status || (paths_cap && !paths_out)) return fail(BGR_E_ARG, "bgr_aligner_fetch: null argument");
+    if (n != a->last_n) return fail(BGR_E_ARG, "bgr_aligner_fetch: n_reads differs from the last bgr_align_device call");
+    path_offsets[0] = 0;
+    if (n == 0) return BGR_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    uint32_t cur[2] = {0, 0};
+    HIP_TRY(hipMemcpy(cur, a->small.p, 8, hipMemcpyDeviceToHost));
+    if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+    a->h_off.resize(n);
+    a->h_len.resize(n);
+    a->h_arena.resize(cur[0]);
+    HIP_TRY(hipMemcpy(status, a->status.p, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a->h_off.data(), a->path_off.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a->h_len.data(), a->path_len.p, n * 4, hipMemcpyDeviceToHost));
+    if (cur[0]) HIP_TRY(hipMemcpy(a->h_arena.data(), a->arena.p, (size_t)cur[0] * 4, hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t len = a->h_len[i];
+        if (w + len > paths_cap) return fail(BGR_E_CAPACITY, "bgr_aligner_fetch: paths_out too small");
+        if (len) memcpy(paths_out + w, a->h_arena.data() + a->h_off[i], (size_t)len * 4);
+        w += len;
+        path_offsets[i + 1] = w;
+    }
+    return BGR_OK;
+}
+
+int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n,
+                    int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
+    if (!a || !p || !path_offsets || (n && (!reads || !read_offsets || !status))) return fail(BGR_E_ARG, "bgr_align_batch: null argument");
+    path_offsets[0] = 0;
+    a->last_n = 0;
+    if (n == 0) return BGR_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    const uint64_t base = read_offsets[0], total = read_offsets[n] - base;
+    uint32_t max_len = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t l = read_offsets[i + 1] - read_offsets[i];
+        if (l > 0x7FFFFFFFull) return fail(BGR_E_ARG, "bgr_align_batch: read longer than 2^31 bases");
+        max_len = std::max<uint32_t>(max_len, (uint32_t)l);
+    }
+    HIP_TRY(a->in_reads.ensure(total + 16));
+    HIP_TRY(a->in_offs.ensure((n + 1) * 8));
+    HIP_TRY(hipMemcpyAsync(a->in_reads.p, reads + base, total, hipMemcpyHostToDevice, a->stream));
+    if (base == 0) {
+        HIP_TRY(hipMemcpyAsync(a->in_offs.p, read_offsets, (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    } else {
+        std::vector<uint64_t> rel(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) rel[i] = read_offsets[i] - base;
+        HIP_TRY(hipMemcpyAsync(a->in_offs.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    }
+    int rc = bgr_align_device(a, p, a->in_reads.p, a->in_offs.p, n, total, max_len);
+    if (rc != BGR_OK) return rc;
+    return bgr_aligner_fetch(a, n, paths_out, paths_cap, path_offsets, status);
+}
+
+int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) {
+    if (!a || !out) return fail(BGR_E_ARG, "bgr_aligner_counters: null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(hipMemcpy(out, static_cast<char*>(a->small.p) + 64, 40, hipMemcpyDeviceToHost));
+    return BGR_OK;
+}
+
+int bgr_aligner_reset_counters(bgr_aligner* a) {
+    if (!a) return fail(BGR_E_ARG, "bgr_aligner_reset_counters: null aligner");
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(hipMemset(static_cast<char*>(a->small.p) + 64, 0, 40));
+    return BGR_OK;
+}
+
+int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms) {
+    if (!a) return fail(BGR_E_ARG, "bgr_aligner_kernel_time: null aligner");
+    HIP_TRY(hipSetDevice(a->device));
+    int rc = drain_timers(a);
+    if (rc != BGR_OK) return rc;
+    if (launches) *launches = a->t_launches;
+    if (total_ms) *total_ms = a->t_ms;
+    return BGR_OK;
+}
+
+int bgr_aligner_reset_kernel_time(bgr_aligner* a) {
+    if (!a) return fail(BGR_E_ARG, "bgr_aligner_reset_kernel_time: null aligner");
+    HIP_TRY(hipSetDevice(a->device));
+    int rc = drain_timers(a);
+    if (rc != BGR_OK) return rc;
+    a->t_launches = 0;
+    a->t_ms = 0;
+    return BGR_OK;
+}
+
+int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]) {
+    if (!a || !out) return fail(BGR_E_ARG, "bgr_aligner_launch_info: null argument");
+    memcpy(out, a->last_launch, sizeof(a->last_launch));
+    return BGR_OK;
+}
+
+// ---- read files / output records (host) ---------------------------------------------------------------
+struct bgr_readset { bgr::ReadSet rs; };
+
+int bgr_readset_load(const char* path, int fastq, uint32_t k, bgr_readset** out) {
+    if (!path || !out) return fail(BGR_E_ARG, "bgr_readset_load: null argument");
+    bgr_readset* r = new bgr_readset();
+    r->rs.clear();
+    std::string err;
+    if (!bgr::parse_reads_file(path, fastq != 0, k, r->rs, err)) { delete r; return fail(BGR_E_IO, err); }
+    *out = r;
+    return BGR_OK;
+}
+uint64_t bgr_readset_count(const bgr_readset* rs) { return rs ? rs->rs.count() : 0; }
+int bgr_readset_view(const bgr_readset* rs, const char** reads, const uint64_t** read_offsets, const char** headers, const uint64_t** header_offsets) {
+    if (!rs) return fail(BGR_E_ARG, "bgr_readset_view: null readset");
+    if (reads) *reads = rs->rs.reads.data();
+    if (read_offsets) *read_offsets = rs->rs.read_offs.data();
+    if (headers) *headers = rs->rs.headers.data();
+    if (header_offsets) *header_offsets = rs->rs.header_offs.data();
+    return BGR_OK;
+}
+void bgr_readset_destroy(bgr_readset* rs) { delete rs; }
+
+int bgr_write_records(void* paths_file, void* notaligned_file, uint64_t n, const char* headers, const uint64_t* hoffs,
+                      const char* reads, const uint64_t* roffs, const int32_t* paths, const uint64_t* poffs) {
+    if (!paths_file || !notaligned_file || (n && (!headers || !hoffs || !reads || !roffs || !poffs))) return fail(BGR_E_ARG, "bgr_write_records: null argument");
+    FILE* pf = static_cast<FILE*>(paths_file);
+    FILE* nf = static_cast<FILE*>(notaligned_file);
+    std::string pbuf, nbuf;
+    pbuf.reserve(1 << 20);
+    nbuf.reserve(1 << 20);
+    char num[16];
+    for (uint64_t i = 0; i < n; ++i) {
+        const char* h = headers + hoffs[i];
+        size_t hn = hoffs[i + 1] - hoffs[i];
+        if (poffs[i + 1] > poffs[i]) {  // alignerGreedy.cpp:406-411 + printPath aligner.cpp:600-609
+            pbuf.append(h, hn);
+            pbuf.push_back('\n');
+            for (uint64_t j = poffs[i]; j < poffs[i + 1]; ++j) {
+                int32_t v = paths[j];
+                uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+                int len = 0;
+                do { num[len++] = (char)('0' + u % 10); u /= 10; } while (u);
+                if (v < 0) pbuf.push_back('-');
+                while (len) pbuf.push_back(num[--len]);
+                pbuf.push_back('.');
+            }
+            pbuf.push_back('\n');
+            if (pbuf.size() > (1 << 20) - 4096) { if (fwrite(pbuf.data(), 1, pbuf.size(), pf) != pbuf.size()) return fail(BGR_E_IO, "write to paths file failed"); pbuf.clear(); }
+        } else {  // alignerGreedy.cpp:421-427
+            nbuf.append(h, hn);
+            nbuf.push_back('\n');
+            nbuf.append(reads + roffs[i], roffs[i + 1] - roffs[i]);
+            nbuf.push_back('\n');
+            if (nbuf.size() > (1 << 20) - 4096) { if (fwrite(nbuf.data(), 1, nbuf.size(), nf) != nbuf.size()) return fail(BGR_E_IO, "write to notAligned file failed"); nbuf.clear(); }
+        }
+    }
+    if (!pbuf.empty() && fwrite(pbuf.data(), 1, pbuf.size(), pf) != pbuf.size()) return fail(BGR_E_IO, "write to paths file failed");
+    if (!nbuf.empty() && fwrite(nbuf.data(), 1, nbuf.size(), nf) != nbuf.size()) return fail(BGR_E_IO, "write to notAligned file failed");
+    return BGR_OK;
+}
+
+}  // extern "C"

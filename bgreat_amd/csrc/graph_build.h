@@ -1,0 +1,40 @@
+// graph_build.h -- host-side construction of the graph blob (graph_layout.h) from unitig sequences.
+// Replaces Aligner::indexUnitigsAux (aligner.cpp:407-534): same key sets, same slot fill order.
+#ifndef BGREAT_AMD_GRAPH_BUILD_H
+#define BGREAT_AMD_GRAPH_BUILD_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "graph_layout.h"
+
+namespace bgr {
+
+struct HostGraph {
+    std::vector<uint64_t> blob;  // 8-byte aligned storage; header at blob[0]
+    const BgrBlobHeader* header() const { return reinterpret_cast<const BgrBlobHeader*>(blob.data()); }
+    uint64_t bytes() const { return header()->blob_bytes; }
+    const uint8_t* base() const { return reinterpret_cast<const uint8_t*>(blob.data()); }
+};
+
+// seqs/offs: n unitig sequences in file order (offs[n+1]).  Loading stops at the first sequence shorter
+// than k, as aligner.cpp:418-420 does.  gamma: MPHF bits per remaining key on each cascade level.
+// Returns false (and sets err) on invalid arguments / limits.
+bool build_graph(uint32_t k, uint64_t n, const char* seqs, const uint64_t* offs, double gamma, HostGraph& out, std::string& err);
+
+// Reads a unitig FASTA the way aligner.cpp:415-417 does: two lines per record, header ignored.
+bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& seqs, std::vector<uint64_t>& offs, std::string& err);
+
+// Host twin of the device lookup (same arithmetic): MPHF index of `key`, or BGR_NONE.  The caller still has
+// to compare keys[idx] with key for membership.
+uint32_t host_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key);
+
+// Fill a BgrDeviceGraph whose pointers are `base` + section offsets (base may be a device address).
+void resolve_device_graph(const BgrBlobHeader* h, const void* base, BgrDeviceGraph& dg);
+
+bool validate_blob(const void* blob, uint64_t bytes, std::string& err);
+
+}  // namespace bgr
+
+#endif

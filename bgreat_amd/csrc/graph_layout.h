@@ -1,0 +1,131 @@
+// graph_layout.h -- the immutable de Bruijn graph index as ONE position-independent blob, laid out for
+// gfx950.  Built on the host (graph_build.cpp), copied to HBM once, broadcast between GPUs as raw bytes.
+// Shared by host code (g++) and device code (hipcc); no HIP types in here.
+//
+// What the reference keeps in std:: containers (aligner.h:65-70: vector<string> unitigs, two boomphf::mphf,
+// two vector<unitigIndices>) becomes:
+//
+//   seq    2-bit packed bases (A0 C1 G2 other 3 == str2num, utils.cpp:117-129), 32 bases per u64, FIRST
+//          base in the MOST significant bits so a (k-1)-window read out of the stream IS the reference's
+//          k-mer integer.  Every unitig is stored twice, forward strand at base offset F and its
+//          reverse complement (utils.cpp:66-73: non-ACG -> 'A') right behind it at F+len, so an oriented
+//          unitig is just (base offset, length) and no kernel ever reverses bits.
+//   exc/excN  optional 1-bit-per-base planes over the same base index space: forward-strand bases that
+//          are not ACGT (they can never equal a read's ACGT; an 'N' can only equal a read's 'N').  Absent
+//          (offset 0) for ordinary graphs.
+//   meta   32 B per unitig id: F, len, and the record index + canonical flag of BOTH end (k-1)-mers, so
+//          a walk step never hashes: the next neighbour record is a direct index.
+//   MPHF   ONE minimal perfect hash over the union of the reference's left and right overlap key sets
+//          (index values are unobservable).  BBHash-style cascade; each level is an
+//          array of 16-byte units {96 bits, u32 rank of the unit}: ONE dwordx4 load answers "is the bit
+//          set" AND gives the minimal index (rank + popcount below the bit).
+//   keys   u64 key per MPHF index (membership check, aligner.cpp:158,219,353,361).
+//   recs   32 B per MPHF index: the 4 "left table" slots and the 4 "right table" slots of that key
+//          (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite, aligner.cpp:466-533).
+//          Bits 30/31 of a slot carry the orientation the reference recomputes by string compare at
+//          query time (aligner.cpp:174,235).
+#ifndef BGREAT_AMD_GRAPH_LAYOUT_H
+#define BGREAT_AMD_GRAPH_LAYOUT_H
+
+#include <stdint.h>
+
+#if defined(__HIP__)
+#define BGR_HD __host__ __device__ __forceinline__
+#else
+#define BGR_HD inline
+#endif
+
+#define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
+#define BGR_MAX_LEVELS 48
+#define BGR_UNIT_BITS 96u
+#define BGR_NONE 0xFFFFFFFFu
+#define BGR_SLOT_ID_MASK 0x3FFFFFFFu
+// slot flag bits (see graph_build.cpp fill_records):
+//   left-table slot : bit30 = unitig forward when asked "who BEGINS with key"      (getBegin(key))
+//                     bit31 = unitig forward when asked "who ENDS with rc(key)"    (getEnd(rc key))
+//   right-table slot: bit30 = unitig forward when asked "who ENDS with key"        (getEnd(key))
+//                     bit31 = unitig forward when asked "who BEGINS with rc(key)"  (getBegin(rc key))
+#define BGR_SLOT_F0 0x40000000u
+#define BGR_SLOT_F1 0x80000000u
+
+// meta flags
+#define BGR_META_CANON_BEG 1u    /* beg <= rc(beg): forward unitig, walking left, next getEnd key is canonical   */
+#define BGR_META_CANON_END 2u    /* end <= rc(end): forward unitig, walking right, next getBegin key is canonical */
+#define BGR_META_CANON_RCBEG 4u  /* rc(beg) <= beg: reversed unitig, walking right                                */
+#define BGR_META_CANON_RCEND 8u  /* rc(end) <= end: reversed unitig, walking left                                 */
+
+typedef struct {
+    uint64_t F;       // base offset of the forward strand in `seq` (reverse complement at F + len)
+    uint32_t len;     // bases
+    uint32_t flags;   // BGR_META_*
+    uint32_t rec_beg; // MPHF index of canonical(first k-1 bases)
+    uint32_t rec_end; // MPHF index of canonical(last k-1 bases)
+    uint64_t pad;
+} BgrUnitigMeta;      // 32 B
+
+typedef struct {
+    uint32_t units;  // number of 96-bit units on this level
+    uint32_t base;   // index of the level's first unit in the unit array
+} BgrLevel;
+
+// Blob header (first 4096 bytes of the blob).  All section offsets are bytes from the blob start and
+// multiples of 256.
+typedef struct {
+    uint64_t magic;
+    uint32_t version, k;
+    uint64_t blob_bytes;
+    uint64_t n_unitigs;     // ids 1..n_unitigs (meta has n_unitigs+1 entries, entry 0 unused)
+    uint64_t n_keys;        // MPHF domain: keys, recs
+    uint64_t n_placed;      // keys placed on cascade levels; the rest sit in the sorted fallback list
+    uint64_t n_fallback;
+    uint64_t seq_words;     // u64 words in seq (incl. 2 trailing pad words)
+    uint64_t total_bases;   // 2 * sum(len)
+    uint64_t n_units;       // total 16-byte MPHF units
+    uint64_t off_units, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback;
+    uint32_t n_levels, has_exc;
+    uint64_t max_unitig_len;
+    uint64_t n_left_keys, n_right_keys;  // sizes of the reference's two key sets (informational)
+    double gamma;
+    BgrLevel levels[BGR_MAX_LEVELS];
+} BgrBlobHeader;
+
+// What a kernel receives by value (pointers resolved against the device copy of the blob).
+typedef struct {
+    const uint32_t* units;   // n_units * 4 u32  (x,y,z = 96 bits, w = rank)
+    const uint64_t* keys;
+    const uint32_t* recs;    // n_keys * 8 u32   (L0..L3, R0..R3)
+    const BgrUnitigMeta* meta;
+    const uint64_t* seq;
+    const uint64_t* exc;     // may be null
+    const uint64_t* excn;    // may be null
+    const uint64_t* fallback;
+    uint32_t k, n_levels, n_keys, n_placed, n_fallback, has_exc;
+    uint32_t units_bytes_lo, pad0;   // size of the unit array in bytes (for LDS staging decisions)
+    BgrLevel levels[BGR_MAX_LEVELS];
+} BgrDeviceGraph;
+
+// ---- hashing shared by the host builder and the device lookup ---------------------------------------
+// 64 -> 64 finaliser (SplitMix64's); the cascade uses double hashing on its two halves:
+//   level l: h_l = ha + l*hb (mod 2^32), unit = mulhi32(h_l, units_l), bit = ((h_l & 0xFFFF) * 96) >> 16.
+BGR_HD uint64_t bgr_mix64(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+BGR_HD uint32_t bgr_level_unit(uint32_t h, uint32_t units) { return (uint32_t)(((uint64_t)h * (uint64_t)units) >> 32); }
+BGR_HD uint32_t bgr_level_bit(uint32_t h) { return ((h & 0xFFFFu) * BGR_UNIT_BITS) >> 16; }
+
+// reverse complement of a (k-1)-digit base-4 number == utils.cpp:182-192 rcb(), by bit tricks
+BGR_HD uint64_t bgr_rev2(uint64_t x) {  // reverse the order of the 32 2-bit digits of x
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+    return (x >> 32) | (x << 32);
+}
+BGR_HD uint64_t bgr_rcb(uint64_t x, uint32_t n) { return (~bgr_rev2(x)) >> (64 - 2 * n); }
+
+#endif

@@ -1,0 +1,156 @@
+/* bgreat_gpu.h -- C-ABI of libbgreat_gpu.so: the MI355X (gfx950) implementation of BGREAT's per-read
+ * de Bruijn-graph mapping path.  Plain pointers and sizes only; no C++/HIP/torch types cross this boundary.
+ *
+ * The reference (Malfoy/BGREAT) has no plugin/FFI interface.  Its in-process boundary for this path is the
+ * worker body alignerGreedy.cpp:378-392 / alignerExhaustive.cpp:273-281, i.e. the member functions
+ *
+ *     vector<uNumber> Aligner::alignReadGreedy(const string& read, bool& overlapFound, uint errors, bool& rc)
+ *                                                       (aligner.h:127, alignerGreedy.cpp:35-57)
+ *     vector<uNumber> Aligner::alignReadExhaustive(const string& read, bool& overlapFound, uint errors)
+ *                                                       (aligner.h:135, alignerExhaustive.cpp:35-58)
+ *
+ * called once per read on an immutable Aligner built by Aligner::Aligner + indexUnitigs()
+ * (aligner.h:80-105, aligner.cpp:407-547), with side effects only on the counters of aligner.h:68.
+ * One-read calls cannot feed a GPU, so every entry point below is the batch form of one of those; each
+ * states the reference interface it replaces.  Results are bit-identical to the reference for the same
+ * reads in the same order.
+ *
+ * Conventions: every function returns 0 on success, a negative BGR_E* code otherwise; bgr_last_error()
+ * gives the text (thread-local).  Handles are opaque.  Nothing here falls back to a CPU implementation:
+ * without a usable HIP device the device functions fail with BGR_E_HIP.
+ */
+#ifndef BGREAT_GPU_H
+#define BGREAT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGR_OK 0
+#define BGR_E_ARG (-1)      /* invalid argument / limit exceeded */
+#define BGR_E_HIP (-2)      /* HIP runtime or device failure */
+#define BGR_E_IO (-3)       /* file could not be opened / read */
+#define BGR_E_CAPACITY (-4) /* caller-provided output buffer too small */
+#define BGR_E_INTERNAL (-5)
+
+/* status byte of one read (alignReadGreedy's return + overlapFound + rc; alignerGreedy.cpp:35-57):
+ *   low 2 bits: 0 = no anchor (noOverlapRead++), 1 = anchored, not aligned (notAligned++), 2 = aligned
+ *   bit 2 (4) : the answer was produced on the reverse-complement retry (`rc` out-parameter)           */
+#define BGR_ST_NOANCHOR 0
+#define BGR_ST_FAILED 1
+#define BGR_ST_ALIGNED 2
+#define BGR_ST_MASK 3
+#define BGR_ST_RC 4
+
+#define BGR_MODE_GREEDY 0      /* alignAll(true, ...)  -> alignReadGreedy      (bgreat.cpp:115, default) */
+#define BGR_MODE_EXHAUSTIVE 1  /* alignAll(false, ...) -> alignReadExhaustive  (bgreat.cpp -b)           */
+
+typedef struct bgr_graph bgr_graph;     /* immutable index: replaces the Aligner's unitigs/MPHF/indices members */
+typedef struct bgr_aligner bgr_aligner; /* per-device mapping context: stream, workspaces, counters            */
+
+typedef struct {
+    uint32_t mode;         /* BGR_MODE_*                                            */
+    uint32_t max_mismatch; /* -m  errorsMax  (bgreat.cpp:78-80, default 2)          */
+    uint32_t effort;       /* -e  tryNumber  (bgreat.cpp:84-86, default 2)          */
+    uint32_t partial;      /* -i  partial    (bgreat.cpp:96-98; exhaustive only)    */
+} bgr_params;
+
+typedef struct {
+    uint32_t k, n_levels;
+    uint64_t n_unitigs, n_keys, n_left_keys, n_right_keys, n_fallback;
+    uint64_t total_bases, blob_bytes, mphf_bytes, max_unitig_len;
+    uint32_t has_exceptions, reserved;
+    double gamma;
+} bgr_graph_info_t;
+
+const char* bgr_last_error(void);
+int bgr_device_count(void); /* number of HIP devices visible, 0 if none / no driver */
+
+/* ---- index ----------------------------------------------------------------------------------------
+ * Replaces Aligner::Aligner + Aligner::indexUnitigs/indexUnitigsAux (aligner.h:80-105, aligner.cpp:407-547).
+ * `seqs`/`offsets[n+1]`: the unitig sequences in file order (ids are 1-based ordinals, as in the reference).
+ * Loading stops at the first sequence shorter than k (aligner.cpp:418-420).  gamma <= 0 selects the default.
+ * The graph is built on the host; inputs are only read during the call. */
+int bgr_graph_build(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, bgr_graph** out);
+/* Same, reading the unitig FASTA exactly as aligner.cpp:415-417 does (2 lines per record, header ignored). */
+int bgr_graph_build_from_fasta(const char* unitig_fasta_path, uint32_t k, double gamma, bgr_graph** out);
+/* The graph as one position-independent byte blob (what is copied to HBM / broadcast between GPUs). */
+const void* bgr_graph_blob(const bgr_graph* g, uint64_t* bytes);
+int bgr_graph_from_blob(const void* blob, uint64_t bytes, bgr_graph** out); /* copies the blob */
+int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* out);
+void bgr_graph_destroy(bgr_graph* g);
+
+/* Device residency.  upload: hipMalloc + H2D of the blob on `device` (idempotent per device).
+ * adopt: the blob already sits in that device's HBM at `dev_blob` (e.g. it was received by an RCCL
+ * broadcast from rank 0); the memory stays owned by the caller and must outlive the graph. */
+int bgr_graph_upload(bgr_graph* g, int device);
+const void* bgr_graph_device_blob(const bgr_graph* g, int device); /* NULL if not resident there */
+int bgr_graph_adopt_device_blob(int device, const void* dev_blob, uint64_t bytes, bgr_graph** out);
+
+/* ---- mapping --------------------------------------------------------------------------------------
+ * bgr_aligner_create replaces the per-thread worker state of alignPartGreedy/alignPartExhaustive
+ * (alignerGreedy.cpp:367-371); it uploads the graph to `device` if needed and owns a HIP stream. */
+int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out);
+void bgr_aligner_destroy(bgr_aligner* a);
+
+/* Batch form of alignReadGreedy / alignReadExhaustive over host buffers (H2D, kernel, D2H; blocking).
+ *   reads / read_offsets[n+1] : concatenated read sequences exactly as getReads (aligner.cpp:46-117) hands
+ *                               them over (characters ACGTN), borrowed for the call.
+ *   paths_out[paths_cap], path_offsets[n+1] : CSR of the returned vector<uNumber> per read, INPUT ORDER;
+ *                               an empty row means "not mapped" (the reference's empty vector).
+ *   status[n] : BGR_ST_* per read.
+ * Counters of aligner.h:68 are accumulated in the aligner (bgr_aligner_counters).                       */
+int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
+                    int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
+
+/* Device-resident form: inputs already in this device's HBM (d_reads bytes, d_read_offsets uint64[n+1]);
+ * results stay in aligner-owned device buffers (bgr_aligner_device_results).  Asynchronous on the
+ * aligner's stream; max_read_len = longest read in the batch, total_bases = read_offsets[n].            */
+int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
+                     uint64_t total_bases, uint32_t max_read_len);
+int bgr_aligner_sync(bgr_aligner* a);
+/* Device pointers of the last bgr_align_device results: status u8[n], path_off u32[n], path_len u32[n],
+ * arena int32[], cursor u32[1] (ints used in the arena).  Row i of the result = arena[path_off[i] .. +path_len[i]). */
+int bgr_aligner_device_results(bgr_aligner* a, void** d_status, void** d_path_off, void** d_path_len, void** d_arena, void** d_cursor);
+/* Copy the last device results to the host in input order (same output contract as bgr_align_batch). */
+int bgr_aligner_fetch(bgr_aligner* a, uint64_t n_reads, int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
+
+/* aligner.h:68 counters since creation/reset: out[0]=readNumber, [1]=noOverlapRead, [2]=alignedRead,
+ * [3]=notAligned, [4]=overlaps (exhaustive only).  Synchronises the stream. */
+int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]);
+int bgr_aligner_reset_counters(bgr_aligner* a);
+
+/* Kernel timing by HIP events recorded on the aligner's stream around every mapping-kernel launch since the
+ * last reset: number of launches and their summed duration in milliseconds.  Synchronises the stream. */
+int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms);
+int bgr_aligner_reset_kernel_time(bgr_aligner* a);
+/* Launch geometry of the last mapping kernel (for logs): blocks, threads per block, dynamic LDS bytes, and
+ * whether the MPHF cascade was staged in LDS. */
+int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
+/* Tuning knobs (0 keeps the default): waves per workgroup, workgroups per CU, force MPHF LDS staging
+ * (0 auto, 1 off, 2 on). */
+int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blocks_per_cu, uint32_t lds_mphf);
+
+/* ---- read files (host) ----------------------------------------------------------------------------
+ * Replaces Aligner::getReads (aligner.cpp:46-117) for a whole file: the accepted (header, read) records
+ * in file order with the reference's drop rules (characters outside ACGTN, size <= 2, FASTA size <= k,
+ * multi-line FASTA, the FASTQ phantom record).  Buffers are owned by the returned object. */
+typedef struct bgr_readset bgr_readset;
+int bgr_readset_load(const char* path, int fastq, uint32_t k, bgr_readset** out);
+uint64_t bgr_readset_count(const bgr_readset* rs);
+/* reads_concat / read_offsets[n+1] / headers_concat / header_offsets[n+1] */
+int bgr_readset_view(const bgr_readset* rs, const char** reads, const uint64_t** read_offsets, const char** headers, const uint64_t** header_offsets);
+void bgr_readset_destroy(bgr_readset* rs);
+
+/* Output formatting of printPath + the fwrite sites (aligner.cpp:600-609, alignerGreedy.cpp:406-427):
+ * appends "header\n" + "int." * n + "\n" records for mapped reads to `paths_file` and "header\nread\n" for the
+ * others to `notaligned_file` (both FILE* opened by the caller, passed as void*). */
+int bgr_write_records(void* paths_file, void* notaligned_file, uint64_t n_reads, const char* headers, const uint64_t* header_offsets,
+                      const char* reads, const uint64_t* read_offsets, const int32_t* paths, const uint64_t* path_offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

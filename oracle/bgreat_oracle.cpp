@@ -263,7 +263,7 @@ struct Mphf {  // BooPHF.h:711-1216, instantiated as mphf<u64, SingleHashFunctor
     uint64_t lookup(uint64_t key) const {
         ++tl_work.lookups;
         if (!built) return ULLONG_MAX;
-        uint64_t s[2];
+        uint64_t s[2] = {0, 0};
         int level;
         uint64_t h = get_level(s, key, &level, 100, true);
         if (level == kLevels - 1) {
@@ -890,6 +890,37 @@ double orc_alg_bytes(void* h) {
     b += (double)w.mm_bases / 4.0 + 16.0 * w.unitig_fetch;
     b += 4.0 * w.path_ints + 8.0 * w.reads;
     return b;
+}
+
+// getReads (aligner.cpp:46-117) over a whole file, batches of 10000 like the worker loop: the accepted
+// (header, read) records in order.  Two-call protocol: pass null buffers to obtain the sizes.
+// out_sizes: [0]=records, [1]=read bytes, [2]=header bytes.
+int orc_parse_file(const char* path, int fastq, int k, uint64_t* out_sizes, char* reads, uint64_t* read_offs, char* headers, uint64_t* header_offs) {
+    Oracle o;
+    o.k = (unsigned)k;
+    Runner run(o);
+    run.fastq = fastq != 0;
+    run.readFile.open(path);
+    if (!run.readFile) return -1;
+    uint64_t n = 0, rb = 0, hb = 0;
+    vector<std::pair<string, string>> batch;
+    while (!run.readFile.eof()) {
+        run.get_reads(batch, 10000);
+        for (auto& hr : batch) {
+            if (reads) {
+                memcpy(headers + hb, hr.first.data(), hr.first.size());
+                memcpy(reads + rb, hr.second.data(), hr.second.size());
+                header_offs[n] = hb;
+                read_offs[n] = rb;
+            }
+            hb += hr.first.size();
+            rb += hr.second.size();
+            ++n;
+        }
+    }
+    if (reads) { header_offs[n] = hb; read_offs[n] = rb; }
+    out_sizes[0] = n; out_sizes[1] = rb; out_sizes[2] = hb;
+    return 0;
 }
 
 // CLI twin of bgreat.cpp:54-130.  Returns 0.  `exh_writes` != 0 makes -b write the paths it computes

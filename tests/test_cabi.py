@@ -1,0 +1,152 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/bgreat_gpu.h declares, the host
+parts (index build, blob round trip, read parser, record writer) behave like the reference, and mapping fails
+loudly without a GPU.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+import bgreat_amd as B
+import oracle_py
+from tools.synth import Synth
+from util import GOLD, ROOT, golden_cases
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    B.build()
+
+
+def test_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bgreat_gpu.h")).read()
+    declared = set(re.findall(r"\b(bgr_[a-z_0-9]+)\s*\(", hdr))
+    types = {"bgr_graph", "bgr_aligner", "bgr_readset", "bgr_params", "bgr_graph_info_t"}
+    declared -= types
+    assert declared == set(B.SYMBOLS), declared ^ set(B.SYMBOLS)
+    L = B.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_graph_build_info_and_blob_roundtrip():
+    s = Synth(30000, 75, 2, 31, 5)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(31, seqs, offs)
+    info = g.info()
+    assert info["k"] == 31 and info["n_unitigs"] == len(offs) - 1
+    assert info["n_keys"] <= info["n_left_keys"] + info["n_right_keys"]
+    assert info["total_bases"] == 2 * int(offs[-1])
+    blob = np.array(g.blob())
+    g2 = B.Graph.from_blob(blob)
+    assert g2.info() == info
+    assert np.array_equal(np.array(g2.blob()), blob)
+    with pytest.raises(B.BgrError):
+        B.Graph.from_blob(blob[:1000])
+    bad = blob.copy()
+    bad[0] ^= 1
+    with pytest.raises(B.BgrError):
+        B.Graph.from_blob(bad)
+
+
+def test_graph_build_rejects_bad_k():
+    seqs = np.frombuffer(b"ACGTACGTAC", dtype=np.uint8)
+    offs = np.array([0, 10], dtype=np.uint64)
+    for k in (0, 1, 33, 64):
+        with pytest.raises(B.BgrError):
+            B.Graph.build(k, seqs, offs)
+
+
+def test_unitig_loading_stops_at_first_short_sequence():
+    g = B.Graph.from_fasta(os.path.join(GOLD, "short_stop_unitig.fa"), 5)
+    assert g.info()["n_unitigs"] == 40   # aligner.cpp:418-420
+    g = B.Graph.from_fasta(os.path.join(GOLD, "toy_unitig.fa"), 4)
+    assert g.info()["n_unitigs"] == 6
+
+
+def test_exception_planes_only_when_needed():
+    assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig.fa"), 5).info()["has_exceptions"] == 0
+    assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig_exc.fa"), 5).info()["has_exceptions"] == 1
+
+
+@pytest.mark.parametrize("name,k,fastq", [("edge_reads.fa", 31, False), ("edge_reads.fa", 25, False), ("edge_reads.fq", 31, True),
+                                          ("edge_reads_nonl.fq", 31, True), ("syn_r150.fa", 31, False), ("long_r150.fq", 31, True),
+                                          ("deg_reads.fa", 5, False), ("toy_reads.fa", 4, False)])
+def test_parser_matches_oracle_getreads(name, k, fastq):
+    path = os.path.join(GOLD, name)
+    r1, ro1, h1, ho1 = B.load_reads(path, k, fastq)
+    r2, ro2, h2, ho2 = oracle_py.parse_file(path, k, fastq)
+    assert np.array_equal(ro1, ro2) and np.array_equal(ho1, ho2)
+    assert np.array_equal(r1, r2) and np.array_equal(h1, h2)
+
+
+def _write_tmp(text):
+    f = tempfile.NamedTemporaryFile("wb", suffix=".fx", delete=False)
+    f.write(text)
+    f.close()
+    return f.name
+
+
+@pytest.mark.parametrize("text,fastq", [
+    (b"", False), (b"", True), (b">h\n", False), (b">h", False), (b">h\nACGTACGT", False), (b"\n>h\nACGTACGT\n", False),
+    (b">a\nACGTACGT\n>b", False), (b">a\nACGTACGT\n>b\n", False), (b">a\nACGT\nACGT\n\n\n>b\nAAAAAAAA\n\n", False),
+    (b"ACGTACGT\nACGTACGT\n", False), (b">a\r\nACGTACGT\r\n", False),
+    (b"@a\nACGTACGT\n+\nIIIIIIII\n", True), (b"@a\nACGTACGT\n+\nIIIIIIII", True), (b"@a\nACGTACGT\n+\n", True),
+    (b"@a\nACGTACGT\n", True), (b"@a\nACGTACGT\n+\nIIIIIIII\n@b\nacgtacgt\n+\nIIIIIIII\n", True),
+    (b"@a\nACGTACGT\n+\nIIIIIIII\n\n", True),
+])
+def test_parser_corner_cases_match_oracle(text, fastq):
+    p = _write_tmp(text)
+    try:
+        a = B.load_reads(p, 5, fastq)
+        b = oracle_py.parse_file(p, 5, fastq)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (text, a, b)
+    finally:
+        os.unlink(p)
+
+
+def test_fastq_phantom_depends_on_batch_boundary():
+    """aligner.cpp:51-68: the phantom record appears unless the record count is a multiple of the 10000-read batch."""
+    rec = b"@r\nACGTACGTAC\n+\nIIIIIIIIII\n"
+    for n in (9999, 10000, 10001, 20000):
+        p = _write_tmp(rec * n)
+        try:
+            a = B.load_reads(p, 5, True)
+            b = oracle_py.parse_file(p, 5, True)
+            assert len(a[1]) == len(b[1]) and np.array_equal(a[0], b[0])
+            assert len(a[1]) - 1 == (n if n % 10000 == 0 else n + 1)
+        finally:
+            os.unlink(p)
+
+
+def test_write_records_matches_golden_format():
+    """printPath + fwrite sites (aligner.cpp:600-609, alignerGreedy.cpp:406-427), fed with the oracle's paths."""
+    case = next(c for c in golden_cases() if c["group"] == "edge" and c["args"][7] == "5")
+    reads, roffs, heads, hoffs = B.load_reads(os.path.join(GOLD, "edge_reads.fa"), 31)
+    o = oracle_py.Oracle(31, fasta=os.path.join(GOLD, "syn_unitig.fa"))
+    paths, poffs, status = o.align(reads, roffs, m=5, effort=2)
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    with tempfile.TemporaryDirectory() as d:
+        pf = libc.fopen(os.path.join(d, "paths").encode(), b"wb")
+        nf = libc.fopen(os.path.join(d, "na").encode(), b"wb")
+        rc = B.lib().bgr_write_records(pf, nf, len(roffs) - 1, heads.ctypes.data, hoffs.ctypes.data, reads.ctypes.data, roffs.ctypes.data,
+                                       paths.ctypes.data if len(paths) else None, poffs.ctypes.data)
+        libc.fclose(pf)
+        libc.fclose(nf)
+        assert rc == 0
+        assert open(os.path.join(d, "paths"), "rb").read().decode("latin-1") == case["paths"]
+        assert open(os.path.join(d, "na"), "rb").read().decode("latin-1") == case["notaligned"]
+
+
+def test_mapping_fails_loudly_without_gpu():
+    if B.device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = B.Graph.from_fasta(os.path.join(GOLD, "toy_unitig.fa"), 4)
+    with pytest.raises(B.BgrError, match="(?i)no HIP device|hip"):
+        B.Aligner(g, 0)

@@ -1,0 +1,167 @@
+"""Parity tests proper: the HIP path (through the C-ABI of include/bgreat_gpu.h) against
+  (1) the committed outputs of the compiled reference (tests/golden), byte for byte, and
+  (2) the oracle (oracle/liboracle.so) on fresh seeded inputs: identical path ints, offsets and status bytes.
+Integer work: the bar is bit-exact everywhere."""
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import bgreat_amd as B
+import oracle_py
+from tools.synth import Synth
+from util import GOLD, check_against_golden, golden_cases, resolve_args, run_cli
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_cases()
+GREEDY = [c for c in CASES if "-b" not in c["args"]]
+
+
+def _argval(args, flag, default):
+    return args[args.index(flag) + 1] if flag in args else default
+
+
+def _format(reads, roffs, heads, hoffs, paths, poffs):
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    with tempfile.TemporaryDirectory() as d:
+        pf = libc.fopen(os.path.join(d, "p").encode(), b"wb")
+        nf = libc.fopen(os.path.join(d, "n").encode(), b"wb")
+        rc = B.lib().bgr_write_records(pf, nf, len(roffs) - 1, heads.ctypes.data, hoffs.ctypes.data, reads.ctypes.data, roffs.ctypes.data,
+                                       paths.ctypes.data if len(paths) else None, poffs.ctypes.data)
+        libc.fclose(pf)
+        libc.fclose(nf)
+        assert rc == 0
+        return open(os.path.join(d, "p"), "rb").read(), open(os.path.join(d, "n"), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def graphs():
+    cache = {}
+
+    def get(path, k):
+        key = (path, k)
+        if key not in cache:
+            g = B.Graph.from_fasta(path, k)
+            cache[key] = (g, B.Aligner(g, 0))
+        return cache[key]
+    yield get
+    cache.clear()
+
+
+@pytest.mark.parametrize("case", GREEDY, ids=["%02d-%s" % (c["id"], c["group"]) for c in GREEDY])
+def test_gpu_matches_reference_golden(case, graphs):
+    args = case["args"]
+    k = int(_argval(args, "-k", "30"))
+    m = int(_argval(args, "-m", "2"))
+    e = int(_argval(args, "-e", "2"))
+    fastq = "-q" in args
+    g, al = graphs(os.path.join(GOLD, _argval(args, "-g", None)), k)
+    al.reset_counters()
+    pbytes, nbytes = b"", b""
+    for f in _argval(args, "-r", None).split(","):
+        reads, roffs, heads, hoffs = B.load_reads(os.path.join(GOLD, f), k, fastq)
+        paths, poffs, status = al.align(reads, roffs, m=m, effort=e)
+        p, n = _format(reads, roffs, heads, hoffs, paths, poffs)
+        pbytes += p
+        nbytes += n
+    cnt = al.counters()
+    out = "Reads : %d\nNo overlap : %d x\nGot overlap : %d x\nOverlap and aligned : %d x\nOverlap but not aligned : %d x\n" % (
+        cnt["reads"], cnt["no_overlap"], cnt["aligned"] + cnt["not_aligned"], cnt["aligned"], cnt["not_aligned"])
+    check_against_golden(case, out, pbytes, nbytes)
+
+
+@pytest.mark.parametrize("case", [c for c in GREEDY if c["group"] in ("toy", "edge", "edge_fq", "multi", "long_fq", "deg")][:12],
+                         ids=lambda c: "%02d-%s" % (c["id"], c["group"]))
+def test_cli_matches_reference_golden(case):
+    out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]))
+    check_against_golden(case, out, paths, na)
+
+
+def _inject_n(reads, rng, frac):
+    reads = reads.copy()
+    idx = rng.random(reads.size) < frac
+    reads[idx] = ord("N")
+    return reads
+
+
+@pytest.mark.parametrize("seed,k,L,m,e,nfrac,d,alleles", [
+    (1, 31, 150, 2, 2, 0.0, 75, 2), (2, 31, 100, 2, 2, 0.0, 75, 2), (3, 31, 250, 5, 4, 0.0, 60, 3), (4, 21, 120, 3, 3, 0.002, 50, 2),
+    (5, 32, 150, 2, 1, 0.0, 140, 2), (6, 31, 150, 0, 2, 0.001, 75, 2), (7, 31, 150, 2, 2, 0.01, 400, 2), (8, 15, 80, 4, 8, 0.005, 40, 4),
+    (9, 31, 33, 2, 2, 0.0, 75, 2), (10, 31, 1000, 8, 2, 0.0005, 75, 2), (11, 8, 60, 3, 1000, 0.0, 20, 4)])
+def test_gpu_matches_oracle_random(seed, k, L, m, e, nfrac, d, alleles):
+    s = Synth(120000, d, alleles, k, 7000 + seed)
+    seqs, offs = s.unitigs()
+    n = 20000 if L <= 250 else 3000
+    reads, roffs = s.reads(0, n, L, m + 1, 8000 + seed)
+    if nfrac:
+        reads = _inject_n(reads, np.random.default_rng(seed), nfrac)
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs)
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=e)
+    p2, po2, st2 = o.align(reads, roffs, m=m, effort=e)
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2)
+    assert np.array_equal(p1, p2)
+    assert al.counters() == {**o.counters(), "overlaps": 0}
+
+
+def test_ragged_and_empty_batches():
+    s = Synth(60000, 75, 2, 31, 77)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(31, seqs, offs)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(31, seqs, offs)
+    # empty batch
+    p, po, st = al.align(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(p) == 0 and len(st) == 0 and list(po) == [0]
+    # ragged lengths 32..400 in one batch (the FASTA parser never hands over reads of length <= k)
+    rng = np.random.default_rng(3)
+    chunks, lens = [], []
+    for i in range(3000):
+        L = int(rng.integers(32, 400))
+        r, _ = s.reads(i, 1, L, 2, 99)
+        chunks.append(r)
+        lens.append(L)
+    reads = np.concatenate(chunks)
+    roffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    p1, po1, st1 = al.align(reads, roffs)
+    p2, po2, st2 = o.align(reads, roffs)
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_mphf_in_lds_and_in_hbm_agree(stage):
+    s = Synth(200000, 75, 2, 31, 55)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 30000, 150, 3, 56)
+    g = B.Graph.build(31, seqs, offs)
+    al = B.Aligner(g, 0)
+    al.configure(lds_mphf=stage)
+    o = oracle_py.Oracle(31, seqs, offs)
+    p1, po1, st1 = al.align(reads, roffs)
+    assert al.launch_info()["mphf_in_lds"] == (stage == 2)
+    p2, po2, st2 = o.align(reads, roffs)
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+
+
+def test_blob_adopted_from_device_memory_maps_identically():
+    """The multi-GPU path: a rank that received the blob bytes in its HBM (RCCL broadcast) adopts them in place."""
+    import torch
+    s = Synth(80000, 75, 2, 31, 21)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 5000, 150, 2, 22)
+    g = B.Graph.build(31, seqs, offs)
+    blob = torch.from_numpy(np.array(g.blob())).to("cuda:0")
+    torch.cuda.synchronize()
+    g2 = B.Graph.adopt_device_blob(0, blob.data_ptr(), blob.numel())
+    a1, a2 = B.Aligner(g, 0), B.Aligner(g2, 0)
+    r1, r2 = a1.align(reads, roffs), a2.align(reads, roffs)
+    for x, y in zip(r1, r2):
+        assert np.array_equal(x, y)
