@@ -5,8 +5,10 @@ bench.py, __graft_entry__) call the same entry points; it contains no algorithm 
 the library is missing it raises, and mapping calls fail when there is no HIP device.
 """
 import ctypes as C
+import importlib.util
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -55,10 +57,27 @@ def build(force=False):
     subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
 
 
+def _pin_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's): whichever is loaded
+    first serves the whole process.  Device pointers only make sense inside ONE runtime, so when torch is
+    installed its copy is loaded first (without importing torch); a later `import torch` then shares it."""
+    if "torch" in sys.modules or os.environ.get("BGREAT_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
+    _pin_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise BgrError("libbgreat_gpu.so is not built (%s); run `make -C bgreat_amd` -- there is no fallback path" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
