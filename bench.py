@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--alg-sample", type=int, default=20_000, help="reads used to count ALGORITHMIC bytes/read with the oracle")
     ap.add_argument("--lds-mphf", type=int, default=0, help="0 auto, 1 HBM/L2 only, 2 force LDS staging")
     ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     args = ap.parse_args()
 
@@ -108,7 +109,7 @@ def main():
 
     # ---- reads: rank r owns global reads [r*K*R, (r+1)*K*R); generated on the host, parked in HBM -----------
     t0 = time.time()
-    ncpu = len(os.sched_getaffinity(0))
+    ncpu = min(len(os.sched_getaffinity(0)), args.cpu_threads)  # the GPU box gives one GPU a 16-core share
     offs_np = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
     offs_t = torch.from_numpy(offs_np.view(np.int64)).to("cuda")
     batches = []

@@ -16,6 +16,7 @@ struct BatchIO {
     uint32_t words_per_read;     // u64 words of each packed per-wave LDS array (max_read_len/32 + 2)
     uint32_t path_cap;           // ints of the per-wave LDS path buffer
     uint32_t arena_cap;          // ints
+    uint32_t arena_chunk;        // ints a wave reserves per global atomic
     uint8_t* status;             // n
     uint32_t* path_off;          // n
     uint32_t* path_len;          // n

@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
     unsigned char* NMb = reinterpret_cast<unsigned char*>(NM);
 
     uint32_t c_reads = 0, c_noov = 0, c_al = 0, c_na = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;  // this wave's slice of the path arena
 
     for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
         const u64 off = io.read_offs[r];
@@ -388,8 +389,17 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
         wave_sync();
         uint32_t abase = 0;
         if ((status & BGR_ST_MASK) == BGR_ST_ALIGNED) {
-            if (lane == 0) abase = atomicAdd(io.cursor, p_n);
-            abase = rl32(abase, 0);
+            // Arena space comes in per-wave chunks: ONE global atomic per ~50 reads instead of one per read
+            // (a single-address atomic saturates near 90 M/s chip-wide, MI355X_MICROARCH.md "dequeue").
+            if (p_n > chunk_end - chunk_pos) {
+                uint32_t want = p_n > io.arena_chunk ? p_n : io.arena_chunk;
+                uint32_t got = 0;
+                if (lane == 0) got = atomicAdd(io.cursor, want);
+                chunk_pos = rl32(got, 0);
+                chunk_end = chunk_pos + want;
+            }
+            abase = chunk_pos;
+            chunk_pos += p_n;
             if (abase + p_n <= io.arena_cap) {
                 for (uint32_t j = lane; j < p_n; j += 64) io.arena[abase + j] = PATH[p_lo + j];
             } else if (lane == 0) {

@@ -257,15 +257,11 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     if (n_reads == 0) return BGR_OK;
     if (!d_reads || !d_read_offsets) return fail(BGR_E_ARG, "bgr_align_device: null device buffer");
     if (n_reads >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: more than 2^32-2 reads in one batch");
-    // every path int consumes at least one read base; +8 per read covers offsets and short reads
-    uint64_t arena_cap = total_bases + 8 * n_reads;
-    if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (bases + 8*reads must stay below 2^32); split it");
     HIP_TRY(hipSetDevice(a->device));
     if (a->ev_used == kTimerRing) { int rc = drain_timers(a); if (rc != BGR_OK) return rc; }
     HIP_TRY(a->status.ensure(n_reads));
     HIP_TRY(a->path_off.ensure(n_reads * 4));
     HIP_TRY(a->path_len.ensure(n_reads * 4));
-    HIP_TRY(a->arena.ensure(arena_cap * 4));
 
     // ---- launch geometry -----------------------------------------------------------------------
     uint32_t words = 0, path_cap = 0;
@@ -301,6 +297,13 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     }
     if (waves == 0) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging");
     cfg.waves_per_block = waves;
+    // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
+    // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
+    // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
+    const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
+    const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk;
+    if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
+    HIP_TRY(a->arena.ensure(arena_cap * 4));
     cfg.stage_mphf = stage ? 1 : 0;
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf;
 
@@ -311,6 +314,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.words_per_read = words;
     io.path_cap = path_cap;
     io.arena_cap = (uint32_t)arena_cap;
+    io.arena_chunk = arena_chunk;
     io.status = static_cast<uint8_t*>(a->status.p);
     io.path_off = static_cast<uint32_t*>(a->path_off.p);
     io.path_len = static_cast<uint32_t*>(a->path_len.p);
