@@ -63,33 +63,33 @@ __device__ __forceinline__ uint32_t compress_even(u64 x) {
     return (uint32_t)x;
 }
 
-struct Mphf {
-    const uint32_t* units;  // global or LDS copy
-};
-
-// MPHF cascade walk for one key per lane.  Returns the minimal index or BGR_NONE; the caller compares keys[idx].
-// `active` lanes only; the level loop is wave-uniform (runs until every active lane has stopped).
+// MPHF cascade walk for one key per lane (graph_layout.h: 2-bit position states).  Returns the minimal index
+// or BGR_NONE; the caller compares keys[idx].  Straight-line body, wave-uniform trip count: the loop runs
+// until no lane is still on a "several keys here" position -- about 2-3 levels at gamma 2, because a lane
+// that lands on an empty position (most read positions are not overlaps) is rejected at once.
+// LV = level descriptors {units, base} staged in LDS.
 template <typename UP>
-__device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, UP units, u64 key, bool active) {
+__device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
     u64 m = bgr_mix64(key);
-    uint32_t hl = (uint32_t)m, hb = (uint32_t)(m >> 32) | 1u;
+    uint32_t hl = (uint32_t)m;
+    const uint32_t hb = (uint32_t)(m >> 32) | 1u;
     uint32_t res = BGR_NONE;
-    for (uint32_t l = 0; l < g.n_levels; ++l, hl += hb) {
+    const uint32_t nl = g.n_levels;
+    for (uint32_t l = 0; l < nl; ++l) {
         if (!__any(active)) break;
-        if (active) {
-            uint32_t u = g.levels[l].base + __umulhi(hl, g.levels[l].units);
-            uint32_t b = bgr_level_bit(hl);
-            uint4 q = reinterpret_cast<const uint4*>(units)[u];
-            uint32_t w = b < 32 ? q.x : (b < 64 ? q.y : q.z);
-            if ((w >> (b & 31)) & 1u) {
-                uint32_t below = (1u << (b & 31)) - 1u;
-                uint32_t r = q.w + __popc(w & below);
-                if (b >= 32) r += __popc(q.x);
-                if (b >= 64) r += __popc(q.y);
-                res = r;
-                active = false;
-            }
-        }
+        const uint2 lv = LV[l];
+        const uint32_t u = lv.y + __umulhi(hl, lv.x);
+        const uint32_t p = bgr_level_pos(hl);
+        const uint4 q = reinterpret_cast<const uint4*>(units)[u];
+        const uint32_t wi = p >> 4, sh = (p & 15) * 2;
+        const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
+        const uint32_t st = (w >> sh) & 3u;
+        uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
+        r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
+        r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
+        if (active && st == 1u) res = r;
+        active = active && st == 3u;
+        hl += hb;
     }
     if (g.n_fallback && __any(active)) {
         if (active) {  // bisection in the (tiny) sorted fallback list
@@ -265,18 +265,20 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;
     const uint32_t K1 = g.k - 1;
-    // LDS: [optional MPHF copy][per-wave: FW3 | FWQ | RCW | NM | PATH]
+    // LDS: [level descriptors 512 B][optional MPHF copy][per-wave: FW3 | FWQ | RCW | NM | PATH]
+    uint2* LV = reinterpret_cast<uint2*>(lds);
+    if (threadIdx.x < BGR_MAX_LEVELS) LV[threadIdx.x] = make_uint2(g.levels[threadIdx.x].units, g.levels[threadIdx.x].base);
     const uint32_t mphf_words = STAGE ? (g.units_bytes_lo + 7) / 8 : 0;
     const uint32_t* units = g.units;
     if (STAGE) {
         const uint4* src = reinterpret_cast<const uint4*>(g.units);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
+        uint4* dst = reinterpret_cast<uint4*>(lds + 64);
         for (uint32_t i = threadIdx.x; i < g.units_bytes_lo / 16; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        units = reinterpret_cast<const uint32_t*>(lds);
+        units = reinterpret_cast<const uint32_t*>(lds + 64);
     }
+    __syncthreads();
     const uint32_t per_wave_words = 4 * W + io.path_cap / 2;
-    u64* FW3 = lds + mphf_words + (u64)wave * per_wave_words;
+    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
     u64* FWQ = FW3 + W;
     u64* RCW = FWQ + W;
     u64* NM = RCW + W;
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
                     rcn = win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
-                uint32_t idx = mphf_lookup(g, units, rep, valid);
+                uint32_t idx = mphf_lookup(g, LV, units, rep, valid);
                 bool hit = false;
                 if (idx != BGR_NONE) hit = g.keys[idx] == rep;   // aligner.cpp:353,361 key check
                 u64 mask = __ballot(hit);
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
                     const u64 rc2 = bgr_rcb(a_num, K1);
                     if (rc2 != a_rcn) {
                         const u64 key2 = a_num < rc2 ? a_num : rc2;
-                        uint32_t i2 = mphf_lookup(g, units, key2, true);
+                        uint32_t i2 = mphf_lookup(g, LV, units, key2, true);
                         bool ok2 = false;
                         if (i2 != BGR_NONE) ok2 = g.keys[i2] == key2;
                         a_rec = ok2 ? i2 : BGR_NONE;

@@ -25,7 +25,8 @@ int fail(int code, const std::string& msg) { tl_err = msg; return code; }
         if (e_ != hipSuccess) return fail(BGR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-const double kDefaultGamma = 1.0;
+const double kDefaultGamma = 2.0;
+const uint32_t kLdsFixed = 512;  // level descriptors at the start of the dynamic LDS
 const int kTimerRing = 256;
 
 }  // namespace
@@ -273,24 +274,24 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     if (a->cfg_lds_mphf != 1) {
         // stage the cascade in LDS when it leaves room for a useful number of waves in the workgroup
         uint32_t min_waves = a->cfg_lds_mphf == 2 ? 1 : 8;
-        if ((uint64_t)mphf_bytes + 16 + (uint64_t)min_waves * per_wave <= lds_cu && a->graph->header.n_units * 16 < 0xFFFFFFFFull) stage = true;
+        if ((uint64_t)mphf_bytes + 16 + kLdsFixed + (uint64_t)min_waves * per_wave <= lds_cu && a->graph->header.n_units * 16 < 0xFFFFFFFFull) stage = true;
     }
     uint32_t waves;
     if (stage) {
-        uint32_t fit = (uint32_t)((lds_cu - mphf_bytes - 16) / per_wave);
+        uint32_t fit = (uint32_t)((lds_cu - mphf_bytes - 16 - kLdsFixed) / per_wave);
         waves = std::min<uint32_t>(16, fit);
         if (a->cfg_waves) waves = std::min(waves, a->cfg_waves);
-        cfg.lds_bytes = ((mphf_bytes + 7) / 8) * 8 + waves * per_wave;
+        cfg.lds_bytes = kLdsFixed + ((mphf_bytes + 7) / 8) * 8 + waves * per_wave;
         uint32_t bpc = std::max<uint32_t>(1, (uint32_t)(lds_cu / cfg.lds_bytes));
         if (a->cfg_blocks_per_cu) bpc = std::min(bpc, a->cfg_blocks_per_cu);
         bpc = std::min<uint32_t>(bpc, std::max<uint32_t>(1, 32 / waves));
         cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
     } else {
         waves = a->cfg_waves ? a->cfg_waves : 4;
-        uint32_t fit = (uint32_t)(lds_cu / per_wave);
+        uint32_t fit = (uint32_t)((lds_cu - kLdsFixed) / per_wave);
         if (fit == 0) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
         waves = std::min(waves, fit);
-        cfg.lds_bytes = waves * per_wave;
+        cfg.lds_bytes = kLdsFixed + waves * per_wave;
         uint32_t bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, 32 / waves);
         bpc = std::min<uint32_t>(bpc, std::max<uint32_t>(1, (uint32_t)(lds_cu / cfg.lds_bytes)));
         cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);

@@ -34,9 +34,10 @@ struct Cascade {
     uint64_t n_placed = 0;
 };
 
-// BBHash-style cascade over `keys` (sorted, unique).  Level l places every remaining key whose bit is hit by
-// no other remaining key; the others move on.  What is left after the last level (or once only a handful
-// remain) goes to a sorted fallback list searched by bisection.
+// BBHash-style cascade over `keys` (sorted, unique) with 2-bit position states (graph_layout.h).  Level l
+// places every remaining key that is alone on its position (state 1); positions hit by several keys get
+// state 3 and those keys move on.  What is left after the last level (or once only a handful remain) goes
+// to a sorted fallback list searched by bisection.
 void build_cascade(const std::vector<uint64_t>& keys, double gamma, Cascade& c) {
     struct Rem { uint64_t key; uint32_t h, hb; };
     std::vector<Rem> rem(keys.size()), next;
@@ -44,32 +45,25 @@ void build_cascade(const std::vector<uint64_t>& keys, double gamma, Cascade& c) 
         uint64_t m = bgr_mix64(keys[i]);
         rem[i] = {keys[i], (uint32_t)m, (uint32_t)(m >> 32) | 1u};
     }
-    std::vector<uint64_t> seen, coll;
     uint32_t base = 0;
     for (int l = 0; l < BGR_MAX_LEVELS && !rem.empty(); ++l) {
-        if (l > 0 && rem.size() <= 4) break;  // a handful left: cheaper in the fallback list than 20 more levels
-        uint64_t want = (uint64_t)std::ceil(gamma * (double)rem.size() / BGR_UNIT_BITS);
+        if (l > 0 && rem.size() <= 4) break;  // a handful left: cheaper in the fallback list than more levels
+        uint64_t want = (uint64_t)std::ceil(gamma * (double)rem.size() / BGR_UNIT_POS);
         uint32_t nu = (uint32_t)std::max<uint64_t>(1, want);
-        uint64_t nbits = (uint64_t)nu * BGR_UNIT_BITS;
-        seen.assign((nbits + 63) / 64, 0);
-        coll.assign((nbits + 63) / 64, 0);
-        for (const Rem& r : rem) {
-            uint64_t pos = (uint64_t)bgr_level_unit(r.h, nu) * BGR_UNIT_BITS + bgr_level_bit(r.h);
-            uint64_t m = 1ULL << (pos & 63);
-            if (seen[pos >> 6] & m) coll[pos >> 6] |= m; else seen[pos >> 6] |= m;
-        }
         size_t ubase = c.units.size();
         c.units.resize(ubase + (size_t)nu * 4, 0);
+        uint32_t* U = c.units.data() + ubase;
+        for (const Rem& r : rem) {  // 0 -> 1 -> 3
+            uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
+            uint32_t& w = U[(size_t)u * 4 + (p >> 4)];
+            uint32_t sh = 2 * (p & 15), st = (w >> sh) & 3u;
+            w |= (st == 0 ? 1u : 3u) << sh;
+        }
         next.clear();
         for (const Rem& r : rem) {
-            uint32_t u = bgr_level_unit(r.h, nu), b = bgr_level_bit(r.h);
-            uint64_t pos = (uint64_t)u * BGR_UNIT_BITS + b;
-            if (coll[pos >> 6] & (1ULL << (pos & 63))) {
-                next.push_back({r.key, r.h + r.hb, r.hb});
-            } else {
-                c.units[ubase + (size_t)u * 4 + (b >> 5)] |= 1u << (b & 31);
-                ++c.n_placed;
-            }
+            uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
+            uint32_t st = (U[(size_t)u * 4 + (p >> 4)] >> (2 * (p & 15))) & 3u;
+            if (st == 3u) next.push_back({r.key, r.h + r.hb, r.hb}); else ++c.n_placed;
         }
         c.levels.push_back({nu, base});
         base += nu;
@@ -77,11 +71,11 @@ void build_cascade(const std::vector<uint64_t>& keys, double gamma, Cascade& c) 
     }
     for (const Rem& r : rem) c.fallback.push_back(r.key);
     std::sort(c.fallback.begin(), c.fallback.end());
-    // rank of every unit = set bits in all units before it (over all levels)
+    // rank of every unit = placed keys in all units before it (over all levels)
     uint32_t run = 0;
     for (size_t u = 0; u < c.units.size() / 4; ++u) {
         c.units[u * 4 + 3] = run;
-        run += __builtin_popcount(c.units[u * 4]) + __builtin_popcount(c.units[u * 4 + 1]) + __builtin_popcount(c.units[u * 4 + 2]);
+        for (int w = 0; w < 3; ++w) run += __builtin_popcount(bgr_unique_mask(c.units[u * 4 + w]));
     }
 }
 
@@ -99,12 +93,14 @@ uint32_t host_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key) 
     uint64_t m = bgr_mix64(key);
     uint32_t hl = (uint32_t)m, hb = (uint32_t)(m >> 32) | 1u;
     for (uint32_t l = 0; l < h->n_levels; ++l, hl += hb) {
-        uint32_t u = h->levels[l].base + bgr_level_unit(hl, h->levels[l].units), b = bgr_level_bit(hl);
+        uint32_t u = h->levels[l].base + bgr_level_unit(hl, h->levels[l].units), p = bgr_level_pos(hl);
         const uint32_t* q = units + (size_t)u * 4;
-        if ((q[b >> 5] >> (b & 31)) & 1u) {
+        uint32_t sh = 2 * (p & 15), st = (q[p >> 4] >> sh) & 3u;
+        if (st == 0) return BGR_NONE;  // no key hashes here
+        if (st == 1) {
             uint32_t r = q[3];
-            for (uint32_t w = 0; w < (b >> 5); ++w) r += __builtin_popcount(q[w]);
-            r += __builtin_popcount(q[b >> 5] & ((1u << (b & 31)) - 1u));
+            for (uint32_t w = 0; w < (p >> 4); ++w) r += __builtin_popcount(bgr_unique_mask(q[w]));
+            r += __builtin_popcount(bgr_unique_mask(q[p >> 4]) & ((1u << sh) - 1u));
             return r;
         }
     }

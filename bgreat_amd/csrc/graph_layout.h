@@ -16,9 +16,12 @@
 //   meta   32 B per unitig id: F, len, and the record index + canonical flag of BOTH end (k-1)-mers, so
 //          a walk step never hashes: the next neighbour record is a direct index.
 //   MPHF   ONE minimal perfect hash over the union of the reference's left and right overlap key sets
-//          (index values are unobservable).  BBHash-style cascade; each level is an
-//          array of 16-byte units {96 bits, u32 rank of the unit}: ONE dwordx4 load answers "is the bit
-//          set" AND gives the minimal index (rank + popcount below the bit).
+//          (index values are unobservable).  BBHash-style cascade, but every position
+//          keeps a 2-bit STATE instead of one bit: 0 = no key hashes here, 1 = exactly one key (placed),
+//          3 = several keys (they all move to the next level).  A query that lands on state 0 is rejected
+//          at once -- most read positions are not overlaps, so most lanes stop on level 0 or 1 -- state 1
+//          gives the minimal index, state 3 continues.  A level is an array of 16-byte units
+//          {48 states, u32 rank = placed keys in all earlier units}: ONE dwordx4 load per level.
 //   keys   u64 key per MPHF index (membership check, aligner.cpp:158,219,353,361).
 //   recs   32 B per MPHF index: the 4 "left table" slots and the 4 "right table" slots of that key
 //          (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite, aligner.cpp:466-533).
@@ -37,7 +40,7 @@
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
 #define BGR_MAX_LEVELS 48
-#define BGR_UNIT_BITS 96u
+#define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
 #define BGR_NONE 0xFFFFFFFFu
 #define BGR_SLOT_ID_MASK 0x3FFFFFFFu
 // slot flag bits (see graph_build.cpp fill_records):
@@ -64,7 +67,7 @@ typedef struct {
 } BgrUnitigMeta;      // 32 B
 
 typedef struct {
-    uint32_t units;  // number of 96-bit units on this level
+    uint32_t units;  // number of 48-position units on this level
     uint32_t base;   // index of the level's first unit in the unit array
 } BgrLevel;
 
@@ -91,7 +94,7 @@ typedef struct {
 
 // What a kernel receives by value (pointers resolved against the device copy of the blob).
 typedef struct {
-    const uint32_t* units;   // n_units * 4 u32  (x,y,z = 96 bits, w = rank)
+    const uint32_t* units;   // n_units * 4 u32  (x,y,z = 48 two-bit states, w = rank)
     const uint64_t* keys;
     const uint32_t* recs;    // n_keys * 8 u32   (L0..L3, R0..R3)
     const BgrUnitigMeta* meta;
@@ -106,7 +109,7 @@ typedef struct {
 
 // ---- hashing shared by the host builder and the device lookup ---------------------------------------
 // 64 -> 64 finaliser (SplitMix64's); the cascade uses double hashing on its two halves:
-//   level l: h_l = ha + l*hb (mod 2^32), unit = mulhi32(h_l, units_l), bit = ((h_l & 0xFFFF) * 96) >> 16.
+//   level l: h_l = ha + l*hb (mod 2^32), unit = mulhi32(h_l, units_l), position = ((h_l & 0xFFFF) * 48) >> 16.
 BGR_HD uint64_t bgr_mix64(uint64_t x) {
     x ^= x >> 30;
     x *= 0xBF58476D1CE4E5B9ULL;
@@ -116,7 +119,9 @@ BGR_HD uint64_t bgr_mix64(uint64_t x) {
     return x;
 }
 BGR_HD uint32_t bgr_level_unit(uint32_t h, uint32_t units) { return (uint32_t)(((uint64_t)h * (uint64_t)units) >> 32); }
-BGR_HD uint32_t bgr_level_bit(uint32_t h) { return ((h & 0xFFFFu) * BGR_UNIT_BITS) >> 16; }
+BGR_HD uint32_t bgr_level_pos(uint32_t h) { return ((h & 0xFFFFu) * BGR_UNIT_POS) >> 16; }
+// placed ("unique", state 1) positions of one state word, as a mask on the even bits
+BGR_HD uint32_t bgr_unique_mask(uint32_t w) { return w & ~(w >> 1) & 0x55555555u; }
 
 // reverse complement of a (k-1)-digit base-4 number == utils.cpp:182-192 rcb(), by bit tricks
 BGR_HD uint64_t bgr_rev2(uint64_t x) {  // reverse the order of the 32 2-bit digits of x
