@@ -24,7 +24,10 @@ for f in find("kt", "*kernel_trace.csv"):
             last = row
 if durs:
     print("  mapping kernel dispatches: %d, durations ms: %s" % (len(durs), ", ".join("%.3f" % (d / 1e6) for d in durs)))
-    print("  VGPR %s  SGPR %s  LDS %s  grid %s  wg %s" % (last.get("VGPR_Count"), last.get("SGPR_Count"), last.get("LDS_Block_Size"), last.get("Grid_Size"), last.get("Workgroup_Size")))
+    print("  VGPR %s  SGPR %s  LDS %s  grid %s  wg %s" % (last.get("VGPR_Count"), last.get("SGPR_Count"), last.get("LDS_Block_Size"), last.get("Grid_Size_X"), last.get("Workgroup_Size_X")))
+    big = [d for d in durs if d > 1_000_000]
+    if big:
+        print("  full-size dispatches: %d, mean %.4f ms" % (len(big), sum(big) / len(big) / 1e6))
 
 print("== PMC (per dispatch of the mapping kernel; mean over dispatches) ==")
 vals = {}
@@ -34,6 +37,8 @@ for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         for row in csv.DictReader(open(f)):
             if "bgr_align" not in row.get("Kernel_Name", ""):
                 continue
+            if int(row["End_Timestamp"]) - int(row["Start_Timestamp"]) < 1_000_000:
+                continue  # skip the small parity-sample launches: only the timed full-size dispatches
             key = (row["Counter_Name"], row["Dispatch_Id"])
             acc[key] = acc.get(key, 0.0) + float(row["Counter_Value"])
         per = {}
