@@ -17,6 +17,7 @@ struct BatchIO {
     uint32_t path_cap;           // ints of the per-wave LDS path buffer
     uint32_t arena_cap;          // ints
     uint32_t arena_chunk;        // ints a wave reserves per global atomic
+    uint32_t frames_per_wave;    // exhaustive mode: DFS frames (20 u32 each) in the per-wave LDS region
     uint8_t* status;             // n
     uint32_t* path_off;          // n
     uint32_t* path_len;          // n
@@ -36,14 +37,22 @@ struct LaunchCfg {
     uint32_t stage_mphf;       // 1: copy the MPHF cascade into LDS at block start
 };
 
-// Per-wave LDS bytes for a batch whose longest read has max_len bases.
-inline uint32_t lds_bytes_per_wave(uint32_t max_len, uint32_t* words, uint32_t* path_cap) {
+// Per-wave LDS bytes for a batch whose longest read has max_len bases (mode 0 greedy, 1 exhaustive).
+inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, uint32_t* words, uint32_t* path_cap, uint32_t* frames) {
     uint32_t w = max_len / 32 + 2;
     uint32_t pc = max_len + 8;
     pc = (pc + 1) & ~1u;
+    uint32_t fr = 0;
+    uint32_t bytes = 4 * 8 * w + 4 * pc;  // FW3 | FWQ | RCW | NM | PATH
+    if (mode != 0) {
+        // every DFS descent consumes at least one read base outside the anchor's k-1 window
+        fr = (max_len >= k - 1 ? max_len - (k - 1) : 0) + 3;
+        bytes = 4 * 8 * w + 3 * 4 * pc + fr * 20 * 4;  // ... OUT | CUR | BEST | frames
+    }
     if (words) *words = w;
     if (path_cap) *path_cap = pc;
-    return 4 * 8 * w + 4 * pc;
+    if (frames) *frames = fr;
+    return bytes;
 }
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);

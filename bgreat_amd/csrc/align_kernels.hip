@@ -8,11 +8,13 @@
 //            cascade (one dwordx4 per level) + one u64 key compare.  __ballot orders the hits by position,
 //            exactly the sequential scan's order; anchors are tried as soon as they are found (the
 //            reference collects `tryNumber` first, but collecting has no side effect).
-//   stage C  greedy extension (alignerGreedy.cpp:167-364): wave-uniform walk; at each step the <=4
+//   stage C  extension.  Greedy (alignerGreedy.cpp:167-364): wave-uniform walk; at each step the <=4
 //            neighbour unitigs are scored in parallel, 16 lanes per candidate, each lane XOR-ing 32-base
-//            chunks of the packed unitig (HBM/L2) against the packed read (LDS) and popcounting.
-//            argmin with lowest-slot tie-break == the reference's "first zero wins, else strict min".
-//   stage D  the path (LDS) is appended to a global arena with one atomicAdd per read.
+//            chunks of the packed unitig (HBM/L2) against the packed read (LDS) and popcounting; argmin with
+//            lowest-slot tie-break == the reference's "first zero wins, else strict min".
+//            Exhaustive (alignerExhaustive.cpp:61-259): the same scoring inside a depth-first search with
+//            an explicit frame stack in LDS (see exh_search).
+//   stage D  the path (LDS) is appended to a global arena, space reserved per wave in chunks.
 //
 // Integer/byte work only: no MFMA anywhere (there is no dense contraction on this path).
 #include "align_kernels.h"
@@ -62,6 +64,12 @@ __device__ __forceinline__ uint32_t compress_even(u64 x) {
     x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
     return (uint32_t)x;
 }
+// reverse the order of the 32 two-bit digits of x: full bit reversal (v_bfrev_b32 x2), then swap the bits of each pair
+__device__ __forceinline__ u64 rev2_fast(u64 x) {
+    u64 y = __builtin_bitreverse64(x);
+    return ((y >> 1) & EVEN_BITS) | ((y & EVEN_BITS) << 1);
+}
+__device__ __forceinline__ u64 rcb_fast(u64 x, uint32_t n) { return (~rev2_fast(x)) >> (64 - 2 * n); }
 
 // MPHF cascade walk for one key per lane (graph_layout.h: 2-bit position states).  Returns the minimal index
 // or BGR_NONE; the caller compares keys[idx].  Straight-line body, wave-uniform trip count: the loop runs
@@ -103,87 +111,143 @@ __device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const u
     }
     return res;
 }
+// membership: MPHF index of key if key is an overlap of the graph, else BGR_NONE (aligner.cpp:158,219,353,361)
+template <typename UP>
+__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
+    uint32_t idx = mphf_lookup(g, LV, units, key, active);
+    if (idx != BGR_NONE && g.keys[idx] != key) idx = BGR_NONE;
+    return idx;
+}
 
-struct Step {  // wave-uniform result of one extension step
-    bool found, fits;
-    int32_t sid;
-    uint32_t miss, ext, next_rec;
-    bool next_canon;
+// ---- stage A + the two derived streams -------------------------------------------------------------------
+// FW3: str2num codes (N->3).  NM: 3 on every N.  RCW: reverseComplements(read) (utils.cpp:66-73, non-ACG -> 'A').
+// FWQ: what the rolling `num` of getNOverlap/getListOverlap holds: str2num codes inside the first window,
+//      nuc2int codes (N->0) for bases entered by update() (aligner.cpp:305-309, utils.cpp:132-140).
+__device__ __forceinline__ bool pack_read(const uint8_t* rd, uint32_t L, uint32_t W, uint32_t K1, u64* FW3, u64* FWQ, u64* RCW, u64* NM, int lane) {
+    unsigned char* FW3b = reinterpret_cast<unsigned char*>(FW3);
+    unsigned char* NMb = reinterpret_cast<unsigned char*>(NM);
+    bool sawN = false;
+    for (uint32_t bi = lane; bi < 8 * W; bi += 64) {
+        uint32_t b0 = bi * 4, code = 0, nmask = 0;
+        if (b0 < L) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t cc = 0, nn = 0;
+                if (b0 + j < L) {
+                    unsigned char ch = rd[b0 + j];
+                    cc = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;  // str2num
+                    nn = (cc == 3u && ch != 'T') ? 3u : 0u;                      // 'N' (the parser admits only ACGTN)
+                }
+                code = (code << 2) | cc;
+                nmask = (nmask << 2) | nn;
+            }
+        }
+        FW3b[bi ^ 7] = (unsigned char)code;
+        NMb[bi ^ 7] = (unsigned char)nmask;
+        sawN |= nmask != 0;
+    }
+    const bool hasN = __any(sawN);
+    wave_sync();
+    for (uint32_t w = lane; w < W; w += 64) {
+        long long p = (long long)L - 32 * ((long long)w + 1);
+        u64 rcw = 0;
+        if (p >= 0) {
+            rcw = ~rev2_fast(win32(FW3, (u64)p));
+        } else if (p > -32) {
+            uint32_t v = (uint32_t)(32 + p);  // valid bases
+            u64 x = FW3[0] >> (64 - 2 * v);
+            rcw = (~rev2_fast(x)) & (~0ULL << (64 - 2 * v));
+        }
+        RCW[w] = rcw;
+        u64 ge;
+        if (32 * w >= K1) ge = ~0ULL;
+        else if (32 * (w + 1) <= K1) ge = 0;
+        else ge = ~0ULL >> (2 * (K1 - 32 * w));
+        FWQ[w] = FW3[w] & ~(NM[w] & ge);
+    }
+    wave_sync();
+    return hasN;
+}
+
+// ---- candidate scoring shared by the greedy and the exhaustive extension -------------------------------
+// The <=4 slots of the neighbour record (getEnd / getBegin, aligner.cpp:147-267) are scored 16 lanes each.
+// DIR 0: left step (alignerGreedy.cpp:167-218,268-319; alignerExhaustive.cpp:109-203)
+// DIR 1: right step whose read slice starts AFTER the k-1 overlap (checkEndGreedy :322-364; every exhaustive
+//        right step, alignerExhaustive.cpp:61-106,206-259)
+// DIR 2: later greedy right steps, whose slice INCLUDES the overlap (mapOnRightEndGreedy :221-265)
+struct Scored {       // per lane; lanes 16c..16c+15 describe candidate c
+    uint32_t cnt;     // Hamming distance over the compared window (full count, not clipped)
+    uint32_t id, ext, mflags, rec_beg, rec_end;
+    bool fwd, fits;
+    int first_zero;   // number of candidates (the reference's nested ifs stop at the first empty slot)
 };
 
-// One extension step of the greedy walks.  DIR 0: left (checkBeginGreedy / mapOnLeftEndGreedy, alignerGreedy.cpp
-// :268-319 / :167-218), 1: first right step (checkEndGreedy :322-364), 2: later right steps (mapOnRightEndGreedy
-// :221-265, whose read slice INCLUDES the k-1 overlap).  Candidates = the <=4 slots of the neighbour record
-// (getEnd / getBegin, aligner.cpp:147-267), scored 16 lanes each.
 template <int DIR>
-__device__ __forceinline__ Step greedy_step(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
-                                            uint32_t K1, uint32_t rec, bool canon, uint32_t pos, uint32_t budget, int lane) {
-    Step out;
-    out.found = false; out.fits = false; out.sid = 0; out.miss = 0; out.ext = 0; out.next_rec = BGR_NONE; out.next_canon = false;
-    if (rec == BGR_NONE) return out;  // key not in the table: getBegin/getEnd return an empty list
+__device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
+                                                   uint32_t K1, uint32_t rec, bool canon, uint32_t pos, int lane) {
+    Scored sc;
     const int c = lane >> 4, sub = lane & 15;
     // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
     const bool useR = (DIR == 0) ? canon : !canon;
     const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
-    uint32_t slot = g.recs[(u64)rec * 8 + (useR ? 4 : 0) + c];
-    uint32_t id = slot & BGR_SLOT_ID_MASK;
-    // the reference's nested ifs stop at the first empty slot
-    u64 zmask = __ballot(id == 0);
-    int first_zero = zmask ? (__ffsll((long long)zmask) - 1) >> 4 : 4;
-    bool valid = c < first_zero;
-    bool fwd = (slot & fbit) != 0;
+    const uint32_t slot = g.recs[(u64)rec * 8 + (useR ? 4 : 0) + c];
+    sc.id = slot & BGR_SLOT_ID_MASK;
+    const u64 zmask = __ballot(sc.id == 0);
+    sc.first_zero = zmask ? (__ffsll((long long)zmask) - 1) >> 4 : 4;
+    const bool valid = c < sc.first_zero;
+    sc.fwd = (slot & fbit) != 0;
     u64 S = 0;
-    uint32_t len = 0, mflags = 0, rec_beg = 0, rec_end = 0;
+    uint32_t len = 0;
+    sc.mflags = 0; sc.rec_beg = 0; sc.rec_end = 0;
     if (valid) {
-        const uint4* mp = reinterpret_cast<const uint4*>(g.meta + id);
-        uint4 m0 = mp[0];
-        uint2 m1 = reinterpret_cast<const uint2*>(mp + 1)[0];
+        const uint4* mp = reinterpret_cast<const uint4*>(g.meta + sc.id);
+        const uint4 m0 = mp[0];
+        const uint2 m1 = reinterpret_cast<const uint2*>(mp + 1)[0];
         S = ((u64)m0.y << 32) | m0.x;
-        len = m0.z; mflags = m0.w; rec_beg = m1.x; rec_end = m1.y;
-        if (!fwd) S += len;
+        len = m0.z; sc.mflags = m0.w; sc.rec_beg = m1.x; sc.rec_end = m1.y;
+        if (!sc.fwd) S += len;
     }
-    uint32_t ext = len - K1;
-    bool fits;
+    sc.ext = len - K1;
     uint32_t n, ustart, rstart;
     if (DIR == 0) {
-        fits = ext >= pos;
-        n = fits ? pos : ext;
-        ustart = fits ? ext - pos : 0;
-        rstart = fits ? 0 : pos - ext;
+        sc.fits = sc.ext >= pos;
+        n = sc.fits ? pos : sc.ext;
+        ustart = sc.fits ? sc.ext - pos : 0;
+        rstart = sc.fits ? 0 : pos - sc.ext;
     } else if (DIR == 1) {
-        uint32_t rl = L - pos - K1;
-        fits = ext >= rl;
-        n = fits ? rl : ext;
+        const uint32_t rl = L - pos - K1;
+        sc.fits = sc.ext >= rl;
+        n = sc.fits ? rl : sc.ext;
         ustart = K1;
         rstart = pos + K1;
     } else {
-        uint32_t rl = L - pos;
-        fits = ext >= rl;
-        n = fits ? rl : (len < rl ? len : rl);  // read.substr(pos, |u|) is clipped at |read|
+        const uint32_t rl = L - pos;
+        sc.fits = sc.ext >= rl;
+        n = sc.fits ? rl : (len < rl ? len : rl);  // read.substr(pos, |u|) is clipped at |read|
         ustart = 0;
         rstart = pos;
     }
     uint32_t cnt = 0;
     if (valid) {
         for (uint32_t t = sub; t * 32 < n; t += 16) {
-            u64 ub = S + ustart + (u64)t * 32;
-            u64 x = win32(g.seq, ub) ^ win32(CMP, (u64)rstart + t * 32);
+            const u64 ub = S + ustart + (u64)t * 32;
+            const u64 x = win32(g.seq, ub) ^ win32(CMP, (u64)rstart + t * 32);
             u64 mm = (x | (x >> 1)) & EVEN_BITS;
             u64 nm = 0;
             if (useN) { nm = win32(NM, (u64)rstart + t * 32) & EVEN_BITS; mm |= nm; }
             if (g.has_exc) {  // forward-strand unitig bases outside ACGT: never equal, except N == N
-                uint32_t e = plane32(g.exc, ub);
+                const uint32_t e = plane32(g.exc, ub);
                 if (e) {
-                    uint32_t en = plane32(g.excn, ub);
+                    const uint32_t en = plane32(g.excn, ub);
                     uint32_t m1 = compress_even(mm) | e;
                     m1 &= ~(en & compress_even(nm));
-                    uint32_t v1 = n - t * 32;
+                    const uint32_t v1 = n - t * 32;
                     if (v1 < 32) m1 &= ~(0xFFFFFFFFu >> v1);
                     cnt += __popc(m1);
                     continue;
                 }
             }
-            uint32_t v = n - t * 32;
+            const uint32_t v = n - t * 32;
             if (v < 32) mm &= ~(~0ULL >> (2 * v));
             cnt += __popcll(mm);
         }
@@ -192,31 +256,56 @@ __device__ __forceinline__ Step greedy_step(const BgrDeviceGraph& g, const u64* 
     cnt += __shfl_xor(cnt, 4);
     cnt += __shfl_xor(cnt, 2);
     cnt += __shfl_xor(cnt, 1);
-    // best = smallest miss, lowest slot on ties, only if miss <= budget
+    sc.cnt = cnt;
+    return sc;
+}
+
+// record index + canonical flag of the (k-1)-mer at the far end of candidate lane `bl`, in walking direction
+template <int DIR>
+__device__ __forceinline__ void next_overlap(const Scored& sc, int bl, bool bfwd, uint32_t* next_rec, bool* next_canon) {
+    const uint32_t bflags = rl32(sc.mflags, bl);
+    if (DIR == 0) {
+        *next_rec = bfwd ? rl32(sc.rec_beg, bl) : rl32(sc.rec_end, bl);
+        *next_canon = (bflags & (bfwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
+    } else {
+        *next_rec = bfwd ? rl32(sc.rec_end, bl) : rl32(sc.rec_beg, bl);
+        *next_canon = (bflags & (bfwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
+    }
+}
+
+// ============================================== greedy ================================================
+struct Step {  // wave-uniform result of one extension step
+    bool found, fits;
+    int32_t sid;
+    uint32_t miss, ext, next_rec;
+    bool next_canon;
+};
+
+template <int DIR>
+__device__ __forceinline__ Step greedy_step(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
+                                            uint32_t K1, uint32_t rec, bool canon, uint32_t pos, uint32_t budget, int lane) {
+    Step out;
+    out.found = false; out.fits = false; out.sid = 0; out.miss = 0; out.ext = 0; out.next_rec = BGR_NONE; out.next_canon = false;
+    if (rec == BGR_NONE) return out;  // key not in the table: getBegin/getEnd return an empty list
+    const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, rec, canon, pos, lane);
+    // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
     uint32_t best = budget + 1;
     int bc = -1;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-        uint32_t tcc = rl32(cnt, cc * 16);
-        if (cc < first_zero && tcc < best) { best = tcc; bc = cc; }
+        const uint32_t tcc = rl32(sc.cnt, cc * 16);
+        if (cc < sc.first_zero && tcc < best) { best = tcc; bc = cc; }
     }
     if (bc < 0) return out;
     const int bl = bc * 16;
-    uint32_t bid = rl32(id, bl);
-    bool bfwd = rl32(fwd ? 1u : 0u, bl) != 0;
-    uint32_t bflags = rl32(mflags, bl);
+    const uint32_t bid = rl32(sc.id, bl);
+    const bool bfwd = rl32(sc.fwd ? 1u : 0u, bl) != 0;
     out.found = true;
-    out.fits = rl32(fits ? 1u : 0u, bl) != 0;
+    out.fits = rl32(sc.fits ? 1u : 0u, bl) != 0;
     out.sid = bfwd ? (int32_t)bid : -(int32_t)bid;
     out.miss = best;
-    out.ext = rl32(ext, bl);
-    if (DIR == 0) {
-        out.next_rec = bfwd ? rl32(rec_beg, bl) : rl32(rec_end, bl);
-        out.next_canon = (bflags & (bfwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
-    } else {
-        out.next_rec = bfwd ? rl32(rec_end, bl) : rl32(rec_beg, bl);
-        out.next_canon = (bflags & (bfwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
-    }
+    out.ext = rl32(sc.ext, bl);
+    next_overlap<DIR>(sc, bl, bfwd, &out.next_rec, &out.next_canon);
     return out;
 }
 
@@ -258,17 +347,130 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
     return true;
 }
 
+// ============================================ exhaustive ==============================================
+// alignerExhaustive.cpp:61-259.  The reference recursion explores a candidate only if its own mismatches are
+// below the best total found so far in that call, adds the best total of the rest of the walk, and keeps the
+// first candidate (slot order) on ties.  That is exactly: among all complete walks of cost <= budget, the
+// one of minimal total cost, ties broken by slot order at the shallowest differing step -- i.e. what a
+// depth-first search in slot order with ONE running best and strict `<` acceptance returns.  Pruning with the
+// running best only skips walks that could not be accepted anyway.
+//
+// Frame (20 u32, in LDS): [0] rec  [1] pos  [2] cost so far  [3] cursor | ncand<<8 | scored<<16 | canon<<17
+//                         [4+4c..] candidate c: sid, next_rec, aux (non-fitting: ext; fitting: the path int
+//                                               emitted when the walk ends there), miss | fits<<16 | next_canon<<17
+#define FR_WORDS 20
+
+template <int DIR>
+__device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
+                                               uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t budget, bool partial,
+                                               uint32_t* FR, int32_t* CUR, int32_t* BEST, uint32_t* best_n, int lane) {
+    // returns the best total (budget+1 if none); the best walk's ints are BEST[0..*best_n) in output order
+    uint32_t best = budget + 1;
+    *best_n = 0;
+    int depth = 0;
+    if (lane == 0) { FR[0] = a_rec; FR[1] = a_pos; FR[2] = 0; FR[3] = a_canon ? (1u << 17) : 0u; }
+    wave_sync();
+    while (depth >= 0) {
+        uint32_t* F = FR + (uint32_t)depth * FR_WORDS;
+        const uint32_t rec = F[0], pos = F[1], cost = F[2];
+        uint32_t ctl = F[3];
+        if (!((ctl >> 16) & 1u)) {
+            // ---- first visit: base cases, then score the candidates once --------------------------
+            const bool end_here = (DIR == 0) ? (pos == 0) : (L - pos - K1 == 0);
+            if (end_here) {
+                // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); right: every depth pushes 0 (:64,:210)
+                if (cost < best) {
+                    best = cost;
+                    if (DIR == 0) {
+                        for (int j = lane; j < depth; j += 64) BEST[j] = CUR[depth - 1 - j];  // far -> near
+                        *best_n = (uint32_t)depth;
+                        if (depth == 0) { if (lane == 0) BEST[0] = 0; *best_n = 1; }
+                    } else {
+                        for (int j = lane; j < depth; j += 64) BEST[j] = CUR[j];              // near -> far
+                        if (lane == 0) BEST[depth] = 0;
+                        *best_n = (uint32_t)depth + 1;
+                    }
+                }
+                wave_sync();
+                --depth;
+                continue;
+            }
+            uint32_t ncand = 0;
+            if (rec != BGR_NONE) {
+                const bool canon = (ctl >> 17) & 1u;
+                const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, rec, canon, pos, lane);
+                ncand = (uint32_t)sc.first_zero;
+                if ((lane & 15) == 0 && (lane >> 4) < sc.first_zero) {
+                    const int c = lane >> 4;
+                    uint32_t nrec, nflag;
+                    if (DIR == 0) {
+                        nrec = sc.fwd ? sc.rec_beg : sc.rec_end;
+                        nflag = sc.mflags & (sc.fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND);
+                    } else {
+                        nrec = sc.fwd ? sc.rec_end : sc.rec_beg;
+                        nflag = sc.mflags & (sc.fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
+                    }
+                    const uint32_t miss = sc.cnt > 0xFFFFu ? 0xFFFFu : sc.cnt;
+                    // fitting: left emits the offset in the last unitig (ext-pos, :126,:175), right |readLeft|+k-1 (:99,:231)
+                    const uint32_t aux = sc.fits ? ((DIR == 0) ? sc.ext - pos : L - pos) : sc.ext;
+                    F[4 + 4 * c] = (uint32_t)(sc.fwd ? (int32_t)sc.id : -(int32_t)sc.id);
+                    F[5 + 4 * c] = nrec;
+                    F[6 + 4 * c] = aux;
+                    F[7 + 4 * c] = miss | (sc.fits ? 1u << 16 : 0u) | (nflag ? 1u << 17 : 0u);
+                }
+            }
+            if (DIR == 1 && depth == 0 && partial && ncand == 0) {  // alignerExhaustive.cpp:217-221 (-i)
+                *best_n = 0;
+                wave_sync();
+                return 0;
+            }
+            ctl = (ctl & (1u << 17)) | (1u << 16) | (ncand << 8);
+            if (lane == 0) F[3] = ctl;
+            wave_sync();
+        }
+        const uint32_t cur = ctl & 0xFFu, ncand = (ctl >> 8) & 0xFFu;
+        if (cur >= ncand) { --depth; continue; }
+        const uint32_t sid = F[4 + 4 * cur], nrec = F[5 + 4 * cur], aux = F[6 + 4 * cur], pk = F[7 + 4 * cur];
+        wave_sync();
+        if (lane == 0) F[3] = ctl + 1;
+        const uint32_t total = cost + (pk & 0xFFFFu);
+        if (total >= best) { wave_sync(); continue; }  // the reference explores a candidate only if miss < best so far
+        if ((pk >> 16) & 1u) {
+            // the walk ends inside this unitig: a complete solution, strictly better than the running best
+            best = total;
+            if (DIR == 0) {  // [offset, this (farthest) unitig, ..., nearest unitig]
+                for (int j = lane; j < depth; j += 64) BEST[2 + j] = CUR[depth - 1 - j];
+                if (lane == 0) { BEST[0] = (int32_t)aux; BEST[1] = (int32_t)sid; }
+            } else {         // [nearest ... this (farthest) unitig, end offset]
+                for (int j = lane; j < depth; j += 64) BEST[j] = CUR[j];
+                if (lane == 0) { BEST[depth] = (int32_t)sid; BEST[depth + 1] = (int32_t)aux; }
+            }
+            *best_n = (uint32_t)depth + 2;
+            wave_sync();
+            continue;
+        }
+        // descend
+        if (lane == 0) {
+            CUR[depth] = (int32_t)sid;
+            uint32_t* N = F + FR_WORDS;
+            N[0] = nrec;
+            N[1] = (DIR == 0) ? pos - aux : pos + aux;
+            N[2] = total;
+            N[3] = ((pk >> 17) & 1u) ? (1u << 17) : 0u;
+        }
+        wave_sync();
+        ++depth;
+    }
+    return best;
+}
+
+// ================================================ kernels ===============================================
 template <bool STAGE>
-__global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
-    extern __shared__ u64 lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int waves = blockDim.x >> 6;
-    const uint32_t W = io.words_per_read;
-    const uint32_t K1 = g.k - 1;
-    // LDS: [level descriptors 512 B][optional MPHF copy][per-wave: FW3 | FWQ | RCW | NM | PATH]
+__device__ __forceinline__ const uint32_t* block_prologue(const BgrDeviceGraph& g, u64* lds, uint2** LVout, uint32_t* mphf_words) {
+    // LDS: [level descriptors 512 B][optional MPHF copy][per-wave regions]
     uint2* LV = reinterpret_cast<uint2*>(lds);
     if (threadIdx.x < BGR_MAX_LEVELS) LV[threadIdx.x] = make_uint2(g.levels[threadIdx.x].units, g.levels[threadIdx.x].base);
-    const uint32_t mphf_words = STAGE ? (g.units_bytes_lo + 7) / 8 : 0;
+    *mphf_words = STAGE ? (g.units_bytes_lo + 7) / 8 : 0;
     const uint32_t* units = g.units;
     if (STAGE) {
         const uint4* src = reinterpret_cast<const uint4*>(g.units);
@@ -277,70 +479,62 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
         units = reinterpret_cast<const uint32_t*>(lds + 64);
     }
     __syncthreads();
+    *LVout = LV;
+    return units;
+}
+
+// Arena space comes in per-wave chunks: ONE global atomic per ~50 reads instead of one per read (a
+// single-address atomic saturates near 90 M/s chip-wide, MI355X_MICROARCH.md "dequeue").
+__device__ __forceinline__ uint32_t publish_path(const BatchIO& io, const int32_t* PATH, uint32_t p_lo, uint32_t p_n,
+                                                 uint32_t* chunk_pos, uint32_t* chunk_end, int lane) {
+    if (p_n > *chunk_end - *chunk_pos) {
+        const uint32_t want = p_n > io.arena_chunk ? p_n : io.arena_chunk;
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(io.cursor, want);
+        *chunk_pos = rl32(got, 0);
+        *chunk_end = *chunk_pos + want;
+    }
+    const uint32_t abase = *chunk_pos;
+    *chunk_pos += p_n;
+    if (abase + p_n <= io.arena_cap) {
+        for (uint32_t j = lane; j < p_n; j += 64) io.arena[abase + j] = PATH[p_lo + j];
+    } else if (lane == 0) {
+        io.cursor[1] = 1;  // overflow: reported by the host as an error
+    }
+    return abase;
+}
+
+template <bool STAGE>
+__global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
     const uint32_t per_wave_words = 4 * W + io.path_cap / 2;
     u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
     u64* FWQ = FW3 + W;
     u64* RCW = FWQ + W;
     u64* NM = RCW + W;
     int32_t* PATH = reinterpret_cast<int32_t*>(NM + W);
-    unsigned char* FW3b = reinterpret_cast<unsigned char*>(FW3);
-    unsigned char* NMb = reinterpret_cast<unsigned char*>(NM);
 
     uint32_t c_reads = 0, c_noov = 0, c_al = 0, c_na = 0;
     uint32_t chunk_pos = 0, chunk_end = 0;  // this wave's slice of the path arena
+    // getNOverlap(read, 0) still looks at position 0 before testing the count (aligner.cpp:349-368)
+    const uint32_t effort = prm.effort ? prm.effort : 1;
 
     for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        // ---- stage A: ASCII -> packed (4 bases per lane per round) ------------------------------
-        bool sawN = false;
-        for (uint32_t bi = lane; bi < 8 * W; bi += 64) {
-            uint32_t b0 = bi * 4, code = 0, nmask = 0;
-            if (b0 < L) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t cc = 0, nn = 0;
-                    if (b0 + j < L) {
-                        unsigned char ch = io.reads[off + b0 + j];
-                        cc = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;  // str2num, utils.cpp:117-129
-                        nn = (cc == 3u && ch != 'T') ? 3u : 0u;                      // 'N' (parser admits only ACGTN)
-                    }
-                    code = (code << 2) | cc;
-                    nmask = (nmask << 2) | nn;
-                }
-            }
-            FW3b[bi ^ 7] = (unsigned char)code;
-            NMb[bi ^ 7] = (unsigned char)nmask;
-            sawN |= nmask != 0;
-        }
-        const bool hasN = __any(sawN);
-        wave_sync();
-        // ---- reverse-complement stream + rolling-update quirk stream ----------------------------
-        for (uint32_t w = lane; w < W; w += 64) {
-            // RCW word w = bases 32w..32w+31 of reverseComplements(read) (utils.cpp:66-73: non-ACG -> 'A' == 3 - 3)
-            long long p = (long long)L - 32 * ((long long)w + 1);
-            u64 rcw = 0;
-            if (p >= 0) {
-                rcw = ~bgr_rev2(win32(FW3, (u64)p));
-            } else if (p > -32) {
-                uint32_t v = (uint32_t)(32 + p);  // valid bases
-                u64 x = FW3[0] >> (64 - 2 * v);
-                rcw = (~bgr_rev2(x)) & (~0ULL << (64 - 2 * v));
-            }
-            RCW[w] = rcw;
-            // FWQ: what getNOverlap's rolling `num` holds: str2num codes inside the first window (N->3),
-            // nuc2int codes (N->0) for every base entered by update() (aligner.cpp:305-309, utils.cpp:132-140)
-            u64 ge;
-            if (32 * w >= K1) ge = ~0ULL;
-            else if (32 * (w + 1) <= K1) ge = 0;
-            else ge = ~0ULL >> (2 * (K1 - 32 * w));
-            FWQ[w] = FW3[w] & ~(NM[w] & ge);
-        }
-        wave_sync();
+        const bool hasN = pack_read(io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
 
         // ---- passes: forward read, then its reverse complement (alignerGreedy.cpp:54) -----------
         uint32_t status = BGR_ST_NOANCHOR, p_lo = 0, p_n = 0;
-        const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
+        uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
+        if (!prm.effort && npos > 1) npos = 1;
         for (int pass = 0; pass < 2; ++pass) {
             const u64* A = pass ? RCW : FWQ;   // forward-strand k-mers of this pass
             const u64* B = pass ? FW3 : RCW;   // reverse-strand k-mers (rolling nuc2intrc: N -> 0)
@@ -348,7 +542,7 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
             const bool useN = (pass == 0) && hasN;
             uint32_t tried = 0;
             bool done = false;
-            for (uint32_t base = 0; base < npos && !done && tried < prm.effort; base += 64) {
+            for (uint32_t base = 0; base < npos && !done && tried < effort; base += 64) {
                 const uint32_t i = base + lane;
                 const bool valid = i < npos;
                 u64 num = 0, rcn = 0;
@@ -357,11 +551,9 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
                     rcn = win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
-                uint32_t idx = mphf_lookup(g, LV, units, rep, valid);
-                bool hit = false;
-                if (idx != BGR_NONE) hit = g.keys[idx] == rep;   // aligner.cpp:353,361 key check
-                u64 mask = __ballot(hit);
-                while (mask && tried < prm.effort) {
+                const uint32_t idx = find_key(g, LV, units, rep, valid);
+                u64 mask = __ballot(idx != BGR_NONE);
+                while (mask && tried < effort) {
                     const int src = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     ++tried;
@@ -369,14 +561,8 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
                     uint32_t a_rec = rl32(idx, src);
                     // getBegin/getEnd recompute rc = rcb(num) (aligner.cpp:149,211); it differs from the
                     // rolling rcnum only when an N was rolled into the window.
-                    const u64 rc2 = bgr_rcb(a_num, K1);
-                    if (rc2 != a_rcn) {
-                        const u64 key2 = a_num < rc2 ? a_num : rc2;
-                        uint32_t i2 = mphf_lookup(g, LV, units, key2, true);
-                        bool ok2 = false;
-                        if (i2 != BGR_NONE) ok2 = g.keys[i2] == key2;
-                        a_rec = ok2 ? i2 : BGR_NONE;
-                    }
+                    const u64 rc2 = rcb_fast(a_num, K1);
+                    if (rc2 != a_rcn) a_rec = find_key(g, LV, units, a_num < rc2 ? a_num : rc2, true);
                     if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, base + src, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
                         done = true;
                         break;
@@ -390,26 +576,8 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
         // ---- stage D: publish ---------------------------------------------------------------------
         wave_sync();
         uint32_t abase = 0;
-        if ((status & BGR_ST_MASK) == BGR_ST_ALIGNED) {
-            // Arena space comes in per-wave chunks: ONE global atomic per ~50 reads instead of one per read
-            // (a single-address atomic saturates near 90 M/s chip-wide, MI355X_MICROARCH.md "dequeue").
-            if (p_n > chunk_end - chunk_pos) {
-                uint32_t want = p_n > io.arena_chunk ? p_n : io.arena_chunk;
-                uint32_t got = 0;
-                if (lane == 0) got = atomicAdd(io.cursor, want);
-                chunk_pos = rl32(got, 0);
-                chunk_end = chunk_pos + want;
-            }
-            abase = chunk_pos;
-            chunk_pos += p_n;
-            if (abase + p_n <= io.arena_cap) {
-                for (uint32_t j = lane; j < p_n; j += 64) io.arena[abase + j] = PATH[p_lo + j];
-            } else if (lane == 0) {
-                io.cursor[1] = 1;  // overflow: reported by the host as an error
-            }
-        } else {
-            p_n = 0;
-        }
+        if ((status & BGR_ST_MASK) == BGR_ST_ALIGNED) abase = publish_path(io, PATH, p_lo, p_n, &chunk_pos, &chunk_end, lane);
+        else p_n = 0;
         if (lane == 0) {
             io.status[r] = (uint8_t)status;
             io.path_off[r] = abase;
@@ -429,28 +597,114 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
     }
 }
 
+// alignReadExhaustive (alignerExhaustive.cpp:35-58): every read position is an anchor candidate
+// (getListOverlap, aligner.cpp:318-342, keeps them all); per anchor the best left walk with budget m, then
+// the best right walk with what is left; no reverse-complement retry.  Only position 0 and positions whose
+// (k-1)-mer is an overlap of the graph can succeed (anywhere else getEnd() is empty), so the position scan
+// is the same lane-parallel membership test as in the greedy kernel.
+template <bool STAGE>
+__global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    // per wave: FW3 | FWQ | RCW | NM | OUT | CUR | BEST | frames
+    const uint32_t per_wave_words = 4 * W + 3 * (io.path_cap / 2) + (io.frames_per_wave * FR_WORDS) / 2;
+    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FWQ = FW3 + W;
+    u64* RCW = FWQ + W;
+    u64* NM = RCW + W;
+    int32_t* OUT = reinterpret_cast<int32_t*>(NM + W);
+    int32_t* CUR = OUT + io.path_cap;
+    int32_t* BEST = CUR + io.path_cap;
+    uint32_t* FR = reinterpret_cast<uint32_t*>(BEST + io.path_cap);
+
+    uint32_t c_reads = 0, c_al = 0, c_na = 0;
+    unsigned long long c_ov = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+    const uint32_t m = prm.max_mismatch;
+
+    for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
+        const u64 off = io.read_offs[r];
+        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
+        const bool hasN = pack_read(io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
+        uint32_t p_n = 0;
+        const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
+        c_ov += npos;
+        bool done = false;
+        for (uint32_t base = 0; base < npos && !done; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < npos;
+            u64 num = 0;
+            if (valid) num = win32(FWQ, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
+            const uint32_t idx = find_key(g, LV, units, num < rc ? num : rc, valid);
+            u64 mask = __ballot(idx != BGR_NONE);
+            if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const uint32_t a_rec = rl32(idx, src), a_pos = base + (uint32_t)src;
+                const u64 a_num = rl64(num, src);
+                const bool a_canon = a_num <= rcb_fast(a_num, K1);
+                uint32_t nl = 0, nr = 0;
+                const uint32_t eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, CUR, BEST, &nl, lane);
+                if (eb > m) continue;
+                for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                wave_sync();
+                const uint32_t ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, CUR, BEST, &nr, lane);
+                if (ee > m - eb) continue;
+                for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];
+                p_n = nl + nr;
+                done = true;
+                break;
+            }
+        }
+        wave_sync();
+        uint32_t abase = 0;
+        if (done) abase = publish_path(io, OUT, 0, p_n, &chunk_pos, &chunk_end, lane);
+        if (lane == 0) {
+            io.status[r] = (uint8_t)(done ? BGR_ST_ALIGNED : BGR_ST_FAILED);
+            io.path_off[r] = abase;
+            io.path_len[r] = p_n;
+        }
+        ++c_reads;
+        c_al += done ? 1 : 0;
+        c_na += done ? 0 : 1;
+        wave_sync();
+    }
+    if (lane == 0 && c_reads) {
+        atomicAdd(&io.counters[0], (unsigned long long)c_reads);
+        if (c_al) atomicAdd(&io.counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&io.counters[3], (unsigned long long)c_na);
+        atomicAdd(&io.counters[4], c_ov);
+    }
+}
+
+template <typename K>
+hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
+    if (cfg.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(cfg.blocks), dim3(cfg.waves_per_block * 64), cfg.lds_bytes, stream, g, io, p);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     if (io.n_reads == 0) return hipSuccess;
-    dim3 grid(cfg.blocks), block(cfg.waves_per_block * 64);
-    if (p.mode != 0) return hipErrorNotSupported;
-    if (cfg.stage_mphf) {
-        if (cfg.lds_bytes > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(bgr_align_greedy_kernel<true>, grid, block, cfg.lds_bytes, stream, g, io, p);
-    } else {
-        if (cfg.lds_bytes > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bgr_align_greedy_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(bgr_align_greedy_kernel<false>, grid, block, cfg.lds_bytes, stream, g, io, p);
+    if (p.mode == 0) {
+        return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
+                              : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
     }
-    return hipGetLastError();
+    return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_kernel<true>, g, io, p, cfg, stream)
+                          : launch_one(bgr_align_exhaustive_kernel<false>, g, io, p, cfg, stream);
 }
 
 }  // namespace bgr

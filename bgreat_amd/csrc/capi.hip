@@ -265,8 +265,8 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     HIP_TRY(a->path_len.ensure(n_reads * 4));
 
     // ---- launch geometry -----------------------------------------------------------------------
-    uint32_t words = 0, path_cap = 0;
-    const uint32_t per_wave = bgr::lds_bytes_per_wave(max_read_len, &words, &path_cap);
+    uint32_t words = 0, path_cap = 0, frames = 0;
+    const uint32_t per_wave = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames);
     const size_t lds_cu = a->lds_per_cu;
     const uint32_t mphf_bytes = a->dg.units_bytes_lo;
     bgr::LaunchCfg cfg;
@@ -316,6 +316,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.path_cap = path_cap;
     io.arena_cap = (uint32_t)arena_cap;
     io.arena_chunk = arena_chunk;
+    io.frames_per_wave = frames;
     io.status = static_cast<uint8_t*>(a->status.p);
     io.path_off = static_cast<uint32_t*>(a->path_off.p);
     io.path_len = static_cast<uint32_t*>(a->path_len.p);

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = golden_cases()
 GREEDY = [c for c in CASES if "-b" not in c["args"]]
+EXH = [c for c in CASES if "-b" in c["args"]]
 
 
 def _argval(args, flag, default):
@@ -54,19 +55,22 @@ def graphs():
     cache.clear()
 
 
-@pytest.mark.parametrize("case", GREEDY, ids=["%02d-%s" % (c["id"], c["group"]) for c in GREEDY])
+@pytest.mark.parametrize("case", GREEDY + EXH, ids=["%02d-%s" % (c["id"], c["group"]) for c in GREEDY + EXH])
 def test_gpu_matches_reference_golden(case, graphs):
+    """Greedy cases: bytes of the unmodified reference.  Exhaustive (-b) cases: counters of the unmodified reference,
+    bytes of what it computes but does not write (tests/golden/README.md)."""
     args = case["args"]
     k = int(_argval(args, "-k", "30"))
     m = int(_argval(args, "-m", "2"))
     e = int(_argval(args, "-e", "2"))
     fastq = "-q" in args
+    mode = B.MODE_EXHAUSTIVE if "-b" in args else B.MODE_GREEDY
     g, al = graphs(os.path.join(GOLD, _argval(args, "-g", None)), k)
     al.reset_counters()
     pbytes, nbytes = b"", b""
     for f in _argval(args, "-r", None).split(","):
         reads, roffs, heads, hoffs = B.load_reads(os.path.join(GOLD, f), k, fastq)
-        paths, poffs, status = al.align(reads, roffs, m=m, effort=e)
+        paths, poffs, status = al.align(reads, roffs, m=m, effort=e, mode=mode, partial="-i" in args)
         p, n = _format(reads, roffs, heads, hoffs, paths, poffs)
         pbytes += p
         nbytes += n
@@ -81,6 +85,36 @@ def test_gpu_matches_reference_golden(case, graphs):
 def test_cli_matches_reference_golden(case):
     out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]))
     check_against_golden(case, out, paths, na)
+
+
+def test_cli_exhaustive_writes_nothing_unless_asked():
+    case = next(c for c in EXH if c["args"][1] == "syn_r150.fa" and c["args"][7] == "2")
+    out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]))
+    assert paths == b"" and na == b""
+    from util import parse_counters
+    assert parse_counters(out) == case["counters"]
+    out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]) + ["--write-exhaustive"])
+    check_against_golden(case, out, paths, na)
+
+
+@pytest.mark.parametrize("seed,k,L,m,partial,nfrac,d,alleles", [
+    (1, 31, 150, 2, False, 0.0, 75, 2), (2, 31, 250, 5, False, 0.0, 40, 4), (3, 31, 200, 5, True, 0.002, 45, 4),
+    (4, 21, 120, 3, False, 0.004, 50, 3), (5, 8, 60, 4, False, 0.0, 20, 4), (6, 31, 150, 0, True, 0.0, 140, 2), (7, 32, 100, 6, False, 0.01, 60, 4)])
+def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, alleles):
+    s = Synth(100000, d, alleles, k, 9000 + seed)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 8000, L, m + 1, 9500 + seed)
+    if nfrac:
+        reads = _inject_n(reads, np.random.default_rng(seed), nfrac)
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs)
+    p1, po1, st1 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE, partial=partial)
+    p2, po2, st2 = o.align(reads, roffs, m=m, mode=1, partial=partial)
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2)
+    assert np.array_equal(p1, p2)
+    assert al.counters() == o.counters()
 
 
 def _inject_n(reads, rng, frac):
