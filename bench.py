@@ -84,24 +84,15 @@ def main():
     t0 = time.time()
     syn = Synth(args.genome, args.site_spacing, args.alleles, args.k, seed_graph)  # every rank needs the genome to draw its reads
     graph_info = None
+    g = None
     if rank == 0:
         seqs, offs = syn.unitigs()
         g = B.Graph.build(args.k, seqs, offs)
         graph_info = g.info()
-        g.upload(dev)
-        nbytes = graph_info["blob_bytes"]
+    blob_keepalive = None
     if world > 1:
-        sz = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device="cuda")
-        dist.broadcast(sz, 0)
-        nbytes = int(sz.item())
-        if rank == 0:
-            blob_t = torch.from_numpy(np.array(g.blob())).to("cuda")
-        else:
-            blob_t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        dist.broadcast(blob_t, 0)  # C1: the only data-path collective; reads never move between GPUs
-        torch.cuda.synchronize()
-        if rank != 0:
-            g = B.Graph.adopt_device_blob(dev, blob_t.data_ptr(), nbytes)
+        from bgreat_amd import dist as D
+        g, blob_keepalive = D.broadcast_graph(g, dist, device=dev)  # C1: the only data-path collective; reads never move
     al = B.Aligner(g, dev)
     al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
     if rank == 0:
@@ -145,15 +136,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = D.max_over_ranks(elapsed, dist, device=dev)
     launches, kernel_ms = al.kernel_time()
     counters = al.counters()
     if dist is not None:  # C2: sum the aligner.h:68 counters over ranks
-        ct = torch.tensor([counters[k] for k in ("reads", "no_overlap", "aligned", "not_aligned")], dtype=torch.int64, device="cuda")
-        dist.all_reduce(ct)
-        counters = dict(zip(("reads", "no_overlap", "aligned", "not_aligned"), (int(x) for x in ct.tolist())))
+        counters = D.reduce_counters(counters, dist, device=dev)
 
     if rank != 0:
         if dist is not None:
