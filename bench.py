@@ -51,8 +51,22 @@ def main():
     ap.add_argument("--lds-mphf", type=int, default=0, help="0 auto, 1 HBM/L2 only, 2 force LDS staging")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
+    ap.add_argument("--workload", default="ecoli", choices=["ecoli", "small", "chr1", "branchy"],
+                    help="ecoli = BASELINE configs[2] (default, the metric's config); small = configs[1]; chr1 = configs[3] graph scale; "
+                         "branchy = configs[4] (exhaustive, m=5, 250 bp)")
+    ap.add_argument("--exhaustive", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     args = ap.parse_args()
+
+    presets = {  # SURVEY.md 8d synthetic inputs; explicit flags given on the command line win over the preset
+        "small": dict(genome=250_000, site_spacing=75, alleles=2, read_len=100, reads_per_step=1_000_000),
+        "chr1": dict(genome=230_000_000, site_spacing=175, alleles=2),
+        "branchy": dict(genome=50_000_000, site_spacing=36, alleles=4, read_len=250, mismatch=5, reads_per_step=2_000_000, exhaustive=True),
+    }
+    for key, val in presets.get(args.workload, {}).items():
+        if getattr(args, key) == ap.get_default(key):
+            setattr(args, key, val)
+    mode = 1 if args.exhaustive else 0
 
     import torch
     import bgreat_amd as B
@@ -117,7 +131,7 @@ def main():
 
     def step(i):
         b = batches[i % K]
-        al.align_device(b.data_ptr(), offs_t.data_ptr(), R, R * L, L, m=args.mismatch, effort=args.effort)
+        al.align_device(b.data_ptr(), offs_t.data_ptr(), R, R * L, L, m=args.mismatch, effort=args.effort, mode=mode)
 
     for i in range(W):
         step(i)
@@ -159,11 +173,11 @@ def main():
     ns = min(args.alg_sample, R)
     s_reads = first_host[: ns * L]
     s_offs = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
-    p2, po2, st2 = orc.align(s_reads, s_offs, m=args.mismatch, effort=args.effort)
+    p2, po2, st2 = orc.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
     alg_bytes_per_read = orc.alg_bytes() / ns
     work = orc.work()
     # parity of the same sample through the GPU path (outside the timed region)
-    p1, po1, st1 = al.align(s_reads, s_offs, m=args.mismatch, effort=args.effort)
+    p1, po1, st1 = al.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
     parity_ok = bool(np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2))
     achieved = alg_bytes_per_read * R / (avg_kernel_ms / 1e3) / 1e9
     traffic = None
@@ -176,12 +190,12 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "kernel": "bgr_align_greedy_kernel", "avg_launch_ms": round(avg_kernel_ms, 4), "launches": launches,
+                "traffic": traffic, "kernel": "bgr_align_exhaustive_kernel" if mode else "bgr_align_greedy_kernel", "avg_launch_ms": round(avg_kernel_ms, 4), "launches": launches,
                 "alg_bytes_per_read": round(alg_bytes_per_read, 1), "reads_per_launch": R}
 
     # ---- CPU baseline: the compiled reference (oracle/_ref/bgreat -t cores) on a bounded sample, N=1 only -------
     cpu = None
-    if world == 1 and args.cpu_sample > 0:
+    if world == 1 and args.cpu_sample > 0 and mode == 0:
         nc = min(args.cpu_sample, R)
         ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
         d = tempfile.mkdtemp(prefix="bgr_cpu_")
@@ -232,10 +246,11 @@ def main():
             shutil.rmtree(d, ignore_errors=True)
 
     out = {
-        "metric": "Mreads/s aligned (k=31, 150bp, m=2)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": K, "warmup": W,
+        "metric": "Mreads/s aligned (k=%d, %dbp, m=%d)" % (args.k, L, args.mismatch), "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: synthetic %dM x %d bp reads per GPU (%d steps x %d), k=%d, m=%d, effort=%d, greedy, E.coli-scale graph (%d unitigs, genome %d bp, %d alleles every ~%d bp)"
-                   % (K * R // 1_000_000, L, K, R, args.k, args.mismatch, args.effort, graph_info["n_unitigs"], args.genome, args.alleles, args.site_spacing),
+        "config": {"workload": "%s: synthetic %.1fM x %d bp reads per GPU (%d steps x %d), k=%d, m=%d, effort=%d, %s, graph of %d unitigs (genome %d bp, %d alleles every ~%d bp)"
+                   % ({"ecoli": "BASELINE configs[2]", "small": "BASELINE configs[1]", "chr1": "BASELINE configs[3] graph scale, one GPU's share", "branchy": "BASELINE configs[4] graph, one GPU's share"}[args.workload],
+                      K * R / 1e6, L, K, R, args.k, args.mismatch, args.effort, "exhaustive" if mode else "greedy", graph_info["n_unitigs"], args.genome, args.alleles, args.site_spacing),
                    "reads_per_step_per_gpu": R, "read_len": L, "k": args.k, "m": args.mismatch, "effort": args.effort,
                    "parallelism": "reads sharded over %d GPU(s); graph blob broadcast once" % world, "launch": al.launch_info()},
         "roofline": roofline, "cpu_baseline": cpu,
