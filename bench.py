@@ -55,6 +55,7 @@ def main():
                     help="ecoli = BASELINE configs[2] (default, the metric's config); small = configs[1]; chr1 = configs[3] graph scale; "
                          "branchy = configs[4] (exhaustive, m=5, 250 bp)")
     ap.add_argument("--exhaustive", action="store_true")
+    ap.add_argument("--gamma", type=float, default=0.0, help="MPHF positions per key and level (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     args = ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
     g = None
     if rank == 0:
         seqs, offs = syn.unitigs()
-        g = B.Graph.build(args.k, seqs, offs)
+        g = B.Graph.build(args.k, seqs, offs, args.gamma)
         graph_info = g.info()
     blob_keepalive = None
     if world > 1:
