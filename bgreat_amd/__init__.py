@@ -102,7 +102,7 @@ def lib():
     L.bgr_align_batch.argtypes = [vp, C.POINTER(Params), vp, vp, u64, vp, u64, vp, vp]
     L.bgr_align_device.argtypes = [vp, C.POINTER(Params), vp, vp, u64, u64, u32]
     L.bgr_aligner_sync.argtypes = [vp]
-    L.bgr_aligner_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.bgr_aligner_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.bgr_aligner_fetch.argtypes = [vp, u64, vp, u64, vp, vp]
     L.bgr_aligner_counters.argtypes = [vp, vp]
     L.bgr_aligner_reset_counters.argtypes = [vp]

@@ -12,18 +12,15 @@ namespace bgr {
 struct BatchIO {
     const uint8_t* reads;        // concatenated ASCII reads
     const uint64_t* read_offs;   // n+1
+    uint2* results;              // n: x = path offset in the arena, y = path length | status << 24
+    int32_t* arena;
+    uint32_t* cursor;            // [0] ints used, [1] overflow flag; counters (5 x u64) start at cursor + 16
     uint32_t n_reads;
     uint32_t words_per_read;     // u64 words of each packed per-wave LDS array (max_read_len/32 + 2)
     uint32_t path_cap;           // ints of the per-wave LDS path buffer
     uint32_t arena_cap;          // ints
     uint32_t arena_chunk;        // ints a wave reserves per global atomic
     uint32_t frames_per_wave;    // exhaustive mode: DFS frames (20 u32 each) in the per-wave LDS region
-    uint8_t* status;             // n
-    uint32_t* path_off;          // n
-    uint32_t* path_len;          // n
-    int32_t* arena;
-    uint32_t* cursor;            // [0] ints used, [1] overflow flag
-    unsigned long long* counters;  // readNumber, noOverlapRead, alignedRead, notAligned, overlaps
 };
 
 struct KernelParams {

@@ -26,6 +26,7 @@ namespace bgr {
 namespace {
 
 typedef uint64_t u64;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
 #define EVEN_BITS 0x5555555555555555ULL
 
@@ -99,14 +100,16 @@ __device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const u
         active = active && st == 3u;
         hl += hb;
     }
-    if (g.n_fallback && __any(active)) {
-        if (active) {  // bisection in the (tiny) sorted fallback list
-            uint32_t lo = 0, hi = g.n_fallback;
+    if ((g.flags & BGR_GF_HAS_FALLBACK) && __any(active)) {
+        if (active) {  // bisection in the (tiny) sorted fallback list; its location comes from the blob header
+            const uint32_t nfb = (uint32_t)g.hdr->n_fallback;
+            const u64* fb = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_fallback);
+            uint32_t lo = 0, hi = nfb;
             while (lo < hi) {
                 uint32_t mid = (lo + hi) >> 1;
-                if (g.fallback[mid] < key) lo = mid + 1; else hi = mid;
+                if (fb[mid] < key) lo = mid + 1; else hi = mid;
             }
-            if (lo < g.n_fallback && g.fallback[lo] == key) res = g.n_placed + lo;
+            if (lo < nfb && fb[lo] == key) res = (uint32_t)g.hdr->n_placed + lo;
         }
     }
     return res;
@@ -128,19 +131,27 @@ __device__ __forceinline__ bool pack_read(const uint8_t* rd, uint32_t L, uint32_
     unsigned char* NMb = reinterpret_cast<unsigned char*>(NM);
     bool sawN = false;
     for (uint32_t bi = lane; bi < 8 * W; bi += 64) {
-        uint32_t b0 = bi * 4, code = 0, nmask = 0;
+        const uint32_t b0 = bi * 4;
+        uint32_t code = 0, nmask = 0;
         if (b0 < L) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t cc = 0, nn = 0;
-                if (b0 + j < L) {
-                    unsigned char ch = rd[b0 + j];
-                    cc = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;  // str2num
-                    nn = (cc == 3u && ch != 'T') ? 3u : 0u;                      // 'N' (the parser admits only ACGTN)
-                }
-                code = (code << 2) | cc;
-                nmask = (nmask << 2) | nn;
+            // 4 ASCII bases in one (possibly unaligned) dword, converted SWAR: A0 C1 G2 T3 = ((c>>1)^(c>>2))&3; 'N' -> 3 + mask
+            const uint32_t nb = L - b0;
+            uint32_t x;
+            if (nb >= 4) {
+                x = *reinterpret_cast<const u32_unaligned*>(rd + b0);
+            } else {  // the last 1..3 bases: never touch bytes past the read (they may be past the buffer)
+                x = rd[b0];
+                if (nb > 1) x |= (uint32_t)rd[b0 + 1] << 8;
+                if (nb > 2) x |= (uint32_t)rd[b0 + 2] << 16;
             }
+            uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+            const uint32_t t = x ^ 0x4E4E4E4Eu;                             // zero byte <=> 'N'
+            const uint32_t isn = ((t - 0x01010101u) & ~t & 0x80808080u) >> 7;  // 0x01 per 'N' byte (exact for the alphabet ACGTN the parser admits)
+            const uint32_t n3 = isn * 3u;
+            c |= n3;
+            if (nb < 4) c &= 0x03030303u >> (8 * (4 - nb));
+            code = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
+            nmask = ((n3 << 6) | (n3 >> 4) | (n3 >> 14) | (n3 >> 24)) & 0xFFu;
         }
         FW3b[bi ^ 7] = (unsigned char)code;
         NMb[bi ^ 7] = (unsigned char)nmask;
@@ -235,10 +246,12 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
             u64 mm = (x | (x >> 1)) & EVEN_BITS;
             u64 nm = 0;
             if (useN) { nm = win32(NM, (u64)rstart + t * 32) & EVEN_BITS; mm |= nm; }
-            if (g.has_exc) {  // forward-strand unitig bases outside ACGT: never equal, except N == N
-                const uint32_t e = plane32(g.exc, ub);
+            if (g.flags & BGR_GF_HAS_EXC) {  // forward-strand unitig bases outside ACGT: never equal, except N == N
+                const u64* exc = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_exc);
+                const uint32_t e = plane32(exc, ub);
                 if (e) {
-                    const uint32_t en = plane32(g.excn, ub);
+                    const u64* excn = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_excn);
+                    const uint32_t en = plane32(excn, ub);
                     uint32_t m1 = compress_even(mm) | e;
                     m1 &= ~(en & compress_even(nm));
                     const uint32_t v1 = n - t * 32;
@@ -469,13 +482,13 @@ template <bool STAGE>
 __device__ __forceinline__ const uint32_t* block_prologue(const BgrDeviceGraph& g, u64* lds, uint2** LVout, uint32_t* mphf_words) {
     // LDS: [level descriptors 512 B][optional MPHF copy][per-wave regions]
     uint2* LV = reinterpret_cast<uint2*>(lds);
-    if (threadIdx.x < BGR_MAX_LEVELS) LV[threadIdx.x] = make_uint2(g.levels[threadIdx.x].units, g.levels[threadIdx.x].base);
-    *mphf_words = STAGE ? (g.units_bytes_lo + 7) / 8 : 0;
+    if (threadIdx.x < BGR_MAX_LEVELS) LV[threadIdx.x] = make_uint2(g.hdr->levels[threadIdx.x].units, g.hdr->levels[threadIdx.x].base);
+    *mphf_words = STAGE ? (g.units_bytes + 7) / 8 : 0;
     const uint32_t* units = g.units;
     if (STAGE) {
         const uint4* src = reinterpret_cast<const uint4*>(g.units);
         uint4* dst = reinterpret_cast<uint4*>(lds + 64);
-        for (uint32_t i = threadIdx.x; i < g.units_bytes_lo / 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < g.units_bytes / 16; i += blockDim.x) dst[i] = src[i];
         units = reinterpret_cast<const uint32_t*>(lds + 64);
     }
     __syncthreads();
@@ -578,11 +591,7 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
         uint32_t abase = 0;
         if ((status & BGR_ST_MASK) == BGR_ST_ALIGNED) abase = publish_path(io, PATH, p_lo, p_n, &chunk_pos, &chunk_end, lane);
         else p_n = 0;
-        if (lane == 0) {
-            io.status[r] = (uint8_t)status;
-            io.path_off[r] = abase;
-            io.path_len[r] = p_n;
-        }
+        if (lane == 0) io.results[r] = make_uint2(abase, p_n | (status << 24));
         ++c_reads;
         c_noov += (status & BGR_ST_MASK) == BGR_ST_NOANCHOR;
         c_al += (status & BGR_ST_MASK) == BGR_ST_ALIGNED;
@@ -590,10 +599,11 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
         wave_sync();
     }
     if (lane == 0 && c_reads) {
-        atomicAdd(&io.counters[0], (unsigned long long)c_reads);
-        if (c_noov) atomicAdd(&io.counters[1], (unsigned long long)c_noov);
-        if (c_al) atomicAdd(&io.counters[2], (unsigned long long)c_al);
-        if (c_na) atomicAdd(&io.counters[3], (unsigned long long)c_na);
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)c_reads);
+        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
     }
 }
 
@@ -667,21 +677,18 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
         wave_sync();
         uint32_t abase = 0;
         if (done) abase = publish_path(io, OUT, 0, p_n, &chunk_pos, &chunk_end, lane);
-        if (lane == 0) {
-            io.status[r] = (uint8_t)(done ? BGR_ST_ALIGNED : BGR_ST_FAILED);
-            io.path_off[r] = abase;
-            io.path_len[r] = p_n;
-        }
+        if (lane == 0) io.results[r] = make_uint2(abase, p_n | ((uint32_t)(done ? BGR_ST_ALIGNED : BGR_ST_FAILED) << 24));
         ++c_reads;
         c_al += done ? 1 : 0;
         c_na += done ? 0 : 1;
         wave_sync();
     }
     if (lane == 0 && c_reads) {
-        atomicAdd(&io.counters[0], (unsigned long long)c_reads);
-        if (c_al) atomicAdd(&io.counters[2], (unsigned long long)c_al);
-        if (c_na) atomicAdd(&io.counters[3], (unsigned long long)c_na);
-        atomicAdd(&io.counters[4], c_ov);
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)c_reads);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        atomicAdd(&counters[4], c_ov);
     }
 }
 

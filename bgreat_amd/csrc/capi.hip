@@ -57,7 +57,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, status, path_off, path_len, arena, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, results, arena, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -67,8 +67,7 @@ struct bgr_aligner {
     int ev_used = 0;
     uint64_t t_launches = 0;
     double t_ms = 0;
-    std::vector<uint8_t> h_status;
-    std::vector<uint32_t> h_off, h_len;
+    std::vector<uint32_t> h_results;
     std::vector<int32_t> h_arena;
 };
 
@@ -234,8 +233,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->status.release(); a->path_off.release();
-        a->path_len.release(); a->arena.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->small.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
@@ -260,15 +258,13 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     if (n_reads >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: more than 2^32-2 reads in one batch");
     HIP_TRY(hipSetDevice(a->device));
     if (a->ev_used == kTimerRing) { int rc = drain_timers(a); if (rc != BGR_OK) return rc; }
-    HIP_TRY(a->status.ensure(n_reads));
-    HIP_TRY(a->path_off.ensure(n_reads * 4));
-    HIP_TRY(a->path_len.ensure(n_reads * 4));
+    HIP_TRY(a->results.ensure(n_reads * 8));
 
     // ---- launch geometry -----------------------------------------------------------------------
     uint32_t words = 0, path_cap = 0, frames = 0;
     const uint32_t per_wave = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames);
     const size_t lds_cu = a->lds_per_cu;
-    const uint32_t mphf_bytes = a->dg.units_bytes_lo;
+    const uint32_t mphf_bytes = a->dg.units_bytes;
     bgr::LaunchCfg cfg;
     bool stage = false;
     if (a->cfg_lds_mphf != 1) {
@@ -317,12 +313,9 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.arena_cap = (uint32_t)arena_cap;
     io.arena_chunk = arena_chunk;
     io.frames_per_wave = frames;
-    io.status = static_cast<uint8_t*>(a->status.p);
-    io.path_off = static_cast<uint32_t*>(a->path_off.p);
-    io.path_len = static_cast<uint32_t*>(a->path_len.p);
+    io.results = static_cast<uint2*>(a->results.p);
     io.arena = static_cast<int32_t*>(a->arena.p);
     io.cursor = static_cast<uint32_t*>(a->small.p);
-    io.counters = reinterpret_cast<unsigned long long*>(static_cast<char*>(a->small.p) + 64);
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode};
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 8, a->stream));
@@ -341,11 +334,9 @@ int bgr_aligner_sync(bgr_aligner* a) {
     return BGR_OK;
 }
 
-int bgr_aligner_device_results(bgr_aligner* a, void** d_status, void** d_path_off, void** d_path_len, void** d_arena, void** d_cursor) {
+int bgr_aligner_device_results(bgr_aligner* a, void** d_results, void** d_arena, void** d_cursor) {
     if (!a) return fail(BGR_E_ARG, "bgr_aligner_device_results: null aligner");
-    if (d_status) *d_status = a->status.p;
-    if (d_path_off) *d_path_off = a->path_off.p;
-    if (d_path_len) *d_path_len = a->path_len.p;
+    if (d_results) *d_results = a->results.p;
     if (d_arena) *d_arena = a->arena.p;
     if (d_cursor) *d_cursor = a->small.p;
     return BGR_OK;
@@ -361,18 +352,16 @@ int bgr_aligner_fetch(bgr_aligner* a, uint64_t n, int32_t* paths_out, uint64_t p
     uint32_t cur[2] = {0, 0};
     HIP_TRY(hipMemcpy(cur, a->small.p, 8, hipMemcpyDeviceToHost));
     if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
-    a->h_off.resize(n);
-    a->h_len.resize(n);
+    a->h_results.resize(2 * n);
     a->h_arena.resize(cur[0]);
-    HIP_TRY(hipMemcpy(status, a->status.p, n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(a->h_off.data(), a->path_off.p, n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(a->h_len.data(), a->path_len.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a->h_results.data(), a->results.p, n * 8, hipMemcpyDeviceToHost));
     if (cur[0]) HIP_TRY(hipMemcpy(a->h_arena.data(), a->arena.p, (size_t)cur[0] * 4, hipMemcpyDeviceToHost));
     uint64_t w = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        uint32_t len = a->h_len[i];
+        const uint32_t off = a->h_results[2 * i], pk = a->h_results[2 * i + 1], len = pk & 0xFFFFFFu;
+        status[i] = (uint8_t)(pk >> 24);
         if (w + len > paths_cap) return fail(BGR_E_CAPACITY, "bgr_aligner_fetch: paths_out too small");
-        if (len) memcpy(paths_out + w, a->h_arena.data() + a->h_off[i], (size_t)len * 4);
+        if (len) memcpy(paths_out + w, a->h_arena.data() + off, (size_t)len * 4);
         w += len;
         path_offsets[i + 1] = w;
     }

@@ -121,17 +121,11 @@ void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGr
     dg.recs = reinterpret_cast<const uint32_t*>(base + h->off_recs);
     dg.meta = reinterpret_cast<const BgrUnitigMeta*>(base + h->off_meta);
     dg.seq = reinterpret_cast<const uint64_t*>(base + h->off_seq);
-    dg.exc = h->off_exc ? reinterpret_cast<const uint64_t*>(base + h->off_exc) : nullptr;
-    dg.excn = h->off_excn ? reinterpret_cast<const uint64_t*>(base + h->off_excn) : nullptr;
-    dg.fallback = reinterpret_cast<const uint64_t*>(base + h->off_fallback);
+    dg.hdr = reinterpret_cast<const BgrBlobHeader*>(base);
     dg.k = h->k;
     dg.n_levels = h->n_levels;
-    dg.n_keys = (uint32_t)h->n_keys;
-    dg.n_placed = (uint32_t)h->n_placed;
-    dg.n_fallback = (uint32_t)h->n_fallback;
-    dg.has_exc = h->has_exc;
-    dg.units_bytes_lo = (uint32_t)(h->n_units * 16);
-    for (uint32_t l = 0; l < h->n_levels; ++l) dg.levels[l] = h->levels[l];
+    dg.flags = (h->has_exc ? BGR_GF_HAS_EXC : 0u) | (h->n_fallback ? BGR_GF_HAS_FALLBACK : 0u);
+    dg.units_bytes = (uint32_t)(h->n_units * 16);
 }
 
 bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {

@@ -92,19 +92,19 @@ typedef struct {
     BgrLevel levels[BGR_MAX_LEVELS];
 } BgrBlobHeader;
 
-// What a kernel receives by value (pointers resolved against the device copy of the blob).
+// What a kernel receives by value (pointers resolved against the device copy of the blob).  Kept small on
+// purpose: everything here lives in SGPRs for the whole kernel; what only rare paths need (exception planes,
+// fallback list, level table) is reached through `hdr`, the blob header in HBM.
+#define BGR_GF_HAS_EXC 1u
+#define BGR_GF_HAS_FALLBACK 2u
 typedef struct {
     const uint32_t* units;   // n_units * 4 u32  (x,y,z = 48 two-bit states, w = rank)
     const uint64_t* keys;
     const uint32_t* recs;    // n_keys * 8 u32   (L0..L3, R0..R3)
     const BgrUnitigMeta* meta;
     const uint64_t* seq;
-    const uint64_t* exc;     // may be null
-    const uint64_t* excn;    // may be null
-    const uint64_t* fallback;
-    uint32_t k, n_levels, n_keys, n_placed, n_fallback, has_exc;
-    uint32_t units_bytes_lo, pad0;   // size of the unit array in bytes (for LDS staging decisions)
-    BgrLevel levels[BGR_MAX_LEVELS];
+    const BgrBlobHeader* hdr;
+    uint32_t k, n_levels, flags, units_bytes;  // units_bytes: size of the unit array (LDS staging)
 } BgrDeviceGraph;
 
 // ---- hashing shared by the host builder and the device lookup ---------------------------------------

@@ -107,13 +107,15 @@ int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, cons
 
 /* Device-resident form: inputs already in this device's HBM (d_reads bytes, d_read_offsets uint64[n+1]);
  * results stay in aligner-owned device buffers (bgr_aligner_device_results).  Asynchronous on the
- * aligner's stream; max_read_len = longest read in the batch, total_bases = read_offsets[n].            */
+ * aligner's stream; max_read_len = longest read in the batch (< 2^24), total_bases = read_offsets[n].
+ * Read characters must be from ACGTN (what getReads lets through).                                      */
 int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
                      uint64_t total_bases, uint32_t max_read_len);
 int bgr_aligner_sync(bgr_aligner* a);
-/* Device pointers of the last bgr_align_device results: status u8[n], path_off u32[n], path_len u32[n],
- * arena int32[], cursor u32[1] (ints used in the arena).  Row i of the result = arena[path_off[i] .. +path_len[i]). */
-int bgr_aligner_device_results(bgr_aligner* a, void** d_status, void** d_path_off, void** d_path_len, void** d_arena, void** d_cursor);
+/* Device pointers of the last bgr_align_device results: results uint32[n][2] = {path offset in the arena,
+ * path length | status << 24}, arena int32[], cursor u32[1] (ints used in the arena).
+ * Row i of the result = arena[results[i][0] .. + (results[i][1] & 0xFFFFFF)]. */
+int bgr_aligner_device_results(bgr_aligner* a, void** d_results, void** d_arena, void** d_cursor);
 /* Copy the last device results to the host in input order (same output contract as bgr_align_batch). */
 int bgr_aligner_fetch(bgr_aligner* a, uint64_t n_reads, int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
 
