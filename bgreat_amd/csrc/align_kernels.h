@@ -25,6 +25,7 @@ struct BatchIO {
 
 struct KernelParams {
     uint32_t max_mismatch, effort, partial, mode;
+    uint32_t debug_stop;  // diagnostic builds only (env BGR_DEBUG_STOP): 1 = stop after packing, 2 = after the position scan
 };
 
 struct LaunchCfg {
@@ -51,6 +52,9 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
     if (frames) *frames = fr;
     return bytes;
 }
+
+// Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive).
+uint32_t resident_waves_per_cu(uint32_t mode);
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);
 

@@ -19,6 +19,8 @@
 // Integer/byte work only: no MFMA anywhere (there is no dense contraction on this path).
 #include "align_kernels.h"
 
+#include <algorithm>
+
 #include "../../include/bgreat_gpu.h"
 
 namespace bgr {
@@ -126,33 +128,38 @@ __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, const uint
 // FW3: str2num codes (N->3).  NM: 3 on every N.  RCW: reverseComplements(read) (utils.cpp:66-73, non-ACG -> 'A').
 // FWQ: what the rolling `num` of getNOverlap/getListOverlap holds: str2num codes inside the first window,
 //      nuc2int codes (N->0) for bases entered by update() (aligner.cpp:305-309, utils.cpp:132-140).
-__device__ __forceinline__ bool pack_read(const uint8_t* rd, uint32_t L, uint32_t W, uint32_t K1, u64* FW3, u64* FWQ, u64* RCW, u64* NM, int lane) {
+// 4 ASCII bases starting at byte 4*bi of the read as one dword (first base in the low byte), 0 past the end
+__device__ __forceinline__ uint32_t load4(const uint8_t* rd, uint32_t L, uint32_t bi) {
+    const uint32_t b0 = bi * 4;
+    uint32_t x = 0;
+    if (b0 < L) {
+        const uint32_t nb = L - b0;
+        if (nb >= 4) {
+            x = *reinterpret_cast<const u32_unaligned*>(rd + b0);  // possibly unaligned dword
+        } else {  // the last 1..3 bases: never touch bytes past the read (they may be past the buffer)
+            x = rd[b0];
+            if (nb > 1) x |= (uint32_t)rd[b0 + 1] << 8;
+            if (nb > 2) x |= (uint32_t)rd[b0 + 2] << 16;
+        }
+    }
+    return x;
+}
+
+// x0 = load4(rd, L, lane)
+__device__ __forceinline__ bool pack_read(uint32_t x0, const uint8_t* rd, uint32_t L, uint32_t W, uint32_t K1, u64* FW3, u64* FWQ, u64* RCW, u64* NM, int lane) {
     unsigned char* FW3b = reinterpret_cast<unsigned char*>(FW3);
     unsigned char* NMb = reinterpret_cast<unsigned char*>(NM);
     bool sawN = false;
     for (uint32_t bi = lane; bi < 8 * W; bi += 64) {
-        const uint32_t b0 = bi * 4;
-        uint32_t code = 0, nmask = 0;
-        if (b0 < L) {
-            // 4 ASCII bases in one (possibly unaligned) dword, converted SWAR: A0 C1 G2 T3 = ((c>>1)^(c>>2))&3; 'N' -> 3 + mask
-            const uint32_t nb = L - b0;
-            uint32_t x;
-            if (nb >= 4) {
-                x = *reinterpret_cast<const u32_unaligned*>(rd + b0);
-            } else {  // the last 1..3 bases: never touch bytes past the read (they may be past the buffer)
-                x = rd[b0];
-                if (nb > 1) x |= (uint32_t)rd[b0 + 1] << 8;
-                if (nb > 2) x |= (uint32_t)rd[b0 + 2] << 16;
-            }
-            uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
-            const uint32_t t = x ^ 0x4E4E4E4Eu;                             // zero byte <=> 'N'
-            const uint32_t isn = ((t - 0x01010101u) & ~t & 0x80808080u) >> 7;  // 0x01 per 'N' byte (exact for the alphabet ACGTN the parser admits)
-            const uint32_t n3 = isn * 3u;
-            c |= n3;
-            if (nb < 4) c &= 0x03030303u >> (8 * (4 - nb));
-            code = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
-            nmask = ((n3 << 6) | (n3 >> 4) | (n3 >> 14) | (n3 >> 24)) & 0xFFu;
-        }
+        const uint32_t x = bi < 64 ? x0 : load4(rd, L, bi);
+        // SWAR over 4 bytes: A0 C1 G2 T3 = ((c>>1)^(c>>2))&3; 'N' -> 3 + mask; a zero byte (past the end) -> 0
+        uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+        const uint32_t t = x ^ 0x4E4E4E4Eu;                                 // zero byte <=> 'N'
+        const uint32_t isn = ((t - 0x01010101u) & ~t & 0x80808080u) >> 7;  // 0x01 per 'N' byte (exact for the alphabet ACGTN the parser admits)
+        const uint32_t n3 = isn * 3u;
+        c |= n3;
+        const uint32_t code = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
+        const uint32_t nmask = ((n3 << 6) | (n3 >> 4) | (n3 >> 14) | (n3 >> 24)) & 0xFFu;
         FW3b[bi ^ 7] = (unsigned char)code;
         NMb[bi ^ 7] = (unsigned char)nmask;
         sawN |= nmask != 0;
@@ -518,7 +525,7 @@ __device__ __forceinline__ uint32_t publish_path(const BatchIO& io, const int32_
 }
 
 template <bool STAGE>
-__global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -542,12 +549,14 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
     for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        const bool hasN = pack_read(io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
+        // (prefetching the next read one iteration ahead was measured: no gain at 24 waves/CU, it only added spills)
+        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
 
         // ---- passes: forward read, then its reverse complement (alignerGreedy.cpp:54) -----------
         uint32_t status = BGR_ST_NOANCHOR, p_lo = 0, p_n = 0;
         uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         if (!prm.effort && npos > 1) npos = 1;
+        if (prm.debug_stop == 1) npos = 0;
         for (int pass = 0; pass < 2; ++pass) {
             const u64* A = pass ? RCW : FWQ;   // forward-strand k-mers of this pass
             const u64* B = pass ? FW3 : RCW;   // reverse-strand k-mers (rolling nuc2intrc: N -> 0)
@@ -566,6 +575,7 @@ __global__ void __launch_bounds__(1024) bgr_align_greedy_kernel(BgrDeviceGraph g
                 const u64 rep = num < rcn ? num : rcn;
                 const uint32_t idx = find_key(g, LV, units, rep, valid);
                 u64 mask = __ballot(idx != BGR_NONE);
+                if (prm.debug_stop == 2) { if (mask) { ++tried; done = true; p_n = 0; } mask = 0; }
                 while (mask && tried < effort) {
                     const int src = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -641,7 +651,7 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
     for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        const bool hasN = pack_read(io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
+        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
         uint32_t p_n = 0;
         const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         c_ov += npos;
@@ -703,6 +713,17 @@ hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, cons
 }
 
 }  // namespace
+
+uint32_t resident_waves_per_cu(uint32_t mode) {
+    hipFuncAttributes fa;
+    const void* fn = mode == 0 ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)
+                               : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true>);
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
+    // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;
+    // the kernels use ~106 SGPRs, which caps a SIMD at 6 waves (800 / (7*16 + 16)).
+    const uint32_t alloc = ((uint32_t)fa.numRegs + 7) / 8 * 8;
+    return 4 * std::min<uint32_t>(6, 512 / alloc);
+}
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     if (io.n_reads == 0) return hipSuccess;

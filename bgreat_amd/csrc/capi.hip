@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -25,7 +26,7 @@ int fail(int code, const std::string& msg) { tl_err = msg; return code; }
         if (e_ != hipSuccess) return fail(BGR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-const double kDefaultGamma = 2.0;
+const double kDefaultGamma = 1.5;  // E. coli-scale cascade = 64 KB: two staged workgroups per CU fit the 160 KB LDS
 const uint32_t kLdsFixed = 512;  // level descriptors at the start of the dynamic LDS
 const int kTimerRing = 256;
 
@@ -265,33 +266,46 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     const uint32_t per_wave = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames);
     const size_t lds_cu = a->lds_per_cu;
     const uint32_t mphf_bytes = a->dg.units_bytes;
+    // Resident waves per CU are bounded by registers (bgr::resident_waves_per_cu); LDS decides how they are grouped:
+    // `b` workgroups per CU of `w` waves each, every staged workgroup holding its own copy of the MPHF cascade.
+    // More resident waves hide more of the walk's dependent-load latency (measured 16 -> 24 waves/CU: +18 %), and a
+    // grid of exactly CUs x b workgroups avoids a partial last round.
     bgr::LaunchCfg cfg;
+    const uint32_t cap = std::max<uint32_t>(4, bgr::resident_waves_per_cu(p->mode));
+    const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
+    uint32_t waves = 0, bpc = 0;
     bool stage = false;
-    if (a->cfg_lds_mphf != 1) {
-        // stage the cascade in LDS when it leaves room for a useful number of waves in the workgroup
-        uint32_t min_waves = a->cfg_lds_mphf == 2 ? 1 : 8;
-        if ((uint64_t)mphf_bytes + 16 + kLdsFixed + (uint64_t)min_waves * per_wave <= lds_cu && a->graph->header.n_units * 16 < 0xFFFFFFFFull) stage = true;
-    }
-    uint32_t waves;
-    if (stage) {
-        uint32_t fit = (uint32_t)((lds_cu - mphf_bytes - 16 - kLdsFixed) / per_wave);
-        waves = std::min<uint32_t>(16, fit);
-        if (a->cfg_waves) waves = std::min(waves, a->cfg_waves);
-        cfg.lds_bytes = kLdsFixed + ((mphf_bytes + 7) / 8) * 8 + waves * per_wave;
-        uint32_t bpc = std::max<uint32_t>(1, (uint32_t)(lds_cu / cfg.lds_bytes));
-        if (a->cfg_blocks_per_cu) bpc = std::min(bpc, a->cfg_blocks_per_cu);
-        bpc = std::min<uint32_t>(bpc, std::max<uint32_t>(1, 32 / waves));
-        cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
+    auto fits = [&](uint32_t b, uint32_t w, bool st) {
+        return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 7) / 8) * 8 : 0) + (uint64_t)w * per_wave) <= lds_fit;
+    };
+    if (a->cfg_waves || a->cfg_blocks_per_cu) {  // explicit tuning through bgr_aligner_configure
+        stage = a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true));
+        waves = a->cfg_waves ? a->cfg_waves : (stage ? 12 : 4);
+        bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
+        while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
+        while (waves > 1 && !fits(bpc, waves, stage)) --waves;
+        if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
     } else {
-        waves = a->cfg_waves ? a->cfg_waves : 4;
-        uint32_t fit = (uint32_t)((lds_cu - kLdsFixed) / per_wave);
-        if (fit == 0) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
-        waves = std::min(waves, fit);
-        cfg.lds_bytes = kLdsFixed + waves * per_wave;
-        uint32_t bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, 32 / waves);
-        bpc = std::min<uint32_t>(bpc, std::max<uint32_t>(1, (uint32_t)(lds_cu / cfg.lds_bytes)));
-        cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
+        uint32_t best_res = 0;
+        if (a->cfg_lds_mphf != 1 && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
+            const uint32_t bs[] = {1, 2, 3, 4, 6};
+            for (uint32_t b : bs) {
+                uint32_t w = std::min<uint32_t>(16, cap / b);
+                while (w > 0 && !fits(b, w, true)) --w;
+                if (w && b * w > best_res) { best_res = b * w; waves = w; bpc = b; stage = true; }
+            }
+        }
+        // without staging: small workgroups, as many as the registers admit
+        uint32_t wn = 4, bn = std::max<uint32_t>(1, cap / wn);
+        while (bn > 1 && !fits(bn, wn, false)) --bn;
+        while (wn > 1 && !fits(bn, wn, false)) --wn;
+        const uint32_t res_n = fits(bn, wn, false) ? bn * wn : 0;
+        if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
+        if (best_res == 0) waves = 0;
     }
+    if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
+    cfg.lds_bytes = kLdsFixed + (stage ? ((mphf_bytes + 7) / 8) * 8 : 0) + waves * per_wave;
+    cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
     if (waves == 0) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging");
     cfg.waves_per_block = waves;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
@@ -316,7 +330,8 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.results = static_cast<uint2*>(a->results.p);
     io.arena = static_cast<int32_t*>(a->arena.p);
     io.cursor = static_cast<uint32_t*>(a->small.p);
-    bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode};
+    const char* dbg = getenv("BGR_DEBUG_STOP");
+    bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, dbg ? (uint32_t)atoi(dbg) : 0u};
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 8, a->stream));
     HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
