@@ -208,23 +208,20 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
     // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
     const bool useR = (DIR == 0) ? canon : !canon;
     const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
-    const uint32_t slot = g.recs[(u64)rec * 8 + (useR ? 4 : 0) + c];
-    sc.id = slot & BGR_SLOT_ID_MASK;
+    // one 16-byte slot per candidate: id + orientation bits, length, base offset (graph_layout.h BgrSlot)
+    const uint4 sl = reinterpret_cast<const uint4*>(g.recs)[(u64)rec * 8 + (useR ? 4 : 0) + c];
+    sc.id = sl.x & BGR_SLOT_ID_MASK;
     const u64 zmask = __ballot(sc.id == 0);
     sc.first_zero = zmask ? (__ffsll((long long)zmask) - 1) >> 4 : 4;
     const bool valid = c < sc.first_zero;
-    sc.fwd = (slot & fbit) != 0;
-    u64 S = 0;
-    uint32_t len = 0;
-    sc.mflags = 0; sc.rec_beg = 0; sc.rec_end = 0;
-    if (valid) {
-        const uint4* mp = reinterpret_cast<const uint4*>(g.meta + sc.id);
-        const uint4 m0 = mp[0];
-        const uint2 m1 = reinterpret_cast<const uint2*>(mp + 1)[0];
-        S = ((u64)m0.y << 32) | m0.x;
-        len = m0.z; sc.mflags = m0.w; sc.rec_beg = m1.x; sc.rec_end = m1.y;
-        if (!sc.fwd) S += len;
-    }
+    sc.fwd = (sl.x & fbit) != 0;
+    const uint32_t len = valid ? sl.y : 0;
+    u64 S = ((u64)sl.w << 32) | sl.z;
+    if (!sc.fwd) S += len;
+    // what the NEXT step needs about this unitig (flags, neighbour record indices): issued now, beside the base loads
+    uint4 m0 = make_uint4(0, 0, 0, 0);
+    if (valid) m0 = *reinterpret_cast<const uint4*>(g.meta + sc.id);
+    sc.mflags = m0.y; sc.rec_beg = m0.z; sc.rec_end = m0.w;
     sc.ext = len - K1;
     uint32_t n, ustart, rstart;
     if (DIR == 0) {

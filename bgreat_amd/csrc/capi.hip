@@ -187,7 +187,7 @@ int bgr_graph_adopt_device_blob(int device, const void* dev_blob, uint64_t bytes
     bgr_graph* g = new bgr_graph();
     hipError_t e = hipMemcpy(&g->header, dev_blob, sizeof(BgrBlobHeader), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete g; return fail(BGR_E_HIP, std::string("header D2H: ") + hipGetErrorString(e)); }
-    if (g->header.magic != BGR_MAGIC || g->header.version != 1 || g->header.blob_bytes != bytes || g->header.n_levels > BGR_MAX_LEVELS) {
+    if (g->header.magic != BGR_MAGIC || g->header.version != BGR_BLOB_VERSION || g->header.blob_bytes != bytes || g->header.n_levels > BGR_MAX_LEVELS) {
         delete g;
         return fail(BGR_E_ARG, "bgr_graph_adopt_device_blob: not a graph blob of that size");
     }

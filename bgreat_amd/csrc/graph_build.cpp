@@ -79,11 +79,14 @@ void build_cascade(const std::vector<uint64_t>& keys, double gamma, Cascade& c) 
     }
 }
 
-inline void fill_slot(uint32_t* s, uint32_t val) {  // aligner.cpp:481-489: first free of 1..3, else overwrite 4
-    if ((s[0] & BGR_SLOT_ID_MASK) == 0) s[0] = val;
-    else if ((s[1] & BGR_SLOT_ID_MASK) == 0) s[1] = val;
-    else if ((s[2] & BGR_SLOT_ID_MASK) == 0) s[2] = val;
-    else s[3] = val;
+inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m) {  // aligner.cpp:481-489: first free of 1..3, else overwrite 4
+    int j = 3;
+    if (s[0].idf == 0) j = 0;
+    else if (s[1].idf == 0) j = 1;
+    else if (s[2].idf == 0) j = 2;
+    s[j].idf = idf;
+    s[j].len = m.len;
+    s[j].F = m.F;
 }
 
 }  // namespace
@@ -118,7 +121,7 @@ void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGr
     memset(&dg, 0, sizeof(dg));
     dg.units = reinterpret_cast<const uint32_t*>(base + h->off_units);
     dg.keys = reinterpret_cast<const uint64_t*>(base + h->off_keys);
-    dg.recs = reinterpret_cast<const uint32_t*>(base + h->off_recs);
+    dg.recs = reinterpret_cast<const BgrSlot*>(base + h->off_recs);
     dg.meta = reinterpret_cast<const BgrUnitigMeta*>(base + h->off_meta);
     dg.seq = reinterpret_cast<const uint64_t*>(base + h->off_seq);
     dg.hdr = reinterpret_cast<const BgrBlobHeader*>(base);
@@ -131,10 +134,10 @@ void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGr
 bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {
     if (bytes < sizeof(BgrBlobHeader)) { err = "blob smaller than its header"; return false; }
     const BgrBlobHeader* h = static_cast<const BgrBlobHeader*>(blob);
-    if (h->magic != BGR_MAGIC || h->version != 1) { err = "not a bgreat graph blob (magic/version)"; return false; }
+    if (h->magic != BGR_MAGIC || h->version != BGR_BLOB_VERSION) { err = "not a bgreat graph blob (magic/version)"; return false; }
     if (h->blob_bytes != bytes) { err = "blob size does not match its header"; return false; }
     if (h->n_levels > BGR_MAX_LEVELS || h->k < 2 || h->k > 32) { err = "corrupt blob header"; return false; }
-    uint64_t ends[] = {h->off_units + h->n_units * 16, h->off_keys + h->n_keys * 8, h->off_recs + h->n_keys * 32,
+    uint64_t ends[] = {h->off_units + h->n_units * 16, h->off_keys + h->n_keys * 8, h->off_recs + h->n_keys * 128,
                        h->off_meta + (h->n_unitigs + 1) * sizeof(BgrUnitigMeta), h->off_seq + h->seq_words * 8,
                        h->off_fallback + h->n_fallback * 8};
     for (uint64_t e : ends) if (e > bytes) { err = "blob section outside the blob"; return false; }
@@ -228,7 +231,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     BgrBlobHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = BGR_MAGIC;
-    h.version = 1;
+    h.version = BGR_BLOB_VERSION;
     h.k = k;
     h.n_unitigs = n;
     h.n_keys = keys.size();
@@ -248,7 +251,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     static_assert(sizeof(BgrBlobHeader) <= 4096, "header must fit its 4 KiB slot");
     h.off_units = off;    off = align256(off + h.n_units * 16 + 16);
     h.off_keys = off;     off = align256(off + h.n_keys * 8 + 8);
-    h.off_recs = off;     off = align256(off + h.n_keys * 32 + 32);
+    h.off_recs = off;     off = align256(off + h.n_keys * 128 + 128);
     h.off_meta = off;     off = align256(off + (n + 1) * sizeof(BgrUnitigMeta));
     h.off_seq = off;      off = align256(off + seq_words * 8);
     if (has_exc) {
@@ -281,17 +284,17 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     }
 
     // ---- slot fill in unitig order (aligner.cpp:466-533) + orientation bits ---------------------
-    uint32_t* recs = reinterpret_cast<uint32_t*>(base + h.off_recs);
+    BgrSlot* recs = reinterpret_cast<BgrSlot*>(base + h.off_recs);
     BgrUnitigMeta* mout = reinterpret_cast<BgrUnitigMeta*>(base + h.off_meta);
     for (uint64_t i = 1; i <= n; ++i) {
         uint64_t beg = begs[i], rcBeg = bgr_rcb(beg, K1), end = ends[i], rcEnd = bgr_rcb(end, K1);
         uint32_t id = (uint32_t)i;
         uint32_t ib = host_lookup(hp, base, std::min(beg, rcBeg)), ie = host_lookup(hp, base, std::min(end, rcEnd));
         // left-table slot of key x : F0 = (beg == x), F1 = (end == rc(x)); right-table slot of key y: F0 = (end == y), F1 = (beg == rc(y))
-        if (beg <= rcBeg) fill_slot(recs + (size_t)ib * 8, id | BGR_SLOT_F0 /* beg == key */ | (end == rcBeg ? BGR_SLOT_F1 : 0));
-        else fill_slot(recs + (size_t)ib * 8 + 4, id | (end == rcBeg ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* beg == rc(key) */);
-        if (end <= rcEnd) fill_slot(recs + (size_t)ie * 8 + 4, id | BGR_SLOT_F0 /* end == key */ | (beg == rcEnd ? BGR_SLOT_F1 : 0));
-        else fill_slot(recs + (size_t)ie * 8, id | (beg == rcEnd ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* end == rc(key) */);
+        if (beg <= rcBeg) fill_slot(recs + (size_t)ib * 8, id | BGR_SLOT_F0 /* beg == key */ | (end == rcBeg ? BGR_SLOT_F1 : 0), meta[i]);
+        else fill_slot(recs + (size_t)ib * 8 + 4, id | (end == rcBeg ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* beg == rc(key) */, meta[i]);
+        if (end <= rcEnd) fill_slot(recs + (size_t)ie * 8 + 4, id | BGR_SLOT_F0 /* end == key */ | (beg == rcEnd ? BGR_SLOT_F1 : 0), meta[i]);
+        else fill_slot(recs + (size_t)ie * 8, id | (beg == rcEnd ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* end == rc(key) */, meta[i]);
         BgrUnitigMeta m = meta[i];
         m.rec_beg = ib;
         m.rec_end = ie;

@@ -13,7 +13,7 @@
 //   exc/excN  optional 1-bit-per-base planes over the same base index space: forward-strand bases that
 //          are not ACGT (they can never equal a read's ACGT; an 'N' can only equal a read's 'N').  Absent
 //          (offset 0) for ordinary graphs.
-//   meta   32 B per unitig id: F, len, and the record index + canonical flag of BOTH end (k-1)-mers, so
+//   meta   32 B per unitig id: len, and the record index + canonical flag of BOTH end (k-1)-mers, so
 //          a walk step never hashes: the next neighbour record is a direct index.
 //   MPHF   ONE minimal perfect hash over the union of the reference's left and right overlap key sets
 //          (index values are unobservable).  BBHash-style cascade, but every position
@@ -23,10 +23,12 @@
 //          gives the minimal index, state 3 continues.  A level is an array of 16-byte units
 //          {48 states, u32 rank = placed keys in all earlier units}: ONE dwordx4 load per level.
 //   keys   u64 key per MPHF index (membership check, aligner.cpp:158,219,353,361).
-//   recs   32 B per MPHF index: the 4 "left table" slots and the 4 "right table" slots of that key
-//          (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite, aligner.cpp:466-533).
-//          Bits 30/31 of a slot carry the orientation the reference recomputes by string compare at
-//          query time (aligner.cpp:174,235).
+//   recs   128 B (one cache line) per MPHF index: the 4 "left table" slots and the 4 "right table" slots of
+//          that key (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite,
+//          aligner.cpp:466-533).  A slot is 16 B {id | orientation bits, len, F}: everything a walk step
+//          needs to start streaming the candidate's bases, so a step is TWO dependent loads (slot, then
+//          bases + meta side by side) instead of three.  Bits 30/31 of the id word carry the orientation the
+//          reference recomputes by string compare at query time (aligner.cpp:174,235).
 #ifndef BGREAT_AMD_GRAPH_LAYOUT_H
 #define BGREAT_AMD_GRAPH_LAYOUT_H
 
@@ -39,6 +41,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
+#define BGR_BLOB_VERSION 3u  /* 3: 2-bit-state cascade, 16-byte slots */
 #define BGR_MAX_LEVELS 48
 #define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
 #define BGR_NONE 0xFFFFFFFFu
@@ -58,13 +61,19 @@
 #define BGR_META_CANON_RCEND 8u  /* rc(end) <= end: reversed unitig, walking left                                 */
 
 typedef struct {
-    uint64_t F;       // base offset of the forward strand in `seq` (reverse complement at F + len)
     uint32_t len;     // bases
     uint32_t flags;   // BGR_META_*
     uint32_t rec_beg; // MPHF index of canonical(first k-1 bases)
     uint32_t rec_end; // MPHF index of canonical(last k-1 bases)
+    uint64_t F;       // base offset of the forward strand in `seq` (reverse complement at F + len)
     uint64_t pad;
-} BgrUnitigMeta;      // 32 B
+} BgrUnitigMeta;      // 32 B; the first 16 B are what a walk step needs about the unitig it has chosen
+
+typedef struct {
+    uint32_t idf;     // unitig id | BGR_SLOT_F0 | BGR_SLOT_F1 ; 0 = empty slot
+    uint32_t len;
+    uint64_t F;
+} BgrSlot;            // 16 B; a neighbour record is BgrSlot[8]: left-table slots 0..3, right-table slots 4..7
 
 typedef struct {
     uint32_t units;  // number of 48-position units on this level
@@ -100,7 +109,7 @@ typedef struct {
 typedef struct {
     const uint32_t* units;   // n_units * 4 u32  (x,y,z = 48 two-bit states, w = rank)
     const uint64_t* keys;
-    const uint32_t* recs;    // n_keys * 8 u32   (L0..L3, R0..R3)
+    const BgrSlot* recs;     // n_keys * 8 slots (L0..L3, R0..R3)
     const BgrUnitigMeta* meta;
     const uint64_t* seq;
     const BgrBlobHeader* hdr;
