@@ -27,7 +27,7 @@ SYMBOLS = [
     "bgr_aligner_sync", "bgr_aligner_device_results", "bgr_aligner_fetch", "bgr_aligner_counters",
     "bgr_aligner_reset_counters", "bgr_aligner_kernel_time", "bgr_aligner_reset_kernel_time", "bgr_aligner_launch_info",
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
-    "bgr_write_records",
+    "bgr_write_records", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
 ]
 
 
@@ -37,6 +37,11 @@ class BgrError(RuntimeError):
 
 class Params(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("max_mismatch", C.c_uint32), ("effort", C.c_uint32), ("partial", C.c_uint32)]
+
+
+class RunOptions(C.Structure):
+    _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
+                ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):
@@ -111,6 +116,10 @@ def lib():
     L.bgr_aligner_launch_info.argtypes = [vp, vp]
     L.bgr_aligner_configure.argtypes = [vp, u32, u32, u32]
     L.bgr_readset_load.argtypes = [C.c_char_p, i32, u32, C.POINTER(vp)]
+    L.bgr_readset_load_parallel.argtypes = [C.c_char_p, i32, u32, u32, u64, C.POINTER(vp)]
+    L.bgr_align_all.argtypes = [vp, C.POINTER(Params), C.POINTER(RunOptions), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_double)]
+    L.bgr_host_alloc.argtypes = [u64, C.POINTER(vp)]
+    L.bgr_host_free.argtypes = [vp]
     L.bgr_readset_count.restype = u64
     L.bgr_readset_count.argtypes = [vp]
     L.bgr_readset_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -271,10 +280,22 @@ class Aligner:
             pass
 
 
-def load_reads(path, k, fastq=False):
+def align_all(graph, reads_csv, paths_file, notaligned_file, m=2, effort=2, mode=MODE_GREEDY, partial=False, n_gpus=1, threads=1,
+              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False):
+    """Aligner::alignAll (aligner.cpp:550-597) as one call -> (counters dict, mapping seconds)."""
+    p = Params(mode, m, effort, int(partial))
+    o = RunOptions(n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, 0)
+    out = np.zeros(5, dtype=np.uint64)
+    secs = C.c_double()
+    _check(lib().bgr_align_all(graph.h, C.byref(p), C.byref(o), reads_csv.encode(), paths_file.encode(), notaligned_file.encode(),
+                               out.ctypes.data, C.byref(secs)))
+    return dict(zip(["reads", "no_overlap", "aligned", "not_aligned", "overlaps"], (int(x) for x in out))), secs.value
+
+
+def load_reads(path, k, fastq=False, threads=1, chunk_bytes=0):
     """getReads (aligner.cpp:46-117) over a whole file -> (reads u8[], read_offs u64[n+1], headers u8[], header_offs u64[n+1])."""
     h = C.c_void_p()
-    _check(lib().bgr_readset_load(path.encode(), int(fastq), k, C.byref(h)))
+    _check(lib().bgr_readset_load_parallel(path.encode(), int(fastq), k, threads, chunk_bytes, C.byref(h)))
     try:
         n = lib().bgr_readset_count(h)
         r, ro, hd, ho = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -32,6 +32,10 @@ const int kTimerRing = 256;
 
 }  // namespace
 
+namespace bgr {
+int set_error(int code, const std::string& msg) { return fail(code, msg); }  // for pipeline.cpp
+}
+
 struct bgr_graph {
     bgr::HostGraph host;  // empty when adopted from a device blob
     BgrBlobHeader header;
@@ -456,15 +460,41 @@ int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]) {
     return BGR_OK;
 }
 
+int bgr_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return fail(BGR_E_ARG, "bgr_host_alloc: null argument");
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    *out = p;
+    return BGR_OK;
+}
+
+int bgr_host_free(void* p) {
+    if (!p) return BGR_OK;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
+    return BGR_OK;
+}
+
 // ---- read files / output records (host) ---------------------------------------------------------------
 struct bgr_readset { bgr::ReadSet rs; };
 
 int bgr_readset_load(const char* path, int fastq, uint32_t k, bgr_readset** out) {
+    return bgr_readset_load_parallel(path, fastq, k, 1, 0, out);
+}
+
+int bgr_readset_load_parallel(const char* path, int fastq, uint32_t k, uint32_t threads, uint64_t chunk_bytes, bgr_readset** out) {
     if (!path || !out) return fail(BGR_E_ARG, "bgr_readset_load: null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(BGR_E_IO, std::string("cannot open read file ") + path);
+    std::vector<char> buf;
+    char tmp[1 << 16];
+    size_t got;
+    while ((got = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+    fclose(f);
     bgr_readset* r = new bgr_readset();
     r->rs.clear();
-    std::string err;
-    if (!bgr::parse_reads_file(path, fastq != 0, k, r->rs, err)) { delete r; return fail(BGR_E_IO, err); }
+    bgr::parse_reads_parallel(buf.data(), buf.size(), fastq != 0, k, threads ? threads : 1, chunk_bytes ? chunk_bytes : (8u << 20), r->rs);
     *out = r;
     return BGR_OK;
 }

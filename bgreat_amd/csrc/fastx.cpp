@@ -5,8 +5,10 @@
 // untouched"), and the two loops below are the same state machines driven through it.
 #include "fastx.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace bgr {
 
@@ -19,9 +21,9 @@ struct Slice {
 
 struct Cursor {
     const char* d;
-    uint64_t n, pos = 0;
+    uint64_t n, pos;
     bool eofbit = false, failbit = false;
-    Cursor(const char* data, uint64_t size) : d(data), n(size) {}
+    Cursor(const char* data, uint64_t begin, uint64_t end) : d(data), n(end), pos(begin) {}
     bool good() const { return !eofbit && !failbit; }
     // std::getline(stream, s): returns false when s is left untouched (stream was not good()).
     bool getline(Slice& s) {
@@ -40,71 +42,153 @@ struct Cursor {
     }
 };
 
+struct ValidTable {
+    bool ok[256];
+    ValidTable() { memset(ok, 0, sizeof(ok)); ok['A'] = ok['C'] = ok['G'] = ok['T'] = ok['N'] = true; }
+};
+const ValidTable kValid;
+
 inline bool valid_chars(const char* p, uint64_t n) {  // aligner.cpp:56-61
-    for (uint64_t i = 0; i < n; ++i) {
-        char c = p[i];
-        if (c != 'A' && c != 'C' && c != 'T' && c != 'G' && c != 'N') return false;
-    }
+    for (uint64_t i = 0; i < n; ++i)
+        if (!kValid.ok[(unsigned char)p[i]]) return false;
     return true;
 }
 
-inline void push(ReadSet& out, const char* h, uint64_t hn, const char* r, uint64_t rn) {
-    out.headers.insert(out.headers.end(), h, h + hn);
-    out.header_offs.push_back(out.headers.size());
-    out.reads.insert(out.reads.end(), r, r + rn);
-    out.read_offs.push_back(out.reads.size());
+inline void push(ParsedChunk& out, const Slice& h, const char* s, uint64_t sn, bool from_joined, const std::string& tmp) {
+    RecSlice r;
+    r.h = h.p;
+    r.hl = (uint32_t)h.n;
+    r.sl = (uint32_t)sn;
+    if (from_joined) {
+        r.s = reinterpret_cast<const char*>((uintptr_t)out.joined.size());
+        out.joined.append(tmp);
+        out.joined_idx.push_back((uint32_t)out.recs.size());
+    } else {
+        r.s = s;
+    }
+    out.recs.push_back(r);
+    out.seq_bytes += sn;
+    out.hdr_bytes += h.n;
 }
 
 const unsigned kBatch = 10000;  // alignerGreedy.cpp:375
 
+void to_readset(const ParsedChunk& c, ReadSet& out) {
+    for (const RecSlice& r : c.recs) {
+        out.headers.insert(out.headers.end(), r.h, r.h + r.hl);
+        out.header_offs.push_back(out.headers.size());
+        out.reads.insert(out.reads.end(), r.s, r.s + r.sl);
+        out.read_offs.push_back(out.reads.size());
+    }
+}
+
 }  // namespace
 
-void parse_reads(const char* data, uint64_t size, bool fastq, uint32_t k, ReadSet& out) {
-    if (out.read_offs.empty()) out.clear();
-    Cursor cur(data, size);
-    std::string joined;  // only for multi-line FASTA records
+void parse_fasta_chunk(const char* data, uint64_t begin, uint64_t end, uint32_t k, ParsedChunk& out) {
+    Cursor cur(data, begin, end);
+    std::string joined;
     while (!cur.eofbit) {  // alignerGreedy.cpp:372  while(!readFile.eof())
-        // ---- one getReads(multiread, 10000) call: its locals start empty ----------------------
-        Slice header, read, inter;
-        if (fastq) {
-            for (unsigned i = 0; i < kBatch; ++i) {
-                cur.getline(header);
-                cur.getline(read);  // untouched (== previous record's sequence) once the stream has failed
-                if (read.n > 2 && valid_chars(read.p, read.n)) push(out, header.p, header.n, read.p, read.n);
-                cur.getline(header);
-                cur.getline(header);
-                if (cur.eofbit) break;
-            }
-        } else {
-            bool returned = false;
-            for (unsigned i = 0; i < kBatch && !returned; ++i) {
-                cur.getline(header);
-                cur.getline(read);
-                bool multi = false;
-                for (;;) {
-                    int c = cur.peek();
-                    const char* rp = multi ? joined.data() : read.p;
-                    uint64_t rn = multi ? joined.size() : read.n;
-                    if (c == '>') {
-                        if (rn > 2 && valid_chars(rp, rn) && rn > k) push(out, header.p, header.n, rp, rn);
-                        read = Slice();  // aligner.cpp:91  read=""
-                        break;
+        Slice header, read, inter;  // one getReads() call: its locals start empty
+        bool returned = false;
+        for (unsigned i = 0; i < kBatch && !returned; ++i) {
+            cur.getline(header);
+            cur.getline(read);
+            bool multi = false;
+            for (;;) {
+                int c = cur.peek();
+                const char* rp = multi ? joined.data() : read.p;
+                uint64_t rn = multi ? joined.size() : read.n;
+                if (c == '>') {
+                    if (rn > 2 && valid_chars(rp, rn) && rn > k) push(out, header, rp, rn, multi, joined);
+                    read = Slice();  // aligner.cpp:91  read=""
+                    break;
+                }
+                if (!cur.eofbit) {
+                    cur.getline(inter);
+                    if (inter.n) {
+                        if (!multi) { joined.assign(read.p, read.n); multi = true; }
+                        joined.append(inter.p, inter.n);
                     }
-                    if (!cur.eofbit) {
-                        cur.getline(inter);
-                        if (inter.n) {
-                            if (!multi) { joined.assign(read.p, read.n); multi = true; }
-                            joined.append(inter.p, inter.n);
-                        }
-                    } else {
-                        if (rn > 2 && valid_chars(rp, rn) && rn > k) push(out, header.p, header.n, rp, rn);
-                        returned = true;
-                        break;
-                    }
+                } else {
+                    if (rn > 2 && valid_chars(rp, rn) && rn > k) push(out, header, rp, rn, multi, joined);
+                    returned = true;
+                    break;
                 }
             }
         }
     }
+    out.fixup();
+}
+
+void parse_fastq_image(const char* data, uint64_t size, ParsedChunk& out) {
+    Cursor cur(data, 0, size);
+    std::string none;
+    while (!cur.eofbit) {
+        Slice header, read;  // one getReads() call: its locals start empty
+        for (unsigned i = 0; i < kBatch; ++i) {
+            cur.getline(header);
+            cur.getline(read);  // untouched (== previous record's sequence) once the stream has failed
+            if (read.n > 2 && valid_chars(read.p, read.n)) push(out, header, read.p, read.n, false, none);
+            cur.getline(header);
+            cur.getline(header);
+            if (cur.eofbit) break;
+        }
+    }
+}
+
+std::vector<uint64_t> split_fasta(const char* data, uint64_t size, uint64_t chunk_bytes) {
+    std::vector<uint64_t> starts(1, 0);
+    if (chunk_bytes == 0) chunk_bytes = 1;
+    // Line 0 is a header whatever it starts with, so the line after it is sequence even if it starts with '>':
+    // a start point must have a previous line that is neither a '>' line nor line 0.
+    const char* nl0 = static_cast<const char*>(memchr(data, '\n', size));
+    const uint64_t line1 = nl0 ? (uint64_t)(nl0 - data) + 1 : size;
+    uint64_t target = chunk_bytes;
+    while (target < size) {
+        uint64_t p = target, found = size;
+        for (;;) {
+            const char* q = static_cast<const char*>(memchr(data + p, '\n', size - p));
+            if (!q) break;
+            const uint64_t ls = (uint64_t)(q - data) + 1;  // start of the next line
+            if (ls >= size) break;
+            if (data[ls] == '>') {
+                uint64_t ps = (uint64_t)(q - data);  // walk back to the start of the line that ends at q
+                while (ps > 0 && data[ps - 1] != '\n') --ps;
+                if (data[ps] != '>' && ps >= line1) { found = ls; break; }
+            }
+            p = ls;
+        }
+        if (found >= size) break;
+        starts.push_back(found);
+        target = found + chunk_bytes;
+    }
+    return starts;
+}
+
+void parse_reads(const char* data, uint64_t size, bool fastq, uint32_t k, ReadSet& out) {
+    if (out.read_offs.empty()) out.clear();
+    ParsedChunk c;
+    if (fastq) parse_fastq_image(data, size, c);
+    else parse_fasta_chunk(data, 0, size, k, c);
+    to_readset(c, out);
+}
+
+void parse_reads_parallel(const char* data, uint64_t size, bool fastq, uint32_t k, unsigned threads, uint64_t chunk_bytes, ReadSet& out) {
+    if (out.read_offs.empty()) out.clear();
+    if (fastq || threads <= 1) { parse_reads(data, size, fastq, k, out); return; }
+    std::vector<uint64_t> starts = split_fasta(data, size, chunk_bytes);
+    std::vector<ParsedChunk> chunks(starts.size());
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < threads; ++t) {
+        ts.emplace_back([&, t]() {
+            for (size_t c = t; c < starts.size(); c += threads) {
+                uint64_t e = c + 1 < starts.size() ? starts[c + 1] : size;
+                parse_fasta_chunk(data, starts[c], e, k, chunks[c]);
+            }
+        });
+    }
+    for (auto& t : ts) t.join();
+    for (const ParsedChunk& c : chunks) to_readset(c, out);
 }
 
 bool parse_reads_file(const std::string& path, bool fastq, uint32_t k, ReadSet& out, std::string& err) {

@@ -17,6 +17,25 @@ struct ReadSet {
     void clear() { reads.clear(); headers.clear(); read_offs.assign(1, 0); header_offs.assign(1, 0); }
 };
 
+// One accepted record as slices: the header always points into the file image; the sequence points into the file
+// image (single-line record) or into the owning chunk's `joined` storage (multi-line FASTA record).
+struct RecSlice {
+    const char* h;
+    const char* s;
+    uint32_t hl, sl;
+};
+
+struct ParsedChunk {
+    std::vector<RecSlice> recs;
+    std::string joined;          // storage of multi-line sequences; recs[].s of those are OFFSETS until fixup()
+    std::vector<uint32_t> joined_idx;  // indices of recs whose s is an offset into `joined`
+    uint64_t seq_bytes = 0, hdr_bytes = 0;
+    void fixup() {  // turn offsets into pointers once `joined` no longer grows
+        for (uint32_t i : joined_idx) recs[i].s = joined.data() + reinterpret_cast<uintptr_t>(recs[i].s);
+        joined_idx.clear();
+    }
+};
+
 // Parses a whole file (memory image) and appends the accepted records to `out`.
 // fastq=false: FASTA (multi-line sequences joined; record kept iff size>2, all chars in ACGTN, size>k).
 // fastq=true : 4-line records (kept iff size>2 and all chars in ACGTN; no size>k test), including the
@@ -24,6 +43,20 @@ struct ReadSet {
 //              file ends with a newline and the record count is not a multiple of the 10000-read batch.
 void parse_reads(const char* data, uint64_t size, bool fastq, uint32_t k, ReadSet& out);
 bool parse_reads_file(const std::string& path, bool fastq, uint32_t k, ReadSet& out, std::string& err);
+
+// ---- chunk-parallel form (same records, same order) --------------------------------------------------------
+// FASTA: the sequential reader's state after a record is "next line is a header", and a line that starts with
+// '>' ends the current record exactly when the line before it does not start with '>' (a '>' line right after a
+// header is consumed as sequence, aligner.cpp:72-73).  So every such position, except one whose previous line is
+// line 0 of the file, is a point where an independent reader can start.  split_fasta returns chunk start
+// offsets (first = 0) about `chunk_bytes` apart at such positions.
+std::vector<uint64_t> split_fasta(const char* data, uint64_t size, uint64_t chunk_bytes);
+// The reference's FASTA state machine over [begin, end) of the image, `end` acting as end-of-file.
+void parse_fasta_chunk(const char* data, uint64_t begin, uint64_t end, uint32_t k, ParsedChunk& out);
+// Whole-image FASTQ (sequential: record starts are only known by counting lines from the top).
+void parse_fastq_image(const char* data, uint64_t size, ParsedChunk& out);
+// Parallel whole-file parse into a ReadSet (threads >= 1); identical result to parse_reads().
+void parse_reads_parallel(const char* data, uint64_t size, bool fastq, uint32_t k, unsigned threads, uint64_t chunk_bytes, ReadSet& out);
 
 }  // namespace bgr
 #endif

@@ -1,0 +1,383 @@
+// pipeline.cpp -- bgr_align_all: the batch form of Aligner::alignAll (aligner.cpp:550-597) as a host pipeline.
+//
+//   reference:  N threads, each: lock; getReads(10000); unlock; per read alignRead*; lock; fwrite; unlock
+//   here     :  parse (chunk-parallel, exact getReads semantics, fastx.cpp)
+//                 -> batches of reads gathered into pinned memory
+//                 -> GPU workers (2 per device, each with its own bgr_aligner/stream: H2D, kernel, D2H of
+//                    consecutive batches overlap)
+//                 -> formatter (range-parallel printPath/record formatting) -> ONE writer, batches in input order
+//
+// so the bytes written are the reference's `-t 1` stream whatever the thread/GPU count.  Pure host C++: talks to
+// the GPU only through the C-ABI (bgr_aligner_create, bgr_align_batch, bgr_host_alloc ...).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bgreat_gpu.h"
+#include "fastx.h"
+
+namespace bgr {
+int set_error(int code, const std::string& msg);  // capi.hip
+}
+
+namespace {
+
+using bgr::ParsedChunk;
+using bgr::RecSlice;
+
+struct MappedFile {
+    const char* data = nullptr;
+    uint64_t size = 0;
+    int fd = -1;
+    bool mapped = false;
+    std::vector<char> fallback;
+    bool open(const std::string& path, std::string& err) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { err = "cannot open read file " + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0) { err = "cannot stat " + path; return false; }
+        size = (uint64_t)st.st_size;
+        if (size == 0) { data = ""; return true; }
+        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p != MAP_FAILED) {
+            data = static_cast<const char*>(p);
+            mapped = true;
+            madvise(p, size, MADV_SEQUENTIAL);
+            return true;
+        }
+        fallback.resize(size);  // pipes etc.: read it
+        uint64_t got = 0;
+        while (got < size) {
+            ssize_t r = ::read(fd, fallback.data() + got, size - got);
+            if (r <= 0) break;
+            got += (uint64_t)r;
+        }
+        size = got;
+        data = fallback.data();
+        return true;
+    }
+    ~MappedFile() {
+        if (mapped) munmap(const_cast<char*>(data), size);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+template <typename F>
+void parallel_for(unsigned threads, size_t n, F fn) {  // fn(task)
+    if (threads <= 1 || n <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> ts;
+    unsigned nt = (unsigned)std::min<size_t>(threads, n);
+    for (unsigned t = 0; t < nt; ++t) ts.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& t : ts) t.join();
+}
+
+struct PinnedBuf {
+    void* p = nullptr;
+    uint64_t cap = 0;
+    bool ensure(uint64_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) bgr_host_free(p);
+        p = nullptr; cap = 0;
+        uint64_t want = bytes + bytes / 4 + 4096;
+        if (bgr_host_alloc(want, &p) != BGR_OK) return false;
+        cap = want;
+        return true;
+    }
+    ~PinnedBuf() { if (p) bgr_host_free(p); }
+};
+
+struct Batch {
+    uint64_t index = 0;
+    std::shared_ptr<MappedFile> file;                     // keeps header/sequence slices valid
+    std::vector<std::unique_ptr<ParsedChunk>> chunks;
+    std::vector<std::pair<const ParsedChunk*, std::pair<uint32_t, uint32_t>>> spans;  // chunk, [first, last) records
+    uint64_t n = 0, bases = 0, path_cap = 0;
+    PinnedBuf reads, offs, paths, poffs, status;
+    std::vector<RecSlice> recs;                           // flattened view of the records of this batch
+    int rc = BGR_OK;
+    std::string err;
+};
+
+template <typename T>
+class Channel {  // bounded FIFO
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    bool push(T v) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_space_.wait(l, [&] { return q_.size() < cap_ || closed_; });
+        if (closed_) return false;
+        q_.push_back(std::move(v));
+        cv_item_.notify_one();
+        return true;
+    }
+    bool pop(T& v) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_item_.wait(l, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        cv_space_.notify_one();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> l(m_);
+        closed_ = true;
+        cv_item_.notify_all();
+        cv_space_.notify_all();
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_item_, cv_space_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+inline void append_int(std::string& b, int32_t v) {  // to_string(v) + '.'  (aligner.cpp:600-609)
+    char num[12];
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    int len = 0;
+    do { num[len++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) b.push_back('-');
+    while (len) b.push_back(num[--len]);
+    b.push_back('.');
+}
+
+void format_range(const Batch& b, uint64_t lo, uint64_t hi, std::string& pbuf, std::string& nbuf) {
+    const int32_t* paths = static_cast<const int32_t*>(b.paths.p);
+    const uint64_t* poffs = static_cast<const uint64_t*>(b.poffs.p);
+    for (uint64_t i = lo; i < hi; ++i) {
+        const RecSlice& r = b.recs[i];
+        if (poffs[i + 1] > poffs[i]) {  // alignerGreedy.cpp:406-411
+            pbuf.append(r.h, r.hl);
+            pbuf.push_back('\n');
+            for (uint64_t j = poffs[i]; j < poffs[i + 1]; ++j) append_int(pbuf, paths[j]);
+            pbuf.push_back('\n');
+        } else {  // alignerGreedy.cpp:421-427
+            nbuf.append(r.h, r.hl);
+            nbuf.push_back('\n');
+            nbuf.append(r.s, r.sl);
+            nbuf.push_back('\n');
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const char* reads_csv,
+                             const char* paths_file, const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds) {
+    if (!graph || !prm || !opt || !reads_csv || !paths_file || !notaligned_file) return bgr::set_error(BGR_E_ARG, "bgr_align_all: null argument");
+    const unsigned n_gpus = std::max<uint32_t>(1, opt->n_gpus);
+    const unsigned threads = std::max<uint32_t>(1, opt->threads);
+    const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes : (8ull << 20);
+    const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (2ull << 20);
+    const bool writes = prm->mode == BGR_MODE_GREEDY || opt->write_exhaustive;
+    bgr_graph_info_t gi;
+    if (bgr_graph_info(graph, &gi) != BGR_OK) return BGR_E_ARG;
+
+    FILE* pathF = fopen(paths_file, "wb");        // aligner.h:85
+    FILE* notF = fopen(notaligned_file, "wb");    // aligner.h:86
+    if (!pathF || !notF) {
+        if (pathF) fclose(pathF);
+        if (notF) fclose(notF);
+        return bgr::set_error(BGR_E_IO, "bgr_align_all: cannot open the output files");
+    }
+
+    // two aligners (streams) per device so that consecutive batches overlap copy and compute
+    const unsigned per_dev = 2;
+    std::vector<bgr_aligner*> aligners;
+    for (unsigned g = 0; g < n_gpus; ++g) {
+        for (unsigned j = 0; j < per_dev; ++j) {
+            bgr_aligner* a = nullptr;
+            int rc = bgr_aligner_create(graph, (int)g, &a);
+            if (rc != BGR_OK) {
+                for (auto* x : aligners) bgr_aligner_destroy(x);
+                fclose(pathF); fclose(notF);
+                return rc;
+            }
+            aligners.push_back(a);
+        }
+    }
+
+    auto t_start = std::chrono::steady_clock::now();
+    // A fixed pool of batch objects circulates producer -> GPU workers -> writer -> producer, so the pinned
+    // buffers are allocated once and the number of batches in flight is bounded.
+    const size_t max_batches = aligners.size() * 2 + 2;
+    Channel<std::unique_ptr<Batch>> to_gpu(max_batches), to_out(max_batches), free_batches(max_batches);
+    for (size_t i = 0; i < max_batches; ++i) free_batches.push(std::make_unique<Batch>());
+    std::atomic<bool> failed{false};
+    std::mutex err_m;
+    std::string first_err;
+    int first_rc = BGR_OK;
+    auto fail = [&](int rc, const std::string& msg) {
+        std::lock_guard<std::mutex> l(err_m);
+        if (!failed.exchange(true)) { first_rc = rc; first_err = msg; }
+    };
+
+    // ---- stage 1: parse + gather -----------------------------------------------------------------------
+    std::thread producer([&]() {
+        uint64_t next_index = 0;
+        std::string list(reads_csv);
+        size_t last = 0;
+        auto emit = [&](std::unique_ptr<Batch> b) {  // gather the sequences of a batch into pinned memory
+            b->index = next_index++;
+            b->n = b->recs.size();
+            uint64_t bases = 0;
+            if (!b->offs.ensure((b->n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            uint64_t* offs = static_cast<uint64_t*>(b->offs.p);
+            for (uint64_t i = 0; i < b->n; ++i) { offs[i] = bases; bases += b->recs[i].sl; }
+            offs[b->n] = bases;
+            b->bases = bases;
+            b->path_cap = 32 * b->n + 64;  // typical paths are a handful of ints; the worker retries with the full bound if not
+            if (!b->reads.ensure(bases + 16) || !b->paths.ensure(b->path_cap * 4) || !b->poffs.ensure((b->n + 1) * 8) ||
+                !b->status.ensure(b->n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            char* dst = static_cast<char*>(b->reads.p);
+            const uint64_t per = (b->n + threads - 1) / threads;
+            Batch* bp = b.get();
+            parallel_for(threads, threads, [&](size_t t) {
+                uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
+                for (uint64_t i = lo; i < hi; ++i) memcpy(dst + offs[i], bp->recs[i].s, bp->recs[i].sl);
+            });
+            return to_gpu.push(std::move(b));
+        };
+        for (size_t i = 0; i <= list.size() && !failed; ++i) {  // aligner.cpp:552-586: comma-separated list
+            if (i != list.size() && list[i] != ',') continue;
+            std::string file = list.substr(last, i - last);
+            last = i + 1;
+            if (opt->echo_files) std::cout << file << std::endl;  // aligner.cpp:559,576
+            auto mf = std::make_shared<MappedFile>();
+            std::string err;
+            if (!mf->open(file, err)) { fail(BGR_E_IO, err); break; }
+            if (opt->fastq) {
+                auto whole = std::make_unique<ParsedChunk>();
+                bgr::parse_fastq_image(mf->data, mf->size, *whole);  // slices point into the file image only
+                const ParsedChunk* wc = whole.get();
+                for (uint64_t lo = 0; lo < wc->recs.size() && !failed; lo += batch_reads) {
+                    std::unique_ptr<Batch> b;
+                    if (!free_batches.pop(b)) break;
+                    b->file = mf;
+                    uint64_t hi = std::min<uint64_t>(wc->recs.size(), lo + batch_reads);
+                    b->recs.assign(wc->recs.begin() + lo, wc->recs.begin() + hi);
+                    if (!emit(std::move(b))) break;
+                }
+                continue;
+            }
+            std::vector<uint64_t> starts = bgr::split_fasta(mf->data, mf->size, chunk_bytes);
+            size_t c = 0;
+            while (c < starts.size() && !failed) {
+                // as many chunks as it takes to reach ~batch_reads (estimated from bytes), at least `threads`
+                size_t group = std::max<size_t>(threads, (size_t)((batch_reads * 170) / chunk_bytes));
+                size_t c_end = std::min(starts.size(), c + group);
+                std::unique_ptr<Batch> b;
+                if (!free_batches.pop(b)) break;
+                b->file = mf;
+                b->chunks.resize(c_end - c);
+                for (auto& ch : b->chunks) ch = std::make_unique<ParsedChunk>();
+                Batch* bp = b.get();
+                parallel_for(threads, c_end - c, [&](size_t j) {
+                    uint64_t e = (c + j + 1 < starts.size()) ? starts[c + j + 1] : mf->size;
+                    bgr::parse_fasta_chunk(mf->data, starts[c + j], e, gi.k, *bp->chunks[j]);
+                });
+                size_t total = 0;
+                for (auto& ch : b->chunks) total += ch->recs.size();
+                b->recs.reserve(total);
+                for (auto& ch : b->chunks) b->recs.insert(b->recs.end(), ch->recs.begin(), ch->recs.end());
+                c = c_end;
+                if (b->recs.empty()) { b->chunks.clear(); b->file.reset(); free_batches.push(std::move(b)); continue; }
+                if (!emit(std::move(b))) break;
+            }
+        }
+        to_gpu.close();
+    });
+
+    // ---- stage 2: GPU workers --------------------------------------------------------------------------
+    std::vector<std::thread> workers;
+    std::atomic<unsigned> live_workers{(unsigned)aligners.size()};
+    for (size_t w = 0; w < aligners.size(); ++w) {
+        workers.emplace_back([&, w]() {
+            std::unique_ptr<Batch> b;
+            while (to_gpu.pop(b)) {
+                if (!failed) {
+                    int rc = bgr_align_batch(aligners[w], prm, static_cast<const char*>(b->reads.p), static_cast<const uint64_t*>(b->offs.p), b->n,
+                                             static_cast<int32_t*>(b->paths.p), b->path_cap, static_cast<uint64_t*>(b->poffs.p),
+                                             static_cast<uint8_t*>(b->status.p));
+                    if (rc == BGR_E_CAPACITY) {  // unusually long paths: fetch the same device results again into a full-size buffer
+                        b->path_cap = b->bases + 8 * b->n + 8;
+                        if (!b->paths.ensure(b->path_cap * 4)) rc = BGR_E_HIP;
+                        else rc = bgr_aligner_fetch(aligners[w], b->n, static_cast<int32_t*>(b->paths.p), b->path_cap, static_cast<uint64_t*>(b->poffs.p),
+                                                    static_cast<uint8_t*>(b->status.p));
+                    }
+                    if (rc != BGR_OK) fail(rc, bgr_last_error());
+                }
+                if (!to_out.push(std::move(b))) break;
+            }
+            if (--live_workers == 0) to_out.close();
+        });
+    }
+
+    // ---- stage 3: format + ordered write -----------------------------------------------------------------
+    std::thread writer([&]() {
+        std::map<uint64_t, std::unique_ptr<Batch>> pending;
+        uint64_t want = 0;
+        std::unique_ptr<Batch> b;
+        std::vector<std::string> pb(threads), nb(threads);
+        while (to_out.pop(b)) {
+            pending[b->index] = std::move(b);
+            while (!pending.empty() && pending.begin()->first == want) {
+                std::unique_ptr<Batch> cur = std::move(pending.begin()->second);
+                pending.erase(pending.begin());
+                ++want;
+                struct Recycle {  // hand the batch (and its pinned buffers) back to the producer
+                    Channel<std::unique_ptr<Batch>>& ch; std::unique_ptr<Batch>& b;
+                    ~Recycle() { b->recs.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
+                } recycle{free_batches, cur};
+                if (failed || !writes) continue;
+                const uint64_t per = (cur->n + threads - 1) / threads;
+                Batch* cp = cur.get();
+                parallel_for(threads, threads, [&](size_t t) {
+                    pb[t].clear(); nb[t].clear();
+                    uint64_t lo = t * per, hi = std::min<uint64_t>(cp->n, lo + per);
+                    if (lo < hi) format_range(*cp, lo, hi, pb[t], nb[t]);
+                });
+                for (unsigned t = 0; t < threads; ++t) {
+                    if (!pb[t].empty() && fwrite(pb[t].data(), 1, pb[t].size(), pathF) != pb[t].size()) fail(BGR_E_IO, "write to the paths file failed");
+                    if (!nb[t].empty() && fwrite(nb[t].data(), 1, nb[t].size(), notF) != nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
+                }
+            }
+        }
+    });
+
+    producer.join();
+    for (auto& t : workers) t.join();
+    writer.join();
+    free_batches.close();
+    fclose(pathF);
+    fclose(notF);
+    uint64_t tot[5] = {0, 0, 0, 0, 0};
+    for (auto* a : aligners) {
+        uint64_t c5[5];
+        if (!failed && bgr_aligner_counters(a, c5) == BGR_OK) for (int j = 0; j < 5; ++j) tot[j] += c5[j];
+        bgr_aligner_destroy(a);
+    }
+    if (counters_out) memcpy(counters_out, tot, sizeof(tot));
+    if (mapping_seconds) *mapping_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (failed) return bgr::set_error(first_rc, first_err);
+    return BGR_OK;
+}

@@ -141,6 +141,8 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
  * multi-line FASTA, the FASTQ phantom record).  Buffers are owned by the returned object. */
 typedef struct bgr_readset bgr_readset;
 int bgr_readset_load(const char* path, int fastq, uint32_t k, bgr_readset** out);
+/* Same records in the same order, parsed by `threads` host threads over chunks of ~chunk_bytes (0 = default). */
+int bgr_readset_load_parallel(const char* path, int fastq, uint32_t k, uint32_t threads, uint64_t chunk_bytes, bgr_readset** out);
 uint64_t bgr_readset_count(const bgr_readset* rs);
 /* reads_concat / read_offsets[n+1] / headers_concat / header_offsets[n+1] */
 int bgr_readset_view(const bgr_readset* rs, const char** reads, const uint64_t** read_offsets, const char** headers, const uint64_t** header_offsets);
@@ -151,6 +153,28 @@ void bgr_readset_destroy(bgr_readset* rs);
  * others to `notaligned_file` (both FILE* opened by the caller, passed as void*). */
 int bgr_write_records(void* paths_file, void* notaligned_file, uint64_t n_reads, const char* headers, const uint64_t* header_offsets,
                       const char* reads, const uint64_t* read_offsets, const int32_t* paths, const uint64_t* path_offsets);
+
+/* ---- whole run -------------------------------------------------------------------------------------
+ * Batch form of Aligner::alignAll (aligner.cpp:550-597): maps every file of the comma-separated list `reads_csv`
+ * and writes `paths_file` / `notaligned_file` (opened "wb" like aligner.h:85-86) with the bytes the reference
+ * produces at -t 1, whatever the thread / GPU count.  Host pipeline: chunk-parallel parsing, pinned batches,
+ * two streams per device, range-parallel formatting, one ordered writer.  counters_out as bgr_aligner_counters. */
+typedef struct {
+    uint32_t n_gpus;           /* devices 0..n_gpus-1 (0 = 1)                                                  */
+    uint32_t threads;          /* host threads for parsing / gathering / formatting (-t; 0 = 1)                */
+    uint64_t batch_reads;      /* target reads per device batch (0 = default 2M)                                */
+    uint64_t chunk_bytes;      /* parser chunk size (0 = default 8 MiB)                                         */
+    uint32_t fastq;            /* -q                                                                            */
+    uint32_t write_exhaustive; /* exhaustive mode writes nothing in the reference; 1 = write  */
+    uint32_t echo_files;       /* print each file name to stdout before mapping it (aligner.cpp:559,576)        */
+    uint32_t reserved;
+} bgr_run_options;
+int bgr_align_all(bgr_graph* g, const bgr_params* p, const bgr_run_options* o, const char* reads_csv, const char* paths_file,
+                  const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds);
+
+/* Page-locked host memory for batches handed to bgr_align_batch (faster H2D/D2H); plain memory works too. */
+int bgr_host_alloc(uint64_t bytes, void** out);
+int bgr_host_free(void* p);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,33 @@ def test_parser_corner_cases_match_oracle(text, fastq):
         os.unlink(p)
 
 
+@pytest.mark.parametrize("name,k", [("edge_reads.fa", 31), ("syn_r150.fa", 31), ("deg_reads.fa", 5), ("toy_reads.fa", 4), ("long_r150.fa", 31)])
+@pytest.mark.parametrize("chunk", [1, 7, 64, 300, 4096])
+def test_chunk_parallel_parser_equals_sequential(name, k, chunk):
+    """split_fasta may only cut where an independent reader is in the same state as the sequential one."""
+    path = os.path.join(GOLD, name)
+    a = B.load_reads(path, k, False, threads=4, chunk_bytes=chunk)
+    b = oracle_py.parse_file(path, k, False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("text", [
+    b">a\n>b\nACGTACGT\n>c\nACGTACGTAA\n", b"ACGTACGT\n>x\nACGTACGT\n>y\nACGTACGTT\n", b">a\nACGTACGT\n\n>b\nACGTACGTA\n>c\n>d\n>e\nACGTAAAA\n",
+    b">a\nACGTACGT\n>b\n>ACGT\n>c\nGGGGGGGG\n\n\n>d\nTTTTTTTT", b"\n\n>a\nACGTACGT\n>b\nCCCCCCCC\n", b">a\r\nACGTACGT\r\n>b\r\nACGTACGG\r\n",
+    b">a\nACGT\nACGT\n>b\nAC\nGT\nAC\nGT\nAAAA\n>c\nACGTNNNN\n"])
+def test_chunk_parallel_parser_torture(text):
+    p = _write_tmp(text)
+    try:
+        want = oracle_py.parse_file(p, 5, False)
+        for chunk in (1, 2, 3, 5, 8, 13, 1000):
+            got = B.load_reads(p, 5, False, threads=3, chunk_bytes=chunk)
+            for x, y in zip(got, want):
+                assert np.array_equal(x, y), (text, chunk)
+    finally:
+        os.unlink(p)
+
+
 def test_fastq_phantom_depends_on_batch_boundary():
     """aligner.cpp:51-68: the phantom record appears unless the record count is a multiple of the 10000-read batch."""
     rec = b"@r\nACGTACGTAC\n+\nIIIIIIIIII\n"

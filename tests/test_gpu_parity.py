@@ -87,6 +87,30 @@ def test_cli_matches_reference_golden(case):
     check_against_golden(case, out, paths, na)
 
 
+@pytest.mark.parametrize("case", [c for c in GREEDY if c["group"] in ("edge", "multi", "syn", "deg")][::5],
+                         ids=lambda c: "%02d-%s" % (c["id"], c["group"]))
+def test_cli_pipeline_threads_and_tiny_chunks_keep_the_t1_stream(case):
+    """Any thread count, batch size and parser chunk size must give the reference's -t 1 bytes."""
+    out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]) + ["-t", "5", "--batch", "37", "--chunk-bytes", "600"])
+    check_against_golden(case, out, paths, na)
+
+
+def test_cli_end_to_end_against_reference_binary(oracle_bins):
+    """200k reads through the whole host pipeline (mmap, chunk-parallel parse, pinned batches, 2 streams, parallel
+    formatting, ordered writer) == the compiled reference at -t 1, byte for byte."""
+    ref = oracle_bins["ref"] or oracle_bins["cli"]
+    with tempfile.TemporaryDirectory() as d:
+        s = Synth(500000, 120, 2, 31, 4242)
+        s.write_unitigs(os.path.join(d, "u.fa"))
+        s.write_reads(os.path.join(d, "r.fa"), 0, 200000, 150, 3, 4243)
+        args = ["-r", os.path.join(d, "r.fa"), "-k", "31", "-g", os.path.join(d, "u.fa"), "-m", "2"]
+        o1, p1, n1 = run_cli(ref, args + ["-t", "1"])
+        o2, p2, n2 = run_cli(B.CLI_PATH, args + ["-t", "8", "--batch", "30000", "--chunk-bytes", "1000000"])
+        from util import parse_counters
+        assert parse_counters(o1) == parse_counters(o2)
+        assert p1 == p2 and n1 == n2
+
+
 def test_cli_exhaustive_writes_nothing_unless_asked():
     case = next(c for c in EXH if c["args"][1] == "syn_r150.fa" and c["args"][7] == "2")
     out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]))
