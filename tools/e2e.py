@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the `bgreat` CLI (file in -> files out) on the GPU box: index build excluded, everything
+else included (mmap + parse + H2D + kernel + D2H + format + write).  Prints one JSON line.
+
+    python tools/e2e.py [--reads 10000000] [--threads 16] [--gpus 1] [--check 1000000]
+"""
+import argparse
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.synth import Synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--check", type=int, default=500_000, help="reads also mapped by the reference binary (-t 1) and compared byte for byte")
+    ap.add_argument("--genome", type=int, default=4_600_000)
+    ap.add_argument("--site-spacing", type=int, default=140)
+    ap.add_argument("--fastq", action="store_true")
+    ap.add_argument("--tmp", default=None)
+    args = ap.parse_args()
+    cli = os.path.join(ROOT, "bgreat_amd", "bin", "bgreat")
+    ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
+    d = tempfile.mkdtemp(prefix="bgr_e2e_", dir=args.tmp)
+    try:
+        s = Synth(args.genome, args.site_spacing, 2, 31, 20261003)
+        s.write_unitigs(os.path.join(d, "u.fa"))
+        ext = "fq" if args.fastq else "fa"
+        t0 = time.time()
+        s.write_reads(os.path.join(d, "r." + ext), 0, args.reads, args.read_len, 2, 77, fastq=args.fastq, threads=args.threads)
+        gen_s = time.time() - t0
+        fsize = os.path.getsize(os.path.join(d, "r." + ext))
+        base = ["-r", os.path.join(d, "r." + ext), "-k", "31", "-g", os.path.join(d, "u.fa"), "-m", "2", "-t", str(args.threads), "--gpus", str(args.gpus)]
+        if args.batch:
+            base += ["--batch", str(args.batch)]
+        if args.fastq:
+            base.append("-q")
+        env = dict(os.environ, BGREAT_TIMING="1")
+        out = {}
+        for rep in range(2):  # second run: page cache warm, device warm
+            rd = os.path.join(d, "run%d" % rep)
+            os.makedirs(rd)
+            t0 = time.time()
+            p = subprocess.run([cli] + base, cwd=rd, env=env, capture_output=True, text=True, check=True)
+            wall = time.time() - t0
+            line = [l for l in p.stderr.splitlines() if l.startswith("bgreat: mapping")][-1]
+            secs = float(line.split()[2])
+            out["run%d" % rep] = {"wall_s": round(wall, 3), "mapping_s": secs, "mreads_per_s": round(args.reads / secs / 1e6, 3),
+                                  "input_GB_per_s": round(fsize / secs / 1e9, 3)}
+        res = {"reads": args.reads, "read_len": args.read_len, "threads": args.threads, "gpus": args.gpus, "input_bytes": fsize,
+               "generate_s": round(gen_s, 1), **out}
+        if args.check and os.path.exists(ref):
+            n = min(args.check, args.reads)
+            s.write_reads(os.path.join(d, "c." + ext), 0, n, args.read_len, 2, 77, fastq=args.fastq, threads=args.threads)
+            cargs = ["-r", os.path.join(d, "c." + ext), "-k", "31", "-g", os.path.join(d, "u.fa"), "-m", "2"] + (["-q"] if args.fastq else [])
+            ra, rb = os.path.join(d, "ca"), os.path.join(d, "cb")
+            os.makedirs(ra)
+            os.makedirs(rb)
+            t0 = time.time()
+            subprocess.run([ref] + cargs + ["-t", "1"], cwd=ra, check=True, stdout=subprocess.DEVNULL)
+            ref_s = time.time() - t0
+            subprocess.run([cli] + cargs + ["-t", str(args.threads)], cwd=rb, check=True, stdout=subprocess.DEVNULL)
+            same = all(hashlib.sha256(open(os.path.join(ra, f), "rb").read()).digest() == hashlib.sha256(open(os.path.join(rb, f), "rb").read()).digest()
+                       for f in ("paths", "notAligned.fa"))
+            res["check"] = {"reads": n, "identical_to_reference_t1": bool(same), "reference_t1_wall_s": round(ref_s, 2)}
+        print(json.dumps(res), flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -169,6 +169,42 @@ void syn_reads(void* h, uint64_t first, uint64_t n, uint32_t L, uint32_t max_sub
     }
     for (auto& t : ts) t.join();
 }
+// same file as syn_write_reads, formatted by `threads` threads in blocks (for multi-GB benchmark inputs)
+int syn_write_reads_mt(void* h, const char* path, uint64_t first, uint64_t n, uint32_t L, uint32_t max_sub, uint64_t seed, int fastq, int threads) {
+    const Synth& s = *static_cast<Synth*>(h);
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    if (threads < 1) threads = 1;
+    const uint64_t block = 1 << 18;
+    std::string qual(L, 'I');
+    for (uint64_t b0 = 0; b0 < n; b0 += block * threads) {
+        std::vector<std::string> bufs(threads);
+        std::vector<std::thread> ts;
+        for (int t = 0; t < threads; ++t) {
+            ts.emplace_back([&, t]() {
+                uint64_t lo = b0 + block * t, hi = std::min<uint64_t>(n, lo + block);
+                if (lo >= hi) return;
+                std::string& o = bufs[t];
+                o.reserve((hi - lo) * (L + 16) * (fastq ? 2 : 1));
+                std::vector<char> rd(L);
+                char hd[32];
+                for (uint64_t i = lo; i < hi; ++i) {
+                    make_read(s, first + i, L, max_sub, seed, rd.data());
+                    int hl = snprintf(hd, sizeof(hd), "%cr%llu\n", fastq ? '@' : '>', (unsigned long long)(first + i));
+                    o.append(hd, hl);
+                    o.append(rd.data(), L);
+                    o.push_back('\n');
+                    if (fastq) { o.append("+\n"); o.append(qual); o.push_back('\n'); }
+                }
+            });
+        }
+        for (auto& t : ts) t.join();
+        for (auto& o : bufs) if (!o.empty()) fwrite(o.data(), 1, o.size(), f);
+    }
+    fclose(f);
+    return 0;
+}
+
 int syn_write_reads(void* h, const char* path, uint64_t first, uint64_t n, uint32_t L, uint32_t max_sub, uint64_t seed, int fastq) {
     const Synth& s = *static_cast<Synth*>(h);
     FILE* f = fopen(path, "wb");

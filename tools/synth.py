@@ -12,7 +12,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libsynth.so")
-        if not os.path.exists(so):
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "synth.cpp")):
             subprocess.check_call(["make", "-C", _HERE, "libsynth.so"])
         L = C.CDLL(so)
         L.syn_create.restype = C.c_void_p
@@ -26,6 +26,7 @@ def lib():
         L.syn_write_unitigs.argtypes = [C.c_void_p, C.c_char_p]
         L.syn_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
         L.syn_write_reads.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
+        L.syn_write_reads_mt.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
         _LIB = L
     return _LIB
 
@@ -61,5 +62,8 @@ class Synth:
         offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
         return out, offs
 
-    def write_reads(self, path, first, n, L, max_sub, seed, fastq=False):
-        assert lib().syn_write_reads(self.h, path.encode(), first, n, L, max_sub, seed, int(fastq)) == 0
+    def write_reads(self, path, first, n, L, max_sub, seed, fastq=False, threads=1):
+        if threads > 1:
+            assert lib().syn_write_reads_mt(self.h, path.encode(), first, n, L, max_sub, seed, int(fastq), threads) == 0
+        else:
+            assert lib().syn_write_reads(self.h, path.encode(), first, n, L, max_sub, seed, int(fastq)) == 0
