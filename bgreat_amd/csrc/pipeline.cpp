@@ -19,6 +19,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <iostream>
@@ -127,6 +128,14 @@ public:
         cv_item_.notify_one();
         return true;
     }
+    bool try_pop(T& v) {
+        std::lock_guard<std::mutex> l(m_);
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        cv_space_.notify_one();
+        return true;
+    }
     bool pop(T& v) {
         std::unique_lock<std::mutex> l(m_);
         cv_item_.wait(l, [&] { return !q_.empty() || closed_; });
@@ -221,7 +230,16 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     // buffers are allocated once and the number of batches in flight is bounded.
     const size_t max_batches = aligners.size() * 2 + 2;
     Channel<std::unique_ptr<Batch>> to_gpu(max_batches), to_out(max_batches), free_batches(max_batches);
-    for (size_t i = 0; i < max_batches; ++i) free_batches.push(std::make_unique<Batch>());
+    std::atomic<size_t> created{0};
+    auto take_batch = [&](std::unique_ptr<Batch>& b) {  // reuse a finished batch; create one only while below the cap
+        if (free_batches.try_pop(b)) return true;
+        if (created.fetch_add(1) < max_batches) { b = std::make_unique<Batch>(); return true; }
+        created.fetch_sub(1);
+        return free_batches.pop(b);
+    };
+    const bool timing = getenv("BGREAT_TIMING") != nullptr;
+    std::atomic<uint64_t> us_parse{0}, us_gather{0}, us_gpu{0}, us_format{0}, us_write{0}, us_alloc{0};
+    auto now_us = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<bool> failed{false};
     std::mutex err_m;
     std::string first_err;
@@ -240,21 +258,25 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             b->index = next_index++;
             b->n = b->recs.size();
             uint64_t bases = 0;
+            const uint64_t tg0 = now_us();
             if (!b->offs.ensure((b->n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
             uint64_t* offs = static_cast<uint64_t*>(b->offs.p);
             for (uint64_t i = 0; i < b->n; ++i) { offs[i] = bases; bases += b->recs[i].sl; }
             offs[b->n] = bases;
             b->bases = bases;
-            b->path_cap = 32 * b->n + 64;  // typical paths are a handful of ints; the worker retries with the full bound if not
+            b->path_cap = 12 * b->n + 4096;  // typical paths are a handful of ints; the worker retries with the full bound if not
             if (!b->reads.ensure(bases + 16) || !b->paths.ensure(b->path_cap * 4) || !b->poffs.ensure((b->n + 1) * 8) ||
                 !b->status.ensure(b->n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
             char* dst = static_cast<char*>(b->reads.p);
+            us_alloc += now_us() - tg0;
+            const uint64_t tg1 = now_us();
             const uint64_t per = (b->n + threads - 1) / threads;
             Batch* bp = b.get();
             parallel_for(threads, threads, [&](size_t t) {
                 uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
                 for (uint64_t i = lo; i < hi; ++i) memcpy(dst + offs[i], bp->recs[i].s, bp->recs[i].sl);
             });
+            us_gather += now_us() - tg1;
             return to_gpu.push(std::move(b));
         };
         for (size_t i = 0; i <= list.size() && !failed; ++i) {  // aligner.cpp:552-586: comma-separated list
@@ -271,7 +293,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 const ParsedChunk* wc = whole.get();
                 for (uint64_t lo = 0; lo < wc->recs.size() && !failed; lo += batch_reads) {
                     std::unique_ptr<Batch> b;
-                    if (!free_batches.pop(b)) break;
+                    if (!take_batch(b)) break;
                     b->file = mf;
                     uint64_t hi = std::min<uint64_t>(wc->recs.size(), lo + batch_reads);
                     b->recs.assign(wc->recs.begin() + lo, wc->recs.begin() + hi);
@@ -286,11 +308,12 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 size_t group = std::max<size_t>(threads, (size_t)((batch_reads * 170) / chunk_bytes));
                 size_t c_end = std::min(starts.size(), c + group);
                 std::unique_ptr<Batch> b;
-                if (!free_batches.pop(b)) break;
+                if (!take_batch(b)) break;
                 b->file = mf;
                 b->chunks.resize(c_end - c);
                 for (auto& ch : b->chunks) ch = std::make_unique<ParsedChunk>();
                 Batch* bp = b.get();
+                const uint64_t tp0 = now_us();
                 parallel_for(threads, c_end - c, [&](size_t j) {
                     uint64_t e = (c + j + 1 < starts.size()) ? starts[c + j + 1] : mf->size;
                     bgr::parse_fasta_chunk(mf->data, starts[c + j], e, gi.k, *bp->chunks[j]);
@@ -299,6 +322,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 for (auto& ch : b->chunks) total += ch->recs.size();
                 b->recs.reserve(total);
                 for (auto& ch : b->chunks) b->recs.insert(b->recs.end(), ch->recs.begin(), ch->recs.end());
+                us_parse += now_us() - tp0;
                 c = c_end;
                 if (b->recs.empty()) { b->chunks.clear(); b->file.reset(); free_batches.push(std::move(b)); continue; }
                 if (!emit(std::move(b))) break;
@@ -315,6 +339,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             std::unique_ptr<Batch> b;
             while (to_gpu.pop(b)) {
                 if (!failed) {
+                    const uint64_t tq0 = now_us();
                     int rc = bgr_align_batch(aligners[w], prm, static_cast<const char*>(b->reads.p), static_cast<const uint64_t*>(b->offs.p), b->n,
                                              static_cast<int32_t*>(b->paths.p), b->path_cap, static_cast<uint64_t*>(b->poffs.p),
                                              static_cast<uint8_t*>(b->status.p));
@@ -325,6 +350,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                                                     static_cast<uint8_t*>(b->status.p));
                     }
                     if (rc != BGR_OK) fail(rc, bgr_last_error());
+                    us_gpu += now_us() - tq0;
                 }
                 if (!to_out.push(std::move(b))) break;
             }
@@ -351,15 +377,19 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 if (failed || !writes) continue;
                 const uint64_t per = (cur->n + threads - 1) / threads;
                 Batch* cp = cur.get();
+                const uint64_t tf0 = now_us();
                 parallel_for(threads, threads, [&](size_t t) {
                     pb[t].clear(); nb[t].clear();
                     uint64_t lo = t * per, hi = std::min<uint64_t>(cp->n, lo + per);
                     if (lo < hi) format_range(*cp, lo, hi, pb[t], nb[t]);
                 });
+                const uint64_t tf1 = now_us();
+                us_format += tf1 - tf0;
                 for (unsigned t = 0; t < threads; ++t) {
                     if (!pb[t].empty() && fwrite(pb[t].data(), 1, pb[t].size(), pathF) != pb[t].size()) fail(BGR_E_IO, "write to the paths file failed");
                     if (!nb[t].empty() && fwrite(nb[t].data(), 1, nb[t].size(), notF) != nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
                 }
+                us_write += now_us() - tf1;
             }
         }
     });
@@ -378,6 +408,9 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     }
     if (counters_out) memcpy(counters_out, tot, sizeof(tot));
     if (mapping_seconds) *mapping_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (timing)
+        fprintf(stderr, "bgreat: stage busy time (s): parse %.3f  alloc %.3f  gather %.3f  gpu(sum over %zu workers) %.3f  format %.3f  write %.3f\n",
+                us_parse / 1e6, us_alloc / 1e6, us_gather / 1e6, aligners.size(), us_gpu / 1e6, us_format / 1e6, us_write / 1e6);
     if (failed) return bgr::set_error(first_rc, first_err);
     return BGR_OK;
 }

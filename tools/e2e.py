@@ -58,6 +58,9 @@ def main():
             wall = time.time() - t0
             line = [l for l in p.stderr.splitlines() if l.startswith("bgreat: mapping")][-1]
             secs = float(line.split()[2])
+            stages = [l for l in p.stderr.splitlines() if "stage busy" in l]
+            if stages:
+                print(stages[-1], file=sys.stderr)
             out["run%d" % rep] = {"wall_s": round(wall, 3), "mapping_s": secs, "mreads_per_s": round(args.reads / secs / 1e6, 3),
                                   "input_GB_per_s": round(fsize / secs / 1e9, 3)}
         res = {"reads": args.reads, "read_len": args.read_len, "threads": args.threads, "gpus": args.gpus, "input_bytes": fsize,
