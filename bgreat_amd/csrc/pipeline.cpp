@@ -159,33 +159,48 @@ private:
     bool closed_ = false;
 };
 
-inline void append_int(std::string& b, int32_t v) {  // to_string(v) + '.'  (aligner.cpp:600-609)
+inline char* put_int(char* o, int32_t v) {  // to_string(v) + '.'  (aligner.cpp:600-609)
     char num[12];
     uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
     int len = 0;
     do { num[len++] = (char)('0' + u % 10); u /= 10; } while (u);
-    if (v < 0) b.push_back('-');
-    while (len) b.push_back(num[--len]);
-    b.push_back('.');
+    if (v < 0) *o++ = '-';
+    while (len) *o++ = num[--len];
+    *o++ = '.';
+    return o;
 }
 
+// Records lo..hi of a batch as the reference writes them: mapped -> "header\n" + "int." * n + "\n" into pbuf
+// (alignerGreedy.cpp:406-411), the others -> "header\nread\n" into nbuf (alignerGreedy.cpp:421-427).
 void format_range(const Batch& b, uint64_t lo, uint64_t hi, std::string& pbuf, std::string& nbuf) {
     const int32_t* paths = static_cast<const int32_t*>(b.paths.p);
     const uint64_t* poffs = static_cast<const uint64_t*>(b.poffs.p);
+    uint64_t pmax = 0, nmax = 0;  // exact upper bounds, so the loop below writes through raw pointers
     for (uint64_t i = lo; i < hi; ++i) {
         const RecSlice& r = b.recs[i];
-        if (poffs[i + 1] > poffs[i]) {  // alignerGreedy.cpp:406-411
-            pbuf.append(r.h, r.hl);
-            pbuf.push_back('\n');
-            for (uint64_t j = poffs[i]; j < poffs[i + 1]; ++j) append_int(pbuf, paths[j]);
-            pbuf.push_back('\n');
-        } else {  // alignerGreedy.cpp:421-427
-            nbuf.append(r.h, r.hl);
-            nbuf.push_back('\n');
-            nbuf.append(r.s, r.sl);
-            nbuf.push_back('\n');
+        const uint64_t np = poffs[i + 1] - poffs[i];
+        if (np) pmax += r.hl + 2 + 12 * np; else nmax += (uint64_t)r.hl + r.sl + 2;
+    }
+    pbuf.resize(pmax);
+    nbuf.resize(nmax);
+    char* po = pmax ? &pbuf[0] : nullptr;
+    char* no = nmax ? &nbuf[0] : nullptr;
+    char* const p0 = po;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const RecSlice& r = b.recs[i];
+        if (poffs[i + 1] > poffs[i]) {
+            memcpy(po, r.h, r.hl); po += r.hl;
+            *po++ = '\n';
+            for (uint64_t j = poffs[i]; j < poffs[i + 1]; ++j) po = put_int(po, paths[j]);
+            *po++ = '\n';
+        } else {
+            memcpy(no, r.h, r.hl); no += r.hl;
+            *no++ = '\n';
+            memcpy(no, r.s, r.sl); no += r.sl;
+            *no++ = '\n';
         }
     }
+    pbuf.resize(pmax ? (size_t)(po - p0) : 0);
 }
 
 }  // namespace
@@ -229,7 +244,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     // A fixed pool of batch objects circulates producer -> GPU workers -> writer -> producer, so the pinned
     // buffers are allocated once and the number of batches in flight is bounded.
     const size_t max_batches = aligners.size() * 2 + 2;
-    Channel<std::unique_ptr<Batch>> to_gpu(max_batches), to_out(max_batches), free_batches(max_batches);
+    Channel<std::unique_ptr<Batch>> to_gather(max_batches), to_gpu(max_batches), to_out(max_batches), free_batches(max_batches);
     std::atomic<size_t> created{0};
     auto take_batch = [&](std::unique_ptr<Batch>& b) {  // reuse a finished batch; create one only while below the cap
         if (free_batches.try_pop(b)) return true;
@@ -254,30 +269,10 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         uint64_t next_index = 0;
         std::string list(reads_csv);
         size_t last = 0;
-        auto emit = [&](std::unique_ptr<Batch> b) {  // gather the sequences of a batch into pinned memory
+        auto emit = [&](std::unique_ptr<Batch> b) {  // number the batch in input order and hand it to the gatherer
             b->index = next_index++;
             b->n = b->recs.size();
-            uint64_t bases = 0;
-            const uint64_t tg0 = now_us();
-            if (!b->offs.ensure((b->n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            uint64_t* offs = static_cast<uint64_t*>(b->offs.p);
-            for (uint64_t i = 0; i < b->n; ++i) { offs[i] = bases; bases += b->recs[i].sl; }
-            offs[b->n] = bases;
-            b->bases = bases;
-            b->path_cap = 12 * b->n + 4096;  // typical paths are a handful of ints; the worker retries with the full bound if not
-            if (!b->reads.ensure(bases + 16) || !b->paths.ensure(b->path_cap * 4) || !b->poffs.ensure((b->n + 1) * 8) ||
-                !b->status.ensure(b->n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            char* dst = static_cast<char*>(b->reads.p);
-            us_alloc += now_us() - tg0;
-            const uint64_t tg1 = now_us();
-            const uint64_t per = (b->n + threads - 1) / threads;
-            Batch* bp = b.get();
-            parallel_for(threads, threads, [&](size_t t) {
-                uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
-                for (uint64_t i = lo; i < hi; ++i) memcpy(dst + offs[i], bp->recs[i].s, bp->recs[i].sl);
-            });
-            us_gather += now_us() - tg1;
-            return to_gpu.push(std::move(b));
+            return to_gather.push(std::move(b));
         };
         for (size_t i = 0; i <= list.size() && !failed; ++i) {  // aligner.cpp:552-586: comma-separated list
             if (i != list.size() && list[i] != ',') continue;
@@ -328,6 +323,40 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 if (!emit(std::move(b))) break;
             }
         }
+        to_gather.close();
+    });
+
+    // ---- stage 1b: gather the sequences of a batch into (pooled) pinned memory ---------------------------
+    std::thread gatherer([&]() {
+        auto gather = [&](std::unique_ptr<Batch> b) {
+            uint64_t bases = 0;
+            const uint64_t tg0 = now_us();
+            if (!b->offs.ensure((b->n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            uint64_t* offs = static_cast<uint64_t*>(b->offs.p);
+            for (uint64_t i = 0; i < b->n; ++i) { offs[i] = bases; bases += b->recs[i].sl; }
+            offs[b->n] = bases;
+            b->bases = bases;
+            b->path_cap = 12 * b->n + 4096;  // typical paths are a handful of ints; the worker retries with the full bound if not
+            if (!b->reads.ensure(bases + 16) || !b->paths.ensure(b->path_cap * 4) || !b->poffs.ensure((b->n + 1) * 8) ||
+                !b->status.ensure(b->n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            char* dst = static_cast<char*>(b->reads.p);
+            us_alloc += now_us() - tg0;
+            const uint64_t tg1 = now_us();
+            const uint64_t per = (b->n + threads - 1) / threads;
+            Batch* bp = b.get();
+            parallel_for(threads, threads, [&](size_t t) {
+                uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
+                for (uint64_t i = lo; i < hi; ++i) memcpy(dst + offs[i], bp->recs[i].s, bp->recs[i].sl);
+            });
+            us_gather += now_us() - tg1;
+            return to_gpu.push(std::move(b));
+        };
+        std::unique_ptr<Batch> b;
+        while (to_gather.pop(b)) {
+            if (failed) { to_out.push(std::move(b)); continue; }
+            if (!gather(std::move(b))) break;
+        }
+        to_gather.close();  // (after a failure: unblock the producer)
         to_gpu.close();
     });
 
@@ -395,6 +424,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     });
 
     producer.join();
+    gatherer.join();
     for (auto& t : workers) t.join();
     writer.join();
     free_batches.close();
