@@ -89,19 +89,26 @@ void parallel_for(unsigned threads, size_t n, F fn) {  // fn(task)
     for (auto& t : ts) t.join();
 }
 
-struct PinnedBuf {
+struct HostBuf {  // grow-only host buffer; `pinned` = page-locked (H2D source), else plain malloc (pinning costs ~0.15 s per GB)
     void* p = nullptr;
     uint64_t cap = 0;
+    bool pinned;
+    explicit HostBuf(bool pin) : pinned(pin) {}
+    void release() {
+        if (!p) return;
+        if (pinned) bgr_host_free(p); else free(p);
+        p = nullptr; cap = 0;
+    }
     bool ensure(uint64_t bytes) {
         if (bytes <= cap) return true;
-        if (p) bgr_host_free(p);
-        p = nullptr; cap = 0;
+        release();
         uint64_t want = bytes + bytes / 4 + 4096;
-        if (bgr_host_alloc(want, &p) != BGR_OK) return false;
+        if (pinned) { if (bgr_host_alloc(want, &p) != BGR_OK) return false; }
+        else { p = malloc(want); if (!p) return false; }
         cap = want;
         return true;
     }
-    ~PinnedBuf() { if (p) bgr_host_free(p); }
+    ~HostBuf() { release(); }
 };
 
 struct Batch {
@@ -110,7 +117,7 @@ struct Batch {
     std::vector<std::unique_ptr<ParsedChunk>> chunks;
     std::vector<std::pair<const ParsedChunk*, std::pair<uint32_t, uint32_t>>> spans;  // chunk, [first, last) records
     uint64_t n = 0, bases = 0, path_cap = 0;
-    PinnedBuf reads, offs, paths, poffs, status;
+    HostBuf reads{true}, offs{true}, paths{false}, poffs{false}, status{false};
     std::vector<RecSlice> recs;                           // flattened view of the records of this batch
     int rc = BGR_OK;
     std::string err;
@@ -211,7 +218,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     const unsigned n_gpus = std::max<uint32_t>(1, opt->n_gpus);
     const unsigned threads = std::max<uint32_t>(1, opt->threads);
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes : (8ull << 20);
-    const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (2ull << 20);
+    const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (1ull << 20);
     const bool writes = prm->mode == BGR_MODE_GREEDY || opt->write_exhaustive;
     bgr_graph_info_t gi;
     if (bgr_graph_info(graph, &gi) != BGR_OK) return BGR_E_ARG;

@@ -162,7 +162,7 @@ int bgr_write_records(void* paths_file, void* notaligned_file, uint64_t n_reads,
 typedef struct {
     uint32_t n_gpus;           /* devices 0..n_gpus-1 (0 = 1)                                                  */
     uint32_t threads;          /* host threads for parsing / gathering / formatting (-t; 0 = 1)                */
-    uint64_t batch_reads;      /* target reads per device batch (0 = default 2M)                                */
+    uint64_t batch_reads;      /* target reads per device batch (0 = default 1M)                                */
     uint64_t chunk_bytes;      /* parser chunk size (0 = default 8 MiB)                                         */
     uint32_t fastq;            /* -q                                                                            */
     uint32_t write_exhaustive; /* exhaustive mode writes nothing in the reference; 1 = write  */
