@@ -223,3 +223,37 @@ def test_blob_adopted_from_device_memory_maps_identically():
     r1, r2 = a1.align(reads, roffs), a2.align(reads, roffs)
     for x, y in zip(r1, r2):
         assert np.array_equal(x, y)
+
+
+def test_full_size_batch_properties():
+    """At the benchmark's batch size (the oracle would need minutes): size-independent properties.
+    (1) determinism: the same batch twice gives identical rows; (2) sharding invariance: mapping the two halves
+    separately and concatenating equals mapping the whole (what the multi-GPU split relies on); (3) counters add up;
+    (4) a seeded sample of rows equals the oracle's."""
+    s = Synth(4_600_000, 140, 2, 31, 20261003)
+    seqs, offs = s.unitigs()
+    n, L = 2_000_000, 150
+    reads, roffs = s.reads(0, n, L, 2, 77, threads=16)
+    g = B.Graph.build(31, seqs, offs)
+    al = B.Aligner(g, 0)
+    al.reset_counters()
+    p1, po1, st1 = al.align(reads, roffs)
+    c1 = al.counters()
+    p2, po2, st2 = al.align(reads, roffs)
+    assert np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2)
+    h = n // 2 + 12345
+    pa, poa, sta = al.align(reads[: h * L], roffs[: h + 1])
+    pb, pob, stb = al.align(reads[h * L:], roffs[h:] - roffs[h])
+    assert np.array_equal(np.concatenate([pa, pb]), p1)
+    assert np.array_equal(np.concatenate([sta, stb]), st1)
+    assert np.array_equal(np.concatenate([poa, pob[1:] + poa[-1]]), po1)
+    assert c1["reads"] == n and c1["reads"] == c1["no_overlap"] + c1["aligned"] + c1["not_aligned"]
+    assert c1["aligned"] == int(((st1 & 3) == 2).sum()) and c1["no_overlap"] == int(((st1 & 3) == 0).sum())
+    rng = np.random.default_rng(5)
+    idx = np.sort(rng.choice(n, 5000, replace=False))
+    sub = np.concatenate([reads[i * L:(i + 1) * L] for i in idx])
+    o = oracle_py.Oracle(31, seqs, offs)
+    ps, pos, sts = o.align(sub, np.arange(len(idx) + 1, dtype=np.uint64) * L)
+    for j, i in enumerate(idx):
+        assert st1[i] == sts[j]
+        assert np.array_equal(p1[int(po1[i]): int(po1[i + 1])], ps[int(pos[j]): int(pos[j + 1])])
