@@ -299,11 +299,17 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
                 if (w && b * w > best_res) { best_res = b * w; waves = w; bpc = b; stage = true; }
             }
         }
-        // without staging: small workgroups, as many as the registers admit
-        uint32_t wn = 4, bn = std::max<uint32_t>(1, cap / wn);
-        while (bn > 1 && !fits(bn, wn, false)) --bn;
-        while (wn > 1 && !fits(bn, wn, false)) --wn;
-        const uint32_t res_n = fits(bn, wn, false) ? bn * wn : 0;
+        // without staging: as many small workgroups as the registers admit; when the per-wave LDS region is large
+        // (long reads, exhaustive frame stacks) fewer, larger workgroups keep more waves resident
+        uint32_t wn = 0, bn = 0, res_n = 0;
+        {
+            const uint32_t bs[] = {6, 4, 3, 2, 1};
+            for (uint32_t b : bs) {
+                uint32_t w = std::min<uint32_t>(b == 6 ? 4 : 16, std::max<uint32_t>(1, cap / b));
+                while (w > 0 && !fits(b, w, false)) --w;
+                if (w && b * w > res_n) { res_n = b * w; wn = w; bn = b; }
+            }
+        }
         if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
         if (best_res == 0) waves = 0;
     }
