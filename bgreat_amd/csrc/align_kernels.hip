@@ -376,12 +376,14 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 //                         [4+4c..] candidate c: sid, next_rec, aux (non-fitting: ext; fitting: the path int
 //                                               emitted when the walk ends there), miss | fits<<16 | next_canon<<17
 #define FR_WORDS 20
+#define EXH_OVERFLOW 0xFFFFFFFFu
 
 template <int DIR>
 __device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
                                                uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t budget, bool partial,
-                                               uint32_t* FR, int32_t* CUR, int32_t* BEST, uint32_t* best_n, int lane) {
-    // returns the best total (budget+1 if none); the best walk's ints are BEST[0..*best_n) in output order
+                                               uint32_t* FR, uint32_t max_frames, int32_t* CUR, int32_t* BEST, uint32_t* best_n, int lane) {
+    // returns the best total (budget+1 if none; EXH_OVERFLOW if the search needs more than max_frames frames);
+    // the best walk's ints are BEST[0..*best_n) in output order
     uint32_t best = budget + 1;
     *best_n = 0;
     int depth = 0;
@@ -467,6 +469,7 @@ __device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u6
             continue;
         }
         // descend
+        if ((uint32_t)depth + 1 >= max_frames) { wave_sync(); return EXH_OVERFLOW; }
         if (lane == 0) {
             CUR[depth] = (int32_t)sid;
             uint32_t* N = F + FR_WORDS;
@@ -645,15 +648,17 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
     uint32_t chunk_pos = 0, chunk_end = 0;
     const uint32_t m = prm.max_mismatch;
 
-    for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
+    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[2] by pass 1)
+    const uint32_t total = io.subset ? io.cursor[2] : io.n_reads;
+    for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
         const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
         uint32_t p_n = 0;
         const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
-        c_ov += npos;
-        bool done = false;
-        for (uint32_t base = 0; base < npos && !done; base += 64) {
+        bool done = false, overflow = false;
+        for (uint32_t base = 0; base < npos && !done && !overflow; base += 64) {
             const uint32_t i = base + lane;
             const bool valid = i < npos;
             u64 num = 0;
@@ -669,11 +674,13 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
                 const u64 a_num = rl64(num, src);
                 const bool a_canon = a_num <= rcb_fast(a_num, K1);
                 uint32_t nl = 0, nr = 0;
-                const uint32_t eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, CUR, BEST, &nl, lane);
+                const uint32_t eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane);
+                if (eb == EXH_OVERFLOW) { overflow = true; break; }
                 if (eb > m) continue;
                 for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
                 wave_sync();
-                const uint32_t ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, CUR, BEST, &nr, lane);
+                const uint32_t ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane);
+                if (ee == EXH_OVERFLOW) { overflow = true; break; }
                 if (ee > m - eb) continue;
                 for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];
                 p_n = nl + nr;
@@ -682,6 +689,11 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
             }
         }
         wave_sync();
+        if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
+            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + 2, 1u)] = r;
+            continue;
+        }
+        c_ov += npos;
         uint32_t abase = 0;
         if (done) abase = publish_path(io, OUT, 0, p_n, &chunk_pos, &chunk_end, lane);
         if (lane == 0) io.results[r] = make_uint2(abase, p_n | ((uint32_t)(done ? BGR_ST_ALIGNED : BGR_ST_FAILED) << 24));

@@ -62,7 +62,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, results, arena, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, results, arena, ovf, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -238,7 +238,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->small.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
@@ -266,66 +266,77 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     HIP_TRY(a->results.ensure(n_reads * 8));
 
     // ---- launch geometry -----------------------------------------------------------------------
-    uint32_t words = 0, path_cap = 0, frames = 0;
-    const uint32_t per_wave = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames);
+    // Exhaustive mode runs in two passes: pass 1 gives every wave a SHALLOW search stack (kExhFrameCap frames) so
+    // that many waves fit a CU's LDS; the rare read whose search goes deeper is listed and mapped by pass 2 with the
+    // worst-case stack (few waves per CU).  Greedy mode is one pass.
+    const char* fc_env = getenv("BGR_EXH_FRAME_CAP");  // tests shrink it to push most reads through pass 2
+    const uint32_t kExhFrameCap = fc_env ? (uint32_t)std::max(2, atoi(fc_env)) : 24;
+    uint32_t words = 0, path_cap = 0, frames = 0, frames_deep = 0;
+    const uint32_t per_wave_deep = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep);
+    const uint32_t per_wave = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames, kExhFrameCap);
+    const bool two_pass = p->mode == BGR_MODE_EXHAUSTIVE && frames < frames_deep;
     const size_t lds_cu = a->lds_per_cu;
     const uint32_t mphf_bytes = a->dg.units_bytes;
     // Resident waves per CU are bounded by registers (bgr::resident_waves_per_cu); LDS decides how they are grouped:
     // `b` workgroups per CU of `w` waves each, every staged workgroup holding its own copy of the MPHF cascade.
     // More resident waves hide more of the walk's dependent-load latency (measured 16 -> 24 waves/CU: +18 %), and a
     // grid of exactly CUs x b workgroups avoids a partial last round.
-    bgr::LaunchCfg cfg;
     const uint32_t cap = std::max<uint32_t>(4, bgr::resident_waves_per_cu(p->mode));
     const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
-    uint32_t waves = 0, bpc = 0;
-    bool stage = false;
-    auto fits = [&](uint32_t b, uint32_t w, bool st) {
-        return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 7) / 8) * 8 : 0) + (uint64_t)w * per_wave) <= lds_fit;
-    };
-    if (a->cfg_waves || a->cfg_blocks_per_cu) {  // explicit tuning through bgr_aligner_configure
-        stage = a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true));
-        waves = a->cfg_waves ? a->cfg_waves : (stage ? 12 : 4);
-        bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
-        while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
-        while (waves > 1 && !fits(bpc, waves, stage)) --waves;
-        if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
-    } else {
-        uint32_t best_res = 0;
-        if (a->cfg_lds_mphf != 1 && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
-            const uint32_t bs[] = {1, 2, 3, 4, 6};
-            for (uint32_t b : bs) {
-                uint32_t w = std::min<uint32_t>(16, cap / b);
-                while (w > 0 && !fits(b, w, true)) --w;
-                if (w && b * w > best_res) { best_res = b * w; waves = w; bpc = b; stage = true; }
+    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bgr::LaunchCfg& cfg) -> bool {
+        uint32_t waves = 0, bpc = 0;
+        bool stage = false;
+        auto fits = [&](uint32_t b, uint32_t w, bool st) {
+            return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 7) / 8) * 8 : 0) + (uint64_t)w * pw) <= lds_fit;
+        };
+        if (allow_tuning && (a->cfg_waves || a->cfg_blocks_per_cu)) {  // explicit tuning through bgr_aligner_configure
+            stage = a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true));
+            waves = a->cfg_waves ? a->cfg_waves : (stage ? 12 : 4);
+            bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
+            while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
+            while (waves > 1 && !fits(bpc, waves, stage)) --waves;
+            if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
+        } else {
+            uint32_t best_res = 0;
+            if (a->cfg_lds_mphf != 1 && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
+                const uint32_t bs[] = {1, 2, 3, 4, 6};
+                for (uint32_t b : bs) {
+                    uint32_t w = std::min<uint32_t>(16, cap / b);
+                    while (w > 0 && !fits(b, w, true)) --w;
+                    if (w && b * w > best_res) { best_res = b * w; waves = w; bpc = b; stage = true; }
+                }
             }
-        }
-        // without staging: as many small workgroups as the registers admit; when the per-wave LDS region is large
-        // (long reads, exhaustive frame stacks) fewer, larger workgroups keep more waves resident
-        uint32_t wn = 0, bn = 0, res_n = 0;
-        {
-            const uint32_t bs[] = {6, 4, 3, 2, 1};
-            for (uint32_t b : bs) {
+            // without staging: as many small workgroups as the registers admit; when the per-wave LDS region is large
+            // (long reads, exhaustive frame stacks) fewer, larger workgroups keep more waves resident
+            uint32_t wn = 0, bn = 0, res_n = 0;
+            const uint32_t bs2[] = {6, 4, 3, 2, 1};
+            for (uint32_t b : bs2) {
                 uint32_t w = std::min<uint32_t>(b == 6 ? 4 : 16, std::max<uint32_t>(1, cap / b));
                 while (w > 0 && !fits(b, w, false)) --w;
                 if (w && b * w > res_n) { res_n = b * w; wn = w; bn = b; }
             }
+            if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
+            if (best_res == 0) waves = 0;
         }
-        if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
-        if (best_res == 0) waves = 0;
-    }
-    if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
-    cfg.lds_bytes = kLdsFixed + (stage ? ((mphf_bytes + 7) / 8) * 8 : 0) + waves * per_wave;
-    cfg.blocks = (uint32_t)std::min<uint64_t>((n_reads + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
-    if (waves == 0) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging");
-    cfg.waves_per_block = waves;
+        if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return false;
+        cfg.lds_bytes = kLdsFixed + (stage ? ((mphf_bytes + 7) / 8) * 8 : 0) + waves * pw;
+        cfg.blocks = (uint32_t)std::min<uint64_t>((n_items + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
+        cfg.waves_per_block = waves;
+        cfg.stage_mphf = stage ? 1 : 0;
+        return true;
+    };
+    bgr::LaunchCfg cfg, cfg_deep;
+    if (!geometry(per_wave, n_reads, true, cfg) || (two_pass && !geometry(per_wave_deep, n_reads, false, cfg_deep)))
+        return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
+    const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
     // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
     const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
-    const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk;
+    const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
+                               (two_pass ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0);
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
-    cfg.stage_mphf = stage ? 1 : 0;
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf;
 
     bgr::BatchIO io;
@@ -337,16 +348,30 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.arena_cap = (uint32_t)arena_cap;
     io.arena_chunk = arena_chunk;
     io.frames_per_wave = frames;
+    io.ovf_list = nullptr;
+    io.subset = nullptr;
+    if (two_pass) {
+        HIP_TRY(a->ovf.ensure(n_reads * 4));
+        io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
+    }
     io.results = static_cast<uint2*>(a->results.p);
     io.arena = static_cast<int32_t*>(a->arena.p);
     io.cursor = static_cast<uint32_t*>(a->small.p);
     const char* dbg = getenv("BGR_DEBUG_STOP");
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, dbg ? (uint32_t)atoi(dbg) : 0u};
 
-    HIP_TRY(hipMemsetAsync(a->small.p, 0, 8, a->stream));
+    HIP_TRY(hipMemsetAsync(a->small.p, 0, 16, a->stream));
     HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
     hipError_t e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (two_pass) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
+        bgr::BatchIO io2 = io;
+        io2.frames_per_wave = frames_deep;
+        io2.subset = io.ovf_list;
+        io2.ovf_list = nullptr;
+        e = bgr::launch_align(a->dg, io2, kp, cfg_deep, a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (deep pass): ") + hipGetErrorString(e));
+    }
     HIP_TRY(hipEventRecord(a->ev_stop[a->ev_used], a->stream));
     ++a->ev_used;
     return BGR_OK;

@@ -141,6 +141,32 @@ def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, 
     assert al.counters() == o.counters()
 
 
+@pytest.mark.parametrize("cap", ["2", "3", "5"])
+def test_exhaustive_deep_stack_second_pass(cap, monkeypatch):
+    """Pass 1 of the exhaustive kernel has a shallow DFS stack; reads that need more go through pass 2.  With a tiny
+    cap nearly every mapped read takes the second pass; results must not change."""
+    monkeypatch.setenv("BGR_EXH_FRAME_CAP", cap)
+    s = Synth(60000, 30, 4, 12, 606)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 6000, 120, 4, 607)
+    g = B.Graph.build(12, seqs, offs)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(12, seqs, offs)
+    p1, po1, st1 = al.align(reads, roffs, m=3, mode=B.MODE_EXHAUSTIVE)
+    p2, po2, st2 = o.align(reads, roffs, m=3, mode=1)
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    assert al.counters() == o.counters()
+    # golden degenerate graph (unitigs of 5..14 bases, walks of many steps)
+    case = next(c for c in EXH if c["args"][1] == "deg_reads.fa" and c["args"][7] == "5" and "-i" not in c["args"])
+    g2 = B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig.fa"), 5)
+    a2 = B.Aligner(g2, 0)
+    reads, roffs, heads, hoffs = B.load_reads(os.path.join(GOLD, "deg_reads.fa"), 5)
+    paths, poffs, status = a2.align(reads, roffs, m=5, mode=B.MODE_EXHAUSTIVE)
+    pb, nb = _format(reads, roffs, heads, hoffs, paths, poffs)
+    from util import sha
+    assert sha(pb) == case["paths_sha256"] and sha(nb) == case["notaligned_sha256"]
+
+
 def _inject_n(reads, rng, frac):
     reads = reads.copy()
     idx = rng.random(reads.size) < frac
