@@ -67,6 +67,16 @@ __device__ __forceinline__ uint32_t compress_even(u64 x) {
     x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
     return (uint32_t)x;
 }
+// Sum over each aligned group of 16 lanes (a DPP "row"), result in every lane of the group: four v_add_u32_dpp,
+// no LDS round trip (ds_bpermute shuffles cost ~7 instructions + an LDS wait each).
+__device__ __forceinline__ uint32_t row16_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]  (lane ^ 1)
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]  (lane ^ 2)
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of the half row
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, true);  // row_mirror: the other half of the row
+    return x;
+}
+
 // reverse the order of the 32 two-bit digits of x: full bit reversal (v_bfrev_b32 x2), then swap the bits of each pair
 __device__ __forceinline__ u64 rev2_fast(u64 x) {
     u64 y = __builtin_bitreverse64(x);
@@ -269,11 +279,7 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
             cnt += __popcll(mm);
         }
     }
-    cnt += __shfl_xor(cnt, 8);
-    cnt += __shfl_xor(cnt, 4);
-    cnt += __shfl_xor(cnt, 2);
-    cnt += __shfl_xor(cnt, 1);
-    sc.cnt = cnt;
+    sc.cnt = row16_sum(cnt);
     return sc;
 }
 
