@@ -120,8 +120,77 @@ void parse_fasta_chunk(const char* data, uint64_t begin, uint64_t end, uint32_t 
     out.fixup();
 }
 
-void parse_fastq_image(const char* data, uint64_t size, ParsedChunk& out) {
-    Cursor cur(data, 0, size);
+static void parse_fastq_range(const char* data, uint64_t begin, uint64_t size, ParsedChunk& out);
+
+void parse_fastq_image(const char* data, uint64_t size, ParsedChunk& out) { parse_fastq_range(data, 0, size, out); }
+
+void parse_fastq_parallel(const char* data, uint64_t size, unsigned threads, uint64_t chunk_bytes, std::vector<ParsedChunk>& chunks) {
+    if (threads < 1) threads = 1;
+    if (chunk_bytes == 0) chunk_bytes = 1;
+    const size_t nc = (size_t)((size + chunk_bytes - 1) / chunk_bytes);
+    chunks.clear();
+    if (threads == 1 || nc < 2) { chunks.resize(1); parse_fastq_range(data, 0, size, chunks[0]); return; }
+    // pass 1: newlines per chunk
+    std::vector<uint64_t> nl(nc + 1, 0);
+    auto run = [&](auto fn) {
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < threads; ++t) ts.emplace_back([&, t]() { for (size_t c = t; c < nc; c += threads) fn(c); });
+        for (auto& t : ts) t.join();
+    };
+    run([&](size_t c) {
+        uint64_t b = c * chunk_bytes, e = std::min<uint64_t>(size, b + chunk_bytes), n = 0;
+        const char* p = data + b;
+        const char* end = data + e;
+        while (p < end && (p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))))) { ++n; ++p; }
+        nl[c + 1] = n;
+    });
+    for (size_t c = 0; c < nc; ++c) nl[c + 1] += nl[c];  // nl[c] = newlines before chunk c = index of the line containing its first byte
+    const uint64_t complete = nl[nc] / 4;                 // records whose four lines all end with a newline
+    const uint64_t par_records = complete ? ((complete - 1) / kBatch) * kBatch : 0;  // a getReads() call boundary
+    chunks.resize(nc + 1);
+    std::vector<uint64_t> tail_start(nc, UINT64_MAX);
+    // pass 2: chunk c owns the records whose header line STARTS inside it
+    run([&](size_t c) {
+        const uint64_t b = c * chunk_bytes, e = std::min<uint64_t>(size, b + chunk_bytes);
+        uint64_t line = nl[c];  // index of the line containing byte b
+        uint64_t pos = b;
+        if (b > 0 && data[b - 1] != '\n') {  // b is inside a line: the first line starting in this chunk is the next one
+            const char* q = static_cast<const char*>(memchr(data + b, '\n', (size_t)(e - b)));
+            if (!q) return;
+            pos = (uint64_t)(q - data) + 1;
+            ++line;
+        }
+        ParsedChunk& out = chunks[c];
+        std::string none;
+        while (pos < e) {
+            if (line % 4 == 0) {
+                const uint64_t rec = line / 4;
+                if (rec >= par_records) { tail_start[c] = pos; return; }
+                const char* h = data + pos;
+                const char* hq = static_cast<const char*>(memchr(h, '\n', (size_t)(size - pos)));
+                const char* s = hq + 1;  // complete record: all four newlines exist
+                const char* sq = static_cast<const char*>(memchr(s, '\n', (size_t)(data + size - s)));
+                Slice hs; hs.p = h; hs.n = (uint64_t)(hq - h);
+                const uint64_t sn = (uint64_t)(sq - s);
+                if (sn > 2 && valid_chars(s, sn)) push(out, hs, s, sn, false, none);
+                pos = (uint64_t)(sq - data) + 1;
+                line += 2;
+            } else {
+                const char* q = static_cast<const char*>(memchr(data + pos, '\n', (size_t)(size - pos)));
+                if (!q) return;
+                pos = (uint64_t)(q - data) + 1;
+                ++line;
+            }
+        }
+    });
+    uint64_t tstart = size;
+    for (size_t c = 0; c < nc; ++c) if (tail_start[c] != UINT64_MAX) { tstart = tail_start[c]; break; }
+    if (par_records == 0) tstart = 0;
+    if (complete == 0 || tstart < size || par_records == 0) parse_fastq_range(data, par_records == 0 ? 0 : tstart, size, chunks[nc]);
+}
+
+static void parse_fastq_range(const char* data, uint64_t begin, uint64_t size, ParsedChunk& out) {
+    Cursor cur(data, begin, size);
     std::string none;
     while (!cur.eofbit) {
         Slice header, read;  // one getReads() call: its locals start empty
@@ -175,7 +244,13 @@ void parse_reads(const char* data, uint64_t size, bool fastq, uint32_t k, ReadSe
 
 void parse_reads_parallel(const char* data, uint64_t size, bool fastq, uint32_t k, unsigned threads, uint64_t chunk_bytes, ReadSet& out) {
     if (out.read_offs.empty()) out.clear();
-    if (fastq || threads <= 1) { parse_reads(data, size, fastq, k, out); return; }
+    if (threads <= 1) { parse_reads(data, size, fastq, k, out); return; }
+    if (fastq) {
+        std::vector<ParsedChunk> chunks;
+        parse_fastq_parallel(data, size, threads, chunk_bytes, chunks);
+        for (const ParsedChunk& c : chunks) to_readset(c, out);
+        return;
+    }
     std::vector<uint64_t> starts = split_fasta(data, size, chunk_bytes);
     std::vector<ParsedChunk> chunks(starts.size());
     std::vector<std::thread> ts;

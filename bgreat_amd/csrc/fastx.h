@@ -53,8 +53,14 @@ bool parse_reads_file(const std::string& path, bool fastq, uint32_t k, ReadSet& 
 std::vector<uint64_t> split_fasta(const char* data, uint64_t size, uint64_t chunk_bytes);
 // The reference's FASTA state machine over [begin, end) of the image, `end` acting as end-of-file.
 void parse_fasta_chunk(const char* data, uint64_t begin, uint64_t end, uint32_t k, ParsedChunk& out);
-// Whole-image FASTQ (sequential: record starts are only known by counting lines from the top).
+// Whole-image FASTQ, sequential.
 void parse_fastq_image(const char* data, uint64_t size, ParsedChunk& out);
+// FASTQ in parallel.  Record j is lines 4j..4j+3 whatever they contain, so a first pass counts the newlines of
+// every chunk (record starts follow from the prefix sums); all records before the last 10000-record boundary are
+// plain "header line + sequence line" (the stream is good there), parsed by `threads` threads into chunks[0..n-2];
+// the rest of the file, which starts exactly where a fresh getReads() call starts, goes through the sequential
+// state machine (phantom record, truncated tails) into the last chunk.
+void parse_fastq_parallel(const char* data, uint64_t size, unsigned threads, uint64_t chunk_bytes, std::vector<ParsedChunk>& chunks);
 // Parallel whole-file parse into a ReadSet (threads >= 1); identical result to parse_reads().
 void parse_reads_parallel(const char* data, uint64_t size, bool fastq, uint32_t k, unsigned threads, uint64_t chunk_bytes, ReadSet& out);
 

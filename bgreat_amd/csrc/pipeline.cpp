@@ -290,17 +290,26 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             std::string err;
             if (!mf->open(file, err)) { fail(BGR_E_IO, err); break; }
             if (opt->fastq) {
-                auto whole = std::make_unique<ParsedChunk>();
-                bgr::parse_fastq_image(mf->data, mf->size, *whole);  // slices point into the file image only
-                const ParsedChunk* wc = whole.get();
-                for (uint64_t lo = 0; lo < wc->recs.size() && !failed; lo += batch_reads) {
-                    std::unique_ptr<Batch> b;
-                    if (!take_batch(b)) break;
-                    b->file = mf;
-                    uint64_t hi = std::min<uint64_t>(wc->recs.size(), lo + batch_reads);
-                    b->recs.assign(wc->recs.begin() + lo, wc->recs.begin() + hi);
-                    if (!emit(std::move(b))) break;
+                std::vector<ParsedChunk> fq;  // slices point into the file image only (no joined storage)
+                const uint64_t tp0 = now_us();
+                bgr::parse_fastq_parallel(mf->data, mf->size, threads, chunk_bytes, fq);
+                us_parse += now_us() - tp0;
+                std::unique_ptr<Batch> b;
+                bool ok = true;
+                for (size_t ci = 0; ci < fq.size() && ok && !failed; ++ci) {
+                    const std::vector<RecSlice>& rs = fq[ci].recs;
+                    size_t lo = 0;
+                    while (lo < rs.size() && ok) {
+                        if (!b) { if (!take_batch(b)) { ok = false; break; } b->file = mf; }
+                        size_t take = std::min<size_t>(rs.size() - lo, (size_t)batch_reads - b->recs.size());
+                        b->recs.insert(b->recs.end(), rs.begin() + lo, rs.begin() + lo + take);
+                        lo += take;
+                        if (b->recs.size() >= batch_reads) ok = emit(std::move(b));
+                    }
                 }
+                if (ok && b && !b->recs.empty()) ok = emit(std::move(b));
+                else if (b) { b->file.reset(); b->recs.clear(); free_batches.push(std::move(b)); }
+                if (!ok) break;
                 continue;
             }
             std::vector<uint64_t> starts = bgr::split_fasta(mf->data, mf->size, chunk_bytes);

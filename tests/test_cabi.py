@@ -135,6 +135,26 @@ def test_chunk_parallel_parser_torture(text):
         os.unlink(p)
 
 
+@pytest.mark.parametrize("n,tail", [(0, b""), (1, b""), (3, b""), (9999, b""), (10000, b""), (10001, b""), (20000, b""), (25003, b""),
+                                    (20000, b"@x\nACGTACGTAA\n"), (10002, b"@x\nACGTACGTAA\n+\nIIIIIIIIII"), (30001, b"\n"), (12000, b"@x\nACGTACGTAA\n+\n")])
+@pytest.mark.parametrize("chunk", [97, 5000, 1 << 20])
+def test_fastq_chunk_parallel_parser_equals_sequential(n, tail, chunk):
+    rng = np.random.default_rng(n + len(tail))
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(1, 40))
+        seq = bytes(rng.choice(list(b"ACGTNacgt"), L, p=[.24, .24, .24, .24, .02, .005, .005, .005, .005]).astype(np.uint8))
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, seq, b"I" * L))
+    p = _write_tmp(b"".join(recs) + tail)
+    try:
+        a = B.load_reads(p, 5, True, threads=5, chunk_bytes=chunk)
+        b = oracle_py.parse_file(p, 5, True)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    finally:
+        os.unlink(p)
+
+
 def test_fastq_phantom_depends_on_batch_boundary():
     """aligner.cpp:51-68: the phantom record appears unless the record count is a multiple of the 10000-read batch."""
     rec = b"@r\nACGTACGTAC\n+\nIIIIIIIIII\n"
