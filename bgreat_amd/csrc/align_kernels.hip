@@ -42,12 +42,14 @@ __device__ __forceinline__ u64 rl64(u64 v, int lane) {
     return ((u64)rl32((uint32_t)(v >> 32), lane) << 32) | rl32((uint32_t)v, lane);
 }
 // 32 bases starting at base p of a first-base-most-significant packed array (needs A[p/32 + 1] readable)
+// Branch-free funnel shift: both words are always loaded (side by side: one 16-byte access), and the low word's
+// contribution vanishes by itself when the window is word aligned.
 template <typename P>
 __device__ __forceinline__ u64 win32(P A, u64 p) {
-    u64 w = p >> 5;
-    uint32_t s = (uint32_t)(p & 31) * 2;
-    u64 hi = A[w], lo = A[w + 1];
-    return s ? (hi << s) | (lo >> (64 - s)) : hi;
+    const u64 w = p >> 5;
+    const uint32_t s = (uint32_t)(p & 31) * 2;
+    const u64 hi = A[w], lo = A[w + 1];
+    return (hi << s) | ((lo >> 1) >> (63 - s));
 }
 // 32 BITS starting at bit q of a 1-bit-per-base plane, most significant first
 __device__ __forceinline__ uint32_t plane32(const u64* P, u64 q) {
@@ -156,7 +158,7 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* rd, uint32_t L, uint32_
 }
 
 // x0 = load4(rd, L, lane)
-__device__ __forceinline__ bool pack_read(uint32_t x0, const uint8_t* rd, uint32_t L, uint32_t W, uint32_t K1, u64* FW3, u64* FWQ, u64* RCW, u64* NM, int lane) {
+__device__ __forceinline__ bool pack_read(uint32_t x0, const uint8_t* rd, uint32_t L, uint32_t W, u64* FW3, u64* NM, int lane) {
     unsigned char* FW3b = reinterpret_cast<unsigned char*>(FW3);
     unsigned char* NMb = reinterpret_cast<unsigned char*>(NM);
     bool sawN = false;
@@ -176,6 +178,13 @@ __device__ __forceinline__ bool pack_read(uint32_t x0, const uint8_t* rd, uint32
     }
     const bool hasN = __any(sawN);
     wave_sync();
+    return hasN;
+}
+
+// RCW (reverse-complement stream) and FWQ (rolling-update quirk stream) from FW3/NM.  Only needed when the read
+// contains N (the rolling k-mers then differ from plain windows) or for the reverse-complement retry; a read
+// without N maps from FW3 alone (FWQ == FW3, and the reverse k-mer of a window is rcb of its forward k-mer).
+__device__ __forceinline__ void derive_streams(uint32_t L, uint32_t W, uint32_t K1, const u64* FW3, u64* FWQ, u64* RCW, const u64* NM, int lane) {
     for (uint32_t w = lane; w < W; w += 64) {
         long long p = (long long)L - 32 * ((long long)w + 1);
         u64 rcw = 0;
@@ -194,7 +203,6 @@ __device__ __forceinline__ bool pack_read(uint32_t x0, const uint8_t* rd, uint32
         FWQ[w] = FW3[w] & ~(NM[w] & ge);
     }
     wave_sync();
-    return hasN;
 }
 
 // ---- candidate scoring shared by the greedy and the exhaustive extension -------------------------------
@@ -556,7 +564,8 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
         // (prefetching the next read one iteration ahead was measured: no gain at 24 waves/CU, it only added spills)
-        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
+        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
+        bool derived = false;
 
         // ---- passes: forward read, then its reverse complement (alignerGreedy.cpp:54) -----------
         uint32_t status = BGR_ST_NOANCHOR, p_lo = 0, p_n = 0;
@@ -564,9 +573,12 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
         if (!prm.effort && npos > 1) npos = 1;
         if (prm.debug_stop == 1) npos = 0;
         for (int pass = 0; pass < 2; ++pass) {
-            const u64* A = pass ? RCW : FWQ;   // forward-strand k-mers of this pass
-            const u64* B = pass ? FW3 : RCW;   // reverse-strand k-mers (rolling nuc2intrc: N -> 0)
-            const u64* CMP = pass ? RCW : FW3; // characters compared by missmatchNumber
+            if ((pass == 1 || hasN) && !derived) { derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane); derived = true; }
+            // A read without N: FWQ == FW3 and the rolling reverse k-mer == rcb(forward k-mer), so pass 0 needs FW3 only.
+            const bool plain = (pass == 0) && !hasN;
+            const u64* A = pass ? RCW : (plain ? FW3 : FWQ);   // forward-strand k-mers of this pass
+            const u64* B = pass ? FW3 : RCW;                   // reverse-strand k-mers (rolling nuc2intrc: N -> 0)
+            const u64* CMP = pass ? RCW : FW3;                 // characters compared by missmatchNumber
             const bool useN = (pass == 0) && hasN;
             uint32_t tried = 0;
             bool done = false;
@@ -576,7 +588,7 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
                 u64 num = 0, rcn = 0;
                 if (valid) {
                     num = win32(A, i) >> (64 - 2 * K1);
-                    rcn = win32(B, L - K1 - i) >> (64 - 2 * K1);
+                    rcn = plain ? rcb_fast(num, K1) : win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
                 const uint32_t idx = find_key(g, LV, units, rep, valid);
@@ -660,7 +672,9 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
         const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, K1, FW3, FWQ, RCW, NM, lane);
+        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
+        if (hasN) derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane);
+        const u64* ROLL = hasN ? FWQ : FW3;  // the rolling `num` stream
         uint32_t p_n = 0;
         const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         bool done = false, overflow = false;
@@ -668,7 +682,7 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
             const uint32_t i = base + lane;
             const bool valid = i < npos;
             u64 num = 0;
-            if (valid) num = win32(FWQ, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            if (valid) num = win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
             const uint32_t idx = find_key(g, LV, units, num < rc ? num : rc, valid);
             u64 mask = __ballot(idx != BGR_NONE);
