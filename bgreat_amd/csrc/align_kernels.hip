@@ -211,12 +211,52 @@ __device__ __forceinline__ void derive_streams(uint32_t L, uint32_t W, uint32_t 
 // DIR 1: right step whose read slice starts AFTER the k-1 overlap (checkEndGreedy :322-364; every exhaustive
 //        right step, alignerExhaustive.cpp:61-106,206-259)
 // DIR 2: later greedy right steps, whose slice INCLUDES the overlap (mapOnRightEndGreedy :221-265)
-struct Scored {       // per lane; lanes 16c..16c+15 describe candidate c
-    uint32_t cnt;     // Hamming distance over the compared window (full count, not clipped)
-    uint32_t id, ext, mflags, rec_beg, rec_end;
-    bool fwd, fits;
-    int first_zero;   // number of candidates (the reference's nested ifs stop at the first empty slot)
+struct Scored {        // per lane; lanes 16c..16c+15 describe candidate c
+    uint32_t cnt;      // Hamming distance over the compared window (full count, not clipped)
+    int32_t sid;       // +id forward, -id reversed (what the reference pushes on the path)
+    uint32_t ext;      // len - (k-1)
+    uint32_t nrec;     // neighbour record at the far end of this unitig in walking direction
+    uint32_t info;     // bit 0: the walk ends inside this unitig ("fits"), bit 1: the far-end k-mer is canonical
+    int first_zero;    // number of candidates (the reference's nested ifs stop at the first empty slot)
 };
+
+// 32 bases of the packed unitig store starting `ub` bases after the start of seq word `fw` (32-bit arithmetic)
+__device__ __forceinline__ u64 seq_win32(const u64* seq, uint32_t fw, uint32_t ub) {
+    const uint32_t boff = (fw + (ub >> 5)) << 3;  // byte offset < 4 GiB (checked when the graph is built)
+    const u64* q = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(seq) + boff);
+    const uint32_t s = (ub & 31) * 2;
+    const u64 hi = q[0], lo = q[1];
+    return (hi << s) | ((lo >> 1) >> (63 - s));
+}
+__device__ __forceinline__ u64 lds_win32(const u64* A, uint32_t p) {
+    const uint32_t s = (p & 31) * 2;
+    const u64 hi = A[p >> 5], lo = A[(p >> 5) + 1];
+    return (hi << s) | ((lo >> 1) >> (63 - s));
+}
+
+// mismatches of one 32-base chunk (v = valid bases in it, 1..32)
+__device__ __forceinline__ uint32_t ham_chunk(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t fw, uint32_t ub,
+                                              uint32_t rb, uint32_t v) {
+    const u64 x = seq_win32(g.seq, fw, ub) ^ lds_win32(CMP, rb);
+    u64 mm = (x | (x >> 1)) & EVEN_BITS;
+    u64 nm = 0;
+    if (useN) { nm = lds_win32(NM, rb) & EVEN_BITS; mm |= nm; }
+    if (g.flags & BGR_GF_HAS_EXC) {  // forward-strand unitig bases outside ACGT: never equal, except N == N
+        const u64 abs_base = (u64)fw * 32 + ub;
+        const u64* exc = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_exc);
+        const uint32_t e = plane32(exc, abs_base);
+        if (e) {
+            const u64* excn = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_excn);
+            const uint32_t en = plane32(excn, abs_base);
+            uint32_t m1 = compress_even(mm) | e;
+            m1 &= ~(en & compress_even(nm));
+            if (v < 32) m1 &= ~(0xFFFFFFFFu >> v);
+            return __popc(m1);
+        }
+    }
+    if (v < 32) mm &= ~(~0ULL >> (2 * v));
+    return __popcll(mm);
+}
 
 template <int DIR>
 __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
@@ -226,82 +266,57 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
     // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
     const bool useR = (DIR == 0) ? canon : !canon;
     const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
-    // one 16-byte slot per candidate: id + orientation bits, length, base offset (graph_layout.h BgrSlot)
-    const uint4 sl = reinterpret_cast<const uint4*>(g.recs)[(u64)rec * 8 + (useR ? 4 : 0) + c];
-    sc.id = sl.x & BGR_SLOT_ID_MASK;
-    const u64 zmask = __ballot(sc.id == 0);
+    // one 16-byte slot per candidate: id + orientation bits, length, sequence address (graph_layout.h BgrSlot)
+    const uint4 sl = reinterpret_cast<const uint4*>(g.recs)[rec * 8u + (useR ? 4u : 0u) + (uint32_t)c];
+    const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+    const u64 zmask = __ballot(id == 0);
     sc.first_zero = zmask ? (__ffsll((long long)zmask) - 1) >> 4 : 4;
     const bool valid = c < sc.first_zero;
-    sc.fwd = (sl.x & fbit) != 0;
+    const bool fwd = (sl.x & fbit) != 0;
     const uint32_t len = valid ? sl.y : 0;
-    u64 S = ((u64)sl.w << 32) | sl.z;
-    if (!sc.fwd) S += len;
+    // oriented strand start: forward at (Fw, Fo), reverse complement `len` bases further
+    const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
     // what the NEXT step needs about this unitig (flags, neighbour record indices): issued now, beside the base loads
     uint4 m0 = make_uint4(0, 0, 0, 0);
-    if (valid) m0 = *reinterpret_cast<const uint4*>(g.meta + sc.id);
-    sc.mflags = m0.y; sc.rec_beg = m0.z; sc.rec_end = m0.w;
+    if (valid) m0 = *reinterpret_cast<const uint4*>(g.meta + id);
+    sc.sid = fwd ? (int32_t)id : -(int32_t)id;
     sc.ext = len - K1;
+    bool fits;
     uint32_t n, ustart, rstart;
     if (DIR == 0) {
-        sc.fits = sc.ext >= pos;
-        n = sc.fits ? pos : sc.ext;
-        ustart = sc.fits ? sc.ext - pos : 0;
-        rstart = sc.fits ? 0 : pos - sc.ext;
-    } else if (DIR == 1) {
-        const uint32_t rl = L - pos - K1;
-        sc.fits = sc.ext >= rl;
-        n = sc.fits ? rl : sc.ext;
-        ustart = K1;
-        rstart = pos + K1;
+        fits = sc.ext >= pos;
+        n = fits ? pos : sc.ext;
+        ustart = fits ? sc.ext - pos : 0;
+        rstart = fits ? 0 : pos - sc.ext;
+        sc.nrec = fwd ? m0.z : m0.w;
+        sc.info = (fits ? 1u : 0u) | ((m0.y & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) ? 2u : 0u);
     } else {
-        const uint32_t rl = L - pos;
-        sc.fits = sc.ext >= rl;
-        n = sc.fits ? rl : (len < rl ? len : rl);  // read.substr(pos, |u|) is clipped at |read|
-        ustart = 0;
-        rstart = pos;
-    }
-    uint32_t cnt = 0;
-    if (valid) {
-        for (uint32_t t = sub; t * 32 < n; t += 16) {
-            const u64 ub = S + ustart + (u64)t * 32;
-            const u64 x = win32(g.seq, ub) ^ win32(CMP, (u64)rstart + t * 32);
-            u64 mm = (x | (x >> 1)) & EVEN_BITS;
-            u64 nm = 0;
-            if (useN) { nm = win32(NM, (u64)rstart + t * 32) & EVEN_BITS; mm |= nm; }
-            if (g.flags & BGR_GF_HAS_EXC) {  // forward-strand unitig bases outside ACGT: never equal, except N == N
-                const u64* exc = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_exc);
-                const uint32_t e = plane32(exc, ub);
-                if (e) {
-                    const u64* excn = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_excn);
-                    const uint32_t en = plane32(excn, ub);
-                    uint32_t m1 = compress_even(mm) | e;
-                    m1 &= ~(en & compress_even(nm));
-                    const uint32_t v1 = n - t * 32;
-                    if (v1 < 32) m1 &= ~(0xFFFFFFFFu >> v1);
-                    cnt += __popc(m1);
-                    continue;
-                }
-            }
-            const uint32_t v = n - t * 32;
-            if (v < 32) mm &= ~(~0ULL >> (2 * v));
-            cnt += __popcll(mm);
+        if (DIR == 1) {
+            const uint32_t rl = L - pos - K1;
+            fits = sc.ext >= rl;
+            n = fits ? rl : sc.ext;
+            ustart = K1;
+            rstart = pos + K1;
+        } else {
+            const uint32_t rl = L - pos;
+            fits = sc.ext >= rl;
+            n = fits ? rl : (len < rl ? len : rl);  // read.substr(pos, |u|) is clipped at |read|
+            ustart = 0;
+            rstart = pos;
         }
+        sc.nrec = fwd ? m0.w : m0.z;
+        sc.info = (fits ? 1u : 0u) | ((m0.y & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) ? 2u : 0u);
+    }
+    if (!valid) n = 0;
+    // lane `sub` of the candidate's 16 compares bases [32*sub, 32*sub+32); windows longer than 512 bases loop on
+    uint32_t cnt = 0;
+    const uint32_t b0 = (uint32_t)sub * 32;
+    if (b0 < n) cnt = ham_chunk(g, CMP, NM, useN, fw, fo + ustart + b0, rstart + b0, n - b0);
+    if (__any(n > 512)) {
+        for (uint32_t b = b0 + 512; b < n; b += 512) cnt += ham_chunk(g, CMP, NM, useN, fw, fo + ustart + b, rstart + b, n - b);
     }
     sc.cnt = row16_sum(cnt);
     return sc;
-}
-
-// record index + canonical flag of the (k-1)-mer at the far end of candidate lane `bl`, in walking direction
-template <int DIR>
-__device__ __forceinline__ void next_overlap(const Scored& sc, int bl, bool bfwd, uint32_t* next_rec, bool* next_canon) {
-    const uint32_t bflags = rl32(sc.mflags, bl);
-    if (DIR == 0) {
-        *next_rec = bfwd ? rl32(sc.rec_beg, bl) : rl32(sc.rec_end, bl);
-        *next_canon = (bflags & (bfwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
-    } else {
-        *next_rec = bfwd ? rl32(sc.rec_end, bl) : rl32(sc.rec_beg, bl);
-        *next_canon = (bflags & (bfwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
-    }
 }
 
 // ============================================== greedy ================================================
@@ -319,24 +334,24 @@ __device__ __forceinline__ Step greedy_step(const BgrDeviceGraph& g, const u64* 
     out.found = false; out.fits = false; out.sid = 0; out.miss = 0; out.ext = 0; out.next_rec = BGR_NONE; out.next_canon = false;
     if (rec == BGR_NONE) return out;  // key not in the table: getBegin/getEnd return an empty list
     const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, rec, canon, pos, lane);
-    // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
-    uint32_t best = budget + 1;
-    int bc = -1;
+    // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min"):
+    // the minimum of (miss << 2 | slot) over the candidates
+    uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-        const uint32_t tcc = rl32(sc.cnt, cc * 16);
-        if (cc < sc.first_zero && tcc < best) { best = tcc; bc = cc; }
+        const uint32_t kc = (rl32(sc.cnt, cc * 16) << 2) | (uint32_t)cc;
+        if (cc < sc.first_zero && kc < key) key = kc;
     }
-    if (bc < 0) return out;
-    const int bl = bc * 16;
-    const uint32_t bid = rl32(sc.id, bl);
-    const bool bfwd = rl32(sc.fwd ? 1u : 0u, bl) != 0;
+    if ((key >> 2) > budget) return out;  // includes "no candidate"
+    const int bl = (int)(key & 3u) * 16;
+    const uint32_t info = rl32(sc.info, bl);
     out.found = true;
-    out.fits = rl32(sc.fits ? 1u : 0u, bl) != 0;
-    out.sid = bfwd ? (int32_t)bid : -(int32_t)bid;
-    out.miss = best;
+    out.fits = (info & 1u) != 0;
+    out.next_canon = (info & 2u) != 0;
+    out.sid = (int32_t)rl32((uint32_t)sc.sid, bl);
+    out.miss = key >> 2;
     out.ext = rl32(sc.ext, bl);
-    next_overlap<DIR>(sc, bl, bfwd, &out.next_rec, &out.next_canon);
+    out.next_rec = rl32(sc.nrec, bl);
     return out;
 }
 
@@ -435,21 +450,14 @@ __device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u6
                 ncand = (uint32_t)sc.first_zero;
                 if ((lane & 15) == 0 && (lane >> 4) < sc.first_zero) {
                     const int c = lane >> 4;
-                    uint32_t nrec, nflag;
-                    if (DIR == 0) {
-                        nrec = sc.fwd ? sc.rec_beg : sc.rec_end;
-                        nflag = sc.mflags & (sc.fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND);
-                    } else {
-                        nrec = sc.fwd ? sc.rec_end : sc.rec_beg;
-                        nflag = sc.mflags & (sc.fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
-                    }
                     const uint32_t miss = sc.cnt > 0xFFFFu ? 0xFFFFu : sc.cnt;
+                    const bool fits = (sc.info & 1u) != 0;
                     // fitting: left emits the offset in the last unitig (ext-pos, :126,:175), right |readLeft|+k-1 (:99,:231)
-                    const uint32_t aux = sc.fits ? ((DIR == 0) ? sc.ext - pos : L - pos) : sc.ext;
-                    F[4 + 4 * c] = (uint32_t)(sc.fwd ? (int32_t)sc.id : -(int32_t)sc.id);
-                    F[5 + 4 * c] = nrec;
+                    const uint32_t aux = fits ? ((DIR == 0) ? sc.ext - pos : L - pos) : sc.ext;
+                    F[4 + 4 * c] = (uint32_t)sc.sid;
+                    F[5 + 4 * c] = sc.nrec;
                     F[6 + 4 * c] = aux;
-                    F[7 + 4 * c] = miss | (sc.fits ? 1u << 16 : 0u) | (nflag ? 1u << 17 : 0u);
+                    F[7 + 4 * c] = miss | (fits ? 1u << 16 : 0u) | ((sc.info & 2u) ? 1u << 17 : 0u);
                 }
             }
             if (DIR == 1 && depth == 0 && partial && ncand == 0) {  // alignerExhaustive.cpp:217-221 (-i)

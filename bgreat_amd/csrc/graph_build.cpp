@@ -86,7 +86,8 @@ inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m) {  // al
     else if (s[2].idf == 0) j = 2;
     s[j].idf = idf;
     s[j].len = m.len;
-    s[j].F = m.F;
+    s[j].Fw = (uint32_t)(m.F >> 5);
+    s[j].Fo = (uint32_t)(m.F & 31);
 }
 
 }  // namespace
@@ -176,6 +177,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         maxlen = std::max(maxlen, len);
     }
     const uint64_t total = 2 * sum, seq_words = (total + 31) / 32 + 2;
+    if (seq_words * 8 >= (1ull << 32)) { err = "graph too large: the packed sequence store must stay below 4 GiB (2^34 bases over both strands)"; return false; }
 
     // ---- pack both strands; collect non-ACGT exceptions of the forward strand -------------------
     std::vector<uint64_t> seq(seq_words, 0), exc, excn;

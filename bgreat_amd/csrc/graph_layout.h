@@ -26,7 +26,7 @@
 //   recs   128 B (one cache line) per MPHF index: the 4 "left table" slots and the 4 "right table" slots of
 //          that key (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite,
 //          aligner.cpp:466-533).  A slot is 16 B {id | orientation bits, len, F}: everything a walk step
-//          needs to start streaming the candidate's bases, so a step is TWO dependent loads (slot, then
+//          needs to start streaming the candidate's bases (F as seq word + base-in-word), so a step is TWO dependent loads (slot, then
 //          bases + meta side by side) instead of three.  Bits 30/31 of the id word carry the orientation the
 //          reference recomputes by string compare at query time (aligner.cpp:174,235).
 #ifndef BGREAT_AMD_GRAPH_LAYOUT_H
@@ -41,7 +41,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 3u  /* 3: 2-bit-state cascade, 16-byte slots */
+#define BGR_BLOB_VERSION 4u  /* 4: 2-bit-state cascade, 16-byte slots with (word, offset) sequence addresses */
 #define BGR_MAX_LEVELS 48
 #define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
 #define BGR_NONE 0xFFFFFFFFu
@@ -72,7 +72,8 @@ typedef struct {
 typedef struct {
     uint32_t idf;     // unitig id | BGR_SLOT_F0 | BGR_SLOT_F1 ; 0 = empty slot
     uint32_t len;
-    uint64_t F;
+    uint32_t Fw;      // forward strand starts at base Fo of seq word Fw  (F = 32*Fw + Fo): 32-bit address arithmetic
+    uint32_t Fo;      //   in the kernels (seq must stay below 4 GiB = 2^34 bases, checked at build time)
 } BgrSlot;            // 16 B; a neighbour record is BgrSlot[8]: left-table slots 0..3, right-table slots 4..7
 
 typedef struct {
