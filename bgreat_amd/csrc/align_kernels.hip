@@ -51,6 +51,12 @@ __device__ __forceinline__ u64 win32(P A, u64 p) {
     const u64 hi = A[w], lo = A[w + 1];
     return (hi << s) | ((lo >> 1) >> (63 - s));
 }
+// the same for the per-wave LDS streams, whose base positions fit 32 bits
+__device__ __forceinline__ u64 lds_win32(const u64* A, uint32_t p) {
+    const uint32_t s = (p & 31) * 2;
+    const u64 hi = A[p >> 5], lo = A[(p >> 5) + 1];
+    return (hi << s) | ((lo >> 1) >> (63 - s));
+}
 // 32 BITS starting at bit q of a 1-bit-per-base plane, most significant first
 __device__ __forceinline__ uint32_t plane32(const u64* P, u64 q) {
     u64 w = q >> 6;
@@ -189,7 +195,7 @@ __device__ __forceinline__ void derive_streams(uint32_t L, uint32_t W, uint32_t 
         long long p = (long long)L - 32 * ((long long)w + 1);
         u64 rcw = 0;
         if (p >= 0) {
-            rcw = ~rev2_fast(win32(FW3, (u64)p));
+            rcw = ~rev2_fast(lds_win32(FW3, (uint32_t)p));
         } else if (p > -32) {
             uint32_t v = (uint32_t)(32 + p);  // valid bases
             u64 x = FW3[0] >> (64 - 2 * v);
@@ -226,11 +232,6 @@ __device__ __forceinline__ u64 seq_win32(const u64* seq, uint32_t fw, uint32_t u
     const u64* q = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(seq) + boff);
     const uint32_t s = (ub & 31) * 2;
     const u64 hi = q[0], lo = q[1];
-    return (hi << s) | ((lo >> 1) >> (63 - s));
-}
-__device__ __forceinline__ u64 lds_win32(const u64* A, uint32_t p) {
-    const uint32_t s = (p & 31) * 2;
-    const u64 hi = A[p >> 5], lo = A[(p >> 5) + 1];
     return (hi << s) | ((lo >> 1) >> (63 - s));
 }
 
@@ -595,8 +596,8 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
                 const bool valid = i < npos;
                 u64 num = 0, rcn = 0;
                 if (valid) {
-                    num = win32(A, i) >> (64 - 2 * K1);
-                    rcn = plain ? rcb_fast(num, K1) : win32(B, L - K1 - i) >> (64 - 2 * K1);
+                    num = lds_win32(A, i) >> (64 - 2 * K1);
+                    rcn = plain ? rcb_fast(num, K1) : lds_win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
                 const uint32_t idx = find_key(g, LV, units, rep, valid);
@@ -606,13 +607,16 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
                     const int src = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     ++tried;
-                    const u64 a_num = rl64(num, src), a_rcn = rl64(rcn, src);
+                    // the anchor's k-mers are re-read from LDS (uniform) rather than kept in two 64-bit VGPRs across the walk
+                    const uint32_t a_pos = base + (uint32_t)src;
+                    const u64 a_num = rl64(lds_win32(A, a_pos) >> (64 - 2 * K1), 0);
+                    const u64 a_rcn = plain ? rcb_fast(a_num, K1) : rl64(lds_win32(B, L - K1 - a_pos) >> (64 - 2 * K1), 0);
                     uint32_t a_rec = rl32(idx, src);
                     // getBegin/getEnd recompute rc = rcb(num) (aligner.cpp:149,211); it differs from the
                     // rolling rcnum only when an N was rolled into the window.
                     const u64 rc2 = rcb_fast(a_num, K1);
                     if (rc2 != a_rcn) a_rec = find_key(g, LV, units, a_num < rc2 ? a_num : rc2, true);
-                    if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, base + src, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
+                    if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, a_pos, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
                         done = true;
                         break;
                     }
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGra
             const uint32_t i = base + lane;
             const bool valid = i < npos;
             u64 num = 0;
-            if (valid) num = win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
             const uint32_t idx = find_key(g, LV, units, num < rc ? num : rc, valid);
             u64 mask = __ballot(idx != BGR_NONE);
