@@ -283,3 +283,32 @@ def test_full_size_batch_properties():
     for j, i in enumerate(idx):
         assert st1[i] == sts[j]
         assert np.array_equal(p1[int(po1[i]): int(po1[i + 1])], ps[int(pos[j]): int(pos[j + 1])])
+
+
+def test_tiny_and_very_long_reads_through_the_api():
+    """Lengths the parsers never hand over (shorter than k-1) and reads of several kb: no crash, oracle-identical."""
+    s = Synth(300000, 90, 2, 31, 909)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(31, seqs, offs)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(31, seqs, offs)
+    chunks, lens = [], []
+    for i, L in enumerate([30, 31, 32, 40, 3000, 64, 8000, 33, 257, 512, 513, 1024, 20000]):
+        r, _ = s.reads(i, 1, L, 3, 910)
+        chunks.append(r)
+        lens.append(L)
+    reads = np.concatenate(chunks)
+    roffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    p1, po1, st1 = al.align(reads, roffs, m=6)
+    p2, po2, st2 = o.align(reads, roffs, m=6)
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    p1, po1, st1 = al.align(reads, roffs, m=6, mode=B.MODE_EXHAUSTIVE)
+    p2, po2, st2 = o.align(reads, roffs, m=6, mode=1)
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    # shorter than k-1: the reference reads out of range here; the library reports "not mapped" instead of crashing
+    short = np.frombuffer(b"ACGTACGTACGTAC" + b"ACG" + b"A", dtype=np.uint8)
+    so = np.array([0, 14, 17, 18, 18], dtype=np.uint64)
+    p, po, st = al.align(short, so)
+    assert len(p) == 0 and list(st & 3) == [0, 0, 0, 0]
+    p, po, st = al.align(short, so, mode=B.MODE_EXHAUSTIVE)
+    assert len(p) == 0 and list(st & 3) == [1, 1, 1, 1]
