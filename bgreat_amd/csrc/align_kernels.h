@@ -23,8 +23,6 @@ struct BatchIO {
     uint32_t frames_per_wave;    // exhaustive mode: DFS frames (20 u32 each) in the per-wave LDS region
     uint32_t* ovf_list;          // exhaustive pass 1: reads whose search outgrew frames_per_wave are listed here (count at cursor[2])
     const uint32_t* subset;      // exhaustive pass 2: map reads subset[0 .. cursor[2]) instead of 0 .. n_reads
-    uint2* anch;                 // greedy split: per read {neighbour record of the first anchor | BGR_ANCH_*, position | canonical << 31}
-    uint64_t* pk;                // greedy split: packed forward read (words_per_read u64 per read), written by the scan kernel
 };
 
 struct KernelParams {
@@ -59,13 +57,8 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
     return bytes;
 }
 
-// Waves of a mapping kernel that one CU can keep resident (register-limited).
-enum KernelId { K_GREEDY = 0, K_EXHAUSTIVE = 1, K_GREEDY_SCAN = 2, K_GREEDY_WALK = 3 };
-uint32_t resident_waves_per_cu(uint32_t kernel_id);
-
-// Greedy mode as three launches (see align_kernels.hip "greedy, split"): scan, walk, fallback for the rest.
-hipError_t launch_greedy_split(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& scan, const LaunchCfg& walk,
-                               const LaunchCfg& mono, hipStream_t stream);
+// Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive).
+uint32_t resident_waves_per_cu(uint32_t mode);
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);
 

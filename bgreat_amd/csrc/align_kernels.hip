@@ -31,9 +31,6 @@ typedef uint64_t u64;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
 #define EVEN_BITS 0x5555555555555555ULL
-// greedy split mode: markers in BatchIO::anch[r].x (any other value = neighbour record of the read's first anchor)
-#define BGR_ANCH_NOWORK 0xFFFFFFFEu  /* the read is final */
-#define BGR_ANCH_SLOW 0xFFFFFFFDu    /* left to the general kernel */
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -573,7 +570,6 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
     const uint32_t effort = prm.effort ? prm.effort : 1;
 
     for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
-        if (io.anch && io.anch[r].x != BGR_ANCH_SLOW) continue;  // split mode: only what scan/walk left to this kernel
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
         // (prefetching the next read one iteration ahead was measured: no gain at 24 waves/CU, it only added spills)
@@ -648,110 +644,6 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
         if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
         if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
         if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
-    }
-}
-
-// ============================================ greedy, split ==============================================
-// The same mapping as bgr_align_greedy_kernel, cut along its phases so that each kernel is small in registers
-// (8 waves per SIMD instead of 6) and straight in control flow:
-//   scan : pack the read, find its FIRST anchor (position order).  No anchor anywhere -> the read is final
-//          ("no overlap").  Reads with N go to the general kernel (their rolling k-mers need the quirk streams).
-//   walk : greedy extension from that first anchor, comparing against the packed read the scan kernel left in HBM.
-//          Success (the common case) -> final.  Failure -> general kernel.
-//   rest : bgr_align_greedy_kernel maps what is marked BGR_ANCH_SLOW from scratch (second anchor, reverse
-//          complement retry, N reads) -- the result of a read never depends on which kernel produced it.
-
-template <bool STAGE>
-__global__ void __launch_bounds__(1024, 8) bgr_greedy_scan_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
-    extern __shared__ u64 lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int waves = blockDim.x >> 6;
-    const uint32_t W = io.words_per_read;
-    const uint32_t K1 = g.k - 1;
-    uint2* LV;
-    uint32_t mphf_words;
-    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
-    u64* FW3 = lds + 64 + mphf_words + (u64)wave * 2 * W;
-    u64* NM = FW3 + W;
-    uint32_t c_reads = 0;
-    for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
-        const u64 off = io.read_offs[r];
-        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
-        if (hasN) {
-            if (lane == 0) io.anch[r] = make_uint2(BGR_ANCH_SLOW, 0);
-            wave_sync();
-            continue;
-        }
-        uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
-        if (!prm.effort && npos > 1) npos = 1;  // getNOverlap(read, 0), aligner.cpp:349-368
-        uint32_t a_rec = BGR_NONE, a_pos = 0;
-        for (uint32_t base = 0; base < npos; base += 64) {
-            const uint32_t i = base + lane;
-            const bool valid = i < npos;
-            u64 num = 0;
-            if (valid) num = lds_win32(FW3, i) >> (64 - 2 * K1);
-            const u64 rcn = rcb_fast(num, K1);  // no N: the rolling reverse k-mer is rcb of the forward one
-            const uint32_t idx = find_key(g, LV, units, num < rcn ? num : rcn, valid);
-            const u64 mask = __ballot(idx != BGR_NONE);
-            if (mask) {
-                const int src = __ffsll((long long)mask) - 1;
-                a_rec = rl32(idx, src);
-                a_pos = base + (uint32_t)src;
-                break;
-            }
-        }
-        if (a_rec == BGR_NONE) {  // alignerGreedy.cpp:37  ++noOverlapRead; return {}
-            if (lane == 0) {
-                io.results[r] = make_uint2(0, (uint32_t)BGR_ST_NOANCHOR << 24);
-                io.anch[r] = make_uint2(BGR_ANCH_NOWORK, 0);
-            }
-            ++c_reads;
-        } else {
-            const u64 a_num = rl64(lds_win32(FW3, a_pos) >> (64 - 2 * K1), 0);
-            const bool canon = a_num <= rcb_fast(a_num, K1);
-            if (lane == 0) io.anch[r] = make_uint2(a_rec, a_pos | (canon ? 0x80000000u : 0u));
-            for (uint32_t w = lane; w < W; w += 64) io.pk[(u64)r * W + w] = FW3[w];
-        }
-        wave_sync();
-    }
-    if (lane == 0 && c_reads) {
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        atomicAdd(&counters[0], (unsigned long long)c_reads);
-        atomicAdd(&counters[1], (unsigned long long)c_reads);
-    }
-}
-
-__global__ void __launch_bounds__(1024, 8) bgr_greedy_walk_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
-    extern __shared__ u64 lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int waves = blockDim.x >> 6;
-    const uint32_t W = io.words_per_read;
-    const uint32_t K1 = g.k - 1;
-    int32_t* PATH = reinterpret_cast<int32_t*>(lds) + (u64)wave * io.path_cap;
-    uint32_t c_al = 0;
-    uint32_t chunk_pos = 0, chunk_end = 0;
-    for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
-        const uint2 a = io.anch[r];
-        if (a.x >= BGR_ANCH_SLOW) continue;  // final already, or left to the general kernel
-        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - io.read_offs[r]);
-        const u64* CMP = io.pk + (u64)r * W;  // packed forward read in HBM (L2-hot: the scan kernel just wrote it)
-        uint32_t p_lo = 0, p_n = 0;
-        const bool ok = greedy_from_anchor(g, CMP, CMP, false, L, K1, a.x, (a.y >> 31) != 0, a.y & 0x7FFFFFFFu, prm.max_mismatch, PATH, &p_lo, &p_n, lane);
-        wave_sync();
-        if (ok) {
-            const uint32_t abase = publish_path(io, PATH, p_lo, p_n, &chunk_pos, &chunk_end, lane);
-            if (lane == 0) io.results[r] = make_uint2(abase, p_n | ((uint32_t)BGR_ST_ALIGNED << 24));
-            ++c_al;
-        } else if (lane == 0) {
-            io.anch[r] = make_uint2(BGR_ANCH_SLOW, 0);
-        }
-        wave_sync();
-    }
-    if (lane == 0 && c_al) {
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        atomicAdd(&counters[0], (unsigned long long)c_al);
-        atomicAdd(&counters[2], (unsigned long long)c_al);
     }
 }
 
@@ -863,30 +755,15 @@ hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, cons
 
 }  // namespace
 
-uint32_t resident_waves_per_cu(uint32_t kernel_id) {
+uint32_t resident_waves_per_cu(uint32_t mode) {
     hipFuncAttributes fa;
-    const void* fn = kernel_id == K_GREEDY ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)
-                   : kernel_id == K_EXHAUSTIVE ? reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true>)
-                   : kernel_id == K_GREEDY_SCAN ? reinterpret_cast<const void*>(&bgr_greedy_scan_kernel<true>)
-                                                : reinterpret_cast<const void*>(&bgr_greedy_walk_kernel);
+    const void* fn = mode == 0 ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)
+                               : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true>);
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
     // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;
-    // SGPRs: a SIMD admits floor(800 / (ceil(sgpr/16)*16 + 16)) waves -- 6 for the ~106-SGPR general kernels.
+    // the kernels use ~106 SGPRs, which caps a SIMD at 6 waves (800 / (7*16 + 16)).
     const uint32_t alloc = ((uint32_t)fa.numRegs + 7) / 8 * 8;
-    const uint32_t sgpr_cap = (kernel_id == K_GREEDY || kernel_id == K_EXHAUSTIVE) ? 6 : 8;  // scan/walk: <= 80 SGPRs
-    return 4 * std::min<uint32_t>(sgpr_cap, 512 / alloc);
-}
-
-hipError_t launch_greedy_split(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& scan, const LaunchCfg& walk,
-                               const LaunchCfg& mono, hipStream_t stream) {
-    if (io.n_reads == 0) return hipSuccess;
-    hipError_t e = scan.stage_mphf ? launch_one(bgr_greedy_scan_kernel<true>, g, io, p, scan, stream)
-                                   : launch_one(bgr_greedy_scan_kernel<false>, g, io, p, scan, stream);
-    if (e != hipSuccess) return e;
-    e = launch_one(bgr_greedy_walk_kernel, g, io, p, walk, stream);
-    if (e != hipSuccess) return e;
-    return mono.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, mono, stream)
-                           : launch_one(bgr_align_greedy_kernel<false>, g, io, p, mono, stream);
+    return 4 * std::min<uint32_t>(6, 512 / alloc);
 }
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {

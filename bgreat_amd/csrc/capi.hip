@@ -62,7 +62,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, results, arena, ovf, anch, pk, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, results, arena, ovf, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -238,7 +238,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->anch.release(); a->pk.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->small.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
@@ -281,16 +281,16 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     // `b` workgroups per CU of `w` waves each, every staged workgroup holding its own copy of the MPHF cascade.
     // More resident waves hide more of the walk's dependent-load latency (measured 16 -> 24 waves/CU: +18 %), and a
     // grid of exactly CUs x b workgroups avoids a partial last round.
-    const uint32_t cap_main = std::max<uint32_t>(4, bgr::resident_waves_per_cu(p->mode == BGR_MODE_GREEDY ? bgr::K_GREEDY : bgr::K_EXHAUSTIVE));
+    const uint32_t cap = std::max<uint32_t>(4, bgr::resident_waves_per_cu(p->mode));
     const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
-    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, uint32_t cap, bool may_stage, bgr::LaunchCfg& cfg) -> bool {
+    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bgr::LaunchCfg& cfg) -> bool {
         uint32_t waves = 0, bpc = 0;
         bool stage = false;
         auto fits = [&](uint32_t b, uint32_t w, bool st) {
             return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 7) / 8) * 8 : 0) + (uint64_t)w * pw) <= lds_fit;
         };
         if (allow_tuning && (a->cfg_waves || a->cfg_blocks_per_cu)) {  // explicit tuning through bgr_aligner_configure
-            stage = may_stage && (a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true)));
+            stage = a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true));
             waves = a->cfg_waves ? a->cfg_waves : (stage ? 12 : 4);
             bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
             while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
@@ -298,7 +298,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
         } else {
             uint32_t best_res = 0;
-            if (may_stage && a->cfg_lds_mphf != 1 && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
+            if (a->cfg_lds_mphf != 1 && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
                 const uint32_t bs[] = {1, 2, 3, 4, 6};
                 for (uint32_t b : bs) {
                     uint32_t w = std::min<uint32_t>(16, cap / b);
@@ -315,7 +315,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
                 while (w > 0 && !fits(b, w, false)) --w;
                 if (w && b * w > res_n) { res_n = b * w; wn = w; bn = b; }
             }
-            if (!may_stage || a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
+            if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
             if (best_res == 0) waves = 0;
         }
         if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return false;
@@ -325,33 +325,19 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         cfg.stage_mphf = stage ? 1 : 0;
         return true;
     };
-    bgr::LaunchCfg cfg, cfg_deep, cfg_scan, cfg_walk;
-    if (!geometry(per_wave, n_reads, true, cap_main, true, cfg) || (two_pass && !geometry(per_wave_deep, n_reads, false, cap_main, true, cfg_deep)))
+    bgr::LaunchCfg cfg, cfg_deep;
+    if (!geometry(per_wave, n_reads, true, cfg) || (two_pass && !geometry(per_wave_deep, n_reads, false, cfg_deep)))
         return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
-    // Greedy mode runs split into scan / walk / general kernels (align_kernels.hip "greedy, split") unless disabled.
-    const char* dbg = getenv("BGR_DEBUG_STOP");
-    const char* split_env = getenv("BGR_GREEDY_SPLIT");
-    bool split = p->mode == BGR_MODE_GREEDY && !dbg && !(split_env && atoi(split_env) == 0) && !(a->cfg_waves || a->cfg_blocks_per_cu);
-    if (split) {
-        const uint32_t cap_scan = std::max<uint32_t>(4, bgr::resident_waves_per_cu(bgr::K_GREEDY_SCAN));
-        const uint32_t cap_walk = std::max<uint32_t>(4, bgr::resident_waves_per_cu(bgr::K_GREEDY_WALK));
-        split = geometry(16 * words, n_reads, false, cap_scan, true, cfg_scan) && geometry(4 * path_cap, n_reads, false, cap_walk, false, cfg_walk);
-    }
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
     // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
     const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
     const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
-                               (two_pass ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0) +
-                               (split ? (uint64_t)cfg_walk.blocks * cfg_walk.waves_per_block * arena_chunk : 0);
+                               (two_pass ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0);
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
-    {
-        const bgr::LaunchCfg& shown = split ? cfg_scan : cfg;
-        a->last_launch[0] = shown.blocks; a->last_launch[1] = shown.waves_per_block * 64; a->last_launch[2] = shown.lds_bytes;
-        a->last_launch[3] = shown.stage_mphf | (split ? 2u : 0u);
-    }
+    a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf;
 
     bgr::BatchIO io;
     io.reads = static_cast<const uint8_t*>(d_reads);
@@ -368,23 +354,15 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         HIP_TRY(a->ovf.ensure(n_reads * 4));
         io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
     }
-    io.anch = nullptr;
-    io.pk = nullptr;
-    if (split) {
-        HIP_TRY(a->anch.ensure(n_reads * 8));
-        HIP_TRY(a->pk.ensure(n_reads * (uint64_t)words * 8));
-        io.anch = static_cast<uint2*>(a->anch.p);
-        io.pk = static_cast<uint64_t*>(a->pk.p);
-    }
     io.results = static_cast<uint2*>(a->results.p);
     io.arena = static_cast<int32_t*>(a->arena.p);
     io.cursor = static_cast<uint32_t*>(a->small.p);
+    const char* dbg = getenv("BGR_DEBUG_STOP");
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, dbg ? (uint32_t)atoi(dbg) : 0u};
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 16, a->stream));
     HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
-    hipError_t e = split ? bgr::launch_greedy_split(a->dg, io, kp, cfg_scan, cfg_walk, cfg, a->stream)
-                         : bgr::launch_align(a->dg, io, kp, cfg, a->stream);
+    hipError_t e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (two_pass) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
         bgr::BatchIO io2 = io;
