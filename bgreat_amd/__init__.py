@@ -27,7 +27,7 @@ SYMBOLS = [
     "bgr_aligner_sync", "bgr_aligner_device_results", "bgr_aligner_fetch", "bgr_aligner_counters",
     "bgr_aligner_reset_counters", "bgr_aligner_kernel_time", "bgr_aligner_reset_kernel_time", "bgr_aligner_launch_info",
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
-    "bgr_write_records", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
+    "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
 ]
 
 
@@ -41,7 +41,8 @@ class Params(C.Structure):
 
 class RunOptions(C.Structure):
     _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
-                ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("reserved", C.c_uint32)]
+                ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("correction", C.c_uint32),
+                ("no_overlap_file", C.c_char_p)]
 
 
 class GraphInfo(C.Structure):
@@ -95,6 +96,7 @@ def lib():
     L.bgr_graph_blob.argtypes = [vp, C.POINTER(u64)]
     L.bgr_graph_from_blob.argtypes = [vp, u64, C.POINTER(vp)]
     L.bgr_graph_info.argtypes = [vp, C.POINTER(GraphInfo)]
+    L.bgr_graph_unitigs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.bgr_graph_destroy.argtypes = [vp]
     L.bgr_graph_destroy.restype = None
     L.bgr_graph_upload.argtypes = [vp, i32]
@@ -281,10 +283,11 @@ class Aligner:
 
 
 def align_all(graph, reads_csv, paths_file, notaligned_file, m=2, effort=2, mode=MODE_GREEDY, partial=False, n_gpus=1, threads=1,
-              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False):
+              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False, correction=False, no_overlap_file=None):
     """Aligner::alignAll (aligner.cpp:550-597) as one call -> (counters dict, mapping seconds)."""
     p = Params(mode, m, effort, int(partial))
-    o = RunOptions(n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, 0)
+    o = RunOptions(n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, int(correction),
+                   no_overlap_file.encode() if no_overlap_file else None)
     out = np.zeros(5, dtype=np.uint64)
     secs = C.c_double()
     _check(lib().bgr_align_all(graph.h, C.byref(p), C.byref(o), reads_csv.encode(), paths_file.encode(), notaligned_file.encode(),

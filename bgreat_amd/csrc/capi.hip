@@ -38,6 +38,8 @@ int set_error(int code, const std::string& msg) { return fail(code, msg); }  // 
 
 struct bgr_graph {
     bgr::HostGraph host;  // empty when adopted from a device blob
+    std::vector<char> ascii;            // the unitig characters as given (only graphs built from sequences have them):
+    std::vector<uint64_t> ascii_offs;   // correction mode spells reads from these, like the reference's vector<string>
     BgrBlobHeader header;
     struct Dev { void* ptr; bool owned; };
     std::map<int, Dev> dev;
@@ -114,7 +116,20 @@ int bgr_graph_build(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint
         return fail(BGR_E_ARG, err);
     }
     g->header = *g->host.header();
+    const uint64_t nu = g->header.n_unitigs;  // loading stopped at the first short sequence
+    g->ascii.assign(seqs + (nu ? offsets[0] : 0), seqs + (nu ? offsets[nu] : 0));
+    g->ascii_offs.resize(nu + 1);
+    for (uint64_t i = 0; i <= nu; ++i) g->ascii_offs[i] = nu ? offsets[i] - offsets[0] : 0;
     *out = g;
+    return BGR_OK;
+}
+
+int bgr_graph_unitigs(const bgr_graph* g, const char** seqs, const uint64_t** offsets, uint64_t* n) {
+    if (!g || !seqs || !offsets || !n) return fail(BGR_E_ARG, "bgr_graph_unitigs: null argument");
+    if (g->ascii_offs.empty()) return fail(BGR_E_ARG, "bgr_graph_unitigs: this graph was created from a blob and carries no unitig characters");
+    *seqs = g->ascii.data();
+    *offsets = g->ascii_offs.data();
+    *n = g->ascii_offs.size() - 1;
     return BGR_OK;
 }
 

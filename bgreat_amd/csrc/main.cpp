@@ -7,6 +7,7 @@
 //                                                   --batch N (reads per device batch, default 1M)
 //                                                   --write-exhaustive (-b normally writes nothing)
 //                                                   --chunk-bytes N (parser chunk size; tests use tiny chunks)
+//                                                   --no-overlap FILE (reads without any anchor go there instead of notAligned.fa)
 #include <getopt.h>
 
 #include <algorithm>
@@ -27,12 +28,13 @@ static void die(const char* what) {
 }
 
 int main(int argc, char** argv) {
-    std::string reads, unitigs("unitig.fa"), pathFile("paths"), notAlignedFile("notAligned.fa");
+    std::string reads, unitigs("unitig.fa"), pathFile("paths"), notAlignedFile("notAligned.fa"), noOverlapFile;
     int errors = 2, threads = 1, ka = 30, effort = 2, gpus = 1;  // bgreat.cpp:56-66 defaults (k is 30, not 31)
     long batch = 1 << 20, chunk_bytes = 0;
     bool brute = false, incomplete = false, fastq = false, correction = false, dog = false, write_exh = false;
     static option longopts[] = {{"gpus", required_argument, nullptr, 1000}, {"batch", required_argument, nullptr, 1001},
                                 {"write-exhaustive", no_argument, nullptr, 1002}, {"chunk-bytes", required_argument, nullptr, 1003},
+                                {"no-overlap", required_argument, nullptr, 1004},
                                 {nullptr, 0, nullptr, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "r:k:g:m:t:e:f:o:a:biqpcG", longopts, nullptr)) != -1) {  // bgreat.cpp:67
@@ -54,6 +56,7 @@ int main(int argc, char** argv) {
             case 1001: batch = std::stol(optarg); break;
             case 1002: write_exh = true; break;
             case 1003: chunk_bytes = std::stol(optarg); break;
+            case 1004: noOverlapFile = optarg; break;
             default: break;  // -o and -p are accepted and ignored, as in the reference (no `case`)
         }
     }
@@ -65,8 +68,8 @@ int main(int argc, char** argv) {
                   << "-c to output corrected reads" << std::endl;
         return 0;
     }
-    if (correction || dog) {
-        fprintf(stderr, "bgreat: -c (correction) and -G (anchors mode) are outside the GPU mapping path and not implemented\n");
+    if (dog) {
+        fprintf(stderr, "bgreat: -G (anchors mode) is outside the GPU mapping path and not implemented\n");
         return 2;
     }
     if (gpus < 1 || batch < 1) { fprintf(stderr, "bgreat: --gpus and --batch must be positive\n"); return 2; }
@@ -89,6 +92,8 @@ int main(int argc, char** argv) {
     opt.fastq = fastq ? 1 : 0;
     opt.write_exhaustive = write_exh ? 1 : 0;
     opt.echo_files = 1;
+    opt.correction = correction ? 1 : 0;
+    opt.no_overlap_file = noOverlapFile.empty() ? nullptr : noOverlapFile.c_str();
     auto start = std::chrono::system_clock::now();
     uint64_t tot[5] = {0, 0, 0, 0, 0};
     double map_secs = 0;

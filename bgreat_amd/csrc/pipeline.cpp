@@ -177,6 +177,45 @@ inline char* put_int(char* o, int32_t v) {  // to_string(v) + '.'  (aligner.cpp:
     return o;
 }
 
+// ---- correction mode (-c): recoverPath / getUnitig / compactionEnd (aligner.cpp:270-302, utils.cpp:171-179) ------
+struct Unitigs {
+    const char* seqs = nullptr;
+    const uint64_t* offs = nullptr;
+    uint64_t n = 0;
+    uint32_t k = 0;
+};
+inline char rc_char(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }  // utils.cpp:52-59
+inline void oriented_unitig(const Unitigs& u, int32_t id, std::string& out) {  // getUnitig: forward, or reverse complement for id < 0
+    out.clear();
+    const uint64_t i = (uint64_t)(id < 0 ? -(int64_t)id : id);
+    if (i == 0 || i > u.n) return;  // unitigs[0] is "" (aligner.cpp:408)
+    const char* s = u.seqs + u.offs[i - 1];
+    const uint64_t len = u.offs[i] - u.offs[i - 1];
+    if (id > 0) { out.assign(s, len); return; }
+    out.resize(len);
+    for (uint64_t j = 0; j < len; ++j) out[j] = rc_char(s[len - 1 - j]);
+}
+// The read as spelled by its path: unitigs glued on their k-1 overlaps, then substr(offset, read length).
+// false = the reference's "bug compaction" exit (no orientation of the next unitig continues the walk).
+bool recover_path(const Unitigs& u, const int32_t* path, uint64_t n, uint32_t read_len, std::string& walk, std::string& tmp, std::string& rc) {
+    const uint32_t K1 = u.k - 1;
+    oriented_unitig(u, path[1], walk);
+    for (uint64_t i = 2; i < n; ++i) {
+        oriented_unitig(u, path[i], tmp);
+        if (walk.empty() || tmp.empty() || walk.size() < K1 || tmp.size() < K1) return false;
+        if (walk.compare(walk.size() - K1, K1, tmp, 0, K1) == 0) { walk.append(tmp, K1, std::string::npos); continue; }
+        rc.resize(tmp.size());
+        for (size_t j = 0; j < tmp.size(); ++j) rc[j] = rc_char(tmp[tmp.size() - 1 - j]);
+        if (walk.compare(walk.size() - K1, K1, rc, 0, K1) == 0) { walk.append(rc, K1, std::string::npos); continue; }
+        return false;
+    }
+    const int32_t off = path[0];
+    if (off < 0 || (uint64_t)off > walk.size()) return false;  // std::out_of_range in the reference
+    walk.erase(0, (size_t)off);
+    if (walk.size() > read_len) walk.resize(read_len);
+    return true;
+}
+
 // Records lo..hi of a batch as the reference writes them: mapped -> "header\n" + "int." * n + "\n" into pbuf
 // (alignerGreedy.cpp:406-411), the others -> "header\nread\n" into nbuf (alignerGreedy.cpp:421-427).
 void format_range(const Batch& b, uint64_t lo, uint64_t hi, std::string& pbuf, std::string& nbuf) {
@@ -210,6 +249,47 @@ void format_range(const Batch& b, uint64_t lo, uint64_t hi, std::string& pbuf, s
     pbuf.resize(pmax ? (size_t)(po - p0) : 0);
 }
 
+// The same with the two opt-in output variants: correction mode (mapped reads are written as header + corrected read,
+// alignerGreedy.cpp:394-404) and the no-overlap split (reads without any anchor go to a third buffer).
+// Returns false on the reference's "bug compaction" condition.
+bool format_range_ext(const Batch& b, uint64_t lo, uint64_t hi, const Unitigs* correct, bool split_no_overlap, std::string& pbuf,
+                      std::string& nbuf, std::string& obuf) {
+    const int32_t* paths = static_cast<const int32_t*>(b.paths.p);
+    const uint64_t* poffs = static_cast<const uint64_t*>(b.poffs.p);
+    const uint8_t* status = static_cast<const uint8_t*>(b.status.p);
+    pbuf.clear(); nbuf.clear(); obuf.clear();
+    std::string walk, tmp, rc;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const RecSlice& r = b.recs[i];
+        const uint64_t np = poffs[i + 1] - poffs[i];
+        if (np) {
+            pbuf.append(r.h, r.hl);
+            pbuf.push_back('\n');
+            if (correct) {
+                if (np < 2 || !recover_path(*correct, paths + poffs[i], np, r.sl, walk, tmp, rc)) return false;
+                if (status[i] & BGR_ST_RC) {  // the path was found on the reverse complement: turn the spelled read back
+                    rc.resize(walk.size());
+                    for (size_t j = 0; j < walk.size(); ++j) rc[j] = rc_char(walk[walk.size() - 1 - j]);
+                    pbuf.append(rc);
+                } else {
+                    pbuf.append(walk);
+                }
+            } else {
+                char num[16];
+                for (uint64_t j = poffs[i]; j < poffs[i + 1]; ++j) { char* e = put_int(num, paths[j]); pbuf.append(num, (size_t)(e - num)); }
+            }
+            pbuf.push_back('\n');
+        } else {
+            std::string& o = (split_no_overlap && (status[i] & BGR_ST_MASK) == BGR_ST_NOANCHOR) ? obuf : nbuf;
+            o.append(r.h, r.hl);
+            o.push_back('\n');
+            o.append(r.s, r.sl);
+            o.push_back('\n');
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const char* reads_csv,
@@ -220,6 +300,20 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes : (8ull << 20);
     const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (1ull << 20);
     const bool writes = prm->mode == BGR_MODE_GREEDY || opt->write_exhaustive;
+    const bool correction = opt->correction && prm->mode == BGR_MODE_GREEDY;  // alignPartExhaustive ignores -c
+    Unitigs unitigs;
+    if (correction) {
+        if (bgr_graph_unitigs(graph, &unitigs.seqs, &unitigs.offs, &unitigs.n) != BGR_OK) return BGR_E_ARG;
+        bgr_graph_info_t gi0;
+        if (bgr_graph_info(graph, &gi0) != BGR_OK) return BGR_E_ARG;
+        unitigs.k = gi0.k;
+    }
+    FILE* ovlF = nullptr;
+    if (opt->no_overlap_file) {
+        ovlF = fopen(opt->no_overlap_file, "wb");
+        if (!ovlF) return bgr::set_error(BGR_E_IO, "bgr_align_all: cannot open the no-overlap file");
+    }
+    const bool extended = correction || ovlF != nullptr;
     bgr_graph_info_t gi;
     if (bgr_graph_info(graph, &gi) != BGR_OK) return BGR_E_ARG;
 
@@ -408,7 +502,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         std::map<uint64_t, std::unique_ptr<Batch>> pending;
         uint64_t want = 0;
         std::unique_ptr<Batch> b;
-        std::vector<std::string> pb(threads), nb(threads);
+        std::vector<std::string> pb(threads), nb(threads), ob(threads);
+        std::vector<char> okv(threads, 1);
         while (to_out.pop(b)) {
             pending[b->index] = std::move(b);
             while (!pending.empty() && pending.begin()->first == want) {
@@ -424,15 +519,20 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 Batch* cp = cur.get();
                 const uint64_t tf0 = now_us();
                 parallel_for(threads, threads, [&](size_t t) {
-                    pb[t].clear(); nb[t].clear();
+                    pb[t].clear(); nb[t].clear(); ob[t].clear();
                     uint64_t lo = t * per, hi = std::min<uint64_t>(cp->n, lo + per);
-                    if (lo < hi) format_range(*cp, lo, hi, pb[t], nb[t]);
+                    if (lo >= hi) return;
+                    if (!extended) format_range(*cp, lo, hi, pb[t], nb[t]);
+                    else okv[t] = format_range_ext(*cp, lo, hi, correction ? &unitigs : nullptr, ovlF != nullptr, pb[t], nb[t], ob[t]) ? 1 : 0;
                 });
+                for (unsigned t = 0; t < threads; ++t)
+                    if (!okv[t]) fail(BGR_E_INTERNAL, "bug compaction: a path does not spell a walk (the reference exits here, aligner.cpp:280-283)");
                 const uint64_t tf1 = now_us();
                 us_format += tf1 - tf0;
                 for (unsigned t = 0; t < threads; ++t) {
                     if (!pb[t].empty() && fwrite(pb[t].data(), 1, pb[t].size(), pathF) != pb[t].size()) fail(BGR_E_IO, "write to the paths file failed");
                     if (!nb[t].empty() && fwrite(nb[t].data(), 1, nb[t].size(), notF) != nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
+                    if (ovlF && !ob[t].empty() && fwrite(ob[t].data(), 1, ob[t].size(), ovlF) != ob[t].size()) fail(BGR_E_IO, "write to the no-overlap file failed");
                 }
                 us_write += now_us() - tf1;
             }
@@ -446,6 +546,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     free_batches.close();
     fclose(pathF);
     fclose(notF);
+    if (ovlF) fclose(ovlF);
     uint64_t tot[5] = {0, 0, 0, 0, 0};
     for (auto* a : aligners) {
         uint64_t c5[5];

@@ -80,6 +80,9 @@ int bgr_graph_build_from_fasta(const char* unitig_fasta_path, uint32_t k, double
 const void* bgr_graph_blob(const bgr_graph* g, uint64_t* bytes);
 int bgr_graph_from_blob(const void* blob, uint64_t bytes, bgr_graph** out); /* copies the blob */
 int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* out);
+/* The unitig characters as they were handed to bgr_graph_build (offsets[n+1]; unitig id i is row i-1), the
+ * reference's `vector<string> unitigs` (aligner.h:70).  Only graphs built from sequences carry them (not blobs). */
+int bgr_graph_unitigs(const bgr_graph* g, const char** seqs, const uint64_t** offsets, uint64_t* n);
 void bgr_graph_destroy(bgr_graph* g);
 
 /* Device residency.  upload: hipMalloc + H2D of the blob on `device` (idempotent per device).
@@ -167,7 +170,11 @@ typedef struct {
     uint32_t fastq;            /* -q                                                                            */
     uint32_t write_exhaustive; /* exhaustive mode writes nothing in the reference; 1 = write  */
     uint32_t echo_files;       /* print each file name to stdout before mapping it (aligner.cpp:559,576)        */
-    uint32_t reserved;
+    uint32_t correction;       /* -c: write header + the read as spelled by its path (recoverPath, aligner.cpp:270-290,
+                                  alignerGreedy.cpp:394-404) instead of the path; greedy mode only                 */
+    const char* no_overlap_file; /* optional third output (NULL = the reference's behaviour): reads WITHOUT any anchor go
+                                  here instead of notAligned.fa -- the split README.md:47-52 documents and
+                                  alignerGreedy.cpp:414-419 disables                                               */
 } bgr_run_options;
 int bgr_align_all(bgr_graph* g, const bgr_params* p, const bgr_run_options* o, const char* reads_csv, const char* paths_file,
                   const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds);

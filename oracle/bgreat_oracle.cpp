@@ -701,6 +701,30 @@ struct Oracle {
     }
 };
 
+// utils.cpp:171-179 compactionEnd: seq1 + (seq2 or its reverse complement) minus the k overlapping characters
+static string compaction_end(const string& seq1, const string& seq2, unsigned k) {
+    size_t s1 = seq1.size(), s2 = seq2.size();
+    if (s1 == 0 || s2 == 0) return "";
+    string rc2(reverse_complements(seq2)), end1(seq1.substr(s1 - k, k)), beg2(seq2.substr(0, k));
+    if (end1 == beg2) return seq1 + seq2.substr(k);
+    string begrc2(rc2.substr(0, k));
+    if (end1 == begrc2) return seq1 + rc2.substr(k);
+    return "";
+}
+// aligner.cpp:293-302 getUnitig + aligner.cpp:270-290 recoverPath (correction mode -c): the read as spelled by its path
+static bool recover_path(const Oracle& o, const vector<unum_t>& numbers, unsigned size, string& out) {
+    auto get_unitig = [&](int position) { return position > 0 ? o.unitigs[position] : reverse_complements(o.unitigs[-position]); };
+    int offset = numbers[0];
+    string path(get_unitig(numbers[1]));
+    for (size_t i = 2; i < numbers.size(); ++i) {
+        string inter(compaction_end(path, get_unitig(numbers[i]), o.k - 1));
+        if (inter.empty()) return false;  // the reference prints "bug compaction" and exits (aligner.cpp:280-283)
+        path = inter;
+    }
+    out = path.substr(offset, size);
+    return true;
+}
+
 // aligner.cpp:600-609 printPath
 static string print_path(const vector<unum_t>& path) {
     string res;
@@ -715,7 +739,7 @@ static string print_path(const vector<unum_t>& path) {
 // ------------------------------------------------------------------------------------------------
 struct Runner {
     Oracle& o;
-    bool fastq = false, exhaustive_writes = false;
+    bool fastq = false, exhaustive_writes = false, correction = false;
     std::ifstream readFile;
     FILE* pathF = nullptr;
     FILE* notMappedF = nullptr;
@@ -774,7 +798,14 @@ struct Runner {
                 uint8_t st;
                 vector<unum_t> path = o.align_one(mode, hr.second, st);
                 if (mode == 1 && !exhaustive_writes) continue;  // -b writes nothing
-                if (!path.empty()) {
+                if (!path.empty() && correction && mode == 0) {  // alignerGreedy.cpp:394-404
+                    string corrected;
+                    if (!recover_path(o, path, (unsigned)hr.second.size(), corrected)) { std::cout << "bug compaction" << std::endl; exit(0); }
+                    if (st & 4) corrected = reverse_complements(corrected);
+                    string rec = hr.first + '\n' + corrected + '\n';
+                    std::lock_guard<std::mutex> g(pathMutex);
+                    fwrite(rec.data(), 1, rec.size(), pathF);
+                } else if (!path.empty()) {
                     string rec = hr.first + '\n' + print_path(path);
                     std::lock_guard<std::mutex> g(pathMutex);
                     fwrite(rec.data(), 1, rec.size(), pathF);
@@ -928,7 +959,7 @@ int orc_parse_file(const char* path, int fastq, int k, uint64_t* out_sizes, char
 int orc_main(int argc, char** argv, int exh_writes) {
     string reads, unitigs("unitig.fa"), pathFile("paths"), notAlignedFile("notAligned.fa");
     int errors = 2, threads = 1, ka = 30, effort = 2;
-    bool brute = false, incomplete = false, fastq = false;
+    bool brute = false, incomplete = false, fastq = false, correction = false;
     for (int i = 1; i < argc; ++i) {  // same single-letter flags as getopt "r:k:g:m:t:e:f:o:a:biqpcG"
         string a = argv[i];
         auto val = [&](void) -> string { return (i + 1 < argc) ? string(argv[++i]) : string(); };
@@ -944,6 +975,7 @@ int orc_main(int argc, char** argv, int exh_writes) {
         else if (a == "-b") brute = true;
         else if (a == "-i") incomplete = true;
         else if (a == "-q") fastq = true;
+        else if (a == "-c") correction = true;
     }
     if (reads.empty()) { printf("-r read_file\n"); return 0; }
     Oracle o;
@@ -953,6 +985,7 @@ int orc_main(int argc, char** argv, int exh_writes) {
     o.partial = incomplete;
     Runner run(o);
     run.fastq = fastq;
+    run.correction = correction;
     run.exhaustive_writes = exh_writes != 0;
     run.pathF = fopen(pathFile.c_str(), "wb");          // aligner.h:85
     run.notMappedF = fopen(notAlignedFile.c_str(), "wb");  // aligner.h:86

@@ -162,6 +162,14 @@ def cases():
             for e in (2, 4):
                 c.append(("deg", ["-r", "deg_reads.fa", "-k", "5", "-g", g, "-m", str(m), "-e", str(e)]))
     c.append(("deg_k6", ["-r", "deg_reads.fa", "-k", "6", "-g", "deg_unitig.fa", "-m", "3"]))
+    # correction mode (-c): header + the read as spelled by its path (recoverPath, aligner.cpp:270-290)
+    for rd, m in (("syn_r150.fa", 0), ("syn_r150.fa", 2), ("syn_r250.fa", 5), ("syn_r100.fa", 5)):
+        c.append(("corr", ["-r", rd, "-k", "31", "-g", "syn_unitig.fa", "-m", str(m), "-c"]))
+    c.append(("corr", ["-r", "edge_reads.fa", "-k", "31", "-g", "syn_unitig.fa", "-m", "5", "-c"]))
+    c.append(("corr", ["-r", "long_r150.fa", "-k", "31", "-g", "long_unitig.fa", "-m", "2", "-c"]))
+    c.append(("corr", ["-r", "long_r150.fq", "-k", "31", "-g", "long_unitig.fa", "-m", "2", "-c", "-q"]))
+    for g in ("deg_unitig.fa", "deg_unitig_exc.fa"):
+        c.append(("corr", ["-r", "deg_reads.fa", "-k", "5", "-g", g, "-m", "2", "-e", "4", "-c"]))
     # exhaustive (-b): counters from the unmodified reference, bytes from bgreat_exh
     for m in (0, 2, 5):
         c.append(("exh", ["-r", "syn_r150.fa", "-k", "31", "-g", "syn_unitig.fa", "-m", str(m), "-b"]))

@@ -17,7 +17,8 @@ from util import GOLD, check_against_golden, golden_cases, resolve_args, run_cli
 pytestmark = pytest.mark.gpu
 
 CASES = golden_cases()
-GREEDY = [c for c in CASES if "-b" not in c["args"]]
+GREEDY = [c for c in CASES if "-b" not in c["args"] and "-c" not in c["args"]]
+CORR = [c for c in CASES if "-c" in c["args"]]
 EXH = [c for c in CASES if "-b" in c["args"]]
 
 
@@ -109,6 +110,28 @@ def test_cli_end_to_end_against_reference_binary(oracle_bins):
         from util import parse_counters
         assert parse_counters(o1) == parse_counters(o2)
         assert p1 == p2 and n1 == n2
+
+
+@pytest.mark.parametrize("case", CORR, ids=lambda c: "%02d-%s" % (c["id"], c["group"]))
+def test_cli_correction_mode_matches_reference_golden(case):
+    """-c: mapped reads are written as header + the read spelled by its path (aligner.cpp:270-290, alignerGreedy.cpp:394-404)."""
+    out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]) + ["-t", "3", "--batch", "101"])
+    check_against_golden(case, out, paths, na)
+
+
+def test_cli_no_overlap_split_is_opt_in():
+    """--no-overlap FILE moves exactly the reads without any anchor out of notAligned.fa; everything else is unchanged."""
+    case = next(c for c in GREEDY if c["group"] == "edge" and c["args"][7] == "2")
+    with tempfile.TemporaryDirectory() as d:
+        nov = os.path.join(d, "noOverlap.fa")
+        out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]) + ["--no-overlap", nov])
+        novb = open(nov, "rb").read()
+    assert paths.decode("latin-1") == case["paths"]
+    recs = lambda b: list(zip(b.split(b"\n")[0::2], b.split(b"\n")[1::2]))
+    want = recs(case["notaligned"].encode("latin-1"))
+    got = recs(na) + recs(novb)
+    assert sorted(want) == sorted(got)
+    assert len(recs(novb)) == case["counters"]["no_overlap"]
 
 
 def test_cli_exhaustive_writes_nothing_unless_asked():
