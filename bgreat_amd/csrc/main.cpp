@@ -97,7 +97,12 @@ int main(int argc, char** argv) {
     auto start = std::chrono::system_clock::now();
     uint64_t tot[5] = {0, 0, 0, 0, 0};
     double map_secs = 0;
-    if (bgr_align_all(graph, &prm, &opt, reads.c_str(), pathFile.c_str(), notAlignedFile.c_str(), tot, &map_secs) != BGR_OK) die("mapping");
+    const int arc = bgr_align_all(graph, &prm, &opt, reads.c_str(), pathFile.c_str(), notAlignedFile.c_str(), tot, &map_secs);
+    if (arc == BGR_E_COMPACTION) {  // aligner.cpp:280-283: cout<<"bug compaction"<<endl; cout<<path<<" "<<unitig<<endl; exit(0);
+        std::cout << bgr_last_error() << std::endl;
+        return 0;
+    }
+    if (arc != BGR_OK) die("mapping");
     const uint64_t rn = tot[0], no = tot[1], ali = tot[2], na = tot[3];
     std::cout << "The End" << std::endl;  // aligner.cpp:588-596
     std::cout << "Reads : " << rn << std::endl;

@@ -251,9 +251,11 @@ void format_range(const Batch& b, uint64_t lo, uint64_t hi, std::string& pbuf, s
 
 // The same with the two opt-in output variants: correction mode (mapped reads are written as header + corrected read,
 // alignerGreedy.cpp:394-404) and the no-overlap split (reads without any anchor go to a third buffer).
-// Returns false on the reference's "bug compaction" condition.
+// Returns false on the reference's "bug compaction" condition (aligner.cpp:280-283: it prints "bug compaction", the walk
+// so far and the unitig that does not continue it, and exits); the buffers then hold the records BEFORE that read and
+// `bug` the two strings the reference prints.
 bool format_range_ext(const Batch& b, uint64_t lo, uint64_t hi, const Unitigs* correct, bool split_no_overlap, std::string& pbuf,
-                      std::string& nbuf, std::string& obuf) {
+                      std::string& nbuf, std::string& obuf, std::string& bug) {
     const int32_t* paths = static_cast<const int32_t*>(b.paths.p);
     const uint64_t* poffs = static_cast<const uint64_t*>(b.poffs.p);
     const uint8_t* status = static_cast<const uint8_t*>(b.status.p);
@@ -263,10 +265,13 @@ bool format_range_ext(const Batch& b, uint64_t lo, uint64_t hi, const Unitigs* c
         const RecSlice& r = b.recs[i];
         const uint64_t np = poffs[i + 1] - poffs[i];
         if (np) {
+            if (correct && (np < 2 || !recover_path(*correct, paths + poffs[i], np, r.sl, walk, tmp, rc))) {
+                bug = walk + " " + tmp;
+                return false;
+            }
             pbuf.append(r.h, r.hl);
             pbuf.push_back('\n');
             if (correct) {
-                if (np < 2 || !recover_path(*correct, paths + poffs[i], np, r.sl, walk, tmp, rc)) return false;
                 if (status[i] & BGR_ST_RC) {  // the path was found on the reverse complement: turn the spelled read back
                     rc.resize(walk.size());
                     for (size_t j = 0; j < walk.size(); ++j) rc[j] = rc_char(walk[walk.size() - 1 - j]);
@@ -501,9 +506,11 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     std::thread writer([&]() {
         std::map<uint64_t, std::unique_ptr<Batch>> pending;
         uint64_t want = 0;
+        bool stop_writing_after_this = false, wrote_last = false;
         std::unique_ptr<Batch> b;
         std::vector<std::string> pb(threads), nb(threads), ob(threads);
         std::vector<char> okv(threads, 1);
+        std::vector<std::string> bugv(threads);
         while (to_out.pop(b)) {
             pending[b->index] = std::move(b);
             while (!pending.empty() && pending.begin()->first == want) {
@@ -514,7 +521,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     Channel<std::unique_ptr<Batch>>& ch; std::unique_ptr<Batch>& b;
                     ~Recycle() { b->recs.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
                 } recycle{free_batches, cur};
-                if (failed || !writes) continue;
+                if ((failed && !stop_writing_after_this) || !writes || wrote_last) continue;
                 const uint64_t per = (cur->n + threads - 1) / threads;
                 Batch* cp = cur.get();
                 const uint64_t tf0 = now_us();
@@ -523,10 +530,18 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     uint64_t lo = t * per, hi = std::min<uint64_t>(cp->n, lo + per);
                     if (lo >= hi) return;
                     if (!extended) format_range(*cp, lo, hi, pb[t], nb[t]);
-                    else okv[t] = format_range_ext(*cp, lo, hi, correction ? &unitigs : nullptr, ovlF != nullptr, pb[t], nb[t], ob[t]) ? 1 : 0;
+                    else okv[t] = format_range_ext(*cp, lo, hi, correction ? &unitigs : nullptr, ovlF != nullptr, pb[t], nb[t], ob[t], bugv[t]) ? 1 : 0;
                 });
+                // "bug compaction": like the reference, everything before the offending read is written, nothing after it
+                unsigned t_stop = threads;
                 for (unsigned t = 0; t < threads; ++t)
-                    if (!okv[t]) fail(BGR_E_INTERNAL, "bug compaction: a path does not spell a walk (the reference exits here, aligner.cpp:280-283)");
+                    if (!okv[t]) { t_stop = t; break; }
+                if (t_stop < threads) {
+                    fail(BGR_E_COMPACTION, "bug compaction\n" + bugv[t_stop]);
+                    for (unsigned t = t_stop + 1; t < threads; ++t) { pb[t].clear(); nb[t].clear(); ob[t].clear(); }
+                    for (auto& ok1 : okv) ok1 = 1;
+                    stop_writing_after_this = true;
+                }
                 const uint64_t tf1 = now_us();
                 us_format += tf1 - tf0;
                 for (unsigned t = 0; t < threads; ++t) {
@@ -534,6 +549,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     if (!nb[t].empty() && fwrite(nb[t].data(), 1, nb[t].size(), notF) != nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
                     if (ovlF && !ob[t].empty() && fwrite(ob[t].data(), 1, ob[t].size(), ovlF) != ob[t].size()) fail(BGR_E_IO, "write to the no-overlap file failed");
                 }
+                if (stop_writing_after_this) wrote_last = true;
                 us_write += now_us() - tf1;
             }
         }

@@ -34,6 +34,9 @@ extern "C" {
 #define BGR_E_IO (-3)       /* file could not be opened / read */
 #define BGR_E_CAPACITY (-4) /* caller-provided output buffer too small */
 #define BGR_E_INTERNAL (-5)
+#define BGR_E_COMPACTION (-6) /* correction mode: a path does not spell a walk -- the reference's "bug compaction" exit
+                                (aligner.cpp:280-283); bgr_last_error() = "bug compaction\n<walk> <unitig>", outputs hold the
+                                records before the offending read, as the reference leaves them */
 
 /* status byte of one read (alignReadGreedy's return + overlapFound + rc; alignerGreedy.cpp:35-57):
  *   low 2 bits: 0 = no anchor (noOverlapRead++), 1 = anchored, not aligned (notAligned++), 2 = aligned
