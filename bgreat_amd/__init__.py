@@ -28,7 +28,13 @@ SYMBOLS = [
     "bgr_aligner_reset_counters", "bgr_aligner_kernel_time", "bgr_aligner_reset_kernel_time", "bgr_aligner_launch_info",
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
+    "bgr_set_build_threads",
 ]
+
+
+class _Borrowed(np.ndarray):
+    """ndarray view of library-owned memory; `_owner` pins the handle that owns it."""
+    _owner = None
 
 
 class BgrError(RuntimeError):
@@ -89,6 +95,8 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     L.bgr_last_error.restype = C.c_char_p
+    L.bgr_set_build_threads.restype = None
+    L.bgr_set_build_threads.argtypes = [C.c_uint32]
     L.bgr_device_count.restype = i32
     L.bgr_graph_build.argtypes = [u32, u64, vp, vp, C.c_double, C.POINTER(vp)]
     L.bgr_graph_build_from_fasta.argtypes = [C.c_char_p, u32, C.c_double, C.POINTER(vp)]
@@ -185,7 +193,9 @@ class Graph:
         p = lib().bgr_graph_blob(self.h, C.byref(n))
         if not p:
             return np.zeros(0, dtype=np.uint8)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,))
+        v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).view(_Borrowed)
+        v._owner = self   # the bytes belong to the graph: keep it alive as long as the view (or a view of it) is
+        return v
 
     def info(self):
         gi = GraphInfo()

@@ -98,6 +98,7 @@ int drain_timers(bgr_aligner* a) {
 extern "C" {
 
 const char* bgr_last_error(void) { return tl_err.c_str(); }
+void bgr_set_build_threads(uint32_t threads) { bgr::set_build_threads(threads); }
 
 int bgr_device_count(void) {
     int n = 0;
@@ -153,7 +154,7 @@ int bgr_graph_from_blob(const void* blob, uint64_t bytes, bgr_graph** out) {
     std::string err;
     if (!bgr::validate_blob(blob, bytes, err)) return fail(BGR_E_ARG, err);
     bgr_graph* g = new bgr_graph();
-    g->host.blob.assign((bytes + 7) / 8, 0);
+    if (!g->host.blob.reset((bytes + 7) / 8)) { delete g; return fail(BGR_E_ARG, "bgr_graph_from_blob: out of memory"); }
     memcpy(g->host.blob.data(), blob, bytes);
     g->header = *g->host.header();
     *out = g;

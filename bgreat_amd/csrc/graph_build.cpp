@@ -4,11 +4,19 @@
 // sets plus flat arrays, because only membership and the slot order are observable.
 #include "graph_build.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
-#include <fstream>
+#include <thread>
 
 namespace bgr {
 
@@ -16,8 +24,69 @@ namespace {
 
 inline uint32_t code_of(char c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; }  // utils.cpp:117-129
 
-inline void put_base(uint64_t* seq, uint64_t pos, uint32_t code) {
-    seq[pos >> 5] |= (uint64_t)code << (62 - 2 * (pos & 31));
+std::atomic<unsigned> g_build_threads{0};
+
+// fn(begin, end, tid) over [0, n) cut into `T` contiguous ranges, one thread each (inline when T == 1).
+template <class Fn>
+void parallel_ranges(unsigned T, uint64_t n, Fn fn) {
+    if (T <= 1 || n < 2) { fn((uint64_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) {
+        uint64_t b = n * t / T, e = n * (t + 1) / T;
+        th.emplace_back([=] { fn(b, e, t); });
+    }
+    for (auto& x : th) x.join();
+}
+
+// Sorts v with T threads: T sorted runs, then rounds of pairwise merges (each merge on its own thread).
+void parallel_sort(std::vector<uint64_t>& v, unsigned T) {
+    if (T <= 1 || v.size() < (1u << 16)) { std::sort(v.begin(), v.end()); return; }
+    std::vector<uint64_t> cut(T + 1);
+    for (unsigned t = 0; t <= T; ++t) cut[t] = v.size() * t / T;
+    parallel_ranges(T, T, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t t = b; t < e; ++t) std::sort(v.begin() + cut[t], v.begin() + cut[t + 1]);
+    });
+    while (cut.size() > 2) {
+        size_t pairs = (cut.size() - 1) / 2;
+        std::vector<std::thread> th;
+        for (size_t p = 0; p < pairs; ++p)
+            th.emplace_back([&, p] { std::inplace_merge(v.begin() + cut[2 * p], v.begin() + cut[2 * p + 1], v.begin() + cut[2 * p + 2]); });
+        for (auto& x : th) x.join();
+        std::vector<uint64_t> nc;
+        for (size_t i = 0; i < cut.size(); i += 2) nc.push_back(cut[i]);
+        if ((cut.size() - 1) % 2) nc.push_back(cut.back());
+        cut.swap(nc);
+    }
+}
+
+struct PhaseTimer {  // BGREAT_TIMING=1: per-phase wall time of the index build on stderr
+    bool on = getenv("BGREAT_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[build] %-10s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// ORs `len` bases of one strand into the packed store at base position `pos`, 32 bases per word; only the first
+// and last word of the run can be shared with a neighbouring run (another thread), so those go through atomics.
+// rc == false: codes of s[0..len); rc == true: 3 - code of s[len-1..0] (utils.cpp:52-59: non-ACG -> 'A').
+inline void pack_strand(uint64_t* seq, uint64_t pos, const char* s, uint32_t len, bool rc) {
+    uint32_t j = 0;
+    while (j < len) {
+        uint64_t w = (pos + j) >> 5;
+        uint32_t o = (uint32_t)((pos + j) & 31), n = std::min<uint32_t>(32 - o, len - j);
+        uint64_t x = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t c = rc ? 3u - code_of(s[len - 1 - (j + i)]) : code_of(s[j + i]);
+            x |= (uint64_t)c << (62 - 2 * (o + i));
+        }
+        if (n == 32) seq[w] = x;
+        else __atomic_fetch_or(&seq[w], x, __ATOMIC_RELAXED);
+        j += n;
+    }
 }
 inline uint64_t window(const uint64_t* seq, uint64_t pos, uint32_t n) {  // n in 1..32 bases starting at base pos
     uint64_t w = pos >> 5;
@@ -38,14 +107,17 @@ struct Cascade {
 // places every remaining key that is alone on its position (state 1); positions hit by several keys get
 // state 3 and those keys move on.  What is left after the last level (or once only a handful remain) goes
 // to a sorted fallback list searched by bisection.
-void build_cascade(const std::vector<uint64_t>& keys, double gamma, Cascade& c) {
+void build_cascade(const std::vector<uint64_t>& keys, double gamma, unsigned T, Cascade& c) {
     struct Rem { uint64_t key; uint32_t h, hb; };
     std::vector<Rem> rem(keys.size()), next;
-    for (size_t i = 0; i < keys.size(); ++i) {
-        uint64_t m = bgr_mix64(keys[i]);
-        rem[i] = {keys[i], (uint32_t)m, (uint32_t)(m >> 32) | 1u};
-    }
+    parallel_ranges(T, keys.size(), [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; ++i) {
+            uint64_t m = bgr_mix64(keys[i]);
+            rem[i] = {keys[i], (uint32_t)m, (uint32_t)(m >> 32) | 1u};
+        }
+    });
     uint32_t base = 0;
+    std::vector<std::vector<Rem>> part(T);
     for (int l = 0; l < BGR_MAX_LEVELS && !rem.empty(); ++l) {
         if (l > 0 && rem.size() <= 4) break;  // a handful left: cheaper in the fallback list than more levels
         uint64_t want = (uint64_t)std::ceil(gamma * (double)rem.size() / BGR_UNIT_POS);
@@ -53,17 +125,34 @@ void build_cascade(const std::vector<uint64_t>& keys, double gamma, Cascade& c) 
         size_t ubase = c.units.size();
         c.units.resize(ubase + (size_t)nu * 4, 0);
         uint32_t* U = c.units.data() + ubase;
-        for (const Rem& r : rem) {  // 0 -> 1 -> 3
-            uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
-            uint32_t& w = U[(size_t)u * 4 + (p >> 4)];
-            uint32_t sh = 2 * (p & 15), st = (w >> sh) & 3u;
-            w |= (st == 0 ? 1u : 3u) << sh;
-        }
+        unsigned Tl = rem.size() < 4096 ? 1 : T;
+        parallel_ranges(Tl, rem.size(), [&](uint64_t b, uint64_t e, unsigned) {  // 0 -> 1 -> 3, any order
+            for (uint64_t i = b; i < e; ++i) {
+                const Rem& r = rem[i];
+                uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
+                uint32_t* w = &U[(size_t)u * 4 + (p >> 4)];
+                uint32_t sh = 2 * (p & 15);
+                uint32_t old = __atomic_fetch_or(w, 1u << sh, __ATOMIC_RELAXED);
+                if ((old >> sh) & 1u) __atomic_fetch_or(w, 2u << sh, __ATOMIC_RELAXED);
+            }
+        });
+        std::vector<uint64_t> placed(Tl, 0);
+        parallel_ranges(Tl, rem.size(), [&](uint64_t b, uint64_t e, unsigned t) {
+            std::vector<Rem>& out = part[t];
+            out.clear();
+            uint64_t np = 0;
+            for (uint64_t i = b; i < e; ++i) {
+                const Rem& r = rem[i];
+                uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
+                uint32_t st = (U[(size_t)u * 4 + (p >> 4)] >> (2 * (p & 15))) & 3u;
+                if (st == 3u) out.push_back({r.key, r.h + r.hb, r.hb}); else ++np;
+            }
+            placed[t] = np;
+        });
         next.clear();
-        for (const Rem& r : rem) {
-            uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
-            uint32_t st = (U[(size_t)u * 4 + (p >> 4)] >> (2 * (p & 15))) & 3u;
-            if (st == 3u) next.push_back({r.key, r.h + r.hb, r.hb}); else ++c.n_placed;
+        for (unsigned t = 0; t < Tl; ++t) {
+            next.insert(next.end(), part[t].begin(), part[t].end());
+            c.n_placed += placed[t];
         }
         c.levels.push_back({nu, base});
         base += nu;
@@ -145,19 +234,68 @@ bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {
     return true;
 }
 
+bool ZeroPages::reset(uint64_t words) {
+    release();
+    if (words == 0) return true;
+    void* p = mmap(nullptr, words * 8, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return false;
+    p_ = static_cast<uint64_t*>(p);
+    words_ = words;
+    return true;
+}
+void ZeroPages::release() {
+    if (p_) munmap(p_, words_ * 8);
+    p_ = nullptr;
+    words_ = 0;
+}
+
+void set_build_threads(unsigned t) { g_build_threads.store(t); }
+unsigned build_threads() {
+    unsigned t = g_build_threads.load();
+    if (t == 0) t = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return t;
+}
+
 bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& seqs, std::vector<uint64_t>& offs, std::string& err) {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) { err = "cannot open unitig file " + path; return false; }
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { err = "cannot open unitig file " + path; return false; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); err = "cannot stat unitig file " + path; return false; }
     seqs.clear();
     offs.assign(1, 0);
-    std::string line;
-    while (!in.eof()) {  // aligner.cpp:415-420
-        std::getline(in, line);
-        std::getline(in, line);
-        if (line.size() < k) break;
-        seqs.insert(seqs.end(), line.begin(), line.end());
-        offs.push_back(seqs.size());
+    uint64_t size = (uint64_t)st.st_size;
+    if (size == 0) { close(fd); return true; }
+    void* mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (mp == MAP_FAILED) { err = "cannot map unitig file " + path; return false; }
+    madvise(mp, size, MADV_SEQUENTIAL);
+    const char* d = static_cast<const char*>(mp);
+    // aligner.cpp:415-420: two getline per record (header ignored, a missing line reads as empty), stop at the
+    // first sequence shorter than k.  Pass 1 finds the record extents, pass 2 copies them in parallel.
+    struct Ext { uint64_t b; uint32_t len; };
+    std::vector<Ext> ext;
+    uint64_t p = 0, total = 0;
+    while (p < size) {
+        const char* nl = static_cast<const char*>(memchr(d + p, '\n', size - p));
+        if (!nl) break;  // header without a sequence line: the sequence reads as "" -> stop
+        uint64_t sb = (uint64_t)(nl - d) + 1;
+        const char* nl2 = sb < size ? static_cast<const char*>(memchr(d + sb, '\n', size - sb)) : nullptr;
+        uint64_t se = nl2 ? (uint64_t)(nl2 - d) : size;
+        if (se - sb < k) break;
+        if (se - sb > 0xFFFFFFFFull) { munmap(mp, size); err = "unitig longer than 2^32-1 bases"; return false; }
+        ext.push_back({sb, (uint32_t)(se - sb)});
+        total += se - sb;
+        p = se + 1;
     }
+    seqs.resize(total);
+    offs.resize(ext.size() + 1);
+    uint64_t o = 0;
+    for (size_t i = 0; i < ext.size(); ++i) { offs[i] = o; o += ext[i].len; }
+    offs[ext.size()] = o;
+    parallel_ranges(build_threads(), ext.size(), [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; ++i) memcpy(seqs.data() + offs[i], d + ext[i].b, ext[i].len);
+    });
+    munmap(mp, size);
     return true;
 }
 
@@ -179,57 +317,71 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     const uint64_t total = 2 * sum, seq_words = (total + 31) / 32 + 2;
     if (seq_words * 8 >= (1ull << 32)) { err = "graph too large: the packed sequence store must stay below 4 GiB (2^34 bases over both strands)"; return false; }
 
-    // ---- pack both strands; collect non-ACGT exceptions of the forward strand -------------------
-    std::vector<uint64_t> seq(seq_words, 0), exc, excn;
+    const unsigned T = build_threads();
+    PhaseTimer tm;
+    // ---- unitig extents + key sets (aligner.cpp:422-433), straight from the characters ----------------
     std::vector<BgrUnitigMeta> meta(n + 1);
     memset(meta.data(), 0, meta.size() * sizeof(BgrUnitigMeta));
-    bool has_exc = false;
-    uint64_t F = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const char* s = seqs + offs[i];
-        uint32_t len = (uint32_t)(offs[i + 1] - offs[i]);
-        for (uint32_t j = 0; j < len; ++j) {
-            char ch = s[j];
-            uint32_t c = code_of(ch);
-            put_base(seq.data(), F + j, c);
-            put_base(seq.data(), F + len + (len - 1 - j), 3 - c);  // utils.cpp:52-59: non-ACG -> 'A' == 3 - 3
-            if (c == 3 && ch != 'T') {
-                if (!has_exc) { exc.assign((total + 63) / 64 + 2, 0); excn.assign((total + 63) / 64 + 2, 0); has_exc = true; }
-                exc[(F + j) >> 6] |= 1ULL << (63 - ((F + j) & 63));
-                if (ch == 'N') excn[(F + j) >> 6] |= 1ULL << (63 - ((F + j) & 63));
-            }
+    {
+        uint64_t F = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            uint32_t len = (uint32_t)(offs[i + 1] - offs[i]);
+            meta[i + 1].F = F;
+            meta[i + 1].len = len;
+            F += 2ull * len;
         }
-        meta[i + 1].F = F;
-        meta[i + 1].len = len;
-        F += 2ull * len;
     }
-
-    // ---- key sets (aligner.cpp:422-433) -----------------------------------------------------------
+    std::vector<uint64_t> begs(n + 1), ends(n + 1);
+    std::vector<uint64_t> lr(2 * n);       // per unitig: its two canonical end keys
+    std::vector<uint8_t> side(2 * n);      // 0 = goes to the left key set, 1 = right
+    std::atomic<bool> any_exc{false};
+    parallel_ranges(T, n, [&](uint64_t b, uint64_t e, unsigned) {
+        bool mine = false;
+        for (uint64_t i = b + 1; i <= e; ++i) {
+            const char* s = seqs + offs[i - 1];
+            const uint32_t len = meta[i].len;
+            uint64_t beg = 0, end = 0;  // str2num of the first / last k-1 characters (utils.cpp:117-129)
+            for (uint32_t j = 0; j < K1; ++j) {
+                beg = beg << 2 | code_of(s[j]);
+                end = end << 2 | code_of(s[len - K1 + j]);
+            }
+            uint64_t rcBeg = bgr_rcb(beg, K1), rcEnd = bgr_rcb(end, K1);
+            begs[i] = beg;
+            ends[i] = end;
+            if (beg <= rcBeg) { lr[2 * i - 2] = beg; side[2 * i - 2] = 0; } else { lr[2 * i - 2] = rcBeg; side[2 * i - 2] = 1; }
+            if (end <= rcEnd) { lr[2 * i - 1] = end; side[2 * i - 1] = 1; } else { lr[2 * i - 1] = rcEnd; side[2 * i - 1] = 0; }
+            if (!mine)
+                for (uint32_t j = 0; j < len; ++j) {
+                    char ch = s[j];
+                    if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') { mine = true; break; }
+                }
+        }
+        if (mine) any_exc.store(true);
+    });
+    const bool has_exc = any_exc.load();
     std::vector<uint64_t> left, right;
     left.reserve(n);
     right.reserve(n);
-    std::vector<uint64_t> begs(n + 1), ends(n + 1);
-    for (uint64_t i = 1; i <= n; ++i) {
-        uint64_t beg = window(seq.data(), meta[i].F, K1), rcBeg = bgr_rcb(beg, K1);
-        uint64_t end = window(seq.data(), meta[i].F + meta[i].len - K1, K1), rcEnd = bgr_rcb(end, K1);
-        begs[i] = beg;
-        ends[i] = end;
-        if (beg <= rcBeg) left.push_back(beg); else right.push_back(rcBeg);
-        if (end <= rcEnd) right.push_back(end); else left.push_back(rcEnd);
+    for (uint64_t j = 0; j < 2 * n; ++j) (side[j] ? right : left).push_back(lr[j]);
+    {
+        unsigned Th = std::max(1u, T / 2);
+        std::thread tl([&] { parallel_sort(left, Th); left.erase(std::unique(left.begin(), left.end()), left.end()); });
+        parallel_sort(right, Th);
+        right.erase(std::unique(right.begin(), right.end()), right.end());
+        tl.join();
     }
-    std::sort(left.begin(), left.end());
-    left.erase(std::unique(left.begin(), left.end()), left.end());
-    std::sort(right.begin(), right.end());
-    right.erase(std::unique(right.begin(), right.end()), right.end());
     std::vector<uint64_t> keys(left.size() + right.size());
     std::merge(left.begin(), left.end(), right.begin(), right.end(), keys.begin());
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     if (keys.size() >= 0x3FFFFFFFull) { err = "too many overlap keys (limit 2^30-1)"; return false; }
+    tm.lap("keys");
 
     Cascade cas;
-    build_cascade(keys, gamma, cas);
+    build_cascade(keys, gamma, T, cas);
+    tm.lap("cascade");
 
-    // ---- blob assembly ----------------------------------------------------------------------------
+    // ---- blob layout ------------------------------------------------------------------------------
+    const uint64_t exc_words = has_exc ? (total + 63) / 64 + 2 : 0;
     BgrBlobHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = BGR_MAGIC;
@@ -257,53 +409,98 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     h.off_meta = off;     off = align256(off + (n + 1) * sizeof(BgrUnitigMeta));
     h.off_seq = off;      off = align256(off + seq_words * 8);
     if (has_exc) {
-        h.off_exc = off;  off = align256(off + exc.size() * 8);
-        h.off_excn = off; off = align256(off + excn.size() * 8);
+        h.off_exc = off;  off = align256(off + exc_words * 8);
+        h.off_excn = off; off = align256(off + exc_words * 8);
     }
     h.off_fallback = off; off = align256(off + h.n_fallback * 8 + 8);
     h.blob_bytes = off;
 
-    out.blob.assign(off / 8, 0);
+    if (!out.blob.reset(off / 8)) { err = "out of memory for the graph blob"; return false; }  // zero pages, touched below in parallel
     uint8_t* base = reinterpret_cast<uint8_t*>(out.blob.data());
     memcpy(base, &h, sizeof(h));
     memcpy(base + h.off_units, cas.units.data(), cas.units.size() * 4);
-    memcpy(base + h.off_seq, seq.data(), seq_words * 8);
-    if (has_exc) {
-        memcpy(base + h.off_exc, exc.data(), exc.size() * 8);
-        memcpy(base + h.off_excn, excn.data(), excn.size() * 8);
-    }
     if (h.n_fallback) memcpy(base + h.off_fallback, cas.fallback.data(), h.n_fallback * 8);
+
+    // ---- pack both strands into the blob; non-ACGT exceptions of the forward strand -----------------
+    uint64_t* seq = reinterpret_cast<uint64_t*>(base + h.off_seq);
+    parallel_ranges(T, n, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b + 1; i <= e; ++i) {
+            const char* s = seqs + offs[i - 1];
+            pack_strand(seq, meta[i].F, s, meta[i].len, false);
+            pack_strand(seq, meta[i].F + meta[i].len, s, meta[i].len, true);
+        }
+    });
+    if (has_exc) {  // rare: bit set = this forward-strand base is not A/C/G/T (exc); it is 'N' (excn)
+        uint64_t* exc = reinterpret_cast<uint64_t*>(base + h.off_exc);
+        uint64_t* excn = reinterpret_cast<uint64_t*>(base + h.off_excn);
+        for (uint64_t i = 1; i <= n; ++i) {
+            const char* s = seqs + offs[i - 1];
+            uint64_t F = meta[i].F;
+            for (uint32_t j = 0; j < meta[i].len; ++j) {
+                char ch = s[j];
+                if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
+                exc[(F + j) >> 6] |= 1ULL << (63 - ((F + j) & 63));
+                if (ch == 'N') excn[(F + j) >> 6] |= 1ULL << (63 - ((F + j) & 63));
+            }
+        }
+    }
+    tm.lap("pack");
 
     // keys by MPHF index (also proves the hash is a bijection onto [0, n_keys))
     uint64_t* kout = reinterpret_cast<uint64_t*>(base + h.off_keys);
     std::vector<uint8_t> taken(keys.size(), 0);
     const BgrBlobHeader* hp = reinterpret_cast<const BgrBlobHeader*>(base);
-    for (uint64_t key : keys) {
-        uint32_t idx = host_lookup(hp, base, key);
-        if (idx == BGR_NONE || idx >= keys.size() || taken[idx]) { err = "internal: MPHF is not a bijection"; return false; }
-        taken[idx] = 1;
-        kout[idx] = key;
-    }
+    std::atomic<bool> bad{false};
+    parallel_ranges(T, keys.size(), [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t j = b; j < e; ++j) {
+            uint64_t key = keys[j];
+            uint32_t idx = host_lookup(hp, base, key);
+            if (idx == BGR_NONE || idx >= keys.size() || __atomic_exchange_n(&taken[idx], (uint8_t)1, __ATOMIC_RELAXED)) { bad.store(true); return; }
+            kout[idx] = key;
+        }
+    });
+    if (bad.load()) { err = "internal: MPHF is not a bijection"; return false; }
+    tm.lap("keytable");
 
     // ---- slot fill in unitig order (aligner.cpp:466-533) + orientation bits ---------------------
+    // Pass 1 (parallel over unitigs): record indices and flags.  Pass 2: the fill order within a record is the
+    // unitig order, so every thread walks all unitigs in order and fills only the records of its own index range.
     BgrSlot* recs = reinterpret_cast<BgrSlot*>(base + h.off_recs);
     BgrUnitigMeta* mout = reinterpret_cast<BgrUnitigMeta*>(base + h.off_meta);
-    for (uint64_t i = 1; i <= n; ++i) {
-        uint64_t beg = begs[i], rcBeg = bgr_rcb(beg, K1), end = ends[i], rcEnd = bgr_rcb(end, K1);
-        uint32_t id = (uint32_t)i;
-        uint32_t ib = host_lookup(hp, base, std::min(beg, rcBeg)), ie = host_lookup(hp, base, std::min(end, rcEnd));
-        // left-table slot of key x : F0 = (beg == x), F1 = (end == rc(x)); right-table slot of key y: F0 = (end == y), F1 = (beg == rc(y))
-        if (beg <= rcBeg) fill_slot(recs + (size_t)ib * 8, id | BGR_SLOT_F0 /* beg == key */ | (end == rcBeg ? BGR_SLOT_F1 : 0), meta[i]);
-        else fill_slot(recs + (size_t)ib * 8 + 4, id | (end == rcBeg ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* beg == rc(key) */, meta[i]);
-        if (end <= rcEnd) fill_slot(recs + (size_t)ie * 8 + 4, id | BGR_SLOT_F0 /* end == key */ | (beg == rcEnd ? BGR_SLOT_F1 : 0), meta[i]);
-        else fill_slot(recs + (size_t)ie * 8, id | (beg == rcEnd ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* end == rc(key) */, meta[i]);
-        BgrUnitigMeta m = meta[i];
-        m.rec_beg = ib;
-        m.rec_end = ie;
-        m.flags = (beg <= rcBeg ? BGR_META_CANON_BEG : 0) | (end <= rcEnd ? BGR_META_CANON_END : 0) |
-                  (rcBeg <= beg ? BGR_META_CANON_RCBEG : 0) | (rcEnd <= end ? BGR_META_CANON_RCEND : 0);
-        mout[i] = m;
-    }
+    parallel_ranges(T, n, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b + 1; i <= e; ++i) {
+            uint64_t beg = begs[i], rcBeg = bgr_rcb(beg, K1), end = ends[i], rcEnd = bgr_rcb(end, K1);
+            BgrUnitigMeta m = meta[i];
+            m.rec_beg = host_lookup(hp, base, std::min(beg, rcBeg));
+            m.rec_end = host_lookup(hp, base, std::min(end, rcEnd));
+            m.flags = (beg <= rcBeg ? BGR_META_CANON_BEG : 0) | (end <= rcEnd ? BGR_META_CANON_END : 0) |
+                      (rcBeg <= beg ? BGR_META_CANON_RCBEG : 0) | (rcEnd <= end ? BGR_META_CANON_RCEND : 0);
+            mout[i] = m;
+        }
+    });
+    tm.lap("lookup");
+    const uint64_t nk = keys.size();
+    parallel_ranges(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
+        const uint64_t lo = nk * tb / T, hi = nk * te / T;
+        for (uint64_t i = 1; i <= n; ++i) {
+            const BgrUnitigMeta& m = mout[i];
+            const bool mb = m.rec_beg >= lo && m.rec_beg < hi, me = m.rec_end >= lo && m.rec_end < hi;
+            if (!mb && !me) continue;
+            uint64_t beg = begs[i], rcBeg = bgr_rcb(beg, K1), end = ends[i], rcEnd = bgr_rcb(end, K1);
+            uint32_t id = (uint32_t)i;
+            uint32_t ib = m.rec_beg, ie = m.rec_end;
+            // left-table slot of key x : F0 = (beg == x), F1 = (end == rc(x)); right-table slot of key y: F0 = (end == y), F1 = (beg == rc(y))
+            if (mb) {
+                if (beg <= rcBeg) fill_slot(recs + (size_t)ib * 8, id | BGR_SLOT_F0 /* beg == key */ | (end == rcBeg ? BGR_SLOT_F1 : 0), m);
+                else fill_slot(recs + (size_t)ib * 8 + 4, id | (end == rcBeg ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* beg == rc(key) */, m);
+            }
+            if (me) {
+                if (end <= rcEnd) fill_slot(recs + (size_t)ie * 8 + 4, id | BGR_SLOT_F0 /* end == key */ | (beg == rcEnd ? BGR_SLOT_F1 : 0), m);
+                else fill_slot(recs + (size_t)ie * 8, id | (beg == rcEnd ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* end == rc(key) */, m);
+            }
+        }
+    });
+    tm.lap("slots");
     return true;
 }
 

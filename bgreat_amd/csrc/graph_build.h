@@ -11,8 +11,26 @@
 
 namespace bgr {
 
+// Anonymous-mmap storage: pages arrive zeroed and are first touched by whichever build thread fills them.
+class ZeroPages {
+public:
+    ZeroPages() = default;
+    ZeroPages(const ZeroPages&) = delete;
+    ZeroPages& operator=(const ZeroPages&) = delete;
+    ~ZeroPages() { release(); }
+    bool reset(uint64_t words);  // releases, then maps `words` zeroed uint64 (false on failure)
+    void release();
+    uint64_t* data() { return p_; }
+    const uint64_t* data() const { return p_; }
+    bool empty() const { return words_ == 0; }
+    uint64_t size() const { return words_; }
+private:
+    uint64_t* p_ = nullptr;
+    uint64_t words_ = 0;
+};
+
 struct HostGraph {
-    std::vector<uint64_t> blob;  // 8-byte aligned storage; header at blob[0]
+    ZeroPages blob;  // page-aligned storage; header at blob[0]
     const BgrBlobHeader* header() const { return reinterpret_cast<const BgrBlobHeader*>(blob.data()); }
     uint64_t bytes() const { return header()->blob_bytes; }
     const uint8_t* base() const { return reinterpret_cast<const uint8_t*>(blob.data()); }
@@ -22,6 +40,11 @@ struct HostGraph {
 // than k, as aligner.cpp:418-420 does.  gamma: MPHF bits per remaining key on each cascade level.
 // Returns false (and sets err) on invalid arguments / limits.
 bool build_graph(uint32_t k, uint64_t n, const char* seqs, const uint64_t* offs, double gamma, HostGraph& out, std::string& err);
+
+// Host threads used by build_graph / read_unitig_fasta (0 = default: the machine's cores, at most 16).  The blob
+// does not depend on the thread count.
+void set_build_threads(unsigned t);
+unsigned build_threads();
 
 // Reads a unitig FASTA the way aligner.cpp:415-417 does: two lines per record, header ignored.
 bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& seqs, std::vector<uint64_t>& offs, std::string& err);

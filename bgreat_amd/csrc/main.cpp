@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
 
     auto t0 = std::chrono::system_clock::now();
     bgr_graph* graph = nullptr;
+    bgr_set_build_threads((uint32_t)std::max(1, threads));
     if (bgr_graph_build_from_fasta(unitigs.c_str(), (uint32_t)ka, 0.0, &graph) != BGR_OK) die("index");
     for (int g = 0; g < gpus; ++g)
         if (bgr_graph_upload(graph, g) != BGR_OK) die("device setup");

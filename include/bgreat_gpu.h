@@ -76,6 +76,9 @@ int bgr_device_count(void); /* number of HIP devices visible, 0 if none / no dri
  * `seqs`/`offsets[n+1]`: the unitig sequences in file order (ids are 1-based ordinals, as in the reference).
  * Loading stops at the first sequence shorter than k (aligner.cpp:418-420).  gamma <= 0 selects the default.
  * The graph is built on the host; inputs are only read during the call. */
+/* Host threads of the index build (the reference: BooPHF's `coreNumber` threads, aligner.cpp:450,458); 0 = default
+ * (all cores, at most 16).  The built graph does not depend on it.  Process-wide. */
+void bgr_set_build_threads(uint32_t threads);
 int bgr_graph_build(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, bgr_graph** out);
 /* Same, reading the unitig FASTA exactly as aligner.cpp:415-417 does (2 lines per record, header ignored). */
 int bgr_graph_build_from_fasta(const char* unitig_fasta_path, uint32_t k, double gamma, bgr_graph** out);

@@ -66,6 +66,39 @@ def test_unitig_loading_stops_at_first_short_sequence():
     assert g.info()["n_unitigs"] == 6
 
 
+def test_index_build_does_not_depend_on_thread_count(tmp_path):
+    """The parallel build (key sort, cascade with atomic state words, range-partitioned slot fill) gives one blob."""
+    s = Synth(1300000, 60, 3, 31, 11)   # > 2^16 end k-mers per side so the parallel sort and cascade really split
+    seqs, offs = s.unitigs()
+    seqs = seqs.copy()
+    seqs[np.arange(5, len(seqs), 40001)] = ord("N")   # exception planes too
+    fa = str(tmp_path / "u.fa")
+    with open(fa, "wb") as f:
+        for i in range(len(offs) - 1):
+            f.write(b">%d\n" % i + seqs[int(offs[i]):int(offs[i + 1])].tobytes() + b"\n")
+    blobs = []
+    try:
+        for T in (1, 2, 3, 8):
+            B.lib().bgr_set_build_threads(T)
+            g = B.Graph.build(31, seqs, offs)
+            assert g.info()["n_left_keys"] > (1 << 15) and g.info()["n_unitigs"] > (1 << 16) and g.info()["has_exceptions"] == 1
+            blobs.append(np.array(g.blob()))
+            blobs.append(np.array(B.Graph.from_fasta(fa, 31).blob()))
+    finally:
+        B.lib().bgr_set_build_threads(0)
+    assert all(np.array_equal(blobs[0], b) for b in blobs[1:])
+
+
+@pytest.mark.parametrize("text,n", [(b"", 0), (b">a", 0), (b">a\n", 0), (b">a\nACGTA", 1), (b">a\nACGTA\n", 1), (b">a\nACGTA\n>b", 1),
+                                    (b">a\nACGTA\n\n\nACGTACG\n", 1), (b">a\nACGTA\n>b\nACG\n>c\nACGTAA\n", 1),
+                                    (b"ACGTA\nACGTAC\nxx\nACGTACGT", 2), (b">a\nACGTA\r\n>b\nACGT\r\n", 2)])
+def test_unitig_fasta_two_lines_per_record(tmp_path, text, n):
+    """aligner.cpp:415-420: header line ignored whatever it holds, a missing line reads as empty, stop at |seq| < k."""
+    fa = str(tmp_path / "u.fa")
+    open(fa, "wb").write(text)
+    assert B.Graph.from_fasta(fa, 5).info()["n_unitigs"] == n
+
+
 def test_exception_planes_only_when_needed():
     assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig.fa"), 5).info()["has_exceptions"] == 0
     assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig_exc.fa"), 5).info()["has_exceptions"] == 1
