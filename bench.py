@@ -85,9 +85,18 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # BGR_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share
+        # the visible devices, collectives run on CPU tensors).  Never used for a reported number.
+        backend = os.environ.get("BGR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            local_rank %= max(1, torch.cuda.device_count())
+    rehearsal = world > 1 and os.environ.get("BGR_BENCH_BACKEND", "nccl") != "nccl"
     dev = local_rank
+    coll_dev = None if rehearsal else dev
     torch.cuda.set_device(dev)
     if B.device_count() < 1:
         sys.exit("bench.py: no HIP device (the mapping path has no CPU fallback)")
@@ -102,12 +111,14 @@ def main():
     g = None
     if rank == 0:
         seqs, offs = syn.unitigs()
+        tb = time.time()
         g = B.Graph.build(args.k, seqs, offs, args.gamma)
         graph_info = g.info()
+        log("index build: %.2fs on the host (%d unitigs)" % (time.time() - tb, graph_info["n_unitigs"]))
     blob_keepalive = None
     if world > 1:
         from bgreat_amd import dist as D
-        g, blob_keepalive = D.broadcast_graph(g, dist, device=dev)  # C1: the only data-path collective; reads never move
+        g, blob_keepalive = D.broadcast_graph(g, dist, device=coll_dev)  # C1: the only data-path collective; reads never move
     al = B.Aligner(g, dev)
     al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
     if rank == 0:
@@ -151,11 +162,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        elapsed = D.max_over_ranks(elapsed, dist, device=dev)
+        elapsed = D.max_over_ranks(elapsed, dist, device=coll_dev)
     launches, kernel_ms = al.kernel_time()
     counters = al.counters()
     if dist is not None:  # C2: sum the aligner.h:68 counters over ranks
-        counters = D.reduce_counters(counters, dist, device=dev)
+        counters = D.reduce_counters(counters, dist, device=coll_dev)
 
     if rank != 0:
         if dist is not None:
@@ -186,7 +197,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("reads_per_launch") == R and tj.get("read_len") == L:
+            if tj.get("reads_per_launch") == R and tj.get("read_len") == L and tj.get("workload") == args.workload and mode == 0:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
