@@ -405,6 +405,12 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 // Frame (20 u32, in LDS): [0] rec  [1] pos  [2] cost so far  [3] cursor | ncand<<8 | scored<<16 | canon<<17
 //                         [4+4c..] candidate c: sid, next_rec, aux (non-fitting: ext; fitting: the path int
 //                                               emitted when the walk ends there), miss | fits<<16 | next_canon<<17
+#ifndef BGR_GREEDY_OCC
+#define BGR_GREEDY_OCC 6
+#endif
+#ifndef BGR_EXH_OCC
+#define BGR_EXH_OCC 6 /* waves per SIMD the exhaustive kernel is compiled for */
+#endif
 #define FR_WORDS 20
 #define EXH_OVERFLOW 0xFFFFFFFFu
 
@@ -548,7 +554,7 @@ __device__ __forceinline__ uint32_t publish_path(const BatchIO& io, const int32_
 }
 
 template <bool STAGE>
-__global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(1024, 6) bgr_align_greedy_kernel(BgrDeviceGrap
 // (k-1)-mer is an overlap of the graph can succeed (anywhere else getEnd() is empty), so the position scan
 // is the same lane-parallel membership test as in the greedy kernel.
 template <bool STAGE>
-__global__ void __launch_bounds__(1024) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -761,7 +767,8 @@ uint32_t resident_waves_per_cu(uint32_t mode) {
                                : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true>);
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
     // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;
-    // the kernels use ~106 SGPRs, which caps a SIMD at 6 waves (800 / (7*16 + 16)).
+    // the kernels use ~106 SGPRs, which caps a SIMD at 6 waves (800 / (7*16 + 16)); compiling for 7 (72 VGPRs,
+    // spills) measured 381 vs 532 Mreads/s greedy, 28 vs 37 exhaustive.
     const uint32_t alloc = ((uint32_t)fa.numRegs + 7) / 8 * 8;
     return 4 * std::min<uint32_t>(6, 512 / alloc);
 }
