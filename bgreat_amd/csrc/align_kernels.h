@@ -23,6 +23,8 @@ struct BatchIO {
     uint32_t frames_per_wave;    // exhaustive mode: DFS frames (20 u32 each) in the per-wave LDS region
     uint32_t* ovf_list;          // exhaustive pass 1: reads whose search outgrew frames_per_wave are listed here (count at cursor[2])
     const uint32_t* subset;      // exhaustive pass 2: map reads subset[0 .. cursor[2]) instead of 0 .. n_reads
+    uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
+    uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
 };
 
 struct KernelParams {
@@ -39,7 +41,11 @@ struct LaunchCfg {
 
 // Per-wave LDS bytes for a batch whose longest read has max_len bases (mode 0 greedy, 1 exhaustive).
 // frame_cap > 0 limits the exhaustive DFS stack (a second pass with the full stack maps the few reads that need more).
-inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, uint32_t* words, uint32_t* path_cap, uint32_t* frames, uint32_t frame_cap = 0) {
+// scratch_words (may be null): u32 words of the search state (OUT | CUR | BEST | frames), which that second pass keeps
+// in HBM; its LDS need is then deep_lds_bytes_per_wave().
+inline uint32_t deep_lds_bytes_per_wave(uint32_t max_len) { return 4 * 8 * (max_len / 32 + 2); }
+inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, uint32_t* words, uint32_t* path_cap, uint32_t* frames, uint32_t frame_cap = 0,
+                                   uint64_t* scratch_words = nullptr) {
     uint32_t w = max_len / 32 + 2;
     uint32_t pc = max_len + 8;
     pc = (pc + 1) & ~1u;
@@ -50,6 +56,7 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
         fr = (max_len >= k - 1 ? max_len - (k - 1) : 0) + 3;
         if (frame_cap && fr > frame_cap) fr = frame_cap;
         bytes = 4 * 8 * w + 3 * 4 * pc + fr * 20 * 4;  // ... OUT | CUR | BEST | frames
+        if (scratch_words) *scratch_words = 3ull * pc + (uint64_t)fr * 20;
     }
     if (words) *words = w;
     if (path_cap) *path_cap = pc;

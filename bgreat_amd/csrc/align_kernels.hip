@@ -658,7 +658,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 // the best right walk with what is left; no reverse-complement retry.  Only position 0 and positions whose
 // (k-1)-mer is an overlap of the graph can succeed (anywhere else getEnd() is empty), so the position scan
 // is the same lane-parallel membership test as in the greedy kernel.
-template <bool STAGE>
+// DEEP (pass 2): the search state (OUT | CUR | BEST | frames) of every wave lives in HBM (io.deep_scratch) instead
+// of LDS, sized for the worst case, so neither the depth of the search nor the read length is bounded by LDS.
+template <bool STAGE, bool DEEP>
 __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -668,13 +670,14 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
     uint2* LV;
     uint32_t mphf_words;
     const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
-    // per wave: FW3 | FWQ | RCW | NM | OUT | CUR | BEST | frames
-    const uint32_t per_wave_words = 4 * W + 3 * (io.path_cap / 2) + (io.frames_per_wave * FR_WORDS) / 2;
+    // per wave: FW3 | FWQ | RCW | NM | OUT | CUR | BEST | frames   (the last four in HBM when DEEP)
+    const uint32_t per_wave_words = DEEP ? 4 * W : 4 * W + 3 * (io.path_cap / 2) + (io.frames_per_wave * FR_WORDS) / 2;
     u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
     u64* FWQ = FW3 + W;
     u64* RCW = FWQ + W;
     u64* NM = RCW + W;
-    int32_t* OUT = reinterpret_cast<int32_t*>(NM + W);
+    int32_t* OUT = DEEP ? reinterpret_cast<int32_t*>(io.deep_scratch + (u64)(blockIdx.x * waves + wave) * io.deep_stride)
+                        : reinterpret_cast<int32_t*>(NM + W);
     int32_t* CUR = OUT + io.path_cap;
     int32_t* BEST = CUR + io.path_cap;
     uint32_t* FR = reinterpret_cast<uint32_t*>(BEST + io.path_cap);
@@ -764,7 +767,7 @@ hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, cons
 uint32_t resident_waves_per_cu(uint32_t mode) {
     hipFuncAttributes fa;
     const void* fn = mode == 0 ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)
-                               : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true>);
+                               : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
     // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;
     // the kernels use ~106 SGPRs, which caps a SIMD at 6 waves (800 / (7*16 + 16)); compiling for 7 (72 VGPRs,
@@ -779,8 +782,9 @@ hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const Kernel
         return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
                               : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
     }
-    return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_kernel<true>, g, io, p, cfg, stream)
-                          : launch_one(bgr_align_exhaustive_kernel<false>, g, io, p, cfg, stream);
+    if (io.deep_scratch) return launch_one(bgr_align_exhaustive_kernel<false, true>, g, io, p, cfg, stream);
+    return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_kernel<true, false>, g, io, p, cfg, stream)
+                          : launch_one(bgr_align_exhaustive_kernel<false, false>, g, io, p, cfg, stream);
 }
 
 }  // namespace bgr

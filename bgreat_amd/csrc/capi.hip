@@ -64,7 +64,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, results, arena, ovf, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, results, arena, ovf, deep, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -254,7 +254,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->deep.release(); a->small.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
@@ -282,15 +282,19 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     HIP_TRY(a->results.ensure(n_reads * 8));
 
     // ---- launch geometry -----------------------------------------------------------------------
-    // Exhaustive mode runs in two passes: pass 1 gives every wave a SHALLOW search stack (kExhFrameCap frames) so
-    // that many waves fit a CU's LDS; the rare read whose search goes deeper is listed and mapped by pass 2 with the
-    // worst-case stack (few waves per CU).  Greedy mode is one pass.
+    // Exhaustive mode runs in two passes: pass 1 gives every wave a SHALLOW search stack (kExhFrameCap frames) in LDS
+    // so that many waves fit a CU; the rare read whose search goes deeper is listed and mapped by pass 2, which
+    // keeps the worst-case search state in HBM.  Reads too long for pass 1's LDS layout all go through pass 2's
+    // kernel directly.  Greedy mode is one pass.
     const char* fc_env = getenv("BGR_EXH_FRAME_CAP");  // tests shrink it to push most reads through pass 2
     const uint32_t kExhFrameCap = fc_env ? (uint32_t)std::max(2, atoi(fc_env)) : 24;
     uint32_t words = 0, path_cap = 0, frames = 0, frames_deep = 0;
-    const uint32_t per_wave_deep = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep);
+    uint64_t deep_stride = 0;
+    bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep, 0, &deep_stride);
+    const uint32_t per_wave_deep = bgr::deep_lds_bytes_per_wave(max_read_len);
     const uint32_t per_wave = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames, kExhFrameCap);
-    const bool two_pass = p->mode == BGR_MODE_EXHAUSTIVE && frames < frames_deep;
+    const bool exhaustive = p->mode == BGR_MODE_EXHAUSTIVE;
+    bool two_pass = exhaustive && frames < frames_deep;
     const size_t lds_cu = a->lds_per_cu;
     const uint32_t mphf_bytes = a->dg.units_bytes;
     // Resident waves per CU are bounded by registers (bgr::resident_waves_per_cu); LDS decides how they are grouped:
@@ -342,15 +346,33 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         return true;
     };
     bgr::LaunchCfg cfg, cfg_deep;
-    if (!geometry(per_wave, n_reads, true, cfg) || (two_pass && !geometry(per_wave_deep, n_reads, false, cfg_deep)))
-        return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
+    bool deep_only = false;  // pass 1 does not fit LDS: every read goes through the deep kernel
+    if (!geometry(per_wave, n_reads, true, cfg)) {
+        if (!exhaustive) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
+        deep_only = two_pass = true;
+    }
+    if (two_pass) {
+        if (!geometry(per_wave_deep, n_reads, false, cfg_deep))
+            return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~160 kb)");
+        // the HBM search state is sized for the worst case per wave: bound the grid by a 2 GiB scratch budget
+        const uint64_t wave_bytes = deep_stride * 4;
+        const uint64_t max_waves = std::max<uint64_t>(1, (2ull << 30) / wave_bytes);
+        if ((uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block > max_waves) {
+            cfg_deep.waves_per_block = (uint32_t)std::min<uint64_t>(cfg_deep.waves_per_block, max_waves);
+            cfg_deep.blocks = (uint32_t)std::max<uint64_t>(1, max_waves / cfg_deep.waves_per_block);
+            cfg_deep.lds_bytes = kLdsFixed + cfg_deep.waves_per_block * per_wave_deep;
+        }
+        if (deep_stride > 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: read too long");
+        HIP_TRY(a->deep.ensure((uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * wave_bytes));
+        if (deep_only) cfg = cfg_deep;
+    }
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
     // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
     const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
     const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
-                               (two_pass ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0);
+                               (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0);
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf;
@@ -366,9 +388,15 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.frames_per_wave = frames;
     io.ovf_list = nullptr;
     io.subset = nullptr;
-    if (two_pass) {
+    io.deep_scratch = nullptr;
+    io.deep_stride = (uint32_t)deep_stride;
+    if (two_pass && !deep_only) {
         HIP_TRY(a->ovf.ensure(n_reads * 4));
         io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
+    }
+    if (deep_only) {
+        io.frames_per_wave = frames_deep;
+        io.deep_scratch = static_cast<uint32_t*>(a->deep.p);
     }
     io.results = static_cast<uint2*>(a->results.p);
     io.arena = static_cast<int32_t*>(a->arena.p);
@@ -380,11 +408,12 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
     hipError_t e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    if (two_pass) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
+    if (two_pass && !deep_only) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
         bgr::BatchIO io2 = io;
         io2.frames_per_wave = frames_deep;
         io2.subset = io.ovf_list;
         io2.ovf_list = nullptr;
+        io2.deep_scratch = static_cast<uint32_t*>(a->deep.p);
         e = bgr::launch_align(a->dg, io2, kp, cfg_deep, a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (deep pass): ") + hipGetErrorString(e));
     }
