@@ -297,6 +297,11 @@ struct Oracle {
     boo::Mphf leftMPHF, rightMPHF;
     vector<UnitigIndices> leftIndices, rightIndices;
     kmer_t offsetUpdate = 0;  // aligner.h:101-102
+    // anchors ("dog") mode, -G: an MPHF over the canonical k-mers of every unitig and their (unitig, offset)
+    bool dogMode = false;                                         // aligner.h:60,82
+    unsigned fracKmer = 1;                                        // aligner.h:95
+    boo::Mphf anchorsMPHF;                                        // aligner.h:65
+    vector<std::pair<uint32_t, uint32_t>> anchorsPosition;        // aligner.h:67
     // run parameters (aligner.h:90-104)
     unsigned errorsMax = 2, tryNumber = 2;
     bool partial = false;
@@ -318,7 +323,7 @@ struct Oracle {
         offsetUpdate <<= (2 * (k - 1));
         unitigs.clear();
         unitigs.push_back("");
-        vector<kmer_t> leftOver, rightOver;
+        vector<kmer_t> leftOver, rightOver, anchors;
         for (const string& line : seqs) {
             if (line.size() < k) break;  // aligner.cpp:418-420: loading stops at the first short sequence
             unitigs.push_back(line);
@@ -326,6 +331,14 @@ struct Oracle {
             if (beg <= rcBeg) leftOver.push_back(beg); else rightOver.push_back(rcBeg);
             kmer_t end = str2num(line.substr(line.size() - k + 1, k - 1)), rcEnd = rcb(end, k - 1);
             if (end <= rcEnd) rightOver.push_back(end); else leftOver.push_back(rcEnd);
+            if (dogMode) {  // aligner.cpp:434-442: every k-mer but the last (j + k < size), NOT deduplicated
+                for (unsigned j = 0; j + k < line.size(); ++j) {
+                    if (j % fracKmer == 0) {
+                        kmer_t seq = str2num(line.substr(j, k)), rcSeq = rcb(seq, k);
+                        anchors.push_back(std::min(seq, rcSeq));
+                    }
+                }
+            }
         }
         std::sort(leftOver.begin(), leftOver.end());
         leftOver.erase(std::unique(leftOver.begin(), leftOver.end()), leftOver.end());
@@ -337,9 +350,20 @@ struct Oracle {
         rightMPHF.build(rightOver, 10.0);  // aligner.cpp:454
         leftIndices.assign(leftOver.size(), UnitigIndices{0, {0, 0, 0, 0}});
         rightIndices.assign(rightOver.size(), UnitigIndices{0, {0, 0, 0, 0}});
+        anchorsMPHF = boo::Mphf();
+        if (dogMode) anchorsMPHF.build(anchors, 10.0);  // aligner.cpp:457-460
+        anchorsPosition.assign(anchors.size(), {0u, 0u});  // aligner.cpp:461,465
         Work saved = tl_work;  // build-time lookups are not per-read work
         for (uint32_t i = 1; i < unitigs.size(); ++i) {  // aligner.cpp:466-533
             const string& line = unitigs[i];
+            if (dogMode) {  // aligner.cpp:468-476: a repeated k-mer keeps its LAST (unitig, offset)
+                for (unsigned j = 0; j + k < line.size(); ++j) {
+                    if (j % fracKmer == 0) {
+                        kmer_t seq = str2num(line.substr(j, k)), rcSeq = rcb(seq, k);
+                        anchorsPosition[anchorsMPHF.lookup(std::min(seq, rcSeq))] = {i, j};
+                    }
+                }
+            }
             kmer_t beg = str2num(line.substr(0, k - 1)), rcBeg = rcb(beg, k - 1);
             if (beg <= rcBeg) fill_slot(leftIndices[leftMPHF.lookup(beg)], beg, i);
             else fill_slot(rightIndices[rightMPHF.lookup(rcBeg)], rcBeg, i);
@@ -589,6 +613,112 @@ struct Oracle {
         return {};
     }
 
+    // ---- anchors ("dog") mode, -G ------------------------------------------- aligner.cpp:381-405
+    // getNAnchors.  NB the rolling update() / updateRC() are the (k-1)-mer ones (aligner.cpp:305-315) applied to
+    // k-mers, and the MPHF answer is used WITHOUT a key check: past position 0 the looked-up value is not the
+    // read's k-mer, and any non-ULLONG_MAX answer (BooPHF returns a rank for many non-keys) becomes an anchor.
+    vector<std::pair<std::pair<uint32_t, uint32_t>, unsigned>> get_n_anchors(const string& read, unsigned n) const {
+        vector<std::pair<std::pair<uint32_t, uint32_t>, unsigned>> list;
+        kmer_t num = str2num(read.substr(0, k)), rcnum = rcb(num, k), rep = std::min(num, rcnum);
+        for (unsigned i = 0;; ++i) {
+            uint64_t hash = anchorsMPHF.lookup(rep);
+            if (hash != ULLONG_MAX) list.push_back({anchorsPosition[hash], i});
+            if (list.size() >= n) return list;
+            if (i + k < read.size()) {
+                update(num, read[i + k]);
+                update_rc(rcnum, read[i + k]);
+                rep = std::min(num, rcnum);
+            } else {
+                return list;
+            }
+        }
+    }
+    // alignerGreedy.cpp:60-164 alignReadGreedyAnchors: place the anchoring unitig on the read (4 cases), then the
+    // usual greedy walks from its two ends.
+    vector<unum_t> align_read_greedy_anchors(const string& read, bool& overlapFound, unsigned errorMax, bool& rc) {
+        auto listAnchors = get_n_anchors(read, tryNumber);
+        if (listAnchors.empty()) { ++noOverlapRead; return {}; }
+        overlapFound = true;
+        vector<unum_t> pathBegin, pathEnd;
+        string unitig;
+        bool returned = false;
+        for (unsigned start = 0; start < (unsigned)listAnchors.size(); ++start) {
+            unsigned unitigNumber = listAnchors[start].first.first, positionUnitig = listAnchors[start].first.second,
+                     positionRead = listAnchors[start].second;
+            unitig = unitigs[unitigNumber];
+            ++tl_work.unitig_fetch;
+            if (unitig.size() < k) continue;  // :72-75 (entry never written: unitig 0 is "")
+            if (str2num(unitig.substr(positionUnitig, k)) != str2num(read.substr(positionRead, k))) {  // :76-83
+                unitig = reverse_complements(unitig);
+                positionUnitig = (unsigned)unitig.size() - k - positionUnitig;
+                returned = true;
+            } else {
+                returned = false;
+            }
+            const unum_t uid = returned ? -(unum_t)unitigNumber : (unum_t)unitigNumber;
+            if (positionRead >= positionUnitig) {
+                if (read.size() - positionRead >= unitig.size() - positionUnitig) {
+                    // CASE 1: unitig included in read (:87-110)
+                    unsigned errors = mismatch_number(read.substr(positionRead - positionUnitig, unitig.size()), unitig, errorMax);
+                    if (errors <= errorMax) {
+                        pathBegin = {};
+                        unsigned errorBegin = left_greedy(read, pathBegin, str2num(unitig.substr(0, k - 1)), positionRead - positionUnitig, errorMax - errors);
+                        if (errorBegin + errors <= errorMax) {
+                            pathEnd = {uid};
+                            unsigned errorsEnd = right_greedy_first(read, pathEnd, str2num(unitig.substr(unitig.size() - k + 1, k - 1)),
+                                                                    positionRead - positionUnitig + (unsigned)unitig.size() - k + 1, errorMax - errors - errorBegin);
+                            if (errorBegin + errors + errorsEnd <= errorMax) {
+                                ++alignedRead;
+                                std::reverse(pathBegin.begin(), pathBegin.end());
+                                pathBegin.insert(pathBegin.end(), pathEnd.begin(), pathEnd.end());
+                                return pathBegin;
+                            }
+                        }
+                    }
+                } else {
+                    // CASE 2: unitig overlaps the read's end (:111-130)
+                    unsigned errors = mismatch_number(read.substr(positionRead - positionUnitig),
+                                                      unitig.substr(0, read.size() - positionRead + positionUnitig), errorMax);
+                    if (errors <= errorMax) {
+                        pathBegin = {};
+                        unsigned errorBegin = left_greedy(read, pathBegin, str2num(unitig.substr(0, k - 1)), positionRead - positionUnitig, errorMax - errors);
+                        if (errorBegin + errors <= errorMax) {
+                            ++alignedRead;
+                            std::reverse(pathBegin.begin(), pathBegin.end());
+                            pathBegin.push_back(uid);
+                            return pathBegin;
+                        }
+                    }
+                }
+            } else {
+                if (read.size() - positionRead >= unitig.size() - positionUnitig) {
+                    // CASE 3: the read starts inside the unitig and runs past its end (:133-148)
+                    unsigned errors = mismatch_number(unitig.substr(positionUnitig - positionRead),
+                                                      read.substr(0, unitig.size() + positionRead - positionUnitig), errorMax);
+                    if (errors <= errorMax) {
+                        pathEnd = {(unum_t)((int)positionUnitig - (int)positionRead), uid};
+                        unsigned errorsEnd = right_greedy_first(read, pathEnd, str2num(unitig.substr(unitig.size() - k + 1, k - 1)),
+                                                                positionRead - positionUnitig + (unsigned)unitig.size() - k + 1, errorMax - errors);
+                        if (errors + errorsEnd <= errorMax) {
+                            ++alignedRead;
+                            return pathEnd;
+                        }
+                    }
+                } else {
+                    // CASE 4: read included in the unitig (:149-160)
+                    unsigned errors = mismatch_number(unitig.substr(positionUnitig - positionRead, read.size()), read, errorMax);
+                    if (errors <= errorMax) {
+                        ++alignedRead;
+                        return {(unum_t)((int)positionUnitig - (int)positionRead), uid};
+                    }
+                }
+            }
+        }
+        if (!rc) { rc = true; return align_read_greedy_anchors(reverse_complements(read), overlapFound, errorMax, rc); }
+        ++notAligned;
+        return {};
+    }
+
     // ---- exhaustive -------------------------------------------------------- alignerExhaustive.cpp
     // alignerExhaustive.cpp:61-106 mapOnRightEndExhaustive / :206-259 checkEndExhaustive.  Same shape at
     // every depth; `top` adds only the partial (-i) early return of :217-221.
@@ -675,7 +805,8 @@ struct Oracle {
         return {};
     }
 
-    // One read through the selected mode; fills the work counters.  mode 0 greedy, 1 exhaustive.
+    // One read through the selected mode; fills the work counters.  mode 0 greedy, 1 exhaustive, 2 greedy from
+    // k-mer anchors (-G; needs dogMode at index time).
     vector<unum_t> align_one(int mode, const string& read, uint8_t& status) {
         bool overlapFound = false, rc = false;
         vector<unum_t> path;
@@ -683,6 +814,9 @@ struct Oracle {
         if (mode == 0) {
             ++readNumber;  // alignerGreedy.cpp:382
             path = align_read_greedy(read, overlapFound, errorsMax, rc);
+        } else if (mode == 2) {
+            ++readNumber;  // alignerGreedy.cpp:382
+            path = align_read_greedy_anchors(read, overlapFound, errorsMax, rc);  // alignerGreedy.cpp:387-388
         } else {
             path = align_read_exhaustive(read, overlapFound, errorsMax);
         }
@@ -798,7 +932,7 @@ struct Runner {
                 uint8_t st;
                 vector<unum_t> path = o.align_one(mode, hr.second, st);
                 if (mode == 1 && !exhaustive_writes) continue;  // -b writes nothing
-                if (!path.empty() && correction && mode == 0) {  // alignerGreedy.cpp:394-404
+                if (!path.empty() && correction && mode != 1) {  // alignerGreedy.cpp:394-404
                     string corrected;
                     if (!recover_path(o, path, (unsigned)hr.second.size(), corrected)) { std::cout << "bug compaction" << std::endl; exit(0); }
                     if (st & 4) corrected = reverse_complements(corrected);
@@ -845,6 +979,24 @@ void* orc_create_from_file(const char* unitig_path, int k) {
 void* orc_create(int k, const char* seqs, const uint64_t* offs, uint64_t n) {
     Oracle* o = new Oracle();
     o->k = (unsigned)k;
+    vector<string> v;
+    v.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) v.emplace_back(seqs + offs[i], seqs + offs[i + 1]);
+    o->index_unitigs(v);
+    return o;
+}
+// Same with the anchors index of -G (dog != 0): mode 2 of orc_align needs it.
+void* orc_create_from_file2(const char* unitig_path, int k, int dog) {
+    Oracle* o = new Oracle();
+    o->k = (unsigned)k;
+    o->dogMode = dog != 0;
+    if (!o->load_unitig_file(unitig_path)) { delete o; return nullptr; }
+    return o;
+}
+void* orc_create2(int k, const char* seqs, const uint64_t* offs, uint64_t n, int dog) {
+    Oracle* o = new Oracle();
+    o->k = (unsigned)k;
+    o->dogMode = dog != 0;
     vector<string> v;
     v.reserve(n);
     for (uint64_t i = 0; i < n; ++i) v.emplace_back(seqs + offs[i], seqs + offs[i + 1]);
@@ -959,7 +1111,7 @@ int orc_parse_file(const char* path, int fastq, int k, uint64_t* out_sizes, char
 int orc_main(int argc, char** argv, int exh_writes) {
     string reads, unitigs("unitig.fa"), pathFile("paths"), notAlignedFile("notAligned.fa");
     int errors = 2, threads = 1, ka = 30, effort = 2;
-    bool brute = false, incomplete = false, fastq = false, correction = false;
+    bool brute = false, incomplete = false, fastq = false, correction = false, dog = false;
     for (int i = 1; i < argc; ++i) {  // same single-letter flags as getopt "r:k:g:m:t:e:f:o:a:biqpcG"
         string a = argv[i];
         auto val = [&](void) -> string { return (i + 1 < argc) ? string(argv[++i]) : string(); };
@@ -976,6 +1128,7 @@ int orc_main(int argc, char** argv, int exh_writes) {
         else if (a == "-i") incomplete = true;
         else if (a == "-q") fastq = true;
         else if (a == "-c") correction = true;
+        else if (a == "-G") dog = true;
     }
     if (reads.empty()) { printf("-r read_file\n"); return 0; }
     Oracle o;
@@ -983,6 +1136,7 @@ int orc_main(int argc, char** argv, int exh_writes) {
     o.errorsMax = (unsigned)errors;
     o.tryNumber = (unsigned)effort;
     o.partial = incomplete;
+    o.dogMode = dog;
     Runner run(o);
     run.fastq = fastq;
     run.correction = correction;
@@ -1000,7 +1154,7 @@ int orc_main(int argc, char** argv, int exh_writes) {
         if (i == reads.size() || reads[i] == ',') {
             string f = reads.substr(last, i - last);
             std::cout << f << std::endl;
-            run.run_file(f, brute ? 1 : 0, nth);
+            run.run_file(f, brute ? 1 : (dog ? 2 : 0), nth);  // -b selects alignPartExhaustive (aligner.cpp:563-567), where -G has no effect
             last = i + 1;
         }
     }
