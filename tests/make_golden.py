@@ -178,6 +178,20 @@ def cases():
     c.append(("exh", ["-r", "syn_r250.fa", "-k", "31", "-g", "syn_unitig.fa", "-m", "5", "-b"]))
     c.append(("exh", ["-r", "long_r150.fa", "-k", "31", "-g", "long_unitig.fa", "-m", "5", "-b", "-i"]))
     c.append(("exh", ["-r", "edge_reads.fa", "-k", "31", "-g", "syn_unitig.fa", "-m", "5", "-b"]))
+    # anchors mode (-G): k-mer anchors looked up WITHOUT a key check (aligner.cpp:387-389), so these bytes also pin the
+    # index values of the BooPHF cascade (false-positive ranks included)
+    c.append(("dog", ["-r", "toy_reads.fa", "-k", "4", "-g", "toy_unitig.fa", "-G"]))
+    for rd, m, e in (("syn_r100.fa", 1, 2), ("syn_r150.fa", 0, 2), ("syn_r150.fa", 2, 2), ("syn_r150.fa", 5, 4), ("syn_r250.fa", 5, 3)):
+        c.append(("dog", ["-r", rd, "-k", "31", "-g", "syn_unitig.fa", "-m", str(m), "-e", str(e), "-G"]))
+    c.append(("dog", ["-r", "syn_r250.fa", "-k", "25", "-g", "syn_unitig.fa", "-m", "5", "-G"]))
+    c.append(("dog", ["-r", "long_r150.fa", "-k", "31", "-g", "long_unitig.fa", "-m", "3", "-G"]))
+    c.append(("dog", ["-r", "long_r150.fq", "-k", "31", "-g", "long_unitig.fa", "-m", "3", "-e", "5", "-q", "-G"]))
+    c.append(("dog", ["-r", "edge_reads.fa", "-k", "31", "-g", "syn_unitig.fa", "-m", "2", "-G"]))
+    c.append(("dog", ["-r", "edge_reads.fq", "-k", "31", "-g", "syn_unitig.fa", "-m", "2", "-q", "-G"]))
+    c.append(("dog", ["-r", "deg_reads.fa", "-k", "5", "-g", "deg_unitig.fa", "-m", "1", "-G"]))
+    c.append(("dog", ["-r", "deg_reads.fa", "-k", "5", "-g", "deg_unitig_exc.fa", "-m", "2", "-e", "4", "-G"]))
+    c.append(("dog", ["-r", "syn_r150.fa", "-k", "31", "-g", "syn_unitig.fa", "-m", "2", "-c", "-G"]))
+    c.append(("dog", ["-r", "long_r150.fa", "-k", "31", "-g", "long_unitig.fa", "-m", "5", "-b", "-G"]))   # -b wins: -G has no effect
     return c
 
 
