@@ -18,6 +18,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "bgreat")
 
 MODE_GREEDY, MODE_EXHAUSTIVE = 0, 1
 ST_NOANCHOR, ST_FAILED, ST_ALIGNED, ST_MASK, ST_RC = 0, 1, 2, 3, 4
+BUILD_ANCHORS = 1
 
 # every symbol include/bgreat_gpu.h declares (checked by tests/test_cabi.py)
 SYMBOLS = [
@@ -28,7 +29,7 @@ SYMBOLS = [
     "bgr_aligner_reset_counters", "bgr_aligner_kernel_time", "bgr_aligner_reset_kernel_time", "bgr_aligner_launch_info",
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
-    "bgr_set_build_threads",
+    "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup",
 ]
 
 
@@ -55,7 +56,7 @@ class GraphInfo(C.Structure):
     _fields_ = [("k", C.c_uint32), ("n_levels", C.c_uint32), ("n_unitigs", C.c_uint64), ("n_keys", C.c_uint64),
                 ("n_left_keys", C.c_uint64), ("n_right_keys", C.c_uint64), ("n_fallback", C.c_uint64),
                 ("total_bases", C.c_uint64), ("blob_bytes", C.c_uint64), ("mphf_bytes", C.c_uint64),
-                ("max_unitig_len", C.c_uint64), ("has_exceptions", C.c_uint32), ("reserved", C.c_uint32),
+                ("max_unitig_len", C.c_uint64), ("has_exceptions", C.c_uint32), ("has_anchors", C.c_uint32),
                 ("gamma", C.c_double)]
 
 
@@ -100,6 +101,9 @@ def lib():
     L.bgr_device_count.restype = i32
     L.bgr_graph_build.argtypes = [u32, u64, vp, vp, C.c_double, C.POINTER(vp)]
     L.bgr_graph_build_from_fasta.argtypes = [C.c_char_p, u32, C.c_double, C.POINTER(vp)]
+    L.bgr_graph_build_ex.argtypes = [u32, u64, vp, vp, C.c_double, u32, C.POINTER(vp)]
+    L.bgr_graph_build_from_fasta_ex.argtypes = [C.c_char_p, u32, C.c_double, u32, C.POINTER(vp)]
+    L.bgr_graph_anchor_lookup.argtypes = [vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.bgr_graph_blob.restype = vp
     L.bgr_graph_blob.argtypes = [vp, C.POINTER(u64)]
     L.bgr_graph_from_blob.argtypes = [vp, u64, C.POINTER(vp)]
@@ -162,18 +166,27 @@ class Graph:
         self.h = handle
 
     @classmethod
-    def build(cls, k, seqs, offsets, gamma=0.0):
+    def build(cls, k, seqs, offsets, gamma=0.0, anchors=False):
+        """anchors=True also builds the k-mer anchors index of -G mode (MODE_ANCHORS)."""
         seqs = _as_u8(seqs)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         h = C.c_void_p()
-        _check(lib().bgr_graph_build(k, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, gamma, C.byref(h)))
+        _check(lib().bgr_graph_build_ex(k, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, gamma, BUILD_ANCHORS if anchors else 0, C.byref(h)))
         return cls(h)
 
     @classmethod
-    def from_fasta(cls, path, k, gamma=0.0):
+    def from_fasta(cls, path, k, gamma=0.0, anchors=False):
         h = C.c_void_p()
-        _check(lib().bgr_graph_build_from_fasta(path.encode(), k, gamma, C.byref(h)))
+        _check(lib().bgr_graph_build_from_fasta_ex(path.encode(), k, gamma, BUILD_ANCHORS if anchors else 0, C.byref(h)))
         return cls(h)
+
+    def anchor_lookup(self, kmer):
+        """(index, unitig, offset) of boomphf::mphf::lookup(kmer) on the anchors index; index None for ULLONG_MAX."""
+        idx, pos = C.c_uint64(), C.c_uint64()
+        _check(lib().bgr_graph_anchor_lookup(self.h, int(kmer), C.byref(idx), C.byref(pos)))
+        if idx.value == 0xFFFFFFFFFFFFFFFF:
+            return None, 0, 0
+        return idx.value, pos.value >> 32, pos.value & 0xFFFFFFFF
 
     @classmethod
     def from_blob(cls, blob):

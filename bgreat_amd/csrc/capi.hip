@@ -14,6 +14,7 @@
 #include "../../include/bgreat_gpu.h"
 #include "align_kernels.h"
 #include "fastx.h"
+#include "anchor_index.h"
 #include "graph_build.h"
 
 namespace {
@@ -108,11 +109,16 @@ int bgr_device_count(void) {
 
 // ---- index ------------------------------------------------------------------------------------------
 int bgr_graph_build(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, bgr_graph** out) {
+    return bgr_graph_build_ex(k, n_unitigs, seqs, offsets, gamma, 0, out);
+}
+
+int bgr_graph_build_ex(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, uint32_t flags, bgr_graph** out) {
     if (!out || (n_unitigs && (!seqs || !offsets))) return fail(BGR_E_ARG, "bgr_graph_build: null argument");
+    if (flags & ~(uint32_t)BGR_BUILD_ANCHORS) return fail(BGR_E_ARG, "bgr_graph_build: unknown flag");
     bgr_graph* g = new bgr_graph();
     std::string err;
     uint64_t zero[1] = {0};
-    if (!bgr::build_graph(k, n_unitigs, seqs, n_unitigs ? offsets : zero, gamma > 0 ? gamma : kDefaultGamma, g->host, err)) {
+    if (!bgr::build_graph(k, n_unitigs, seqs, n_unitigs ? offsets : zero, gamma > 0 ? gamma : kDefaultGamma, flags, g->host, err)) {
         delete g;
         return fail(BGR_E_ARG, err);
     }
@@ -135,12 +141,26 @@ int bgr_graph_unitigs(const bgr_graph* g, const char** seqs, const uint64_t** of
 }
 
 int bgr_graph_build_from_fasta(const char* path, uint32_t k, double gamma, bgr_graph** out) {
+    return bgr_graph_build_from_fasta_ex(path, k, gamma, 0, out);
+}
+
+int bgr_graph_build_from_fasta_ex(const char* path, uint32_t k, double gamma, uint32_t flags, bgr_graph** out) {
     if (!path || !out) return fail(BGR_E_ARG, "bgr_graph_build_from_fasta: null argument");
     std::vector<char> seqs;
     std::vector<uint64_t> offs;
     std::string err;
     if (!bgr::read_unitig_fasta(path, k, seqs, offs, err)) return fail(BGR_E_IO, err);
-    return bgr_graph_build(k, offs.size() - 1, seqs.data(), offs.data(), gamma, out);
+    return bgr_graph_build_ex(k, offs.size() - 1, seqs.data(), offs.data(), gamma, flags, out);
+}
+
+int bgr_graph_anchor_lookup(const bgr_graph* g, uint64_t kmer, uint64_t* index_out, uint64_t* position_out) {
+    if (!g || !index_out) return fail(BGR_E_ARG, "bgr_graph_anchor_lookup: null argument");
+    if (g->host.blob.empty()) return fail(BGR_E_ARG, "bgr_graph_anchor_lookup: graph has no host blob");
+    if (!g->header.anc_n) return fail(BGR_E_ARG, "bgr_graph_anchor_lookup: the graph was built without BGR_BUILD_ANCHORS");
+    const uint64_t idx = bgr::anchor_lookup(g->host.header(), g->host.base(), kmer);
+    *index_out = idx;
+    if (position_out) *position_out = idx == ~0ULL ? 0 : reinterpret_cast<const uint64_t*>(g->host.base() + g->header.off_anc_pos)[idx];
+    return BGR_OK;
 }
 
 const void* bgr_graph_blob(const bgr_graph* g, uint64_t* bytes) {
@@ -168,7 +188,7 @@ int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* o) {
     o->k = h.k; o->n_levels = h.n_levels; o->n_unitigs = h.n_unitigs; o->n_keys = h.n_keys;
     o->n_left_keys = h.n_left_keys; o->n_right_keys = h.n_right_keys; o->n_fallback = h.n_fallback;
     o->total_bases = h.total_bases; o->blob_bytes = h.blob_bytes; o->mphf_bytes = h.n_units * 16;
-    o->max_unitig_len = h.max_unitig_len; o->has_exceptions = h.has_exc; o->gamma = h.gamma;
+    o->max_unitig_len = h.max_unitig_len; o->has_exceptions = h.has_exc; o->has_anchors = h.anc_n ? 1 : 0; o->gamma = h.gamma;
     return BGR_OK;
 }
 

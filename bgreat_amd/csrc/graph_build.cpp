@@ -3,6 +3,8 @@
 // two boomphf::mphf + two vector<unitigIndices>; here it is one cascade MPHF over the union of both key
 // sets plus flat arrays, because only membership and the slot order are observable.
 #include "graph_build.h"
+#include "anchor_index.h"
+#include "host_parallel.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -25,50 +27,6 @@ namespace {
 inline uint32_t code_of(char c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; }  // utils.cpp:117-129
 
 std::atomic<unsigned> g_build_threads{0};
-
-// fn(begin, end, tid) over [0, n) cut into `T` contiguous ranges, one thread each (inline when T == 1).
-template <class Fn>
-void parallel_ranges(unsigned T, uint64_t n, Fn fn) {
-    if (T <= 1 || n < 2) { fn((uint64_t)0, n, 0u); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; ++t) {
-        uint64_t b = n * t / T, e = n * (t + 1) / T;
-        th.emplace_back([=] { fn(b, e, t); });
-    }
-    for (auto& x : th) x.join();
-}
-
-// Sorts v with T threads: T sorted runs, then rounds of pairwise merges (each merge on its own thread).
-void parallel_sort(std::vector<uint64_t>& v, unsigned T) {
-    if (T <= 1 || v.size() < (1u << 16)) { std::sort(v.begin(), v.end()); return; }
-    std::vector<uint64_t> cut(T + 1);
-    for (unsigned t = 0; t <= T; ++t) cut[t] = v.size() * t / T;
-    parallel_ranges(T, T, [&](uint64_t b, uint64_t e, unsigned) {
-        for (uint64_t t = b; t < e; ++t) std::sort(v.begin() + cut[t], v.begin() + cut[t + 1]);
-    });
-    while (cut.size() > 2) {
-        size_t pairs = (cut.size() - 1) / 2;
-        std::vector<std::thread> th;
-        for (size_t p = 0; p < pairs; ++p)
-            th.emplace_back([&, p] { std::inplace_merge(v.begin() + cut[2 * p], v.begin() + cut[2 * p + 1], v.begin() + cut[2 * p + 2]); });
-        for (auto& x : th) x.join();
-        std::vector<uint64_t> nc;
-        for (size_t i = 0; i < cut.size(); i += 2) nc.push_back(cut[i]);
-        if ((cut.size() - 1) % 2) nc.push_back(cut.back());
-        cut.swap(nc);
-    }
-}
-
-struct PhaseTimer {  // BGREAT_TIMING=1: per-phase wall time of the index build on stderr
-    bool on = getenv("BGREAT_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void lap(const char* what) {
-        if (!on) return;
-        auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[build] %-10s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
-        t0 = t1;
-    }
-};
 
 // ORs `len` bases of one strand into the packed store at base position `pos`, 32 bases per word; only the first
 // and last word of the run can be shared with a neighbouring run (another thread), so those go through atomics.
@@ -231,6 +189,15 @@ bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {
                        h->off_meta + (h->n_unitigs + 1) * sizeof(BgrUnitigMeta), h->off_seq + h->seq_words * 8,
                        h->off_fallback + h->n_fallback * 8};
     for (uint64_t e : ends) if (e > bytes) { err = "blob section outside the blob"; return false; }
+    if (h->anc_n) {
+        uint64_t aends[] = {h->off_anc_bits + h->anc_words * 8, h->off_anc_ranks + h->anc_rank_words * 8,
+                            h->off_anc_final + h->anc_n_final * 16, h->off_anc_pos + h->anc_n * 8};
+        for (uint64_t e : aends) if (e > bytes) { err = "blob section outside the blob"; return false; }
+        for (int i = 0; i < BGR_ANC_LEVELS; ++i) {
+            const BgrAncLevel& lv = h->anc_levels[i];
+            if (lv.domain == 0 || lv.word_base + 1 + lv.domain / 64 > h->anc_words) { err = "corrupt anchors index"; return false; }
+        }
+    }
     return true;
 }
 
@@ -299,7 +266,7 @@ bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& s
     return true;
 }
 
-bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* offs, double gamma, HostGraph& out, std::string& err) {
+bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* offs, double gamma, uint32_t flags, HostGraph& out, std::string& err) {
     if (k < 2 || k > 32) { err = "k must be in [2,32] (kmer is uint64_t, utils.h:27)"; return false; }
     if (!(gamma >= 0.5 && gamma <= 64.0)) { err = "gamma must be in [0.5,64]"; return false; }
     const uint32_t K1 = k - 1;
@@ -380,6 +347,33 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     build_cascade(keys, gamma, T, cas);
     tm.lap("cascade");
 
+    // ---- anchors index of -G (aligner.cpp:434-442,457-462): canonical k-mers j = 0 .. len-k-1 of every unitig ----
+    AnchorMphf anc;
+    std::vector<uint64_t> anc_first;  // index of each unitig's first anchor in the key sequence
+    if (flags & BGR_BUILD_ANCHORS) {
+        anc_first.assign(n + 2, 0);
+        for (uint64_t i = 1; i <= n; ++i) anc_first[i + 1] = anc_first[i] + (meta[i].len > k ? meta[i].len - k : 0);
+        std::vector<uint64_t> akeys(anc_first[n + 1]);
+        const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+        parallel_ranges(T, n, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t i = b + 1; i <= e; ++i) {
+                const char* s = seqs + offs[i - 1];
+                const uint32_t len = meta[i].len;
+                if (len <= k) continue;
+                uint64_t x = 0;
+                for (uint32_t j = 0; j < k - 1; ++j) x = x << 2 | code_of(s[j]);
+                uint64_t* o = akeys.data() + anc_first[i];
+                for (uint32_t j = 0; j + k < len; ++j) {
+                    x = (x << 2 | code_of(s[j + k - 1])) & kmask;
+                    const uint64_t rc = bgr_rcb(x, k);
+                    o[j] = x < rc ? x : rc;
+                }
+            }
+        });
+        build_anchor_mphf(akeys, T, anc);
+        tm.lap("anchors");
+    }
+
     // ---- blob layout ------------------------------------------------------------------------------
     const uint64_t exc_words = has_exc ? (total + 63) / 64 + 2 : 0;
     BgrBlobHeader h;
@@ -413,6 +407,18 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         h.off_excn = off; off = align256(off + exc_words * 8);
     }
     h.off_fallback = off; off = align256(off + h.n_fallback * 8 + 8);
+    if (flags & BGR_BUILD_ANCHORS) {
+        h.anc_n = anc.n;
+        h.anc_last_rank = anc.last_rank;
+        h.anc_n_final = anc.final_kv.size() / 2;
+        h.anc_words = anc.bits.size();
+        h.anc_rank_words = anc.ranks.size();
+        memcpy(h.anc_levels, anc.levels, sizeof(h.anc_levels));
+        h.off_anc_bits = off;  off = align256(off + h.anc_words * 8 + 8);
+        h.off_anc_ranks = off; off = align256(off + h.anc_rank_words * 8 + 8);
+        h.off_anc_final = off; off = align256(off + h.anc_n_final * 16 + 16);
+        h.off_anc_pos = off;   off = align256(off + h.anc_n * 8 + 8);
+    }
     h.blob_bytes = off;
 
     if (!out.blob.reset(off / 8)) { err = "out of memory for the graph blob"; return false; }  // zero pages, touched below in parallel
@@ -501,6 +507,35 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         }
     });
     tm.lap("slots");
+
+    if (h.anc_n) {  // aligner.cpp:465-476: anchorsPosition[lookup(canon)] = {i, j} in unitig order, i.e. the LAST one wins
+        memcpy(base + h.off_anc_bits, anc.bits.data(), anc.bits.size() * 8);
+        memcpy(base + h.off_anc_ranks, anc.ranks.data(), anc.ranks.size() * 8);
+        if (!anc.final_kv.empty()) memcpy(base + h.off_anc_final, anc.final_kv.data(), anc.final_kv.size() * 8);
+        uint64_t* apos = reinterpret_cast<uint64_t*>(base + h.off_anc_pos);
+        const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+        std::atomic<bool> oob{false};
+        parallel_ranges(T, n, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t i = b + 1; i <= e; ++i) {
+                const char* s = seqs + offs[i - 1];
+                const uint32_t len = meta[i].len;
+                if (len <= k) continue;
+                uint64_t x = 0;
+                for (uint32_t j = 0; j < k - 1; ++j) x = x << 2 | code_of(s[j]);
+                for (uint32_t j = 0; j + k < len; ++j) {
+                    x = (x << 2 | code_of(s[j + k - 1])) & kmask;
+                    const uint64_t rc = bgr_rcb(x, k);
+                    const uint64_t idx = anchor_lookup(hp, base, x < rc ? x : rc);
+                    if (idx >= h.anc_n) { oob.store(true); return; }
+                    const uint64_t v = i << 32 | j;  // later (i, j) is larger: "last wins" == maximum
+                    uint64_t cur = __atomic_load_n(&apos[idx], __ATOMIC_RELAXED);
+                    while (cur < v && !__atomic_compare_exchange_n(&apos[idx], &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                }
+            }
+        });
+        if (oob.load()) { err = "internal: anchors index out of range"; return false; }
+        tm.lap("anc_pos");
+    }
     return true;
 }
 

@@ -39,7 +39,9 @@ struct HostGraph {
 // seqs/offs: n unitig sequences in file order (offs[n+1]).  Loading stops at the first sequence shorter
 // than k, as aligner.cpp:418-420 does.  gamma: MPHF bits per remaining key on each cascade level.
 // Returns false (and sets err) on invalid arguments / limits.
-bool build_graph(uint32_t k, uint64_t n, const char* seqs, const uint64_t* offs, double gamma, HostGraph& out, std::string& err);
+// flags: BGR_BUILD_ANCHORS adds the anchors index of -G mode (graph_layout.h).
+#define BGR_BUILD_ANCHORS 1u
+bool build_graph(uint32_t k, uint64_t n, const char* seqs, const uint64_t* offs, double gamma, uint32_t flags, HostGraph& out, std::string& err);
 
 // Host threads used by build_graph / read_unitig_fasta (0 = default: the machine's cores, at most 16).  The blob
 // does not depend on the thread count.

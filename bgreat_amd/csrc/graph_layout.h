@@ -41,7 +41,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 4u  /* 4: 2-bit-state cascade, 16-byte slots with (word, offset) sequence addresses */
+#define BGR_BLOB_VERSION 5u  /* 5: optional anchors index (-G) sections; 4: 2-bit-state cascade, 16-byte slots */
 #define BGR_MAX_LEVELS 48
 #define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
 #define BGR_NONE 0xFFFFFFFFu
@@ -81,6 +81,22 @@ typedef struct {
     uint32_t base;   // index of the level's first unit in the unit array
 } BgrLevel;
 
+// ---- anchors index (-G, optional) --------------------------------------------------------------------
+// The reference's anchors mode looks read k-mers up in a boomphf::mphf over the canonical k-mers of all unitigs
+// and uses the answer WITHOUT a key check (aligner.cpp:387-389): a non-key that lands on a set bit gets the rank
+// of that bit as its "index".  Those indices are therefore observable, and this section is BooPHF's structure bit
+// for bit (BooPHF.h:425-660 bitVector, :732-780 constructor, :1010-1054 setup, gamma 10, 25 levels):
+//   anc_bits   per level 1 + domain/64 u64 words, bit p of a level = word p>>6, bit p&63 (LSB first)
+//   anc_ranks  per level one u64 per 8 words: set bits before that block, counted over all levels so far
+//   anc_final  keys left after 24 levels (in practice: repeated k-mers), sorted {key, index} pairs
+//   anc_pos    per index (unitig id << 32 | offset of the k-mer in that unitig), 0 = never written
+#define BGR_ANC_LEVELS 25
+typedef struct {
+    uint64_t domain;     // hash domain of the level (multiple of 64)
+    uint64_t word_base;  // first u64 of the level in anc_bits
+    uint64_t rank_base;  // first u64 of the level in anc_ranks
+} BgrAncLevel;
+
 // Blob header (first 4096 bytes of the blob).  All section offsets are bytes from the blob start and
 // multiples of 256.
 typedef struct {
@@ -100,6 +116,13 @@ typedef struct {
     uint64_t n_left_keys, n_right_keys;  // sizes of the reference's two key sets (informational)
     double gamma;
     BgrLevel levels[BGR_MAX_LEVELS];
+    // anchors index (all zero when the graph was built without it)
+    uint64_t anc_n;          // anchors = k-mers of all unitigs but each unitig's last, repeats included (aligner.cpp:434-442)
+    uint64_t anc_last_rank;  // set bits over all levels; indices of anc_final entries start here
+    uint64_t anc_n_final;
+    uint64_t anc_words, anc_rank_words;
+    uint64_t off_anc_bits, off_anc_ranks, off_anc_final, off_anc_pos;
+    BgrAncLevel anc_levels[BGR_ANC_LEVELS];
 } BgrBlobHeader;
 
 // What a kernel receives by value (pointers resolved against the device copy of the blob).  Kept small on
@@ -132,6 +155,31 @@ BGR_HD uint32_t bgr_level_unit(uint32_t h, uint32_t units) { return (uint32_t)((
 BGR_HD uint32_t bgr_level_pos(uint32_t h) { return ((h & 0xFFFFu) * BGR_UNIT_POS) >> 16; }
 // placed ("unique", state 1) positions of one state word, as a mask on the even bits
 BGR_HD uint32_t bgr_unique_mask(uint32_t w) { return w & ~(w >> 1) & 0x55555555u; }
+
+// ---- BooPHF's hashing, needed bit-exact by the anchors index (BooPHF.h:251-264 hash64, :336-356 the level hashes)
+BGR_HD uint64_t bgr_boo_hash64(uint64_t key, uint64_t seed) {
+    uint64_t h = seed;
+    h ^= (h << 7) ^ (key * (h >> 3)) ^ (~((h << 11) + (key ^ (h >> 5))));
+    h = (~h) + (h << 21);
+    h = h ^ (h >> 24);
+    h = (h + (h << 3)) + (h << 8);
+    h = h ^ (h >> 14);
+    h = (h + (h << 2)) + (h << 4);
+    h = h ^ (h >> 28);
+    h = h + (h << 31);
+    return h;
+}
+#define BGR_BOO_SEED0 0xAAAAAAAA55555555ULL
+#define BGR_BOO_SEED1 0x33333333CCCCCCCCULL
+// level 0 and 1 hash with the two seeds; level >= 2 is xorshift128+ on the state (s0, s1) = (h0, h1)
+BGR_HD uint64_t bgr_boo_next(uint64_t* s0, uint64_t* s1) {
+    uint64_t a = *s0;
+    const uint64_t b = *s1;
+    *s0 = b;
+    a ^= a << 23;
+    *s1 = a ^ b ^ (a >> 17) ^ (b >> 26);
+    return *s1 + b;
+}
 
 // reverse complement of a (k-1)-digit base-4 number == utils.cpp:182-192 rcb(), by bit tricks
 BGR_HD uint64_t bgr_rev2(uint64_t x) {  // reverse the order of the 32 2-bit digits of x

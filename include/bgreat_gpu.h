@@ -64,7 +64,7 @@ typedef struct {
     uint32_t k, n_levels;
     uint64_t n_unitigs, n_keys, n_left_keys, n_right_keys, n_fallback;
     uint64_t total_bases, blob_bytes, mphf_bytes, max_unitig_len;
-    uint32_t has_exceptions, reserved;
+    uint32_t has_exceptions, has_anchors; /* has_anchors: built with BGR_BUILD_ANCHORS (needed by BGR_MODE_ANCHORS) */
     double gamma;
 } bgr_graph_info_t;
 
@@ -82,6 +82,17 @@ void bgr_set_build_threads(uint32_t threads);
 int bgr_graph_build(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, bgr_graph** out);
 /* Same, reading the unitig FASTA exactly as aligner.cpp:415-417 does (2 lines per record, header ignored). */
 int bgr_graph_build_from_fasta(const char* unitig_fasta_path, uint32_t k, double gamma, bgr_graph** out);
+/* The same two with build flags.  BGR_BUILD_ANCHORS = the reference's dogMode index (`-G`, aligner.cpp:434-442,
+ * 457-476): an MPHF over the canonical k-mers of all unitigs plus their (unitig, offset) table, the structure of
+ * boomphf::mphf bit for bit because the reference consumes its answers for non-keys too (aligner.cpp:387-389).
+ * Costs ~9.5 bytes per unitig base on the host and in HBM. */
+#define BGR_BUILD_ANCHORS 1u
+int bgr_graph_build_ex(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, uint32_t flags, bgr_graph** out);
+int bgr_graph_build_from_fasta_ex(const char* unitig_fasta_path, uint32_t k, double gamma, uint32_t flags, bgr_graph** out);
+/* boomphf::mphf::lookup on the anchors index, host side (BooPHF.h:783-818): the index of a canonical k-mer, a false
+ * index for many non-keys, UINT64_MAX otherwise; *position_out (may be NULL) = unitig id << 32 | offset stored
+ * there.  Used by the CPU tests to pin the index against the oracle's. */
+int bgr_graph_anchor_lookup(const bgr_graph* g, uint64_t kmer, uint64_t* index_out, uint64_t* position_out);
 /* The graph as one position-independent byte blob (what is copied to HBM / broadcast between GPUs). */
 const void* bgr_graph_blob(const bgr_graph* g, uint64_t* bytes);
 int bgr_graph_from_blob(const void* blob, uint64_t bytes, bgr_graph** out); /* copies the blob */

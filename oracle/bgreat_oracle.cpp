@@ -1038,6 +1038,21 @@ int orc_anchors(void* h, const char* read, uint64_t len, int effort, uint64_t* k
     for (auto& a : l) { if (c < cap) { kmers[c] = a.first; pos[c] = a.second; ++c; } }
     return c;
 }
+// anchorsMPHF.lookup(kmer) and the anchorsPosition entry behind it (needs dog != 0 at creation).  Returns 0 and sets
+// *index = ULLONG_MAX when the lookup answers "not a key".
+int orc_anchor_lookup(void* h, uint64_t kmer, uint64_t* index, uint32_t* unitig, uint32_t* offset) {
+    Oracle* o = static_cast<Oracle*>(h);
+    Work saved = tl_work;
+    uint64_t idx = o->anchorsMPHF.lookup(kmer);
+    tl_work = saved;
+    *index = idx;
+    *unitig = *offset = 0;
+    if (idx == ULLONG_MAX) return 0;
+    if (idx >= o->anchorsPosition.size()) return -1;
+    *unitig = o->anchorsPosition[idx].first;
+    *offset = o->anchorsPosition[idx].second;
+    return 1;
+}
 // counters: readNumber, noOverlapRead, alignedRead, notAligned, overlaps   (aligner.h:68)
 void orc_counters(void* h, uint64_t out[5]) {
     Oracle* o = static_cast<Oracle*>(h);

@@ -22,6 +22,12 @@ def lib():
         L.orc_create.argtypes = [C.c_int, vp, vp, u64]
         L.orc_create_from_file.restype = vp
         L.orc_create_from_file.argtypes = [C.c_char_p, C.c_int]
+        L.orc_create2.restype = vp
+        L.orc_create2.argtypes = [C.c_int, vp, vp, u64, C.c_int]
+        L.orc_create_from_file2.restype = vp
+        L.orc_create_from_file2.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.orc_anchor_lookup.restype = C.c_int
+        L.orc_anchor_lookup.argtypes = [vp, u64, vp, vp, vp]
         L.orc_destroy.argtypes = [vp]
         L.orc_unitig_count.restype = u64
         L.orc_unitig_count.argtypes = [vp]
@@ -44,15 +50,23 @@ WORK_FIELDS = ["reads", "read_bases", "lookups", "probes_all", "probes_nonempty"
 
 
 class Oracle:
-    def __init__(self, k, seqs=None, offsets=None, fasta=None):
+    def __init__(self, k, seqs=None, offsets=None, fasta=None, anchors=False):
+        """anchors=True: index with dogMode (-G), needed by mode 2 and anchor_lookup."""
         if fasta is not None:
-            self.h = lib().orc_create_from_file(fasta.encode(), k)
+            self.h = lib().orc_create_from_file2(fasta.encode(), k, int(anchors))
         else:
             seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-            self.h = lib().orc_create(k, seqs.ctypes.data, offsets.ctypes.data, len(offsets) - 1)
+            self.h = lib().orc_create2(k, seqs.ctypes.data, offsets.ctypes.data, len(offsets) - 1, int(anchors))
         if not self.h:
             raise RuntimeError("oracle: cannot create")
+
+    def anchor_lookup(self, kmer):
+        """(index, unitig, offset) of anchorsMPHF.lookup(kmer) / anchorsPosition; index None for ULLONG_MAX."""
+        idx, u, o = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        rc = lib().orc_anchor_lookup(self.h, int(kmer), C.byref(idx), C.byref(u), C.byref(o))
+        assert rc >= 0
+        return (None, 0, 0) if rc == 0 else (idx.value, u.value, o.value)
 
     def align(self, reads, offsets, m=2, effort=2, mode=0, partial=False):
         reads = np.ascontiguousarray(reads, dtype=np.uint8)

@@ -99,6 +99,56 @@ def test_unitig_fasta_two_lines_per_record(tmp_path, text, n):
     assert B.Graph.from_fasta(fa, 5).info()["n_unitigs"] == n
 
 
+def _canon(x, k):
+    rc = 0
+    y = x
+    for _ in range(k):
+        rc = (rc << 2) | (3 - (y & 3))
+        y >>= 2
+    return min(x, rc)
+
+
+@pytest.mark.parametrize("fa,k", [("toy_unitig.fa", 4), ("deg_unitig.fa", 5), ("deg_unitig_exc.fa", 5), ("syn_unitig.fa", 31),
+                                  ("syn_unitig.fa", 32), ("syn_unitig.fa", 12), ("long_unitig.fa", 31)])
+def test_anchors_index_is_boophf_bit_for_bit(fa, k):
+    """-G consumes MPHF answers for non-keys (aligner.cpp:387-389): the product's anchors index must return what the
+    oracle's BooPHF restatement (pinned by the -G goldens) returns, for every unitig k-mer and for random non-keys."""
+    path = os.path.join(GOLD, fa)
+    try:
+        graphs = []
+        for T in (1, 4):
+            B.lib().bgr_set_build_threads(T)
+            graphs.append(B.Graph.from_fasta(path, k, anchors=True))
+    finally:
+        B.lib().bgr_set_build_threads(0)
+    g = graphs[0]
+    assert g.info()["has_anchors"] == 1 and np.array_equal(np.array(g.blob()), np.array(graphs[1].blob()))
+    o = oracle_py.Oracle(k, fasta=path, anchors=True)
+    code = {"A": 0, "C": 1, "G": 2}
+    keys = []
+    for line in open(path).read().split("\n")[1::2]:
+        if len(line) < k:
+            break
+        for j in range(0, max(0, len(line) - k)):
+            x = 0
+            for ch in line[j:j + k]:
+                x = (x << 2) | code.get(ch, 3)
+            keys.append(_canon(x, k))
+    assert keys
+    rng = np.random.default_rng(5)
+    keys = keys[:4000] + [int(v) & ((1 << (2 * k)) - 1) for v in rng.integers(0, 1 << 62, 3000)] + [0, (1 << (2 * k)) - 1]
+    hits = 0
+    for x in keys:
+        a, b = g.anchor_lookup(x), o.anchor_lookup(x)
+        assert a == b, (x, a, b)
+        hits += a[0] is not None
+    assert hits >= min(4000, len(keys) - 3002)
+    g2 = B.Graph.from_blob(np.array(g.blob()))   # the sections survive the blob round trip
+    assert g2.anchor_lookup(keys[0]) == g.anchor_lookup(keys[0]) and g2.info() == g.info()
+    with pytest.raises(B.BgrError):
+        B.Graph.from_fasta(path, k).anchor_lookup(keys[0])
+
+
 def test_exception_planes_only_when_needed():
     assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig.fa"), 5).info()["has_exceptions"] == 0
     assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig_exc.fa"), 5).info()["has_exceptions"] == 1
