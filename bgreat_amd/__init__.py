@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbgreat_gpu.so")
 CLI_PATH = os.path.join(_HERE, "bin", "bgreat")
 
-MODE_GREEDY, MODE_EXHAUSTIVE = 0, 1
+MODE_GREEDY, MODE_EXHAUSTIVE, MODE_ANCHORS = 0, 1, 2
 ST_NOANCHOR, ST_FAILED, ST_ALIGNED, ST_MASK, ST_RC = 0, 1, 2, 3, 4
 BUILD_ANCHORS = 1
 

@@ -292,7 +292,9 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
 int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
                      uint64_t total_bases, uint32_t max_read_len) {
     if (!a || !p) return fail(BGR_E_ARG, "bgr_align_device: null argument");
-    if (p->mode > BGR_MODE_EXHAUSTIVE) return fail(BGR_E_ARG, "bgr_align_device: unknown mode");
+    if (p->mode > BGR_MODE_ANCHORS) return fail(BGR_E_ARG, "bgr_align_device: unknown mode");
+    if (p->mode == BGR_MODE_ANCHORS && !a->graph->header.anc_n)
+        return fail(BGR_E_ARG, "bgr_align_device: BGR_MODE_ANCHORS needs a graph built with BGR_BUILD_ANCHORS");
     a->last_n = n_reads;
     if (n_reads == 0) return BGR_OK;
     if (!d_reads || !d_read_offsets) return fail(BGR_E_ARG, "bgr_align_device: null device buffer");
@@ -310,9 +312,10 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     const uint32_t kExhFrameCap = fc_env ? (uint32_t)std::max(2, atoi(fc_env)) : 24;
     uint32_t words = 0, path_cap = 0, frames = 0, frames_deep = 0;
     uint64_t deep_stride = 0;
-    bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep, 0, &deep_stride);
+    const uint32_t lmode = p->mode == BGR_MODE_EXHAUSTIVE ? 1u : 0u;  // anchors mode uses the greedy per-wave layout
+    bgr::lds_bytes_per_wave(lmode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep, 0, &deep_stride);
     const uint32_t per_wave_deep = bgr::deep_lds_bytes_per_wave(max_read_len);
-    const uint32_t per_wave = bgr::lds_bytes_per_wave(p->mode, a->dg.k, max_read_len, &words, &path_cap, &frames, kExhFrameCap);
+    const uint32_t per_wave = bgr::lds_bytes_per_wave(lmode, a->dg.k, max_read_len, &words, &path_cap, &frames, kExhFrameCap);
     const bool exhaustive = p->mode == BGR_MODE_EXHAUSTIVE;
     bool two_pass = exhaustive && frames < frames_deep;
     const size_t lds_cu = a->lds_per_cu;
@@ -330,7 +333,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 7) / 8) * 8 : 0) + (uint64_t)w * pw) <= lds_fit;
         };
         if (allow_tuning && (a->cfg_waves || a->cfg_blocks_per_cu)) {  // explicit tuning through bgr_aligner_configure
-            stage = a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true));
+            stage = p->mode != BGR_MODE_ANCHORS && (a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true)));
             waves = a->cfg_waves ? a->cfg_waves : (stage ? 12 : 4);
             bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
             while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
@@ -338,7 +341,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
         } else {
             uint32_t best_res = 0;
-            if (a->cfg_lds_mphf != 1 && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
+            if (a->cfg_lds_mphf != 1 && p->mode != BGR_MODE_ANCHORS && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
                 const uint32_t bs[] = {1, 2, 3, 4, 6};
                 for (uint32_t b : bs) {
                     uint32_t w = std::min<uint32_t>(16, cap / b);

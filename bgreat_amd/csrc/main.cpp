@@ -68,22 +68,19 @@ int main(int argc, char** argv) {
                   << "-c to output corrected reads" << std::endl;
         return 0;
     }
-    if (dog) {
-        fprintf(stderr, "bgreat: -G (anchors mode) is outside the GPU mapping path and not implemented\n");
-        return 2;
-    }
     if (gpus < 1 || batch < 1) { fprintf(stderr, "bgreat: --gpus and --batch must be positive\n"); return 2; }
 
     auto t0 = std::chrono::system_clock::now();
     bgr_graph* graph = nullptr;
     bgr_set_build_threads((uint32_t)std::max(1, threads));
-    if (bgr_graph_build_from_fasta(unitigs.c_str(), (uint32_t)ka, 0.0, &graph) != BGR_OK) die("index");
+    if (bgr_graph_build_from_fasta_ex(unitigs.c_str(), (uint32_t)ka, 0.0, dog ? BGR_BUILD_ANCHORS : 0u, &graph) != BGR_OK) die("index");
     for (int g = 0; g < gpus; ++g)
         if (bgr_graph_upload(graph, g) != BGR_OK) die("device setup");
     auto t1 = std::chrono::system_clock::now();
     std::cout << "Indexing in seconds : " << std::chrono::duration_cast<std::chrono::seconds>(t1 - t0).count() << std::endl;  // aligner.cpp:546
 
-    bgr_params prm = {brute ? (uint32_t)BGR_MODE_EXHAUSTIVE : (uint32_t)BGR_MODE_GREEDY, (uint32_t)errors, (uint32_t)effort, incomplete ? 1u : 0u};
+    // -b selects alignPartExhaustive, where -G has no effect (aligner.cpp:563-567, alignerGreedy.cpp:387)
+    bgr_params prm = {brute ? (uint32_t)BGR_MODE_EXHAUSTIVE : (dog ? (uint32_t)BGR_MODE_ANCHORS : (uint32_t)BGR_MODE_GREEDY), (uint32_t)errors, (uint32_t)effort, incomplete ? 1u : 0u};
     bgr_run_options opt;
     memset(&opt, 0, sizeof(opt));
     opt.n_gpus = (uint32_t)gpus;

@@ -304,8 +304,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     const unsigned threads = std::max<uint32_t>(1, opt->threads);
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes : (8ull << 20);
     const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (1ull << 20);
-    const bool writes = prm->mode == BGR_MODE_GREEDY || opt->write_exhaustive;
-    const bool correction = opt->correction && prm->mode == BGR_MODE_GREEDY;  // alignPartExhaustive ignores -c
+    const bool writes = prm->mode != BGR_MODE_EXHAUSTIVE || opt->write_exhaustive;
+    const bool correction = opt->correction && prm->mode != BGR_MODE_EXHAUSTIVE;  // alignPartExhaustive ignores -c
     Unitigs unitigs;
     if (correction) {
         if (bgr_graph_unitigs(graph, &unitigs.seqs, &unitigs.offs, &unitigs.n) != BGR_OK) return BGR_E_ARG;

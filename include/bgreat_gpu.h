@@ -49,6 +49,8 @@ extern "C" {
 
 #define BGR_MODE_GREEDY 0      /* alignAll(true, ...)  -> alignReadGreedy      (bgreat.cpp:115, default) */
 #define BGR_MODE_EXHAUSTIVE 1  /* alignAll(false, ...) -> alignReadExhaustive  (bgreat.cpp -b)           */
+#define BGR_MODE_ANCHORS 2     /* dogMode (bgreat.cpp -G) -> alignReadGreedyAnchors (alignerGreedy.cpp:60-164); the graph
+                                  must have been built with BGR_BUILD_ANCHORS */
 
 typedef struct bgr_graph bgr_graph;     /* immutable index: replaces the Aligner's unitigs/MPHF/indices members */
 typedef struct bgr_aligner bgr_aligner; /* per-device mapping context: stream, workspaces, counters            */

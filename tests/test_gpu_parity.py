@@ -46,10 +46,10 @@ def _format(reads, roffs, heads, hoffs, paths, poffs):
 def graphs():
     cache = {}
 
-    def get(path, k):
-        key = (path, k)
+    def get(path, k, anchors=False):
+        key = (path, k, anchors)
         if key not in cache:
-            g = B.Graph.from_fasta(path, k)
+            g = B.Graph.from_fasta(path, k, anchors=anchors)
             cache[key] = (g, B.Aligner(g, 0))
         return cache[key]
     yield get
@@ -65,8 +65,8 @@ def test_gpu_matches_reference_golden(case, graphs):
     m = int(_argval(args, "-m", "2"))
     e = int(_argval(args, "-e", "2"))
     fastq = "-q" in args
-    mode = B.MODE_EXHAUSTIVE if "-b" in args else B.MODE_GREEDY
-    g, al = graphs(os.path.join(GOLD, _argval(args, "-g", None)), k)
+    mode = B.MODE_EXHAUSTIVE if "-b" in args else (B.MODE_ANCHORS if "-G" in args else B.MODE_GREEDY)   # -b wins over -G
+    g, al = graphs(os.path.join(GOLD, _argval(args, "-g", None)), k, mode == B.MODE_ANCHORS)
     al.reset_counters()
     pbytes, nbytes = b"", b""
     for f in _argval(args, "-r", None).split(","):
@@ -81,7 +81,8 @@ def test_gpu_matches_reference_golden(case, graphs):
     check_against_golden(case, out, pbytes, nbytes)
 
 
-@pytest.mark.parametrize("case", [c for c in GREEDY if c["group"] in ("toy", "edge", "edge_fq", "multi", "long_fq", "deg")][:12],
+@pytest.mark.parametrize("case", [c for c in GREEDY if c["group"] in ("toy", "edge", "edge_fq", "multi", "long_fq", "deg")][:12] +
+                         [c for c in GREEDY if c["group"] == "dog"],
                          ids=lambda c: "%02d-%s" % (c["id"], c["group"]))
 def test_cli_matches_reference_golden(case):
     out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]))
@@ -94,6 +95,38 @@ def test_cli_pipeline_threads_and_tiny_chunks_keep_the_t1_stream(case):
     """Any thread count, batch size and parser chunk size must give the reference's -t 1 bytes."""
     out, paths, na = run_cli(B.CLI_PATH, resolve_args(case["args"]) + ["-t", "5", "--batch", "37", "--chunk-bytes", "600"])
     check_against_golden(case, out, paths, na)
+
+
+@pytest.mark.parametrize("k,L,m,e,seed", [(31, 150, 2, 2, 1), (21, 100, 3, 1, 2), (32, 250, 5, 4, 3), (12, 60, 1, 3, 4), (31, 33, 0, 2, 5),
+                                          (25, 400, 4, 0, 6), (8, 40, 2, 5, 7)])
+def test_anchors_mode_random_vs_oracle(k, L, m, e, seed):
+    """-G on fresh graphs and reads (both strands, substitutions, some N): identical ints, offsets and status bytes."""
+    s = Synth(60000, 3 * k, 3, k, 100 + seed)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(k, seqs, offs, anchors=True)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs, anchors=True)
+    n = 3000
+    reads, roffs = s.reads(0, n, L, m + 1, 200 + seed)
+    reads = reads.copy()
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(len(reads), size=n // 10, replace=False)
+    reads[idx] = ord("N")
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=e, mode=B.MODE_ANCHORS)
+    p2, po2, st2 = o.align(reads, roffs, m=m, effort=e, mode=2)
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    assert ((st1 & 3) == B.ST_ALIGNED).sum() > n // 20
+    assert al.counters() == o.counters()
+
+
+def test_anchors_mode_needs_the_anchors_index():
+    s = Synth(30000, 90, 2, 31, 3)
+    seqs, offs = s.unitigs()
+    al = B.Aligner(B.Graph.build(31, seqs, offs), 0)
+    reads, roffs = s.reads(0, 10, 100, 1, 4)
+    with pytest.raises(B.BgrError, match="BGR_BUILD_ANCHORS"):
+        al.align(reads, roffs, mode=B.MODE_ANCHORS)
 
 
 def test_cli_end_to_end_against_reference_binary(oracle_bins):
