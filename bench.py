@@ -55,6 +55,7 @@ def main():
                     help="ecoli = BASELINE configs[2] (default, the metric's config); small = configs[1]; chr1 = configs[3] graph scale; "
                          "branchy = configs[4] (exhaustive, m=5, 250 bp)")
     ap.add_argument("--exhaustive", action="store_true")
+    ap.add_argument("--anchors", action="store_true", help="-G: greedy mapping from k-mer anchors (diagnostic; not the headline metric)")
     ap.add_argument("--gamma", type=float, default=0.0, help="MPHF positions per key and level (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     args = ap.parse_args()
@@ -67,7 +68,7 @@ def main():
     for key, val in presets.get(args.workload, {}).items():
         if getattr(args, key) == ap.get_default(key):
             setattr(args, key, val)
-    mode = 1 if args.exhaustive else 0
+    mode = 1 if args.exhaustive else (2 if args.anchors else 0)
 
     import torch
     import bgreat_amd as B
@@ -112,7 +113,7 @@ def main():
     if rank == 0:
         seqs, offs = syn.unitigs()
         tb = time.time()
-        g = B.Graph.build(args.k, seqs, offs, args.gamma)
+        g = B.Graph.build(args.k, seqs, offs, args.gamma, anchors=(mode == 2))
         graph_info = g.info()
         log("index build: %.2fs on the host (%d unitigs)" % (time.time() - tb, graph_info["n_unitigs"]))
     blob_keepalive = None
@@ -181,7 +182,7 @@ def main():
     # ---- ALGORITHMIC bytes per read: SURVEY.md 8d formula, counted by the oracle on a sample of this workload ----
     import oracle_py
     seqs, offs = syn.unitigs()
-    orc = oracle_py.Oracle(args.k, seqs, offs)
+    orc = oracle_py.Oracle(args.k, seqs, offs, anchors=(mode == 2))
     ns = min(args.alg_sample, R)
     s_reads = first_host[: ns * L]
     s_offs = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
@@ -202,7 +203,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "kernel": "bgr_align_exhaustive_kernel" if mode else "bgr_align_greedy_kernel", "avg_launch_ms": round(avg_kernel_ms, 4), "launches": launches,
+                "traffic": traffic, "kernel": ("bgr_align_greedy_kernel", "bgr_align_exhaustive_kernel", "bgr_align_anchors_kernel")[mode], "avg_launch_ms": round(avg_kernel_ms, 4), "launches": launches,
                 "alg_bytes_per_read": round(alg_bytes_per_read, 1), "reads_per_launch": R}
 
     # ---- CPU baseline: the compiled reference (oracle/_ref/bgreat -t cores) on a bounded sample, N=1 only -------
@@ -262,7 +263,7 @@ def main():
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: synthetic %.1fM x %d bp reads per GPU (%d steps x %d), k=%d, m=%d, effort=%d, %s, graph of %d unitigs (genome %d bp, %d alleles every ~%d bp)"
                    % ({"ecoli": "BASELINE configs[2]", "small": "BASELINE configs[1]", "chr1": "BASELINE configs[3] graph scale, one GPU's share", "branchy": "BASELINE configs[4] graph, one GPU's share"}[args.workload],
-                      K * R / 1e6, L, K, R, args.k, args.mismatch, args.effort, "exhaustive" if mode else "greedy", graph_info["n_unitigs"], args.genome, args.alleles, args.site_spacing),
+                      K * R / 1e6, L, K, R, args.k, args.mismatch, args.effort, ("greedy", "exhaustive", "greedy from k-mer anchors (-G)")[mode], graph_info["n_unitigs"], args.genome, args.alleles, args.site_spacing),
                    "reads_per_step_per_gpu": R, "read_len": L, "k": args.k, "m": args.mismatch, "effort": args.effort,
                    "parallelism": "reads sharded over %d GPU(s); graph blob broadcast once" % world, "launch": al.launch_info()},
         "roofline": roofline, "cpu_baseline": cpu,

@@ -453,6 +453,9 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 #ifndef BGR_GREEDY_OCC
 #define BGR_GREEDY_OCC 6
 #endif
+#ifndef BGR_ANC_OCC
+#define BGR_ANC_OCC 4 /* 128 VGPRs, no spills: 220 vs 200 Mreads/s at 6 */
+#endif
 #ifndef BGR_EXH_OCC
 #define BGR_EXH_OCC 6 /* waves per SIMD the exhaustive kernel is compiled for */
 #endif
@@ -776,7 +779,7 @@ __device__ __forceinline__ uint32_t ham_span(const BgrDeviceGraph& g, const u64*
     return rl32(cnt, 0) + rl32(cnt, 16) + rl32(cnt, 32) + rl32(cnt, 48);
 }
 
-__global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_anchors_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, BGR_ANC_OCC) bgr_align_anchors_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
