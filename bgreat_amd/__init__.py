@@ -328,8 +328,10 @@ def load_reads(path, k, fastq=False, threads=1, chunk_bytes=0):
         _check(lib().bgr_readset_view(h, C.byref(r), C.byref(ro), C.byref(hd), C.byref(ho)))
         roffs = np.ctypeslib.as_array(C.cast(ro, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
         hoffs = np.ctypeslib.as_array(C.cast(ho, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
-        reads = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint8)), shape=(max(int(roffs[n]), 1),))[: int(roffs[n])].copy() if n else np.zeros(0, np.uint8)
-        heads = np.ctypeslib.as_array(C.cast(hd, C.POINTER(C.c_uint8)), shape=(max(int(hoffs[n]), 1),))[: int(hoffs[n])].copy() if n else np.zeros(0, np.uint8)
+        def _bytes(ptr, total):  # an empty vector hands out a null pointer
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(total,)).copy() if total else np.zeros(0, np.uint8)
+        reads = _bytes(r, int(roffs[n]))
+        heads = _bytes(hd, int(hoffs[n]))
         return reads, roffs, heads, hoffs
     finally:
         lib().bgr_readset_destroy(h)

@@ -67,6 +67,11 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
 // Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive).
 uint32_t resident_waves_per_cu(uint32_t mode);
 
+// (results, arena) of the last mapping launch -> input-ordered CSR on the device.  phase 0: block_sums[ceil(n/4096)] and
+// *total (all path ints); phase 1: path_offsets[n+1], paths[total] (nothing is stored past paths_cap), status[n].
+hipError_t launch_csr(const uint2* results, const int32_t* arena, uint32_t n, uint32_t* block_sums, unsigned long long* total,
+                      unsigned long long* path_offsets, int32_t* paths, uint8_t* status, uint32_t paths_cap, int phase, hipStream_t stream);
+
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);
 
 }  // namespace bgr

@@ -1035,6 +1035,104 @@ hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, cons
 
 }  // namespace
 
+// ======================================= results -> CSR, on the device =======================================
+// The mapping kernels leave every path where its wave found room in the arena.  These three small kernels turn
+// (results, arena) into what the C-ABI hands out -- input-ordered path_offsets[n+1], dense paths, status bytes -- so
+// the host neither loops over the reads nor copies the arena: 4096 reads per workgroup (4 per thread), block sums,
+// one-workgroup scan of the sums, then the gather.
+constexpr uint32_t kCsrThreads = 1024, kCsrItems = 4, kCsrTile = kCsrThreads * kCsrItems;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_waves, uint32_t* block_total) {
+    // inclusive scan inside the wave by DPP-free shuffles, then across the 16 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) lds_waves[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+        const uint32_t t = lds_waves[w];
+        if (w < (uint32_t)wave) before += t;
+        total += t;
+    }
+    __syncthreads();
+    *block_total = total;
+    return before + inc - v;
+}
+
+__global__ void __launch_bounds__(kCsrThreads) bgr_csr_block_sums(const uint2* results, uint32_t n, uint32_t* block_sums) {
+    __shared__ uint32_t lw[16];
+    const uint32_t base = blockIdx.x * kCsrTile + threadIdx.x * kCsrItems;
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kCsrItems; ++j) if (base + j < n) s += results[base + j].y & 0xFFFFFFu;
+    uint32_t total;
+    (void)block_exclusive_scan(s, lw, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one workgroup: block_sums[b] -> ints before tile b; total[0] = all ints
+__global__ void __launch_bounds__(kCsrThreads) bgr_csr_scan_sums(uint32_t* block_sums, uint32_t nb, unsigned long long* total_out) {
+    __shared__ uint32_t lw[16];
+    __shared__ unsigned long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += kCsrThreads) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, lw, &total);
+        const unsigned long long carry = carry_s;
+        if (i < nb) block_sums[i] = (uint32_t)(carry + ex);  // < 2^32: the arena holds fewer than 2^32 ints
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ void __launch_bounds__(kCsrThreads) bgr_csr_gather(const uint2* results, const int32_t* arena, uint32_t n, const uint32_t* block_offs,
+                                                             unsigned long long* path_offsets, int32_t* paths, uint8_t* status, uint32_t paths_cap) {
+    __shared__ uint32_t lw[16];
+    const uint32_t base = blockIdx.x * kCsrTile + threadIdx.x * kCsrItems;
+    uint2 r[kCsrItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kCsrItems; ++j) {
+        r[j] = base + j < n ? results[base + j] : make_uint2(0, 0);
+        s += r[j].y & 0xFFFFFFu;
+    }
+    uint32_t total;
+    uint32_t w = block_offs[blockIdx.x] + block_exclusive_scan(s, lw, &total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) path_offsets[0] = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kCsrItems; ++j) {
+        if (base + j >= n) break;
+        const uint32_t len = r[j].y & 0xFFFFFFu;
+        if (w + len <= paths_cap)
+            for (uint32_t q = 0; q < len; ++q) paths[w + q] = arena[r[j].x + q];
+        w += len;
+        path_offsets[base + j + 1] = w;
+        status[base + j] = (uint8_t)(r[j].y >> 24);
+    }
+}
+
+hipError_t launch_csr(const uint2* results, const int32_t* arena, uint32_t n, uint32_t* block_sums, unsigned long long* total,
+                      unsigned long long* path_offsets, int32_t* paths, uint8_t* status, uint32_t paths_cap, int phase, hipStream_t stream) {
+    const uint32_t nb = (n + kCsrTile - 1) / kCsrTile;
+    if (phase == 0) {  // lengths -> tile offsets + total
+        hipLaunchKernelGGL(bgr_csr_block_sums, dim3(nb), dim3(kCsrThreads), 0, stream, results, n, block_sums);
+        hipLaunchKernelGGL(bgr_csr_scan_sums, dim3(1), dim3(kCsrThreads), 0, stream, block_sums, nb, total);
+    } else {           // gather (the caller has sized `paths` from the total)
+        hipLaunchKernelGGL(bgr_csr_gather, dim3(nb), dim3(kCsrThreads), 0, stream, results, arena, n, block_sums, path_offsets, paths, status, paths_cap);
+    }
+    return hipGetLastError();
+}
+
 uint32_t resident_waves_per_cu(uint32_t mode) {
     hipFuncAttributes fa;
     const void* fn = mode == 0 ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)

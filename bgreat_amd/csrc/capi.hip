@@ -65,7 +65,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, results, arena, ovf, deep, small;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, results, arena, ovf, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -75,8 +75,6 @@ struct bgr_aligner {
     int ev_used = 0;
     uint64_t t_launches = 0;
     double t_ms = 0;
-    std::vector<uint32_t> h_results;
-    std::vector<int32_t> h_arena;
 };
 
 namespace {
@@ -275,6 +273,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
         a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->deep.release(); a->small.release();
+        a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
@@ -467,22 +466,31 @@ int bgr_aligner_fetch(bgr_aligner* a, uint64_t n, int32_t* paths_out, uint64_t p
     if (n == 0) return BGR_OK;
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
-    uint32_t cur[2] = {0, 0};
-    HIP_TRY(hipMemcpy(cur, a->small.p, 8, hipMemcpyDeviceToHost));
+    // results -> CSR on the device (launch_csr), then three plain copies into the caller's arrays
+    const uint64_t nb = (n + 4095) / 4096;
+    HIP_TRY(a->csr_sums.ensure(nb * 4 + 64));
+    HIP_TRY(a->csr_poffs.ensure((n + 1) * 8));
+    HIP_TRY(a->csr_status.ensure(n));
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(static_cast<char*>(a->small.p) + 128);
+    hipError_t e = bgr::launch_csr(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), (uint32_t)n,
+                                   static_cast<uint32_t*>(a->csr_sums.p), d_total, nullptr, nullptr, nullptr, 0, 0, a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("csr launch: ") + hipGetErrorString(e));
+    uint64_t hs[17];  // cursor[0..1] @0, path-int total @128
+    HIP_TRY(hipMemcpyAsync(hs, a->small.p, sizeof(hs), hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    const uint32_t* cur = reinterpret_cast<const uint32_t*>(hs);
     if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
-    a->h_results.resize(2 * n);
-    a->h_arena.resize(cur[0]);
-    HIP_TRY(hipMemcpy(a->h_results.data(), a->results.p, n * 8, hipMemcpyDeviceToHost));
-    if (cur[0]) HIP_TRY(hipMemcpy(a->h_arena.data(), a->arena.p, (size_t)cur[0] * 4, hipMemcpyDeviceToHost));
-    uint64_t w = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint32_t off = a->h_results[2 * i], pk = a->h_results[2 * i + 1], len = pk & 0xFFFFFFu;
-        status[i] = (uint8_t)(pk >> 24);
-        if (w + len > paths_cap) return fail(BGR_E_CAPACITY, "bgr_aligner_fetch: paths_out too small");
-        if (len) memcpy(paths_out + w, a->h_arena.data() + off, (size_t)len * 4);
-        w += len;
-        path_offsets[i + 1] = w;
-    }
+    const uint64_t total = hs[16];
+    if (total > paths_cap) return fail(BGR_E_CAPACITY, "bgr_aligner_fetch: paths_out too small");
+    HIP_TRY(a->csr_paths.ensure(total * 4 + 16));
+    e = bgr::launch_csr(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), (uint32_t)n,
+                        static_cast<uint32_t*>(a->csr_sums.p), d_total, static_cast<unsigned long long*>(a->csr_poffs.p),
+                        static_cast<int32_t*>(a->csr_paths.p), static_cast<uint8_t*>(a->csr_status.p), (uint32_t)std::min<uint64_t>(total, 0xFFFFFFFFull), 1, a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("csr launch: ") + hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(path_offsets, a->csr_poffs.p, (n + 1) * 8, hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipMemcpyAsync(status, a->csr_status.p, n, hipMemcpyDeviceToHost, a->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(paths_out, a->csr_paths.p, total * 4, hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
     return BGR_OK;
 }
 

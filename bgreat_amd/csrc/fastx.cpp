@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace bgr {
 
@@ -54,6 +57,34 @@ inline bool valid_chars(const char* p, uint64_t n) {  // aligner.cpp:56-61
     return true;
 }
 
+// One pass over a line: returns the position of its '\n' (or `end`), and whether every byte before it is one of
+// ACGTN (aligner.cpp:56-61).  Replaces memchr + valid_chars on the sequence line of a record (the bulk of a file).
+inline const char* scan_line(const char* p, const char* end, bool& valid) {
+    unsigned bad = 0;
+#if defined(__SSE2__)
+    const __m128i vA = _mm_set1_epi8('A'), vC = _mm_set1_epi8('C'), vG = _mm_set1_epi8('G'), vT = _mm_set1_epi8('T'),
+                  vN = _mm_set1_epi8('N'), vNL = _mm_set1_epi8('\n');
+    while (p + 16 <= end) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p));
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, vA), _mm_cmpeq_epi8(v, vC)),
+                                                     _mm_or_si128(_mm_cmpeq_epi8(v, vG), _mm_cmpeq_epi8(v, vT))), _mm_cmpeq_epi8(v, vN));
+        const unsigned m_nl = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, vNL));
+        const unsigned m_bad = ~(unsigned)_mm_movemask_epi8(ok) & 0xFFFFu;
+        if (m_nl) {
+            const unsigned idx = (unsigned)__builtin_ctz(m_nl);
+            bad |= m_bad & ((1u << idx) - 1u);
+            valid = bad == 0;
+            return p + idx;
+        }
+        bad |= m_bad;
+        p += 16;
+    }
+#endif
+    for (; p < end && *p != '\n'; ++p) bad |= kValid.ok[(unsigned char)*p] ? 0u : 1u;
+    valid = bad == 0;
+    return p;
+}
+
 inline void push(ParsedChunk& out, const Slice& h, const char* s, uint64_t sn, bool from_joined, const std::string& tmp) {
     RecSlice r;
     r.h = h.p;
@@ -87,11 +118,26 @@ void to_readset(const ParsedChunk& c, ReadSet& out) {
 void parse_fasta_chunk(const char* data, uint64_t begin, uint64_t end, uint32_t k, ParsedChunk& out) {
     Cursor cur(data, begin, end);
     std::string joined;
+    out.recs.reserve(out.recs.size() + (size_t)((end - begin) / 96) + 16);
     while (!cur.eofbit) {  // alignerGreedy.cpp:372  while(!readFile.eof())
         Slice header, read, inter;  // one getReads() call: its locals start empty
         bool returned = false;
         for (unsigned i = 0; i < kBatch && !returned; ++i) {
             cur.getline(header);
+            // Fast path for the shape nearly every record has: the stream is good, the sequence line ends with a
+            // newline and the next line starts with '>'.  Exactly what the general machine below does for it
+            // (getline, peek == '>', the three tests, read = ""), with the newline search and the character test fused.
+            if (cur.good() && cur.pos < cur.n) {
+                bool ok;
+                const char* b = data + cur.pos;
+                const char* q = scan_line(b, data + cur.n, ok);
+                if (q + 1 < data + cur.n && q[1] == '>') {
+                    const uint64_t rn = (uint64_t)(q - b);
+                    if (rn > 2 && ok && rn > k) push(out, header, b, rn, false, joined);
+                    cur.pos = (uint64_t)(q - data) + 1;
+                    continue;
+                }
+            }
             cur.getline(read);
             bool multi = false;
             for (;;) {
@@ -169,10 +215,11 @@ void parse_fastq_parallel(const char* data, uint64_t size, unsigned threads, uin
                 const char* h = data + pos;
                 const char* hq = static_cast<const char*>(memchr(h, '\n', (size_t)(size - pos)));
                 const char* s = hq + 1;  // complete record: all four newlines exist
-                const char* sq = static_cast<const char*>(memchr(s, '\n', (size_t)(data + size - s)));
+                bool ok;
+                const char* sq = scan_line(s, data + size, ok);
                 Slice hs; hs.p = h; hs.n = (uint64_t)(hq - h);
                 const uint64_t sn = (uint64_t)(sq - s);
-                if (sn > 2 && valid_chars(s, sn)) push(out, hs, s, sn, false, none);
+                if (sn > 2 && ok) push(out, hs, s, sn, false, none);
                 pos = (uint64_t)(sq - data) + 1;
                 line += 2;
             } else {

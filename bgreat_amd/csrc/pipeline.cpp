@@ -502,13 +502,32 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         });
     }
 
-    // ---- stage 3: format + ordered write -----------------------------------------------------------------
+    // ---- stage 3: format (range-parallel) in batch order, stage 4: one thread writes the formatted buffers ----------
+    struct OutBufs { std::vector<std::string> pb, nb, ob; };
+    Channel<std::unique_ptr<OutBufs>> to_io(2), free_bufs(4);
+    for (int i = 0; i < 3; ++i) {
+        auto ob = std::make_unique<OutBufs>();
+        ob->pb.resize(threads); ob->nb.resize(threads); ob->ob.resize(threads);
+        free_bufs.push(std::move(ob));
+    }
+    std::thread io_thread([&]() {
+        std::unique_ptr<OutBufs> o;
+        while (to_io.pop(o)) {
+            const uint64_t tw0 = now_us();
+            for (unsigned t = 0; t < threads; ++t) {
+                if (!o->pb[t].empty() && fwrite(o->pb[t].data(), 1, o->pb[t].size(), pathF) != o->pb[t].size()) fail(BGR_E_IO, "write to the paths file failed");
+                if (!o->nb[t].empty() && fwrite(o->nb[t].data(), 1, o->nb[t].size(), notF) != o->nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
+                if (ovlF && !o->ob[t].empty() && fwrite(o->ob[t].data(), 1, o->ob[t].size(), ovlF) != o->ob[t].size()) fail(BGR_E_IO, "write to the no-overlap file failed");
+            }
+            us_write += now_us() - tw0;
+            free_bufs.push(std::move(o));
+        }
+    });
     std::thread writer([&]() {
         std::map<uint64_t, std::unique_ptr<Batch>> pending;
         uint64_t want = 0;
         bool stop_writing_after_this = false, wrote_last = false;
         std::unique_ptr<Batch> b;
-        std::vector<std::string> pb(threads), nb(threads), ob(threads);
         std::vector<char> okv(threads, 1);
         std::vector<std::string> bugv(threads);
         while (to_out.pop(b)) {
@@ -522,6 +541,9 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     ~Recycle() { b->recs.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
                 } recycle{free_batches, cur};
                 if ((failed && !stop_writing_after_this) || !writes || wrote_last) continue;
+                std::unique_ptr<OutBufs> o;
+                if (!free_bufs.pop(o)) continue;
+                std::vector<std::string>&pb = o->pb, &nb = o->nb, &ob = o->ob;
                 const uint64_t per = (cur->n + threads - 1) / threads;
                 Batch* cp = cur.get();
                 const uint64_t tf0 = now_us();
@@ -542,24 +564,21 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     for (auto& ok1 : okv) ok1 = 1;
                     stop_writing_after_this = true;
                 }
-                const uint64_t tf1 = now_us();
-                us_format += tf1 - tf0;
-                for (unsigned t = 0; t < threads; ++t) {
-                    if (!pb[t].empty() && fwrite(pb[t].data(), 1, pb[t].size(), pathF) != pb[t].size()) fail(BGR_E_IO, "write to the paths file failed");
-                    if (!nb[t].empty() && fwrite(nb[t].data(), 1, nb[t].size(), notF) != nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
-                    if (ovlF && !ob[t].empty() && fwrite(ob[t].data(), 1, ob[t].size(), ovlF) != ob[t].size()) fail(BGR_E_IO, "write to the no-overlap file failed");
-                }
+                us_format += now_us() - tf0;
+                to_io.push(std::move(o));  // the formatted records never point into the batch: it can be recycled now
                 if (stop_writing_after_this) wrote_last = true;
-                us_write += now_us() - tf1;
             }
         }
+        to_io.close();
     });
 
     producer.join();
     gatherer.join();
     for (auto& t : workers) t.join();
     writer.join();
+    io_thread.join();
     free_batches.close();
+    free_bufs.close();
     fclose(pathF);
     fclose(notF);
     if (ovlF) fclose(ovlF);

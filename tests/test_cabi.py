@@ -191,6 +191,52 @@ def test_parser_corner_cases_match_oracle(text, fastq):
         os.unlink(p)
 
 
+@pytest.mark.parametrize("fastq", [False, True])
+def test_parser_random_line_soup_matches_oracle(fastq, tmp_path):
+    """Random files built from lines of every kind (sequence lines of all lengths around the 16-byte SIMD step, headers,
+    '>' / '@' in odd places, blanks, CR, lower case, other letters, with and without a final newline): the product
+    parser (sequential and chunk-parallel, fast path and general machine) == the oracle's ifstream state machine."""
+    rng = np.random.default_rng(77 + fastq)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def seq(n):
+        return alpha[rng.integers(0, 4, n)].tobytes()
+
+    def line():
+        r = rng.integers(0, 20)
+        n = int(rng.choice([0, 1, 2, 3, 5, 6, 7, 15, 16, 17, 31, 32, 33, 47, 48, 49, 100]))
+        if r < 9:
+            return seq(n)
+        if r < 13:
+            return (b"@" if fastq else b">") + b"h%d" % rng.integers(0, 99)
+        if r == 13:
+            return b""
+        if r == 14:
+            return seq(n) + b"\r"
+        if r == 15:
+            x = bytearray(seq(n + 1)); x[int(rng.integers(0, n + 1))] = int(rng.choice(list(b"NNacgtRX> @+")))
+            return bytes(x)
+        if r == 16:
+            return b">" + seq(n)
+        if r == 17:
+            return b"+"
+        if r == 18:
+            return b"I" * n
+        return seq(n) + b"N"
+    for it in range(120):
+        nl = int(rng.integers(0, 40))
+        text = b"\n".join(line() for _ in range(nl))
+        if rng.integers(0, 2):
+            text += b"\n"
+        p = str(tmp_path / ("s%d.fx" % it))
+        open(p, "wb").write(text)
+        want = oracle_py.parse_file(p, 5, fastq)
+        for kw in ({}, {"threads": 3, "chunk_bytes": int(rng.choice([1, 9, 40, 200]))}):
+            got = B.load_reads(p, 5, fastq, **kw)
+            for x, y in zip(got, want):
+                assert np.array_equal(x, y), (it, kw, text)
+
+
 @pytest.mark.parametrize("name,k", [("edge_reads.fa", 31), ("syn_r150.fa", 31), ("deg_reads.fa", 5), ("toy_reads.fa", 4), ("long_r150.fa", 31)])
 @pytest.mark.parametrize("chunk", [1, 7, 64, 300, 4096])
 def test_chunk_parallel_parser_equals_sequential(name, k, chunk):
