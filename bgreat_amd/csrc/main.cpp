@@ -4,7 +4,7 @@
 //
 //   bgreat -r reads.fa[,more.fa] -k 31 -g unitigs.fa -m 2 -t 8 [-e effort] [-f paths] [-a notAligned.fa] [-q] [-b] [-i]
 //   extensions (opt-in, absent from the reference): --gpus N  (shard each batch over N devices, input order kept)
-//                                                   --batch N (reads per device batch, default 1M)
+//                                                   --batch N (reads per device batch, default 128k)
 //                                                   --write-exhaustive (-b normally writes nothing)
 //                                                   --chunk-bytes N (parser chunk size; tests use tiny chunks)
 //                                                   --no-overlap FILE (reads without any anchor go there instead of notAligned.fa)
@@ -30,7 +30,7 @@ static void die(const char* what) {
 int main(int argc, char** argv) {
     std::string reads, unitigs("unitig.fa"), pathFile("paths"), notAlignedFile("notAligned.fa"), noOverlapFile;
     int errors = 2, threads = 1, ka = 30, effort = 2, gpus = 1;  // bgreat.cpp:56-66 defaults (k is 30, not 31)
-    long batch = 1 << 20, chunk_bytes = 0;
+    long batch = 1 << 17, chunk_bytes = 0;
     bool brute = false, incomplete = false, fastq = false, correction = false, dog = false, write_exh = false;
     static option longopts[] = {{"gpus", required_argument, nullptr, 1000}, {"batch", required_argument, nullptr, 1001},
                                 {"write-exhaustive", no_argument, nullptr, 1002}, {"chunk-bytes", required_argument, nullptr, 1003},

@@ -10,6 +10,7 @@
 // so the bytes written are the reference's `-t 1` stream whatever the thread/GPU count.  Pure host C++: talks to
 // the GPU only through the C-ABI (bgr_aligner_create, bgr_align_batch, bgr_host_alloc ...).
 #include <fcntl.h>
+#include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -79,17 +80,71 @@ struct MappedFile {
     }
 };
 
-template <typename F>
-void parallel_for(unsigned threads, size_t n, F fn) {  // fn(task)
-    if (threads <= 1 || n <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> ts;
-    unsigned nt = (unsigned)std::min<size_t>(threads, n);
-    for (unsigned t = 0; t < nt; ++t) ts.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
-    for (auto& t : ts) t.join();
-}
+// Persistent workers shared by the parse, gather and format stages (a batch is a few hundred thousand reads: spawning
+// threads per stage and batch cost more than the work).  run(n, fn): fn(0..n-1) on the workers and the calling
+// thread, returns when all are done; concurrent run() calls from different stage threads interleave.
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned n) {
+        for (unsigned i = 0; i + 1 < n; ++i) ts_.emplace_back([this]() { loop(); });
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : ts_) t.join();
+    }
+    template <typename F>
+    void run(size_t n, F fn) {
+        if (n == 0) return;
+        if (n == 1 || ts_.empty()) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+        Job job;
+        job.n = n;
+        job.fn = [&fn](size_t i) { fn(i); };
+        const size_t helpers = std::min<size_t>(ts_.size(), n - 1);
+        job.pending = helpers;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            for (size_t i = 0; i < helpers; ++i) q_.push_back(&job);
+        }
+        cv_.notify_all();
+        work(job);
+        std::unique_lock<std::mutex> l(job.m);
+        job.cv.wait(l, [&] { return job.pending == 0; });
+    }
+private:
+    struct Job {
+        size_t n = 0;
+        std::atomic<size_t> next{0};
+        std::function<void(size_t)> fn;
+        std::mutex m;
+        std::condition_variable cv;
+        size_t pending = 0;
+    };
+    static void work(Job& j) { for (size_t i; (i = j.next.fetch_add(1)) < j.n;) j.fn(i); }
+    void loop() {
+        for (;;) {
+            Job* j = nullptr;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                j = q_.front();
+                q_.pop_front();
+            }
+            work(*j);
+            std::lock_guard<std::mutex> l(j->m);  // notify under the lock: the job lives on the caller's stack
+            if (--j->pending == 0) j->cv.notify_one();
+        }
+    }
+    std::vector<std::thread> ts_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Job*> q_;
+    bool stop_ = false;
+};
 
-struct HostBuf {  // grow-only host buffer; `pinned` = page-locked (H2D source), else plain malloc (pinning costs ~0.15 s per GB)
+struct HostBuf {  // grow-only host buffer; `pinned` = page-locked (20 GB/s to allocate on an idle process, several times slower
+                  // while parser threads are faulting the input file in: the pool is sized and allocated before they start)
     void* p = nullptr;
     uint64_t cap = 0;
     bool pinned;
@@ -111,13 +166,17 @@ struct HostBuf {  // grow-only host buffer; `pinned` = page-locked (H2D source),
     ~HostBuf() { release(); }
 };
 
+struct Pinned {  // the page-locked buffers of one batch in flight: sources / targets of the async copies
+    HostBuf reads{true}, offs{true}, paths{true}, poffs{true}, status{true};
+};
+
 struct Batch {
     uint64_t index = 0;
     std::shared_ptr<MappedFile> file;                     // keeps header/sequence slices valid
     std::vector<std::unique_ptr<ParsedChunk>> chunks;
     std::vector<std::pair<const ParsedChunk*, std::pair<uint32_t, uint32_t>>> spans;  // chunk, [first, last) records
     uint64_t n = 0, bases = 0, path_cap = 0;
-    HostBuf reads{true}, offs{true}, paths{false}, poffs{false}, status{false};
+    std::unique_ptr<Pinned> pin;                          // attached by the gatherer, handed back by the formatter
     std::vector<RecSlice> recs;                           // flattened view of the records of this batch
     int rc = BGR_OK;
     std::string err;
@@ -219,8 +278,8 @@ bool recover_path(const Unitigs& u, const int32_t* path, uint64_t n, uint32_t re
 // Records lo..hi of a batch as the reference writes them: mapped -> "header\n" + "int." * n + "\n" into pbuf
 // (alignerGreedy.cpp:406-411), the others -> "header\nread\n" into nbuf (alignerGreedy.cpp:421-427).
 void format_range(const Batch& b, uint64_t lo, uint64_t hi, std::string& pbuf, std::string& nbuf) {
-    const int32_t* paths = static_cast<const int32_t*>(b.paths.p);
-    const uint64_t* poffs = static_cast<const uint64_t*>(b.poffs.p);
+    const int32_t* paths = static_cast<const int32_t*>(b.pin->paths.p);
+    const uint64_t* poffs = static_cast<const uint64_t*>(b.pin->poffs.p);
     uint64_t pmax = 0, nmax = 0;  // exact upper bounds, so the loop below writes through raw pointers
     for (uint64_t i = lo; i < hi; ++i) {
         const RecSlice& r = b.recs[i];
@@ -256,9 +315,9 @@ void format_range(const Batch& b, uint64_t lo, uint64_t hi, std::string& pbuf, s
 // `bug` the two strings the reference prints.
 bool format_range_ext(const Batch& b, uint64_t lo, uint64_t hi, const Unitigs* correct, bool split_no_overlap, std::string& pbuf,
                       std::string& nbuf, std::string& obuf, std::string& bug) {
-    const int32_t* paths = static_cast<const int32_t*>(b.paths.p);
-    const uint64_t* poffs = static_cast<const uint64_t*>(b.poffs.p);
-    const uint8_t* status = static_cast<const uint8_t*>(b.status.p);
+    const int32_t* paths = static_cast<const int32_t*>(b.pin->paths.p);
+    const uint64_t* poffs = static_cast<const uint64_t*>(b.pin->poffs.p);
+    const uint8_t* status = static_cast<const uint8_t*>(b.pin->status.p);
     pbuf.clear(); nbuf.clear(); obuf.clear();
     std::string walk, tmp, rc;
     for (uint64_t i = lo; i < hi; ++i) {
@@ -302,8 +361,11 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     if (!graph || !prm || !opt || !reads_csv || !paths_file || !notaligned_file) return bgr::set_error(BGR_E_ARG, "bgr_align_all: null argument");
     const unsigned n_gpus = std::max<uint32_t>(1, opt->n_gpus);
     const unsigned threads = std::max<uint32_t>(1, opt->threads);
-    const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes : (8ull << 20);
-    const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (1ull << 20);
+    // Defaults: 128k reads per batch keeps the page-locked staging small (it costs ~0.2 s per GB to allocate) and the
+    // pipeline fine-grained; the parser chunk is a thread's share of a batch.
+    const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (1ull << 17);
+    const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes
+                                                  : std::min<uint64_t>(8ull << 20, std::max<uint64_t>(256ull << 10, batch_reads * 170 / threads));
     const bool writes = prm->mode != BGR_MODE_EXHAUSTIVE || opt->write_exhaustive;
     const bool correction = opt->correction && prm->mode != BGR_MODE_EXHAUSTIVE;  // alignPartExhaustive ignores -c
     Unitigs unitigs;
@@ -347,6 +409,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     }
 
     auto t_start = std::chrono::steady_clock::now();
+    WorkerPool pool(threads + 2);  // + 2: the stage threads mostly wait inside run()
     // A fixed pool of batch objects circulates producer -> GPU workers -> writer -> producer, so the pinned
     // buffers are allocated once and the number of batches in flight is bounded.
     const size_t max_batches = aligners.size() * 2 + 2;
@@ -369,6 +432,35 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         std::lock_guard<std::mutex> l(err_m);
         if (!failed.exchange(true)) { first_rc = rc; first_err = msg; }
     };
+    // The page-locked buffers cost ~0.2 s per GB to allocate, so they are few (one set per batch between gather and
+    // format), sized from the input up front, allocated by their own thread while the parsers already run, and reused.
+    const size_t n_pins = aligners.size() * 2 + 1;
+    Channel<std::unique_ptr<Pinned>> free_pins(n_pins + 1);
+    std::thread pin_allocator([&]() {
+        const uint64_t ta0 = now_us();
+        uint64_t total_in = 0, max_file = 0;
+        std::string list(reads_csv);
+        size_t last = 0;
+        for (size_t i = 0; i <= list.size(); ++i) {
+            if (i != list.size() && list[i] != ',') continue;
+            struct stat st;
+            if (stat(list.substr(last, i - last).c_str(), &st) == 0) { total_in += (uint64_t)st.st_size; max_file = std::max<uint64_t>(max_file, (uint64_t)st.st_size); }
+            last = i + 1;
+        }
+        const uint64_t group0 = std::max<uint64_t>(threads, (batch_reads * 170) / chunk_bytes);
+        const uint64_t est_bytes = std::min<uint64_t>(max_file, opt->fastq ? batch_reads * 160 : group0 * chunk_bytes);
+        const uint64_t est_n = std::min<uint64_t>(batch_reads + batch_reads / 4, est_bytes / 16 + 1);
+        const size_t need = est_bytes ? (size_t)std::min<uint64_t>(n_pins, (total_in + est_bytes - 1) / est_bytes + 1) : 1;
+        for (size_t i = 0; i < n_pins; ++i) {
+            auto pn = std::make_unique<Pinned>();
+            if (i < need) {  // best effort: the stages grow what turns out too small
+                (void)(pn->reads.ensure(est_bytes + 16) && pn->offs.ensure((est_n + 1) * 8) && pn->paths.ensure((8 * est_n + 4096) * 4) &&
+                       pn->poffs.ensure((est_n + 1) * 8) && pn->status.ensure(est_n + 1));
+            }
+            if (!free_pins.push(std::move(pn))) break;
+        }
+        us_alloc += now_us() - ta0;
+    });
 
     // ---- stage 1: parse + gather -----------------------------------------------------------------------
     std::thread producer([&]() {
@@ -424,7 +516,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 for (auto& ch : b->chunks) ch = std::make_unique<ParsedChunk>();
                 Batch* bp = b.get();
                 const uint64_t tp0 = now_us();
-                parallel_for(threads, c_end - c, [&](size_t j) {
+                pool.run(c_end - c, [&](size_t j) {
                     uint64_t e = (c + j + 1 < starts.size()) ? starts[c + j + 1] : mf->size;
                     bgr::parse_fasta_chunk(mf->data, starts[c + j], e, gi.k, *bp->chunks[j]);
                 });
@@ -445,21 +537,22 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     std::thread gatherer([&]() {
         auto gather = [&](std::unique_ptr<Batch> b) {
             uint64_t bases = 0;
+            if (!free_pins.pop(b->pin)) return false;
             const uint64_t tg0 = now_us();
-            if (!b->offs.ensure((b->n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            uint64_t* offs = static_cast<uint64_t*>(b->offs.p);
+            if (!b->pin->offs.ensure((b->n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            uint64_t* offs = static_cast<uint64_t*>(b->pin->offs.p);
             for (uint64_t i = 0; i < b->n; ++i) { offs[i] = bases; bases += b->recs[i].sl; }
             offs[b->n] = bases;
             b->bases = bases;
-            b->path_cap = 12 * b->n + 4096;  // typical paths are a handful of ints; the worker retries with the full bound if not
-            if (!b->reads.ensure(bases + 16) || !b->paths.ensure(b->path_cap * 4) || !b->poffs.ensure((b->n + 1) * 8) ||
-                !b->status.ensure(b->n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            char* dst = static_cast<char*>(b->reads.p);
+            b->path_cap = 8 * b->n + 4096;  // typical paths are a handful of ints; the worker retries with the full bound if not
+            if (!b->pin->reads.ensure(bases + 16) || !b->pin->paths.ensure(b->path_cap * 4) || !b->pin->poffs.ensure((b->n + 1) * 8) ||
+                !b->pin->status.ensure(b->n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            char* dst = static_cast<char*>(b->pin->reads.p);
             us_alloc += now_us() - tg0;
             const uint64_t tg1 = now_us();
             const uint64_t per = (b->n + threads - 1) / threads;
             Batch* bp = b.get();
-            parallel_for(threads, threads, [&](size_t t) {
+            pool.run(threads, [&](size_t t) {
                 uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
                 for (uint64_t i = lo; i < hi; ++i) memcpy(dst + offs[i], bp->recs[i].s, bp->recs[i].sl);
             });
@@ -484,14 +577,14 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             while (to_gpu.pop(b)) {
                 if (!failed) {
                     const uint64_t tq0 = now_us();
-                    int rc = bgr_align_batch(aligners[w], prm, static_cast<const char*>(b->reads.p), static_cast<const uint64_t*>(b->offs.p), b->n,
-                                             static_cast<int32_t*>(b->paths.p), b->path_cap, static_cast<uint64_t*>(b->poffs.p),
-                                             static_cast<uint8_t*>(b->status.p));
+                    int rc = bgr_align_batch(aligners[w], prm, static_cast<const char*>(b->pin->reads.p), static_cast<const uint64_t*>(b->pin->offs.p), b->n,
+                                             static_cast<int32_t*>(b->pin->paths.p), b->path_cap, static_cast<uint64_t*>(b->pin->poffs.p),
+                                             static_cast<uint8_t*>(b->pin->status.p));
                     if (rc == BGR_E_CAPACITY) {  // unusually long paths: fetch the same device results again into a full-size buffer
                         b->path_cap = b->bases + 8 * b->n + 8;
-                        if (!b->paths.ensure(b->path_cap * 4)) rc = BGR_E_HIP;
-                        else rc = bgr_aligner_fetch(aligners[w], b->n, static_cast<int32_t*>(b->paths.p), b->path_cap, static_cast<uint64_t*>(b->poffs.p),
-                                                    static_cast<uint8_t*>(b->status.p));
+                        if (!b->pin->paths.ensure(b->path_cap * 4)) rc = BGR_E_HIP;
+                        else rc = bgr_aligner_fetch(aligners[w], b->n, static_cast<int32_t*>(b->pin->paths.p), b->path_cap, static_cast<uint64_t*>(b->pin->poffs.p),
+                                                    static_cast<uint8_t*>(b->pin->status.p));
                     }
                     if (rc != BGR_OK) fail(rc, bgr_last_error());
                     us_gpu += now_us() - tq0;
@@ -514,11 +607,16 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         std::unique_ptr<OutBufs> o;
         while (to_io.pop(o)) {
             const uint64_t tw0 = now_us();
-            for (unsigned t = 0; t < threads; ++t) {
-                if (!o->pb[t].empty() && fwrite(o->pb[t].data(), 1, o->pb[t].size(), pathF) != o->pb[t].size()) fail(BGR_E_IO, "write to the paths file failed");
-                if (!o->nb[t].empty() && fwrite(o->nb[t].data(), 1, o->nb[t].size(), notF) != o->nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
-                if (ovlF && !o->ob[t].empty() && fwrite(o->ob[t].data(), 1, o->ob[t].size(), ovlF) != o->ob[t].size()) fail(BGR_E_IO, "write to the no-overlap file failed");
-            }
+            pool.run(2, [&](size_t w) {  // the files are independent streams: one writer each
+                for (unsigned t = 0; t < threads; ++t) {
+                    if (w == 0) {
+                        if (!o->pb[t].empty() && fwrite(o->pb[t].data(), 1, o->pb[t].size(), pathF) != o->pb[t].size()) fail(BGR_E_IO, "write to the paths file failed");
+                    } else {
+                        if (!o->nb[t].empty() && fwrite(o->nb[t].data(), 1, o->nb[t].size(), notF) != o->nb[t].size()) fail(BGR_E_IO, "write to the notAligned file failed");
+                        if (ovlF && !o->ob[t].empty() && fwrite(o->ob[t].data(), 1, o->ob[t].size(), ovlF) != o->ob[t].size()) fail(BGR_E_IO, "write to the no-overlap file failed");
+                    }
+                }
+            });
             us_write += now_us() - tw0;
             free_bufs.push(std::move(o));
         }
@@ -537,9 +635,9 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 pending.erase(pending.begin());
                 ++want;
                 struct Recycle {  // hand the batch (and its pinned buffers) back to the producer
-                    Channel<std::unique_ptr<Batch>>& ch; std::unique_ptr<Batch>& b;
-                    ~Recycle() { b->recs.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
-                } recycle{free_batches, cur};
+                    Channel<std::unique_ptr<Batch>>& ch; Channel<std::unique_ptr<Pinned>>& pins; std::unique_ptr<Batch>& b;
+                    ~Recycle() { if (b->pin) pins.push(std::move(b->pin)); b->recs.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
+                } recycle{free_batches, free_pins, cur};
                 if ((failed && !stop_writing_after_this) || !writes || wrote_last) continue;
                 std::unique_ptr<OutBufs> o;
                 if (!free_bufs.pop(o)) continue;
@@ -547,7 +645,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 const uint64_t per = (cur->n + threads - 1) / threads;
                 Batch* cp = cur.get();
                 const uint64_t tf0 = now_us();
-                parallel_for(threads, threads, [&](size_t t) {
+                pool.run(threads, [&](size_t t) {
                     pb[t].clear(); nb[t].clear(); ob[t].clear();
                     uint64_t lo = t * per, hi = std::min<uint64_t>(cp->n, lo + per);
                     if (lo >= hi) return;
@@ -577,6 +675,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     for (auto& t : workers) t.join();
     writer.join();
     io_thread.join();
+    free_pins.close();
+    pin_allocator.join();
     free_batches.close();
     free_bufs.close();
     fclose(pathF);

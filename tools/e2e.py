@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--chunk-bytes", type=int, default=0)
     ap.add_argument("--check", type=int, default=500_000, help="reads also mapped by the reference binary (-t 1) and compared byte for byte")
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--site-spacing", type=int, default=140)
@@ -46,6 +47,8 @@ def main():
         base = ["-r", os.path.join(d, "r." + ext), "-k", "31", "-g", os.path.join(d, "u.fa"), "-m", "2", "-t", str(args.threads), "--gpus", str(args.gpus)]
         if args.batch:
             base += ["--batch", str(args.batch)]
+        if args.chunk_bytes:
+            base += ["--chunk-bytes", str(args.chunk_bytes)]
         if args.fastq:
             base.append("-q")
         env = dict(os.environ, BGREAT_TIMING="1")
