@@ -345,16 +345,19 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
                 for (uint32_t b : bs) {
                     uint32_t w = std::min<uint32_t>(16, cap / b);
                     while (w > 0 && !fits(b, w, true)) --w;
+                    if (w > 4) w -= w % 4;  // whole waves per SIMD: 5-, 7-wave workgroups measured up to 40 % slower
                     if (w && b * w > best_res) { best_res = b * w; waves = w; bpc = b; stage = true; }
                 }
             }
             // without staging: as many small workgroups as the registers admit; when the per-wave LDS region is large
             // (long reads, exhaustive frame stacks) fewer, larger workgroups keep more waves resident
             uint32_t wn = 0, bn = 0, res_n = 0;
-            const uint32_t bs2[] = {6, 4, 3, 2, 1};
+            // (4-wave workgroups first: a workgroup whose wave count is not a multiple of the 4 SIMDs measured far slower)
+            const uint32_t bs2[] = {6, 5, 4, 3, 2, 1};
             for (uint32_t b : bs2) {
-                uint32_t w = std::min<uint32_t>(b == 6 ? 4 : 16, std::max<uint32_t>(1, cap / b));
+                uint32_t w = std::min<uint32_t>(b >= 5 ? 4 : 16, std::max<uint32_t>(1, cap / b));
                 while (w > 0 && !fits(b, w, false)) --w;
+                if (w > 4) w -= w % 4;
                 if (w && b * w > res_n) { res_n = b * w; wn = w; bn = b; }
             }
             if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
