@@ -27,7 +27,6 @@ int fail(int code, const std::string& msg) { tl_err = msg; return code; }
         if (e_ != hipSuccess) return fail(BGR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-const double kDefaultGamma = 1.5;  // E. coli-scale cascade = 64 KB: two staged workgroups per CU fit the 160 KB LDS
 const uint32_t kLdsFixed = 512;  // level descriptors at the start of the dynamic LDS
 const int kTimerRing = 256;
 
@@ -116,7 +115,7 @@ int bgr_graph_build_ex(uint32_t k, uint64_t n_unitigs, const char* seqs, const u
     bgr_graph* g = new bgr_graph();
     std::string err;
     uint64_t zero[1] = {0};
-    if (!bgr::build_graph(k, n_unitigs, seqs, n_unitigs ? offsets : zero, gamma > 0 ? gamma : kDefaultGamma, flags, g->host, err)) {
+    if (!bgr::build_graph(k, n_unitigs, seqs, n_unitigs ? offsets : zero, gamma > 0 ? gamma : 0.0, flags, g->host, err)) {
         delete g;
         return fail(BGR_E_ARG, err);
     }

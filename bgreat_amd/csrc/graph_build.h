@@ -37,7 +37,7 @@ struct HostGraph {
 };
 
 // seqs/offs: n unitig sequences in file order (offs[n+1]).  Loading stops at the first sequence shorter
-// than k, as aligner.cpp:418-420 does.  gamma: MPHF bits per remaining key on each cascade level.
+// than k, as aligner.cpp:418-420 does.  gamma: MPHF positions per remaining key on each cascade level (0 = choose: 1.5 when the cascade fits LDS staging, else 2).
 // Returns false (and sets err) on invalid arguments / limits.
 // flags: BGR_BUILD_ANCHORS adds the anchors index of -G mode (graph_layout.h).
 #define BGR_BUILD_ANCHORS 1u
