@@ -97,19 +97,29 @@ __device__ __forceinline__ u64 rcb_fast(u64 x, uint32_t n) { return (~rev2_fast(
 // until no lane is still on a "several keys here" position -- about 2-3 levels at gamma 2, because a lane
 // that lands on an empty position (most read positions are not overlaps) is rejected at once.
 // LV = level descriptors {units, base} staged in LDS.
-template <typename UP>
+// SPEC (cascade in L2/HBM, not staged in LDS): the unit of level l+1 is requested together with level l's -- its
+// address needs only the hash (double hashing), not level l's answer -- so two dependent-looking loads are in flight
+// at once; lanes that stop on level l simply drop it.
+template <bool SPEC, typename UP>
 __device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
     u64 m = bgr_mix64(key);
     uint32_t hl = (uint32_t)m;
     const uint32_t hb = (uint32_t)(m >> 32) | 1u;
     uint32_t res = BGR_NONE;
     const uint32_t nl = g.n_levels;
+    uint4 qn = make_uint4(0, 0, 0, 0);
+    if (SPEC && active && nl) { const uint2 lv = LV[0]; qn = reinterpret_cast<const uint4*>(units)[lv.y + __umulhi(hl, lv.x)]; }
     for (uint32_t l = 0; l < nl; ++l) {
         if (!__any(active)) break;
-        const uint2 lv = LV[l];
-        const uint32_t u = lv.y + __umulhi(hl, lv.x);
+        uint4 q;
+        if (SPEC) {
+            q = qn;
+            if (active && l + 1 < nl) { const uint2 lv1 = LV[l + 1]; qn = reinterpret_cast<const uint4*>(units)[lv1.y + __umulhi(hl + hb, lv1.x)]; }
+        } else {
+            const uint2 lv = LV[l];
+            q = reinterpret_cast<const uint4*>(units)[lv.y + __umulhi(hl, lv.x)];
+        }
         const uint32_t p = bgr_level_pos(hl);
-        const uint4 q = reinterpret_cast<const uint4*>(units)[u];
         const uint32_t wi = p >> 4, sh = (p & 15) * 2;
         const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
         const uint32_t st = (w >> sh) & 3u;
@@ -135,9 +145,9 @@ __device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const u
     return res;
 }
 // membership: MPHF index of key if key is an overlap of the graph, else BGR_NONE (aligner.cpp:158,219,353,361)
-template <typename UP>
+template <bool SPEC, typename UP>
 __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
-    uint32_t idx = mphf_lookup(g, LV, units, key, active);
+    uint32_t idx = mphf_lookup<SPEC>(g, LV, units, key, active);
     if (idx != BGR_NONE && g.keys[idx] != key) idx = BGR_NONE;
     return idx;
 }
@@ -654,7 +664,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                     rcn = plain ? rcb_fast(num, K1) : lds_win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
-                const uint32_t idx = find_key(g, LV, units, rep, valid);
+                const uint32_t idx = find_key<!STAGE>(g, LV, units, rep, valid);
                 u64 mask = __ballot(idx != BGR_NONE);
                 if (prm.debug_stop == 2) { if (mask) { ++tried; done = true; p_n = 0; } mask = 0; }
                 while (mask && tried < effort) {
@@ -669,7 +679,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                     // getBegin/getEnd recompute rc = rcb(num) (aligner.cpp:149,211); it differs from the
                     // rolling rcnum only when an N was rolled into the window.
                     const u64 rc2 = rcb_fast(a_num, K1);
-                    if (rc2 != a_rcn) a_rec = find_key(g, LV, units, a_num < rc2 ? a_num : rc2, true);
+                    if (rc2 != a_rcn) a_rec = find_key<false>(g, LV, units, a_num < rc2 ? a_num : rc2, true);
                     if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, a_pos, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
                         done = true;
                         break;
@@ -976,7 +986,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
             u64 num = 0;
             if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
-            const uint32_t idx = find_key(g, LV, units, num < rc ? num : rc, valid);
+            const uint32_t idx = find_key<!STAGE>(g, LV, units, num < rc ? num : rc, valid);
             u64 mask = __ballot(idx != BGR_NONE);
             if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
             while (mask) {
