@@ -135,6 +135,9 @@ inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m) {  // al
     s[j].len = m.len;
     s[j].Fw = (uint32_t)(m.F >> 5);
     s[j].Fo = (uint32_t)(m.F & 31);
+    s[j].mflags = m.flags;
+    s[j].rec_beg = m.rec_beg;
+    s[j].rec_end = m.rec_end;
 }
 
 }  // namespace
@@ -185,7 +188,7 @@ bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {
     if (h->magic != BGR_MAGIC || h->version != BGR_BLOB_VERSION) { err = "not a bgreat graph blob (magic/version)"; return false; }
     if (h->blob_bytes != bytes) { err = "blob size does not match its header"; return false; }
     if (h->n_levels > BGR_MAX_LEVELS || h->k < 2 || h->k > 32) { err = "corrupt blob header"; return false; }
-    uint64_t ends[] = {h->off_units + h->n_units * 16, h->off_keys + h->n_keys * 8, h->off_recs + h->n_keys * 128,
+    uint64_t ends[] = {h->off_units + h->n_units * 16, h->off_keys + h->n_keys * 8, h->off_recs + h->n_keys * sizeof(BgrSlot) * 8,
                        h->off_meta + (h->n_unitigs + 1) * sizeof(BgrUnitigMeta), h->off_seq + h->seq_words * 8,
                        h->off_fallback + h->n_fallback * 8};
     for (uint64_t e : ends) if (e > bytes) { err = "blob section outside the blob"; return false; }
@@ -340,7 +343,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     std::vector<uint64_t> keys(left.size() + right.size());
     std::merge(left.begin(), left.end(), right.begin(), right.end(), keys.begin());
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-    if (keys.size() >= 0x3FFFFFFFull) { err = "too many overlap keys (limit 2^30-1)"; return false; }
+    if (keys.size() >= 0x0FFFFFFFull) { err = "too many overlap keys (limit 2^28-1)"; return false; }
     tm.lap("keys");
 
     // gamma 0 = choose: a cascade that can be staged in LDS twice per CU (<= ~66 KB, about one byte per key at 1.5)
@@ -403,7 +406,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     static_assert(sizeof(BgrBlobHeader) <= 4096, "header must fit its 4 KiB slot");
     h.off_units = off;    off = align256(off + h.n_units * 16 + 16);
     h.off_keys = off;     off = align256(off + h.n_keys * 8 + 8);
-    h.off_recs = off;     off = align256(off + h.n_keys * 128 + 128);
+    h.off_recs = off;     off = align256(off + h.n_keys * sizeof(BgrSlot) * 8 + 256);
     h.off_meta = off;     off = align256(off + (n + 1) * sizeof(BgrUnitigMeta));
     h.off_seq = off;      off = align256(off + seq_words * 8);
     if (has_exc) {

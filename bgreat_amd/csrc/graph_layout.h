@@ -23,12 +23,13 @@
 //          gives the minimal index, state 3 continues.  A level is an array of 16-byte units
 //          {48 states, u32 rank = placed keys in all earlier units}: ONE dwordx4 load per level.
 //   keys   u64 key per MPHF index (membership check, aligner.cpp:158,219,353,361).
-//   recs   128 B (one cache line) per MPHF index: the 4 "left table" slots and the 4 "right table" slots of
-//          that key (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite,
-//          aligner.cpp:466-533).  A slot is 16 B {id | orientation bits, len, F}: everything a walk step
-//          needs to start streaming the candidate's bases (F as seq word + base-in-word), so a step is TWO dependent loads (slot, then
-//          bases + meta side by side) instead of three.  Bits 30/31 of the id word carry the orientation the
-//          reference recomputes by string compare at query time (aligner.cpp:174,235).
+//   recs   256 B per MPHF index: the 4 "left table" slots (one 128-byte line) and the 4 "right table" slots (the
+//          next line) of that key (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite,
+//          aligner.cpp:466-533).  A slot is 32 B: {id | orientation bits, len, F as seq word + base-in-word} --
+//          everything a walk step needs to start streaming the candidate's bases -- plus the unitig's own end
+//          records and canonical flags, i.e. where the walk goes NEXT.  So a step is slot -> bases (two dependent
+//          loads, no per-unitig meta fetch beside the bases).  Bits 30/31 of the id word carry
+//          the orientation the reference recomputes by string compare at query time (aligner.cpp:174,235).
 #ifndef BGREAT_AMD_GRAPH_LAYOUT_H
 #define BGREAT_AMD_GRAPH_LAYOUT_H
 
@@ -41,7 +42,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 5u  /* 5: optional anchors index (-G) sections; 4: 2-bit-state cascade, 16-byte slots */
+#define BGR_BLOB_VERSION 6u  /* 6: 32-byte slots carrying the unitig's end records; 5: optional anchors index (-G) sections */
 #define BGR_MAX_LEVELS 48
 #define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
 #define BGR_NONE 0xFFFFFFFFu
@@ -74,7 +75,11 @@ typedef struct {
     uint32_t len;
     uint32_t Fw;      // forward strand starts at base Fo of seq word Fw  (F = 32*Fw + Fo): 32-bit address arithmetic
     uint32_t Fo;      //   in the kernels (seq must stay below 4 GiB = 2^34 bases, checked at build time)
-} BgrSlot;            // 16 B; a neighbour record is BgrSlot[8]: left-table slots 0..3, right-table slots 4..7
+    uint32_t mflags;  // BGR_META_* of this unitig
+    uint32_t rec_beg; // == meta[id].rec_beg / rec_end: the neighbour records at the unitig's two ends
+    uint32_t rec_end;
+    uint32_t pad;
+} BgrSlot;            // 32 B; a neighbour record is BgrSlot[8]: left-table slots 0..3, right-table slots 4..7
 
 typedef struct {
     uint32_t units;  // number of 48-position units on this level
