@@ -233,7 +233,9 @@ def _inject_n(reads, rng, frac):
 @pytest.mark.parametrize("seed,k,L,m,e,nfrac,d,alleles", [
     (1, 31, 150, 2, 2, 0.0, 75, 2), (2, 31, 100, 2, 2, 0.0, 75, 2), (3, 31, 250, 5, 4, 0.0, 60, 3), (4, 21, 120, 3, 3, 0.002, 50, 2),
     (5, 32, 150, 2, 1, 0.0, 140, 2), (6, 31, 150, 0, 2, 0.001, 75, 2), (7, 31, 150, 2, 2, 0.01, 400, 2), (8, 15, 80, 4, 8, 0.005, 40, 4),
-    (9, 31, 33, 2, 2, 0.0, 75, 2), (10, 31, 1000, 8, 2, 0.0005, 75, 2), (11, 8, 60, 3, 1000, 0.0, 20, 4)])
+    (9, 31, 33, 2, 2, 0.0, 75, 2), (10, 31, 1000, 8, 2, 0.0005, 75, 2), (11, 8, 60, 3, 1000, 0.0, 20, 4),
+    (12, 31, 150, 2, 0, 0.002, 75, 2), (13, 5, 40, 2, 2, 0.01, 12, 3), (14, 4, 30, 1, 3, 0.0, 9, 2), (15, 31, 150, 200, 2, 0.001, 75, 2),
+    (16, 3, 20, 1, 2, 0.0, 8, 2)])
 def test_gpu_matches_oracle_random(seed, k, L, m, e, nfrac, d, alleles):
     s = Synth(120000, d, alleles, k, 7000 + seed)
     seqs, offs = s.unitigs()
