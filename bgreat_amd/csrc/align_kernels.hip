@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
     u64* NM = RCW + W;
     int32_t* PATH = reinterpret_cast<int32_t*>(NM + W);
 
-    uint32_t c_reads = 0, c_noov = 0, c_al = 0, c_na = 0;
+    uint32_t c_lane = 0;                    // per-lane status counter (a VGPR: the kernel is short of SGPRs, not of VGPRs)
     uint32_t chunk_pos = 0, chunk_end = 0;  // this wave's slice of the path arena
     // getNOverlap(read, 0) still looks at position 0 before testing the count (aligner.cpp:349-368)
     const uint32_t effort = prm.effort ? prm.effort : 1;
@@ -645,7 +645,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
         uint32_t status = BGR_ST_NOANCHOR, p_lo = 0, p_n = 0;
         uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         if (!prm.effort && npos > 1) npos = 1;
+#ifdef BGR_PHASE_TIMING  /* diagnostic builds: env BGR_DEBUG_STOP = 1 stops after packing, 2 after the position scan */
         if (prm.debug_stop == 1) npos = 0;
+#endif
         for (int pass = 0; pass < 2; ++pass) {
             if ((pass == 1 || hasN) && !derived) { derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane); derived = true; }
             // A read without N: FWQ == FW3 and the rolling reverse k-mer == rcb(forward k-mer), so pass 0 needs FW3 only.
@@ -667,7 +669,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                 const u64 rep = num < rcn ? num : rcn;
                 const uint32_t idx = find_key<!STAGE>(g, LV, units, rep, valid);
                 u64 mask = __ballot(idx != BGR_NONE);
+#ifdef BGR_PHASE_TIMING
                 if (prm.debug_stop == 2) { if (mask) { ++tried; done = true; p_n = 0; } mask = 0; }
+#endif
                 while (mask && tried < effort) {
                     const int src = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -697,18 +701,16 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
         if ((status & BGR_ST_MASK) == BGR_ST_ALIGNED) abase = publish_path(io, PATH, p_lo, p_n, &chunk_pos, &chunk_end, lane);
         else p_n = 0;
         if (lane == 0) io.results[r] = make_uint2(abase, p_n | (status << 24));
-        ++c_reads;
-        c_noov += (status & BGR_ST_MASK) == BGR_ST_NOANCHOR;
-        c_al += (status & BGR_ST_MASK) == BGR_ST_ALIGNED;
-        c_na += (status & BGR_ST_MASK) == BGR_ST_FAILED;
+        c_lane += (uint32_t)lane == (status & BGR_ST_MASK);  // lane s counts the reads that ended with status s
         wave_sync();
     }
-    if (lane == 0 && c_reads) {
+    {   // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        atomicAdd(&counters[0], (unsigned long long)c_reads);
-        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
-        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
-        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        const uint32_t total = rl32(c_lane, BGR_ST_NOANCHOR) + rl32(c_lane, BGR_ST_FAILED) + rl32(c_lane, BGR_ST_ALIGNED);
+        if (lane == 0 && total) atomicAdd(&counters[0], (unsigned long long)total);
+        if (lane == BGR_ST_NOANCHOR && c_lane) atomicAdd(&counters[1], (unsigned long long)c_lane);
+        if (lane == BGR_ST_ALIGNED && c_lane) atomicAdd(&counters[2], (unsigned long long)c_lane);
+        if (lane == BGR_ST_FAILED && c_lane) atomicAdd(&counters[3], (unsigned long long)c_lane);
     }
 }
 
