@@ -725,7 +725,8 @@ struct AncView {
     const u64* fin;
     const u64* pos;
     u64 n_final, last_rank;
-    u64 lv_domain, lv_word_base, lv_rank_base;  // lane l < 24 holds level l
+    u64 lv_domain, lv_word_base, lv_rank_base, lv_magic;  // lane l < n_active holds level l
+    uint32_t n_active;                                    // levels that hold set bits (the rest cannot answer)
 };
 
 __device__ __forceinline__ AncView anc_view(const BgrDeviceGraph& g, int lane) {
@@ -738,10 +739,12 @@ __device__ __forceinline__ AncView anc_view(const BgrDeviceGraph& g, int lane) {
     a.pos = reinterpret_cast<const u64*>(base + h->off_anc_pos);
     a.n_final = h->anc_n_final;
     a.last_rank = h->anc_last_rank;
-    const int l = lane < BGR_ANC_LEVELS - 1 ? lane : 0;
+    a.n_active = (uint32_t)h->anc_active_levels;
+    const int l = lane < (int)a.n_active ? lane : 0;
     a.lv_domain = h->anc_levels[l].domain;
     a.lv_word_base = h->anc_levels[l].word_base;
     a.lv_rank_base = h->anc_levels[l].rank_base;
+    a.lv_magic = h->anc_levels[l].magic;
     return a;
 }
 
@@ -749,14 +752,14 @@ __device__ __forceinline__ AncView anc_view(const BgrDeviceGraph& g, int lane) {
 __device__ __forceinline__ u64 anc_lookup(const AncView& a, u64 key, int lane) {
     u64 s0 = bgr_boo_hash64(key, BGR_BOO_SEED0), s1 = bgr_boo_hash64(key, BGR_BOO_SEED1);
     u64 hv = lane == 0 ? s0 : s1;
-    for (int i = 2; i < BGR_ANC_LEVELS - 1; ++i) {  // BooPHF.h:336-356: the level hashes are a sequence, walked in step
+    for (int i = 2; i < (int)a.n_active; ++i) {  // BooPHF.h:336-356: the level hashes are a sequence, walked in step
         const u64 v = bgr_boo_next(&s0, &s1);
         if (lane == i) hv = v;
     }
     bool hit = false;
     u64 pos = 0;
-    if (lane < BGR_ANC_LEVELS - 1) {
-        pos = hv % a.lv_domain;
+    if (lane < (int)a.n_active) {
+        pos = bgr_mod_magic(hv, a.lv_domain, a.lv_magic);
         hit = (a.bits[a.lv_word_base + (pos >> 6)] >> (pos & 63)) & 1;
     }
     const u64 mask = __ballot(hit);

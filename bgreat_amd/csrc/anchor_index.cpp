@@ -36,6 +36,7 @@ void build_anchor_mphf(const std::vector<uint64_t>& keys, unsigned T, AnchorMphf
         uint64_t d = (((uint64_t)((double)hash_domain * std::pow(p, (double)i)) + 63) / 64) * 64;
         if (d == 0) d = 64;
         out.levels[i].domain = d;
+        out.levels[i].magic = ~0ULL / d + ((d & (d - 1)) == 0 ? 1 : 0);  // floor(2^64 / d); (2^64-1)/d falls one short only when d | 2^64
         out.levels[i].word_base = words;
         out.levels[i].rank_base = rwords;
         const uint64_t nw = 1 + d / 64;  // BooPHF.h:425-429 bitVector(n): 1 + n/64 words
@@ -88,10 +89,12 @@ void build_anchor_mphf(const std::vector<uint64_t>& keys, unsigned T, AnchorMphf
         rem.swap(next);
         // BooPHF.h:594-607 build_ranks
         uint64_t* R = out.ranks.data() + out.levels[i].rank_base;
+        const uint64_t before = offset;
         for (uint64_t w = 0; w < nw; ++w) {
             if ((w & 7) == 0) R[w >> 3] = offset;
             offset += (uint64_t)__builtin_popcountll(B[w]);
         }
+        if (offset != before) out.active_levels = (uint32_t)i + 1;
     }
     {   // level 24 holds no bits (BooPHF.h:891-899: its keys go to the exact map) but is still ranked
         const int i = BGR_ANC_LEVELS - 1;
@@ -115,13 +118,14 @@ uint64_t anchor_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key
     if (h->anc_n == 0) return ~0ULL;
     const uint64_t* bits = reinterpret_cast<const uint64_t*>(base + h->off_anc_bits);
     uint64_t s0 = 0, s1 = 0;
-    for (int i = 0; i < BGR_ANC_LEVELS - 1; ++i) {  // BooPHF.h:1058-1087 getLevel
+    const int active = (int)h->anc_active_levels;  // the levels above hold no set bit: probing them cannot answer
+    for (int i = 0; i < active; ++i) {  // BooPHF.h:1058-1087 getLevel
         uint64_t hh;
         if (i == 0) hh = s0 = bgr_boo_hash64(key, BGR_BOO_SEED0);
         else if (i == 1) hh = s1 = bgr_boo_hash64(key, BGR_BOO_SEED1);
         else hh = bgr_boo_next(&s0, &s1);
         const BgrAncLevel& lv = h->anc_levels[i];
-        const uint64_t pos = hh % lv.domain;
+        const uint64_t pos = bgr_mod_magic(hh, lv.domain, lv.magic);
         const uint64_t* B = bits + lv.word_base;
         if ((B[pos >> 6] >> (pos & 63)) & 1) {  // BooPHF.h:609-622 rank
             const uint64_t* R = reinterpret_cast<const uint64_t*>(base + h->off_anc_ranks) + lv.rank_base;

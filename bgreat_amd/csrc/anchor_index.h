@@ -13,6 +13,7 @@ namespace bgr {
 
 struct AnchorMphf {
     uint64_t n = 0, last_rank = 0;
+    uint32_t active_levels = 0;  // levels 0 .. active_levels-1 hold set bits
     BgrAncLevel levels[BGR_ANC_LEVELS];
     std::vector<uint64_t> bits, ranks;
     std::vector<uint64_t> final_kv;  // {key, index} pairs sorted by key (index excludes last_rank)

@@ -200,6 +200,7 @@ bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {
             const BgrAncLevel& lv = h->anc_levels[i];
             if (lv.domain == 0 || lv.word_base + 1 + lv.domain / 64 > h->anc_words) { err = "corrupt anchors index"; return false; }
         }
+        if (h->anc_active_levels >= BGR_ANC_LEVELS) { err = "corrupt anchors index"; return false; }
     }
     return true;
 }
@@ -420,6 +421,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         h.anc_n_final = anc.final_kv.size() / 2;
         h.anc_words = anc.bits.size();
         h.anc_rank_words = anc.ranks.size();
+        h.anc_active_levels = anc.active_levels;
         memcpy(h.anc_levels, anc.levels, sizeof(h.anc_levels));
         h.off_anc_bits = off;  off = align256(off + h.anc_words * 8 + 8);
         h.off_anc_ranks = off; off = align256(off + h.anc_rank_words * 8 + 8);

@@ -42,7 +42,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 6u  /* 6: 32-byte slots carrying the unitig's end records; 5: optional anchors index (-G) sections */
+#define BGR_BLOB_VERSION 7u  /* 7: anchors levels with division magic; 6: 32-byte slots carrying the unitig's end records */
 #define BGR_MAX_LEVELS 48
 #define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
 #define BGR_NONE 0xFFFFFFFFu
@@ -100,6 +100,7 @@ typedef struct {
     uint64_t domain;     // hash domain of the level (multiple of 64)
     uint64_t word_base;  // first u64 of the level in anc_bits
     uint64_t rank_base;  // first u64 of the level in anc_ranks
+    uint64_t magic;      // floor(2^64 / domain): h % domain by one 64x64 high multiply and at most two subtractions
 } BgrAncLevel;
 
 // Blob header (first 4096 bytes of the blob).  All section offsets are bytes from the blob start and
@@ -126,6 +127,7 @@ typedef struct {
     uint64_t anc_last_rank;  // set bits over all levels; indices of anc_final entries start here
     uint64_t anc_n_final;
     uint64_t anc_words, anc_rank_words;
+    uint64_t anc_active_levels;  // levels 0 .. anc_active_levels-1 hold set bits; the rest are all zero and cannot answer
     uint64_t off_anc_bits, off_anc_ranks, off_anc_final, off_anc_pos;
     BgrAncLevel anc_levels[BGR_ANC_LEVELS];
 } BgrBlobHeader;
@@ -184,6 +186,19 @@ BGR_HD uint64_t bgr_boo_next(uint64_t* s0, uint64_t* s1) {
     a ^= a << 23;
     *s1 = a ^ b ^ (a >> 17) ^ (b >> 26);
     return *s1 + b;
+}
+
+// h % d for d >= 2 with magic = floor(2^64 / d): q = mulhi(h, magic) underestimates floor(h / d) by at most 2
+BGR_HD uint64_t bgr_mod_magic(uint64_t h, uint64_t d, uint64_t magic) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t q = __umul64hi(h, magic);
+#else
+    const uint64_t q = (uint64_t)(((unsigned __int128)h * magic) >> 64);
+#endif
+    uint64_t r = h - q * d;
+    if (r >= d) r -= d;
+    if (r >= d) r -= d;
+    return r;
 }
 
 // reverse complement of a (k-1)-digit base-4 number == utils.cpp:182-192 rcb(), by bit tricks
