@@ -999,7 +999,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const uint32_t a_rec = rl32(idx, src), a_pos = base + (uint32_t)src;
-                const u64 a_num = rl64(num, src);
+                const u64 a_num = rl64(lds_win32(ROLL, a_pos) >> (64 - 2 * K1), 0);  // re-read (uniform) instead of keeping `num` live across the search
                 const bool a_canon = a_num <= rcb_fast(a_num, K1);
                 uint32_t nl = 0, nr = 0;
                 const uint32_t eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane);
