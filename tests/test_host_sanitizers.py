@@ -1,0 +1,26 @@
+"""Sanitizer runs of the host-side code (GPU AddressSanitizer is not available on the pool: CPU build only).
+The reader (fastx.cpp) and the index builder (graph_build.cpp, anchor_index.cpp) are compiled with the harness
+tests/sanitize_host.cpp under ASan+UBSan and under TSan and driven over the golden inputs."""
+import os
+import subprocess
+
+import pytest
+
+from util import GOLD, ROOT
+
+SRC = os.path.join(ROOT, "bgreat_amd", "csrc")
+
+
+@pytest.mark.parametrize("flags", ["-fsanitize=address,undefined", "-fsanitize=thread"])
+def test_host_parser_and_index_builder_are_sanitizer_clean(flags, tmp_path):
+    exe = str(tmp_path / "sanitize_host")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", flags, "-I" + SRC, "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "sanitize_host.cpp")] + [os.path.join(SRC, f) for f in ("fastx.cpp", "graph_build.cpp", "anchor_index.cpp")] + \
+          ["-o", exe, "-lpthread"]
+    subprocess.check_call(cmd)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               TSAN_OPTIONS="halt_on_error=1")
+    p = subprocess.run([exe, GOLD], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "MISMATCH" not in p.stdout and "long_r150.fq: 121 records" in p.stdout
+    assert "ERROR: " not in p.stderr and "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
