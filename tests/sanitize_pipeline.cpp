@@ -1,0 +1,107 @@
+// Harness of tests/test_host_sanitizers.py for the host pipeline (bgreat_amd/csrc/pipeline.cpp: producer, gatherer,
+// stream workers, formatter, writers, worker pool, page-locked ring) under ThreadSanitizer / AddressSanitizer.
+// The GPU side of the C-ABI is replaced by the stand-in below (TEST INFRASTRUCTURE, never linked into the product): a
+// read "maps" iff its length is odd, with the path [len, -index_in_batch, 7] -- enough to check that every record
+// comes out once, in input order, in the right file, with the right bytes.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/bgreat_gpu.h"
+#include "fastx.h"
+
+struct bgr_graph { uint32_t k; };
+struct bgr_aligner { uint64_t counters[5] = {0, 0, 0, 0, 0}; };
+static thread_local std::string tl_err;
+namespace bgr { int set_error(int code, const std::string& msg) { tl_err = msg; return code; } }
+extern "C" {
+const char* bgr_last_error(void) { return tl_err.c_str(); }
+int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* o) { memset(o, 0, sizeof(*o)); o->k = g->k; return BGR_OK; }
+int bgr_graph_unitigs(const bgr_graph*, const char**, const uint64_t**, uint64_t*) { return BGR_E_ARG; }
+int bgr_aligner_create(bgr_graph*, int, bgr_aligner** out) { *out = new bgr_aligner(); return BGR_OK; }
+void bgr_aligner_destroy(bgr_aligner* a) { delete a; }
+int bgr_host_alloc(uint64_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? BGR_OK : BGR_E_HIP; }
+int bgr_host_free(void* p) { free(p); return BGR_OK; }
+int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) { memcpy(out, a->counters, sizeof(a->counters)); return BGR_OK; }
+int bgr_aligner_fetch(bgr_aligner*, uint64_t, int32_t*, uint64_t, uint64_t*, uint8_t*) { return BGR_E_INTERNAL; }
+int bgr_align_batch(bgr_aligner* a, const bgr_params*, const char*, const uint64_t* offs, uint64_t n, int32_t* paths, uint64_t cap,
+                    uint64_t* poffs, uint8_t* status) {
+    std::this_thread::sleep_for(std::chrono::microseconds(200 + (n * 7919) % 900));  // let the stages interleave
+    uint64_t w = 0;
+    poffs[0] = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t len = offs[i + 1] - offs[i];
+        if (len & 1) {
+            if (w + 3 > cap) return BGR_E_CAPACITY;
+            paths[w++] = (int32_t)len; paths[w++] = -(int32_t)i; paths[w++] = 7;
+            status[i] = BGR_ST_ALIGNED;
+            ++a->counters[2];
+        } else {
+            status[i] = BGR_ST_FAILED;
+            ++a->counters[3];
+        }
+        poffs[i + 1] = w;
+        ++a->counters[0];
+    }
+    return BGR_OK;
+}
+}
+
+static std::string slurp(const std::string& p) { std::ifstream in(p, std::ios::binary); std::stringstream ss; ss << in.rdbuf(); return ss.str(); }
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    const std::string gold = argv[1], tmp = argv[2];
+    struct Case { const char* file; bool fastq; };
+    const Case cases[] = {{"syn_r150.fa", false}, {"edge_reads.fa", false}, {"long_r150.fq", true}, {"deg_reads.fa", false}};
+    for (const Case& c : cases) {
+        for (unsigned threads : {1u, 6u}) {
+            for (uint64_t batch : {1ull, 37ull, 100000ull}) {
+                const std::string in = gold + "/" + c.file, pf = tmp + "/p", nf = tmp + "/n";
+                bgr_graph g{c.fastq ? 31u : 5u};
+                bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
+                bgr_run_options opt;
+                memset(&opt, 0, sizeof(opt));
+                opt.n_gpus = 2; opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 700; opt.fastq = c.fastq;
+                uint64_t tot[5]; double secs;
+                const std::string list = in + "," + in;  // two files: the batches of the second must follow the first's
+                if (bgr_align_all(&g, &prm, &opt, list.c_str(), pf.c_str(), nf.c_str(), tot, &secs) != BGR_OK) { printf("FAIL run: %s\n", bgr_last_error()); return 1; }
+                // expected bytes straight from the sequential parser
+                const std::string d = slurp(in);
+                bgr::ReadSet rs; bgr::parse_reads(d.data(), d.size(), c.fastq, g.k, rs);
+                std::string ep, en;
+                // the stand-in numbers reads within a device batch: rebuild the batching (FASTQ: exactly `batch` records per
+                // batch and file; FASTA: by chunk groups, so only the batch-independent fields are checked there)
+                uint64_t aligned = 0;
+                for (int rep = 0; rep < 2; ++rep)
+                    for (uint64_t i = 0; i < rs.count(); ++i) {
+                        const std::string h(rs.headers.data() + rs.header_offs[i], rs.headers.data() + rs.header_offs[i + 1]);
+                        const std::string r(rs.reads.data() + rs.read_offs[i], rs.reads.data() + rs.read_offs[i + 1]);
+                        if (r.size() & 1) { ep += h + "\n" + std::to_string(r.size()) + ".#.7.\n"; ++aligned; }
+                        else en += h + "\n" + r + "\n";
+                    }
+                std::string gp = slurp(pf), gn = slurp(nf);
+                // blank out the per-batch index (second int of every path) before comparing
+                std::string gp2; gp2.reserve(gp.size());
+                { std::istringstream ss(gp); std::string line; bool header = true;
+                  while (std::getline(ss, line)) {
+                      if (!header) { size_t a = line.find('.'), b = line.find('.', a + 1); if (a == std::string::npos || b == std::string::npos) { printf("FAIL path line\n"); return 1; } line = line.substr(0, a + 1) + "#" + line.substr(b); }
+                      gp2 += line + "\n"; header = !header; } }
+                if (gp2 != ep || gn != en || tot[0] != 2 * rs.count() || tot[2] != aligned) {
+                    printf("FAIL %s threads=%u batch=%llu: paths %zu/%zu notAligned %zu/%zu reads %llu/%llu\n", c.file, threads, (unsigned long long)batch,
+                           gp2.size(), ep.size(), gn.size(), en.size(), (unsigned long long)tot[0], (unsigned long long)(2 * rs.count()));
+                    return 1;
+                }
+            }
+        }
+        printf("%s ok\n", c.file);
+    }
+    return 0;
+}
