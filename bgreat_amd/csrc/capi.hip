@@ -504,6 +504,24 @@ int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, cons
     if (n == 0) return BGR_OK;
     HIP_TRY(hipSetDevice(a->device));
     const uint64_t base = read_offsets[0], total = read_offsets[n] - base;
+    // One launch addresses its path arena with 32 bits: a batch beyond that (~13 M reads of 150 bp) is mapped in pieces.
+    const char* lim_env = getenv("BGR_BATCH_SPLIT_LIMIT");  // tests lower it to walk this path with small inputs
+    const uint64_t lim = lim_env ? std::max<uint64_t>(4096, strtoull(lim_env, nullptr, 10)) : 0xFFFFFFFFull - (256ull << 20);
+    if (n > 1 && (2 * (total + 8 * n) >= lim || n >= 0x7FFFFFFFull)) {
+        uint64_t w = 0;
+        for (uint64_t i0 = 0; i0 < n;) {
+            uint64_t i1 = i0 + 1;  // longest piece below half the limit (at least one read)
+            while (i1 < n && 2 * ((read_offsets[i1 + 1] - read_offsets[i0]) + 8 * (i1 + 1 - i0)) < lim / 2 && i1 + 1 - i0 < (1ull << 30)) ++i1;
+            int rc = bgr_align_batch(a, p, reads, read_offsets + i0, i1 - i0, paths_out ? paths_out + w : nullptr, paths_cap - w, path_offsets + i0, status + i0);
+            if (rc != BGR_OK) return rc;
+            const uint64_t got = path_offsets[i1];
+            for (uint64_t i = i0; i <= i1; ++i) path_offsets[i] += w;
+            w += got;
+            i0 = i1;
+        }
+        a->last_n = 0;  // several launches: bgr_aligner_fetch has nothing to re-read
+        return BGR_OK;
+    }
     uint32_t max_len = 0;
     for (uint64_t i = 0; i < n; ++i) {
         uint64_t l = read_offsets[i + 1] - read_offsets[i];

@@ -123,7 +123,8 @@ void bgr_aligner_destroy(bgr_aligner* a);
  *   paths_out[paths_cap], path_offsets[n+1] : CSR of the returned vector<uNumber> per read, INPUT ORDER;
  *                               an empty row means "not mapped" (the reference's empty vector).
  *   status[n] : BGR_ST_* per read.
- * Counters of aligner.h:68 are accumulated in the aligner (bgr_aligner_counters).                       */
+ * Counters of aligner.h:68 are accumulated in the aligner (bgr_aligner_counters).  Any batch size: one launch
+ * addresses its path arena with 32 bits (about 13 M reads of 150 bp); a larger batch is mapped in pieces.     */
 int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
                     int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
 

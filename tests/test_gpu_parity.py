@@ -398,6 +398,24 @@ def test_full_size_batch_properties():
         assert np.array_equal(p1[int(po1[i]): int(po1[i + 1])], ps[int(pos[j]): int(pos[j + 1])])
 
 
+def test_oversized_batch_is_mapped_in_pieces(monkeypatch):
+    """bgr_align_batch splits a batch whose path arena would not fit 32-bit addressing; with the limit lowered the split
+    path runs on a small batch and must give the rows of the unsplit call."""
+    s = Synth(300000, 90, 2, 31, 4)
+    seqs, offs = s.unitigs()
+    al = B.Aligner(B.Graph.build(31, seqs, offs), 0)
+    reads, roffs = s.reads(0, 50000, 150, 2, 5)
+    p1, po1, st1 = al.align(reads, roffs)
+    al.reset_counters()
+    monkeypatch.setenv("BGR_BATCH_SPLIT_LIMIT", str(3_000_000))   # pieces of ~4 600 reads
+    p2, po2, st2 = al.align(reads, roffs)
+    assert np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2)
+    assert al.counters()["reads"] == 50000
+    monkeypatch.setenv("BGR_BATCH_SPLIT_LIMIT", "4096")           # one read per piece
+    p3, po3, st3 = al.align(reads[: 300 * 150], roffs[:301])
+    assert np.array_equal(p3, p1[: int(po1[300])]) and np.array_equal(po3, po1[:301]) and np.array_equal(st3, st1[:300])
+
+
 def test_tiny_and_very_long_reads_through_the_api():
     """Lengths the parsers never hand over (shorter than k-1) and reads of several kb: no crash, oracle-identical."""
     s = Synth(300000, 90, 2, 31, 909)
