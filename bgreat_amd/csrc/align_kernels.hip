@@ -5,16 +5,21 @@
 //            window read out of LDS is the reference's k-mer integer, utils.cpp:117-129).
 //   stage B  anchors (aligner.cpp:345-378 getNOverlap): lane i owns read position base+i, builds the
 //            forward and reverse-complement (k-1)-mers from LDS, takes the smaller, and walks the MPHF
-//            cascade (one dwordx4 per level) + one u64 key compare.  __ballot orders the hits by position,
-//            exactly the sequential scan's order; anchors are tried as soon as they are found (the
+//            cascade (one dwordx4 per level; from LDS when the cascade is staged there, else from L2/HBM with
+//            the next level's unit requested ahead) + one u64 key compare.  __ballot orders the hits by
+//            position, exactly the sequential scan's order; anchors are tried as soon as they are found (the
 //            reference collects `tryNumber` first, but collecting has no side effect).
 //   stage C  extension.  Greedy (alignerGreedy.cpp:167-364): wave-uniform walk; at each step the <=4
 //            neighbour unitigs are scored in parallel, 16 lanes per candidate, each lane XOR-ing 32-base
 //            chunks of the packed unitig (HBM/L2) against the packed read (LDS) and popcounting; argmin with
 //            lowest-slot tie-break == the reference's "first zero wins, else strict min".
 //            Exhaustive (alignerExhaustive.cpp:61-259): the same scoring inside a depth-first search with
-//            an explicit frame stack in LDS (see exh_search).
-//   stage D  the path (LDS) is appended to a global arena, space reserved per wave in chunks.
+//            an explicit frame stack in LDS (see exh_search); a second pass keeps that state in HBM for the
+//            rare deep search and for reads too long for LDS.
+//            Anchors mode (-G, alignerGreedy.cpp:60-164): k-mer anchors through BooPHF's exact structure, the
+//            anchoring unitig placed on the read, then the greedy walks from its two ends.
+//   stage D  the path (LDS) is appended to a global arena, space reserved per wave in chunks; launch_csr turns
+//            (results, arena) into input-ordered CSR arrays on the device.
 //
 // Integer/byte work only: no MFMA anywhere (there is no dense contraction on this path).
 #include "align_kernels.h"
