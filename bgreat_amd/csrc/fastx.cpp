@@ -170,70 +170,90 @@ static void parse_fastq_range(const char* data, uint64_t begin, uint64_t size, P
 
 void parse_fastq_image(const char* data, uint64_t size, ParsedChunk& out) { parse_fastq_range(data, 0, size, out); }
 
+FastqPlan::FastqPlan(const char* data, uint64_t size, uint64_t chunk_bytes)
+    : data_(data), size_(size), chunk_bytes_(chunk_bytes ? chunk_bytes : 1) {
+    nc_ = (size_t)((size_ + chunk_bytes_ - 1) / chunk_bytes_);
+    nl_.assign(nc_ + 1, 0);
+    tail_start_.assign(nc_, UINT64_MAX);
+}
+
+void FastqPlan::count_chunk(size_t c) {  // pass 1: newlines in chunk c
+    uint64_t b = c * chunk_bytes_, e = std::min<uint64_t>(size_, b + chunk_bytes_), n = 0;
+    const char* p = data_ + b;
+    const char* end = data_ + e;
+    while (p < end && (p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))))) { ++n; ++p; }
+    nl_[c + 1] = n;
+}
+
+void FastqPlan::finish_counts() {
+    for (size_t c = 0; c < nc_; ++c) nl_[c + 1] += nl_[c];  // nl_[c] = newlines before chunk c = index of the line containing its first byte
+    complete_ = nc_ ? nl_[nc_] / 4 : 0;                      // records whose four lines all end with a newline
+    par_records_ = complete_ ? ((complete_ - 1) / kBatch) * kBatch : 0;  // a getReads() call boundary
+}
+
+bool FastqPlan::parse_chunk(size_t c, ParsedChunk& out) {  // pass 2: chunk c owns the records whose header line STARTS inside it
+    const char* data = data_;
+    const uint64_t size = size_;
+    const uint64_t b = c * chunk_bytes_, e = std::min<uint64_t>(size, b + chunk_bytes_);
+    uint64_t line = nl_[c];  // index of the line containing byte b
+    uint64_t pos = b;
+    if (b > 0 && data[b - 1] != '\n') {  // b is inside a line: the first line starting in this chunk is the next one
+        const char* q = static_cast<const char*>(memchr(data + b, '\n', (size_t)(e - b)));
+        if (!q) return true;
+        pos = (uint64_t)(q - data) + 1;
+        ++line;
+    }
+    std::string none;
+    out.recs.reserve(out.recs.size() + (size_t)((e - b) / 200) + 16);
+    while (pos < e) {
+        if (line % 4 == 0) {
+            const uint64_t rec = line / 4;
+            if (rec >= par_records_) { tail_start_[c] = pos; return false; }
+            const char* h = data + pos;
+            const char* hq = static_cast<const char*>(memchr(h, '\n', (size_t)(size - pos)));
+            const char* s = hq + 1;  // complete record: all four newlines exist
+            bool ok;
+            const char* sq = scan_line(s, data + size, ok);
+            Slice hs; hs.p = h; hs.n = (uint64_t)(hq - h);
+            const uint64_t sn = (uint64_t)(sq - s);
+            if (sn > 2 && ok) push(out, hs, s, sn, false, none);
+            pos = (uint64_t)(sq - data) + 1;
+            line += 2;
+        } else {
+            const char* q = static_cast<const char*>(memchr(data + pos, '\n', (size_t)(size - pos)));
+            if (!q) return true;
+            pos = (uint64_t)(q - data) + 1;
+            ++line;
+        }
+    }
+    return true;
+}
+
+bool FastqPlan::parse_tail(ParsedChunk& out) {
+    uint64_t tstart = size_;
+    for (size_t c = 0; c < nc_; ++c) if (tail_start_[c] != UINT64_MAX) { tstart = tail_start_[c]; break; }
+    if (par_records_ == 0) tstart = 0;
+    if (complete_ == 0 || tstart < size_ || par_records_ == 0) { parse_fastq_range(data_, tstart, size_, out); return true; }
+    return false;
+}
+
 void parse_fastq_parallel(const char* data, uint64_t size, unsigned threads, uint64_t chunk_bytes, std::vector<ParsedChunk>& chunks) {
     if (threads < 1) threads = 1;
-    if (chunk_bytes == 0) chunk_bytes = 1;
-    const size_t nc = (size_t)((size + chunk_bytes - 1) / chunk_bytes);
+    FastqPlan plan(data, size, chunk_bytes);
+    const size_t nc = plan.chunks();
     chunks.clear();
     if (threads == 1 || nc < 2) { chunks.resize(1); parse_fastq_range(data, 0, size, chunks[0]); return; }
-    // pass 1: newlines per chunk
-    std::vector<uint64_t> nl(nc + 1, 0);
     auto run = [&](auto fn) {
         std::vector<std::thread> ts;
         for (unsigned t = 0; t < threads; ++t) ts.emplace_back([&, t]() { for (size_t c = t; c < nc; c += threads) fn(c); });
         for (auto& t : ts) t.join();
     };
-    run([&](size_t c) {
-        uint64_t b = c * chunk_bytes, e = std::min<uint64_t>(size, b + chunk_bytes), n = 0;
-        const char* p = data + b;
-        const char* end = data + e;
-        while (p < end && (p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))))) { ++n; ++p; }
-        nl[c + 1] = n;
-    });
-    for (size_t c = 0; c < nc; ++c) nl[c + 1] += nl[c];  // nl[c] = newlines before chunk c = index of the line containing its first byte
-    const uint64_t complete = nl[nc] / 4;                 // records whose four lines all end with a newline
-    const uint64_t par_records = complete ? ((complete - 1) / kBatch) * kBatch : 0;  // a getReads() call boundary
+    run([&](size_t c) { plan.count_chunk(c); });
+    plan.finish_counts();
     chunks.resize(nc + 1);
-    std::vector<uint64_t> tail_start(nc, UINT64_MAX);
-    // pass 2: chunk c owns the records whose header line STARTS inside it
-    run([&](size_t c) {
-        const uint64_t b = c * chunk_bytes, e = std::min<uint64_t>(size, b + chunk_bytes);
-        uint64_t line = nl[c];  // index of the line containing byte b
-        uint64_t pos = b;
-        if (b > 0 && data[b - 1] != '\n') {  // b is inside a line: the first line starting in this chunk is the next one
-            const char* q = static_cast<const char*>(memchr(data + b, '\n', (size_t)(e - b)));
-            if (!q) return;
-            pos = (uint64_t)(q - data) + 1;
-            ++line;
-        }
-        ParsedChunk& out = chunks[c];
-        std::string none;
-        while (pos < e) {
-            if (line % 4 == 0) {
-                const uint64_t rec = line / 4;
-                if (rec >= par_records) { tail_start[c] = pos; return; }
-                const char* h = data + pos;
-                const char* hq = static_cast<const char*>(memchr(h, '\n', (size_t)(size - pos)));
-                const char* s = hq + 1;  // complete record: all four newlines exist
-                bool ok;
-                const char* sq = scan_line(s, data + size, ok);
-                Slice hs; hs.p = h; hs.n = (uint64_t)(hq - h);
-                const uint64_t sn = (uint64_t)(sq - s);
-                if (sn > 2 && ok) push(out, hs, s, sn, false, none);
-                pos = (uint64_t)(sq - data) + 1;
-                line += 2;
-            } else {
-                const char* q = static_cast<const char*>(memchr(data + pos, '\n', (size_t)(size - pos)));
-                if (!q) return;
-                pos = (uint64_t)(q - data) + 1;
-                ++line;
-            }
-        }
-    });
-    uint64_t tstart = size;
-    for (size_t c = 0; c < nc; ++c) if (tail_start[c] != UINT64_MAX) { tstart = tail_start[c]; break; }
-    if (par_records == 0) tstart = 0;
-    if (complete == 0 || tstart < size || par_records == 0) parse_fastq_range(data, par_records == 0 ? 0 : tstart, size, chunks[nc]);
+    if (plan.sequential_only()) { plan.parse_tail(chunks[nc]); return; }
+    run([&](size_t c) { plan.parse_chunk(c, chunks[c]); });
+    plan.parse_tail(chunks[nc]);
 }
 
 static void parse_fastq_range(const char* data, uint64_t begin, uint64_t size, ParsedChunk& out) {

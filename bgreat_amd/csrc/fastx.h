@@ -61,6 +61,25 @@ void parse_fastq_image(const char* data, uint64_t size, ParsedChunk& out);
 // the rest of the file, which starts exactly where a fresh getReads() call starts, goes through the sequential
 // state machine (phantom record, truncated tails) into the last chunk.
 void parse_fastq_parallel(const char* data, uint64_t size, unsigned threads, uint64_t chunk_bytes, std::vector<ParsedChunk>& chunks);
+// The same in steps, for a caller that overlaps parsing with what follows: count_chunk(c) for every chunk (any order,
+// any threads), finish_counts(), then parse_chunk(c, out) in any order -- it returns false once chunk c reaches the
+// sequential tail (no later chunk needs parsing then) -- and parse_tail(out) last (false: nothing was left for it).
+class FastqPlan {
+public:
+    FastqPlan(const char* data, uint64_t size, uint64_t chunk_bytes);
+    size_t chunks() const { return nc_; }
+    void count_chunk(size_t c);
+    void finish_counts();
+    bool sequential_only() const { return complete_ == 0 || par_records_ == 0; }  // everything goes through parse_tail
+    bool parse_chunk(size_t c, ParsedChunk& out);
+    bool parse_tail(ParsedChunk& out);
+private:
+    const char* data_;
+    uint64_t size_, chunk_bytes_;
+    size_t nc_ = 0;
+    std::vector<uint64_t> nl_, tail_start_;
+    uint64_t complete_ = 0, par_records_ = 0;
+};
 // Parallel whole-file parse into a ReadSet (threads >= 1); identical result to parse_reads().
 void parse_reads_parallel(const char* data, uint64_t size, bool fastq, uint32_t k, unsigned threads, uint64_t chunk_bytes, ReadSet& out);
 

@@ -481,14 +481,17 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             std::string err;
             if (!mf->open(file, err)) { fail(BGR_E_IO, err); break; }
             if (opt->fastq) {
-                std::vector<ParsedChunk> fq;  // slices point into the file image only (no joined storage)
-                const uint64_t tp0 = now_us();
-                bgr::parse_fastq_parallel(mf->data, mf->size, threads, chunk_bytes, fq);
+                // FASTQ: newline counts first (they fix which line of a record every chunk starts in), then the chunks
+                // group by group, so that the later stages already work on the first batches while the rest is parsed
+                bgr::FastqPlan plan(mf->data, mf->size, chunk_bytes);
+                const size_t nc = plan.chunks();
+                uint64_t tp0 = now_us();
+                pool.run(nc, [&](size_t c) { plan.count_chunk(c); });
+                plan.finish_counts();
                 us_parse += now_us() - tp0;
                 std::unique_ptr<Batch> b;
                 bool ok = true;
-                for (size_t ci = 0; ci < fq.size() && ok && !failed; ++ci) {
-                    const std::vector<RecSlice>& rs = fq[ci].recs;
+                auto feed = [&](const std::vector<RecSlice>& rs) {  // slices point into the file image only (no joined storage)
                     size_t lo = 0;
                     while (lo < rs.size() && ok) {
                         if (!b) { if (!take_batch(b)) { ok = false; break; } b->file = mf; }
@@ -497,6 +500,27 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                         lo += take;
                         if (b->recs.size() >= batch_reads) ok = emit(std::move(b));
                     }
+                };
+                const size_t group = std::max<size_t>(threads, (size_t)((batch_reads * 330) / chunk_bytes));
+                bool tail = plan.sequential_only();
+                for (size_t c = 0; c < nc && !tail && ok && !failed; c += group) {
+                    const size_t c_end = std::min(nc, c + group);
+                    std::vector<ParsedChunk> fq(c_end - c);
+                    std::vector<char> done(c_end - c, 1);
+                    tp0 = now_us();
+                    pool.run(c_end - c, [&](size_t j) { done[j] = plan.parse_chunk(c + j, fq[j]) ? 1 : 0; });
+                    us_parse += now_us() - tp0;
+                    for (size_t j = 0; j < fq.size() && ok; ++j) {
+                        feed(fq[j].recs);
+                        if (!done[j]) { tail = true; break; }  // this chunk ran into the sequential tail: nothing after it is parsed here
+                    }
+                }
+                if (ok && !failed) {
+                    ParsedChunk last;
+                    tp0 = now_us();
+                    plan.parse_tail(last);
+                    us_parse += now_us() - tp0;
+                    feed(last.recs);
                 }
                 if (ok && b && !b->recs.empty()) ok = emit(std::move(b));
                 else if (b) { b->file.reset(); b->recs.clear(); free_batches.push(std::move(b)); }

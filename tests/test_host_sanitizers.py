@@ -41,5 +41,5 @@ def test_host_pipeline_is_sanitizer_clean(flags, tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
     p = subprocess.run([exe, GOLD, str(out)], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert p.stdout.count(" ok") == 4 and "FAIL" not in p.stdout
+    assert p.stdout.count(" ok") == 5 and "FAIL" not in p.stdout
     assert "ERROR: " not in p.stderr and "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
