@@ -25,6 +25,7 @@ struct BatchIO {
     const uint32_t* subset;      // exhaustive pass 2: map reads subset[0 .. cursor[2]) instead of 0 .. n_reads
     uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
+    uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
 };
 
 struct KernelParams {
@@ -48,7 +49,7 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
                                    uint64_t* scratch_words = nullptr) {
     uint32_t w = max_len / 32 + 2;
     uint32_t pc = max_len + 8;
-    pc = (pc + 1) & ~1u;
+    pc = (pc + 3) & ~3u;  // multiple of 4 ints: what lies behind the path buffers stays 16-byte aligned
     uint32_t fr = 0;
     uint32_t bytes = 4 * 8 * w + 4 * pc;  // FW3 | FWQ | RCW | NM | PATH
     if (mode != 0) {
@@ -57,6 +58,12 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
         if (frame_cap && fr > frame_cap) fr = frame_cap;
         bytes = 4 * 8 * w + 3 * 4 * pc + fr * 20 * 4;  // ... OUT | CUR | BEST | frames
         if (scratch_words) *scratch_words = 3ull * pc + (uint64_t)fr * 20;
+    }
+    if (mode == 2) {  // exhaustive pass 1 with the level-by-level search: FW3 | FWQ | RCW | NM | OUT | BEST | tables
+        fr = (max_len >= k - 1 ? max_len - (k - 1) : 0) + 3;
+        if (frame_cap && fr > frame_cap) fr = frame_cap;
+        const uint32_t table_words = 32 + fr * (52 + 1);
+        bytes = 4 * 8 * w + 2 * 4 * pc + 16 * ((table_words + 3) / 4);
     }
     if (words) *words = w;
     if (path_cap) *path_cap = pc;

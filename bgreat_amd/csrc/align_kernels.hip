@@ -577,6 +577,211 @@ __device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u6
     return best;
 }
 
+// ---- the same search, level by level ------------------------------------------------------------------------
+// exh_search visits one (record, read position) node per loop iteration and comes back to it once per candidate.
+// A node's best continuation does not depend on how the walk got there, so the search can also run as a dynamic
+// programme over the levels of the walk (level = number of unitigs taken):
+//   forward   all nodes of a level at once -- up to 4 nodes x 4 slots = 16 candidates, 4 lanes each -- are scored;
+//             candidates within the budget that do not end inside their unitig give the next level's nodes, and
+//             candidates reaching the same (record, position, strand) share one node (what the depth-first search
+//             re-explores once per way of getting there);
+//   backward  cost(node) = min over its candidates, first slot on ties, of mismatches + cost(child): the value and the
+//             choice the reference's recursion arrives at (its strict `<` keeps the first minimum; a candidate it
+//             does not explore because miss >= best-so-far could not have been strictly better);
+//   then the walk is read off from the root.
+// The result is that of exh_search.  Levels are ~13 for a 250 bp read where exh_search takes ~500 iterations.
+// A level with more than 4 distinct nodes, or more than `max_levels` levels, returns EXH_OVERFLOW (the read then
+// goes to the depth-first kernel's second pass).
+// Tables (u32 words, LDS): T[0..32) two node arrays {rec, pos, strand, cheapest way here} x 4; per level 52 words:
+// 16 candidates x {sid, aux, miss | fits<<16 | alive<<17 | child<<18}, 4 node words {cost | argmin<<16 | end<<18 | used<<19};
+// then max_levels words of scratch for reading the walk off.
+#define DP_LEVEL_WORDS 52
+#define DP_FITS (1u << 16)
+#define DP_ALIVE (1u << 17)
+#define DP_END (1u << 18)
+#define DP_USED (1u << 19)
+
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true); }
+
+template <int DIR>
+__device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
+                                           uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t budget, bool partial,
+                                           uint32_t* T, uint32_t max_levels, int32_t* BEST, uint32_t* best_n, int lane) {
+    const int i = lane >> 4, c = (lane >> 2) & 3, sub = lane & 3, k = lane >> 2;
+    const bool leader = sub == 0;
+    *best_n = 0;
+    if (lane == 0) { T[0] = a_rec; T[1] = a_pos; T[2] = a_canon ? 1u : 0u; T[3] = 0; }
+    wave_sync();
+    uint32_t n_cur = 1, lvl = 0;
+    for (; n_cur; ++lvl) {
+        if (lvl >= max_levels) { wave_sync(); return EXH_OVERFLOW; }
+        const uint4 nd = reinterpret_cast<const uint4*>(T)[(lvl & 1) * 4 + i];
+        const bool nvalid = (uint32_t)i < n_cur;
+        const uint32_t rec = nd.x, pos = nd.y, prefix = nd.w;
+        const bool canon = (nd.z & 1u) != 0;
+        const bool end_here = nvalid && ((DIR == 0) ? (pos == 0) : (L - pos - K1 == 0));
+        const bool has_rec = nvalid && !end_here && rec != BGR_NONE;
+        const bool useR = (DIR == 0) ? canon : !canon;
+        const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
+        uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
+        if (has_rec) {
+            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + (useR ? 4u : 0u) + (uint32_t)c) * 2;
+            sl = sp[0];
+            m0 = sp[1];
+        }
+        const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+        const u64 zmask = __ballot(leader && (!has_rec || id == 0));
+        const uint32_t nb = (uint32_t)(zmask >> (16 * i)) & 0x1111u;
+        const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+        if (DIR == 1 && partial && lvl == 0) {  // alignerExhaustive.cpp:217-221 (-i): nothing starts here, nothing to pay
+            const bool none = rl32(first_zero, 0) == 0 && !(rl32(end_here ? 1u : 0u, 0));
+            if (none) { wave_sync(); return 0; }
+        }
+        const bool valid = has_rec && (uint32_t)c < first_zero;
+        const bool fwd = (sl.x & fbit) != 0;
+        const uint32_t len = valid ? sl.y : 0;
+        const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+        const int32_t sid = fwd ? (int32_t)id : -(int32_t)id;
+        const uint32_t ext = len - K1;
+        bool fits;
+        uint32_t n, ustart, rstart, nrec;
+        bool ncanon;
+        if (DIR == 0) {
+            fits = ext >= pos;
+            n = fits ? pos : ext;
+            ustart = fits ? ext - pos : 0;
+            rstart = fits ? 0 : pos - ext;
+            nrec = fwd ? m0.y : m0.z;
+            ncanon = (m0.x & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
+        } else {
+            const uint32_t rl = L - pos - K1;
+            fits = ext >= rl;
+            n = fits ? rl : ext;
+            ustart = K1;
+            rstart = pos + K1;
+            nrec = fwd ? m0.z : m0.y;
+            ncanon = (m0.x & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
+        }
+        if (!valid) n = 0;
+        uint32_t cnt = 0;
+        for (uint32_t b = (uint32_t)sub * 32; b < n; b += 128) cnt += ham_chunk(g, CMP, NM, useN, fw, fo + ustart + b, rstart + b, n - b);
+        cnt += quad_xor1(cnt);
+        cnt += quad_xor2(cnt);
+        const uint32_t miss = cnt > 0xFFFFu ? 0xFFFFu : cnt;
+        const uint32_t ptotal = prefix + miss;
+        const bool alive = valid && ptotal <= budget;  // a walk through here costs at least this much
+        const uint32_t aux = fits ? ((DIR == 0) ? ext - pos : L - pos) : 0u;
+        const bool need = alive && !fits;
+        const uint32_t npos = (DIR == 0) ? pos - ext : pos + ext;
+        const u64 key = (u64)nrec << 32 | (u64)(npos << 1) | (ncanon ? 1u : 0u);
+        // candidates that reach the same node share it: the first of them (slot order over the level) creates it
+        const u64 needmask = __ballot(need && leader);
+        uint32_t first_k = (uint32_t)k;
+        for (u64 mm = needmask; mm; mm &= mm - 1) {
+            const int src = __ffsll((long long)mm) - 1;
+            const u64 kk = rl64(key, src);
+            if (need && kk == key && (uint32_t)(src >> 2) < first_k) first_k = (uint32_t)(src >> 2);
+        }
+        const bool is_first = need && leader && first_k == (uint32_t)k;
+        const u64 fmask = __ballot(is_first);
+        const uint32_t n_next = (uint32_t)__popcll(fmask);
+        if (n_next > 4) { wave_sync(); return EXH_OVERFLOW; }
+        const uint32_t child = (uint32_t)__popcll(fmask & ((1ULL << (4 * first_k)) - 1));
+        uint32_t* NX = T + ((lvl + 1) & 1) * 16;
+        if (is_first) { NX[child * 4] = nrec; NX[child * 4 + 1] = npos; NX[child * 4 + 2] = ncanon ? 1u : 0u; NX[child * 4 + 3] = 0xFFFFFFFFu; }
+        uint32_t* LV_ = T + 32 + lvl * DP_LEVEL_WORDS;
+        if (leader && nvalid) {
+            LV_[3 * k] = (uint32_t)sid;
+            LV_[3 * k + 1] = aux;
+            LV_[3 * k + 2] = miss | (fits ? DP_FITS : 0u) | (alive ? DP_ALIVE : 0u) | (child << 18);
+        }
+        if (leader && c == 0) LV_[48 + i] = (nvalid ? DP_USED : 0u) | (end_here ? DP_END : 0u);
+        wave_sync();
+        if (need && leader) atomicMin(&NX[child * 4 + 3], ptotal);
+        wave_sync();
+        n_cur = n_next;
+    }
+    const uint32_t levels = lvl;
+    // ---- backward: cheapest continuation of every node, first slot on ties --------------------------------
+    for (int l = (int)levels - 1; l >= 0; --l) {
+        uint32_t* LV_ = T + 32 + (uint32_t)l * DP_LEVEL_WORDS;
+        uint32_t sel = 0xFFFFFFFFu;
+        if (lane < 16) {
+            const uint32_t used = LV_[48 + (lane >> 2)] & DP_USED;
+            uint32_t total = 0xFFFFu;
+            if (used) {
+                const uint32_t pk = LV_[3 * lane + 2];
+                if (pk & DP_ALIVE) {
+                    uint32_t cc = 0;
+                    if (!(pk & DP_FITS)) cc = ((uint32_t)l + 1 < levels) ? (T[32 + ((uint32_t)l + 1) * DP_LEVEL_WORDS + 48 + ((pk >> 18) & 3u)] & 0xFFFFu) : 0xFFFFu;
+                    total = (pk & 0xFFFFu) + cc;
+                    if (total > 0xFFFFu) total = 0xFFFFu;
+                }
+            }
+            sel = total << 2 | (uint32_t)(lane & 3);
+        }
+        uint32_t o = quad_xor1(sel);
+        sel = o < sel ? o : sel;
+        o = quad_xor2(sel);
+        sel = o < sel ? o : sel;
+        wave_sync();
+        if (lane < 16 && (lane & 3) == 0) {
+            const uint32_t fl = LV_[48 + (lane >> 2)];
+            const uint32_t cost = (fl & DP_END) ? 0u : (sel >> 2);
+            LV_[48 + (lane >> 2)] = (fl & (DP_END | DP_USED)) | cost | ((sel & 3u) << 16);
+        }
+        wave_sync();
+    }
+    const uint32_t root = T[32 + 48];
+    const uint32_t s = (root & DP_END) ? 0u : (root & 0xFFFFu);
+    if (s > budget) return budget + 1;
+    // ---- read the walk off (lane 0; at most `levels` steps) -------------------------------------------------
+    if (lane == 0) {
+        int32_t* W_ = reinterpret_cast<int32_t*>(T + 32 + max_levels * DP_LEVEL_WORDS);
+        uint32_t d = 0, node = 0, n_out = 0;
+        for (;;) {
+            const uint32_t* LV_ = T + 32 + d * DP_LEVEL_WORDS;
+            const uint32_t w = LV_[48 + node];
+            if (w & DP_END) {
+                // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); right: every depth pushes 0 (:64,:210)
+                if (DIR == 0) {
+                    if (d == 0) { BEST[0] = 0; n_out = 1; }
+                    else { for (uint32_t j = 0; j < d; ++j) BEST[j] = W_[d - 1 - j]; n_out = d; }
+                } else {
+                    for (uint32_t j = 0; j < d; ++j) BEST[j] = W_[j];
+                    BEST[d] = 0;
+                    n_out = d + 1;
+                }
+                break;
+            }
+            const uint32_t cc = (w >> 16) & 3u;
+            const uint32_t* C = LV_ + 3 * (node * 4 + cc);
+            const int32_t sid = (int32_t)C[0];
+            const uint32_t aux = C[1], pk = C[2];
+            if (pk & DP_FITS) {
+                if (DIR == 0) {  // [offset, this (farthest) unitig, ..., nearest unitig]
+                    BEST[0] = (int32_t)aux; BEST[1] = sid;
+                    for (uint32_t j = 0; j < d; ++j) BEST[2 + j] = W_[d - 1 - j];
+                } else {         // [nearest ... this (farthest) unitig, end offset]
+                    for (uint32_t j = 0; j < d; ++j) BEST[j] = W_[j];
+                    BEST[d] = sid; BEST[d + 1] = (int32_t)aux;
+                }
+                n_out = d + 2;
+                break;
+            }
+            W_[d] = sid;
+            node = (pk >> 18) & 3u;
+            if (++d >= levels) break;  // (cannot happen: a finite cost ends in a fitting candidate or an end node)
+        }
+        T[0] = n_out;
+    }
+    wave_sync();
+    *best_n = rl32(T[0], 0);
+    wave_sync();
+    return s;
+}
+
 // ================================================ kernels ===============================================
 template <bool STAGE>
 __device__ __forceinline__ const uint32_t* block_prologue(const BgrDeviceGraph& g, u64* lds, uint2** LVout, uint32_t* mphf_words) {
@@ -1044,6 +1249,99 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
     }
 }
 
+// Pass 1 of exhaustive mode with the level-by-level search (exh_dp); what it cannot hold goes to the overflow list and
+// through bgr_align_exhaustive_kernel<false, true>.
+template <bool STAGE>
+__global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_dp_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    // per wave: FW3 | FWQ | RCW | NM | OUT | BEST | tables (32 + levels * 52 + levels words, see exh_dp)
+    const uint32_t table_words = 32 + io.frames_per_wave * (DP_LEVEL_WORDS + 1);
+    const uint32_t per_wave_words = 4 * W + 2 * (io.path_cap / 2) + ((table_words + 3) / 4) * 2;  // whole 16-byte units
+    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FWQ = FW3 + W;
+    u64* RCW = FWQ + W;
+    u64* NM = RCW + W;
+    int32_t* OUT = reinterpret_cast<int32_t*>(NM + W);
+    int32_t* BEST = OUT + io.path_cap;
+    uint32_t* T = reinterpret_cast<uint32_t*>(BEST + io.path_cap);
+
+    uint32_t c_reads = 0, c_al = 0, c_na = 0;
+    unsigned long long c_ov = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+    const uint32_t m = prm.max_mismatch;
+
+    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[2] by pass 1)
+    const uint32_t total = io.subset ? io.cursor[2] : io.n_reads;
+    for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        const uint32_t r = io.subset ? io.subset[it] : it;
+        const u64 off = io.read_offs[r];
+        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
+        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
+        if (hasN) derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane);
+        const u64* ROLL = hasN ? FWQ : FW3;  // the rolling `num` stream
+        uint32_t p_n = 0;
+        const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
+        bool done = false, overflow = false;
+        for (uint32_t base = 0; base < npos && !done && !overflow; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < npos;
+            u64 num = 0;
+            if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
+            const uint32_t idx = find_key<!STAGE>(g, LV, units, num < rc ? num : rc, valid);
+            u64 mask = __ballot(idx != BGR_NONE);
+            if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const uint32_t a_rec = rl32(idx, src), a_pos = base + (uint32_t)src;
+                const u64 a_num = rl64(lds_win32(ROLL, a_pos) >> (64 - 2 * K1), 0);  // re-read (uniform) instead of keeping `num` live across the search
+                const bool a_canon = a_num <= rcb_fast(a_num, K1);
+                uint32_t nl = 0, nr = 0;
+                const uint32_t eb = exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, T, io.frames_per_wave, BEST, &nl, lane);
+                if (eb == EXH_OVERFLOW) { overflow = true; break; }
+                if (eb > m) continue;
+                for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                wave_sync();
+                const uint32_t ee = exh_dp<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, T, io.frames_per_wave, BEST, &nr, lane);
+                if (ee == EXH_OVERFLOW) { overflow = true; break; }
+                if (ee > m - eb) continue;
+                for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];
+                p_n = nl + nr;
+                done = true;
+                break;
+            }
+        }
+        wave_sync();
+        if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
+            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + 2, 1u)] = r;
+            continue;
+        }
+        c_ov += npos;
+        uint32_t abase = 0;
+        if (done) abase = publish_path(io, OUT, 0, p_n, &chunk_pos, &chunk_end, lane);
+        if (lane == 0) io.results[r] = make_uint2(abase, p_n | ((uint32_t)(done ? BGR_ST_ALIGNED : BGR_ST_FAILED) << 24));
+        ++c_reads;
+        c_al += done ? 1 : 0;
+        c_na += done ? 0 : 1;
+        wave_sync();
+    }
+    if (lane == 0 && c_reads) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)c_reads);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        atomicAdd(&counters[4], c_ov);
+    }
+}
+
 template <typename K>
 hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     if (cfg.lds_bytes > 48 * 1024) {
@@ -1175,6 +1473,8 @@ hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const Kernel
     }
     if (p.mode == 2) return launch_one(bgr_align_anchors_kernel, g, io, p, cfg, stream);
     if (io.deep_scratch) return launch_one(bgr_align_exhaustive_kernel<false, true>, g, io, p, cfg, stream);
+    if (io.level_search) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_dp_kernel<true>, g, io, p, cfg, stream)
+                                               : launch_one(bgr_align_exhaustive_dp_kernel<false>, g, io, p, cfg, stream);
     return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_kernel<true, false>, g, io, p, cfg, stream)
                           : launch_one(bgr_align_exhaustive_kernel<false, false>, g, io, p, cfg, stream);
 }

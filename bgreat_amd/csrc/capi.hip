@@ -313,9 +313,12 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     const uint32_t lmode = p->mode == BGR_MODE_EXHAUSTIVE ? 1u : 0u;  // anchors mode uses the greedy per-wave layout
     bgr::lds_bytes_per_wave(lmode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep, 0, &deep_stride);
     const uint32_t per_wave_deep = bgr::deep_lds_bytes_per_wave(max_read_len);
-    const uint32_t per_wave = bgr::lds_bytes_per_wave(lmode, a->dg.k, max_read_len, &words, &path_cap, &frames, kExhFrameCap);
     const bool exhaustive = p->mode == BGR_MODE_EXHAUSTIVE;
-    bool two_pass = exhaustive && frames < frames_deep;
+    // pass 1 of exhaustive mode runs the level-by-level search (exh_dp) unless BGR_EXH_DP=0 asks for the depth-first one
+    const char* dp_env = getenv("BGR_EXH_DP");
+    const bool level_search = exhaustive && !(dp_env && atoi(dp_env) == 0);
+    const uint32_t per_wave = bgr::lds_bytes_per_wave(level_search ? 2u : lmode, a->dg.k, max_read_len, &words, &path_cap, &frames, kExhFrameCap);
+    bool two_pass = exhaustive && (frames < frames_deep || level_search);  // the level search can also overflow on a wide level
     const size_t lds_cu = a->lds_per_cu;
     const uint32_t mphf_bytes = a->dg.units_bytes;
     // Resident waves per CU are bounded by registers (bgr::resident_waves_per_cu); LDS decides how they are grouped:
@@ -414,11 +417,13 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.subset = nullptr;
     io.deep_scratch = nullptr;
     io.deep_stride = (uint32_t)deep_stride;
+    io.level_search = level_search ? 1u : 0u;
     if (two_pass && !deep_only) {
         HIP_TRY(a->ovf.ensure(n_reads * 4));
         io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
     }
     if (deep_only) {
+        io.level_search = 0;
         io.frames_per_wave = frames_deep;
         io.deep_scratch = static_cast<uint32_t*>(a->deep.p);
     }
@@ -438,6 +443,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         io2.subset = io.ovf_list;
         io2.ovf_list = nullptr;
         io2.deep_scratch = static_cast<uint32_t*>(a->deep.p);
+        io2.level_search = 0;
         e = bgr::launch_align(a->dg, io2, kp, cfg_deep, a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (deep pass): ") + hipGetErrorString(e));
     }
