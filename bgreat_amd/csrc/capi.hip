@@ -315,9 +315,21 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     const uint32_t per_wave_deep = bgr::deep_lds_bytes_per_wave(max_read_len);
     const bool exhaustive = p->mode == BGR_MODE_EXHAUSTIVE;
     // pass 1 of exhaustive mode runs the level-by-level search (exh_dp) unless BGR_EXH_DP=0 asks for the depth-first one
+    // Which one is faster depends on how much the walks branch within the mismatch budget: the depth-first search wins
+    // on a graph with an occasional 2-way bubble (about 1.2x), the level search where a read crosses many multi-way
+    // sites (3.6x at 4 alleles every ~36 bp, m=5).  Estimate: (extra candidates per record) x (m+1) x (unitigs per read).
     const char* dp_env = getenv("BGR_EXH_DP");
-    const bool level_search = exhaustive && !(dp_env && atoi(dp_env) == 0);
-    const uint32_t per_wave = bgr::lds_bytes_per_wave(level_search ? 2u : lmode, a->dg.k, max_read_len, &words, &path_cap, &frames, kExhFrameCap);
+    bool level_search = false;
+    if (exhaustive) {
+        const BgrBlobHeader& gh = a->graph->header;
+        const double mean_ext = std::max(1.0, (double)gh.total_bases / (2.0 * (double)std::max<uint64_t>(1, gh.n_unitigs)) - (double)(gh.k - 1));
+        const double branching = (gh.slot_fill_x100 / 100.0 - 1.0) * (double)(p->max_mismatch + 1) * ((double)max_read_len / mean_ext);
+        level_search = dp_env ? atoi(dp_env) != 0 : branching >= 15.0;
+    }
+    // level search: a level is one unitig of the walk; 16 levels cover 250 bp reads on a graph that branches every ~36 bp
+    const uint32_t level_cap = fc_env ? kExhFrameCap : std::max<uint32_t>(16, (max_read_len / 64) * 4);
+    const uint32_t per_wave = bgr::lds_bytes_per_wave(level_search ? 2u : lmode, a->dg.k, max_read_len, &words, &path_cap, &frames,
+                                                      level_search ? level_cap : kExhFrameCap);
     bool two_pass = exhaustive && (frames < frames_deep || level_search);  // the level search can also overflow on a wide level
     const size_t lds_cu = a->lds_per_cu;
     const uint32_t mphf_bytes = a->dg.units_bytes;
@@ -356,12 +368,18 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             uint32_t wn = 0, bn = 0, res_n = 0;
             // (4-wave workgroups first: a workgroup whose wave count is not a multiple of the 4 SIMDs measured far slower)
             const uint32_t bs2[] = {6, 5, 4, 3, 2, 1};
+            uint32_t w4 = 0, b4 = 0;  // the best grouping made of 4-wave workgroups
             for (uint32_t b : bs2) {
                 uint32_t w = std::min<uint32_t>(b >= 5 ? 4 : 16, std::max<uint32_t>(1, cap / b));
                 while (w > 0 && !fits(b, w, false)) --w;
                 if (w > 4) w -= w % 4;
                 if (w && b * w > res_n) { res_n = b * w; wn = w; bn = b; }
+                const uint32_t wq = std::min<uint32_t>(w, 4);
+                if (wq && b * wq > b4 * w4) { w4 = wq; b4 = b; }
             }
+            // one wave per SIMD and workgroup schedules best (8-wave workgroups measured 87 vs 123 Mreads/s at 24 vs 20
+            // resident waves): take that grouping unless it gives up more than a fifth of the resident waves
+            if (w4 == 4 && b4 * w4 * 5 >= res_n * 4) { res_n = b4 * w4; wn = w4; bn = b4; }
             if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
             if (best_res == 0) waves = 0;
         }

@@ -515,6 +515,25 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
             }
         }
     });
+    {   // how branchy the graph is: filled slots per non-empty half record (decides the exhaustive search formulation)
+        std::vector<uint64_t> filled(T, 0), halves(T, 0);
+        parallel_ranges(T, 2 * nk, [&](uint64_t b, uint64_t e, unsigned t) {
+            uint64_t f = 0, hh = 0;
+            for (uint64_t j = b; j < e; ++j) {
+                const BgrSlot* sl4 = recs + j * 4;
+                if (!sl4[0].idf) continue;
+                ++hh;
+                for (int q = 0; q < 4; ++q) f += sl4[q].idf != 0;
+            }
+            filled[t] = f;
+            halves[t] = hh;
+        });
+        uint64_t f = 0, hh = 0;
+        for (unsigned t = 0; t < T; ++t) { f += filled[t]; hh += halves[t]; }
+        BgrBlobHeader* hw = reinterpret_cast<BgrBlobHeader*>(base);
+        hw->slot_fill_x100 = hh ? (uint32_t)(100 * f / hh) : 100;
+        if (getenv("BGREAT_TIMING")) fprintf(stderr, "[build] slot fill %.2f per non-empty half record\n", hw->slot_fill_x100 / 100.0);
+    }
     tm.lap("slots");
 
     if (h.anc_n) {  // aligner.cpp:465-476: anchorsPosition[lookup(canon)] = {i, j} in unitig order, i.e. the LAST one wins

@@ -42,7 +42,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 7u  /* 7: anchors levels with division magic; 6: 32-byte slots carrying the unitig's end records */
+#define BGR_BLOB_VERSION 8u  /* 8: slot_fill_x100; 7: anchors levels with division magic; 6: 32-byte slots carrying the unitig's end records */
 #define BGR_MAX_LEVELS 48
 #define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
 #define BGR_NONE 0xFFFFFFFFu
@@ -120,6 +120,7 @@ typedef struct {
     uint32_t n_levels, has_exc;
     uint64_t max_unitig_len;
     uint64_t n_left_keys, n_right_keys;  // sizes of the reference's two key sets (informational)
+    uint32_t slot_fill_x100, pad0;       // 100 x mean number of filled slots per non-empty half record (how branchy the graph is)
     double gamma;
     BgrLevel levels[BGR_MAX_LEVELS];
     // anchors index (all zero when the graph was built without it)

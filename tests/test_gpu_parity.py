@@ -57,10 +57,12 @@ def graphs():
 
 
 @pytest.mark.parametrize("case", GREEDY + EXH, ids=["%02d-%s" % (c["id"], c["group"]) for c in GREEDY + EXH])
-def test_gpu_matches_reference_golden(case, graphs):
+def test_gpu_matches_reference_golden(case, graphs, monkeypatch):
     """Greedy cases: bytes of the unmodified reference.  Exhaustive (-b) cases: counters of the unmodified reference,
     bytes of what it computes but does not write (tests/golden/README.md)."""
     args = case["args"]
+    if "-b" in args:   # alternate between the two formulations of the exhaustive search over the cases
+        monkeypatch.setenv("BGR_EXH_DP", str(case["id"] & 1))
     k = int(_argval(args, "-k", "30"))
     m = int(_argval(args, "-m", "2"))
     e = int(_argval(args, "-e", "2"))
@@ -235,7 +237,10 @@ def test_cli_exhaustive_writes_nothing_unless_asked():
 @pytest.mark.parametrize("seed,k,L,m,partial,nfrac,d,alleles", [
     (1, 31, 150, 2, False, 0.0, 75, 2), (2, 31, 250, 5, False, 0.0, 40, 4), (3, 31, 200, 5, True, 0.002, 45, 4),
     (4, 21, 120, 3, False, 0.004, 50, 3), (5, 8, 60, 4, False, 0.0, 20, 4), (6, 31, 150, 0, True, 0.0, 140, 2), (7, 32, 100, 6, False, 0.01, 60, 4)])
-def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, alleles):
+@pytest.mark.parametrize("search", ["depth-first", "by-level"])
+def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, alleles, search, monkeypatch):
+    """Both formulations of the exhaustive search (exh_search, exh_dp; the library picks one per graph and budget)."""
+    monkeypatch.setenv("BGR_EXH_DP", "1" if search == "by-level" else "0")
     s = Synth(100000, d, alleles, k, 9000 + seed)
     seqs, offs = s.unitigs()
     reads, roffs = s.reads(0, 8000, L, m + 1, 9500 + seed)
@@ -253,10 +258,12 @@ def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, 
 
 
 @pytest.mark.parametrize("cap", ["2", "3", "5"])
-def test_exhaustive_deep_stack_second_pass(cap, monkeypatch):
-    """Pass 1 of the exhaustive kernel has a shallow DFS stack; reads that need more go through pass 2.  With a tiny
-    cap nearly every mapped read takes the second pass; results must not change."""
+@pytest.mark.parametrize("search", ["depth-first", "by-level"])
+def test_exhaustive_deep_stack_second_pass(cap, search, monkeypatch):
+    """Pass 1 of the exhaustive kernel has a shallow stack (depth-first search) or few levels (level search); reads that
+    need more go through pass 2.  With a tiny cap nearly every mapped read takes the second pass; results must not change."""
     monkeypatch.setenv("BGR_EXH_FRAME_CAP", cap)
+    monkeypatch.setenv("BGR_EXH_DP", "1" if search == "by-level" else "0")
     s = Synth(60000, 30, 4, 12, 606)
     seqs, offs = s.unitigs()
     reads, roffs = s.reads(0, 6000, 120, 4, 607)
