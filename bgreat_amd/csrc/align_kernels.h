@@ -71,7 +71,8 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
     return bytes;
 }
 
-// Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive).
+// Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive depth-first,
+// 2 anchors, 3 exhaustive level search).
 uint32_t resident_waves_per_cu(uint32_t mode);
 
 // (results, arena) of the last mapping launch -> input-ordered CSR on the device.  phase 0: block_sums[ceil(n/4096)] and

@@ -472,6 +472,9 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 #ifndef BGR_ANC_OCC
 #define BGR_ANC_OCC 4 /* 128 VGPRs, no spills: 220 vs 200 Mreads/s at 6 */
 #endif
+#ifndef BGR_DP_OCC
+#define BGR_DP_OCC 6
+#endif
 #ifndef BGR_EXH_OCC
 #define BGR_EXH_OCC 6 /* waves per SIMD the exhaustive kernel is compiled for */
 #endif
@@ -1252,7 +1255,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
 // Pass 1 of exhaustive mode with the level-by-level search (exh_dp); what it cannot hold goes to the overflow list and
 // through bgr_align_exhaustive_kernel<false, true>.
 template <bool STAGE>
-__global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_dp_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -1456,6 +1459,7 @@ uint32_t resident_waves_per_cu(uint32_t mode) {
     hipFuncAttributes fa;
     const void* fn = mode == 0 ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)
                    : mode == 2 ? reinterpret_cast<const void*>(&bgr_align_anchors_kernel)
+                   : mode == 3 ? reinterpret_cast<const void*>(&bgr_align_exhaustive_dp_kernel<false>)
                                : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
     // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;

@@ -337,7 +337,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     // `b` workgroups per CU of `w` waves each, every staged workgroup holding its own copy of the MPHF cascade.
     // More resident waves hide more of the walk's dependent-load latency (measured 16 -> 24 waves/CU: +18 %), and a
     // grid of exactly CUs x b workgroups avoids a partial last round.
-    const uint32_t cap = std::max<uint32_t>(4, bgr::resident_waves_per_cu(p->mode));
+    const uint32_t cap = std::max<uint32_t>(4, bgr::resident_waves_per_cu(level_search ? 3u : p->mode));  // 3: the level-search kernel
     const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
     auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bgr::LaunchCfg& cfg) -> bool {
         uint32_t waves = 0, bpc = 0;
