@@ -1187,8 +1187,8 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
     uint32_t chunk_pos = 0, chunk_end = 0;
     const uint32_t m = prm.max_mismatch;
 
-    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[2] by pass 1)
-    const uint32_t total = io.subset ? io.cursor[2] : io.n_reads;
+    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[subset_ctr] by the pass before)
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
     for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
         const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
@@ -1231,7 +1231,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
         }
         wave_sync();
         if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
-            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + 2, 1u)] = r;
+            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
             continue;
         }
         c_ov += npos;
@@ -1280,8 +1280,8 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
     uint32_t chunk_pos = 0, chunk_end = 0;
     const uint32_t m = prm.max_mismatch;
 
-    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[2] by pass 1)
-    const uint32_t total = io.subset ? io.cursor[2] : io.n_reads;
+    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[subset_ctr] by the pass before)
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
     for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
         const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
@@ -1324,7 +1324,7 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
         }
         wave_sync();
         if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
-            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + 2, 1u)] = r;
+            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
             continue;
         }
         c_ov += npos;

@@ -64,7 +64,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, results, arena, ovf, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, results, arena, ovf, ovf2, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -271,7 +271,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->deep.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->deep.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -390,8 +390,13 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         cfg.stage_mphf = stage ? 1 : 0;
         return true;
     };
-    bgr::LaunchCfg cfg, cfg_deep;
+    bgr::LaunchCfg cfg, cfg_deep, cfg_mid;
     bool deep_only = false;  // pass 1 does not fit LDS: every read goes through the deep kernel
+    // level search: what it cannot hold (a level wider than 4 nodes, too many levels) goes to the depth-first kernel with
+    // its LDS stack first, and only what overflows that one to the HBM-stack pass
+    uint32_t frames_mid = 0;
+    const uint32_t per_wave_mid = bgr::lds_bytes_per_wave(1u, a->dg.k, max_read_len, nullptr, nullptr, &frames_mid, kExhFrameCap);
+    bool mid_pass = false;
     if (!geometry(per_wave, n_reads, true, cfg)) {
         if (!exhaustive) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
         deep_only = two_pass = true;
@@ -410,6 +415,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         if (deep_stride > 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: read too long");
         HIP_TRY(a->deep.ensure((uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * wave_bytes));
         if (deep_only) cfg = cfg_deep;
+        mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, cfg_mid);
     }
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
@@ -417,7 +423,8 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
     const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
     const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
-                               (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0);
+                               (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0) +
+                               (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0);
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf;
@@ -436,9 +443,12 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.deep_scratch = nullptr;
     io.deep_stride = (uint32_t)deep_stride;
     io.level_search = level_search ? 1u : 0u;
+    io.subset_ctr = 2;
+    io.ovf_ctr = 2;
     if (two_pass && !deep_only) {
         HIP_TRY(a->ovf.ensure(n_reads * 4));
         io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
+        if (mid_pass) HIP_TRY(a->ovf2.ensure(n_reads * 4));
     }
     if (deep_only) {
         io.level_search = 0;
@@ -456,9 +466,25 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     hipError_t e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (two_pass && !deep_only) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
+        const uint32_t* pending = io.ovf_list;
+        uint32_t pending_ctr = 2;
+        if (mid_pass) {  // depth-first search, LDS stack, over what the level search listed; its own overflow goes to list 2
+            bgr::BatchIO iom = io;
+            iom.level_search = 0;
+            iom.frames_per_wave = frames_mid;
+            iom.subset = io.ovf_list;
+            iom.subset_ctr = 2;
+            iom.ovf_list = static_cast<uint32_t*>(a->ovf2.p);
+            iom.ovf_ctr = 3;
+            e = bgr::launch_align(a->dg, iom, kp, cfg_mid, a->stream);
+            if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (depth-first pass): ") + hipGetErrorString(e));
+            pending = iom.ovf_list;
+            pending_ctr = 3;
+        }
         bgr::BatchIO io2 = io;
         io2.frames_per_wave = frames_deep;
-        io2.subset = io.ovf_list;
+        io2.subset = pending;
+        io2.subset_ctr = pending_ctr;
         io2.ovf_list = nullptr;
         io2.deep_scratch = static_cast<uint32_t*>(a->deep.p);
         io2.level_search = 0;
