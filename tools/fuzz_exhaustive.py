@@ -1,0 +1,39 @@
+"""Randomised parity campaign for the exhaustive level search (exh_dp) against the oracle: 60 random (k, site spacing, alleles,
+read length, m, -i, N rate, level cap) configurations per seed, N in unitigs now and then, small caps to push reads through
+the depth-first and HBM-stack passes.  Run on a GPU box: python tools/fuzz_exhaustive.py [seed].  (Test infrastructure.)"""
+import os, sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tools")
+import numpy as np
+import bgreat_amd as B, oracle_py
+from synth import Synth
+os.environ["BGR_EXH_DP"] = "1"
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)
+bad = 0
+fracs = []
+t0 = time.time()
+for it in range(60):
+    k = int(rng.choice([5, 8, 12, 15, 21, 25, 31, 32]))
+    d = int(rng.integers(k + 2, 4 * k))
+    alleles = int(rng.integers(2, 5))
+    L = int(rng.integers(k + 2, 320))
+    m = int(rng.integers(0, 7))
+    partial = bool(rng.integers(0, 2))
+    nfrac = float(rng.choice([0, 0, 0.002, 0.01]))
+    s = Synth(int(rng.integers(20000, 150000)), d, alleles, k, 1000 + it)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 2500, L, m + 1, 5000 + it)
+    if nfrac:
+        reads = reads.copy(); idx = rng.choice(len(reads), size=max(1, int(len(reads) * nfrac)), replace=False); reads[idx] = ord("N")
+    if it % 7 == 3:   # unitigs with N as well
+        seqs = seqs.copy(); seqs[rng.choice(len(seqs), size=20, replace=False)] = ord("N")
+    g = B.Graph.build(k, seqs, offs); al = B.Aligner(g, 0); o = oracle_py.Oracle(k, seqs, offs)
+    cap = str(int(rng.choice([3, 6, 16, 24])))
+    os.environ["BGR_EXH_FRAME_CAP"] = cap
+    p1, po1, st1 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE, partial=partial)
+    p2, po2, st2 = o.align(reads, roffs, m=m, mode=1, partial=partial)
+    ok = np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2) and al.counters() == o.counters()
+    fracs.append(float(((st1 & 3) == 2).mean()))
+    if not ok:
+        bad += 1
+        print("MISMATCH", it, dict(k=k, d=d, alleles=alleles, L=L, m=m, partial=partial, nfrac=nfrac, cap=cap), flush=True)
+print("configs 60 bad", bad, "aligned fractions: mean %.2f, >0.5 in %d configs, >0.1 in %d" % (np.mean(fracs), sum(f > 0.5 for f in fracs), sum(f > 0.1 for f in fracs)), "%.1fs" % (time.time() - t0))
