@@ -1,6 +1,7 @@
-"""Randomised parity campaign for the exhaustive level search (exh_dp) against the oracle: 60 random (k, site spacing, alleles,
+"""Randomised parity campaign against the oracle (written for the exhaustive level search, exh_dp; also greedy / anchors): 60 random (k, site spacing, alleles,
 read length, m, -i, N rate, level cap) configurations per seed, N in unitigs now and then, small caps to push reads through
-the depth-first and HBM-stack passes.  Run on a GPU box: python tools/fuzz_exhaustive.py [seed].  (Test infrastructure.)"""
+the depth-first and HBM-stack passes.  Run on a GPU box: python tools/fuzz_parity.py [seed] [exhaustive|greedy|anchors].
+(Test infrastructure.)"""
 import os, sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tools")
 import numpy as np
@@ -8,6 +9,7 @@ import bgreat_amd as B, oracle_py
 from synth import Synth
 os.environ["BGR_EXH_DP"] = "1"
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)
+MODE = sys.argv[2] if len(sys.argv) > 2 else "exhaustive"   # exhaustive | greedy | anchors
 bad = 0
 fracs = []
 t0 = time.time()
@@ -26,12 +28,22 @@ for it in range(60):
         reads = reads.copy(); idx = rng.choice(len(reads), size=max(1, int(len(reads) * nfrac)), replace=False); reads[idx] = ord("N")
     if it % 7 == 3:   # unitigs with N as well
         seqs = seqs.copy(); seqs[rng.choice(len(seqs), size=20, replace=False)] = ord("N")
-    g = B.Graph.build(k, seqs, offs); al = B.Aligner(g, 0); o = oracle_py.Oracle(k, seqs, offs)
+    anc = MODE == "anchors"
+    g = B.Graph.build(k, seqs, offs, anchors=anc); al = B.Aligner(g, 0); o = oracle_py.Oracle(k, seqs, offs, anchors=anc)
+    effort = int(rng.choice([0, 1, 2, 2, 3, 8]))
     cap = str(int(rng.choice([3, 6, 16, 24])))
     os.environ["BGR_EXH_FRAME_CAP"] = cap
-    p1, po1, st1 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE, partial=partial)
-    p2, po2, st2 = o.align(reads, roffs, m=m, mode=1, partial=partial)
-    ok = np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2) and al.counters() == o.counters()
+    if MODE == "exhaustive":
+        p1, po1, st1 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE, partial=partial)
+        p2, po2, st2 = o.align(reads, roffs, m=m, mode=1, partial=partial)
+    else:
+        gm, om = (B.MODE_ANCHORS, 2) if anc else (B.MODE_GREEDY, 0)
+        p1, po1, st1 = al.align(reads, roffs, m=m, effort=effort, mode=gm)
+        p2, po2, st2 = o.align(reads, roffs, m=m, effort=effort, mode=om)
+    c1, c2 = al.counters(), o.counters()
+    if MODE != "exhaustive":
+        c1["overlaps"] = c2["overlaps"] = 0
+    ok = np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2) and c1 == c2
     fracs.append(float(((st1 & 3) == 2).mean()))
     if not ok:
         bad += 1
