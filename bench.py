@@ -203,7 +203,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "kernel": ("bgr_align_greedy_kernel", "bgr_align_exhaustive_kernel", "bgr_align_anchors_kernel")[mode], "avg_launch_ms": round(avg_kernel_ms, 4), "launches": launches,
+                "traffic": traffic, "kernel": ("bgr_align_greedy_kernel", "bgr_align_exhaustive_dp_kernel" if al.launch_info().get("level_search") else "bgr_align_exhaustive_kernel", "bgr_align_anchors_kernel")[mode], "avg_launch_ms": round(avg_kernel_ms, 4), "launches": launches,
                 "alg_bytes_per_read": round(alg_bytes_per_read, 1), "reads_per_launch": R}
 
     # ---- CPU baseline: the compiled reference (oracle/_ref/bgreat -t cores) on a bounded sample, N=1 only -------

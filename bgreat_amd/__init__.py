@@ -291,7 +291,8 @@ class Aligner:
     def launch_info(self):
         out = np.zeros(4, dtype=np.uint32)
         _check(lib().bgr_aligner_launch_info(self.h, out.ctypes.data))
-        return {"blocks": int(out[0]), "threads": int(out[1]), "lds_bytes": int(out[2]), "mphf_in_lds": bool(out[3])}
+        return {"blocks": int(out[0]), "threads": int(out[1]), "lds_bytes": int(out[2]), "mphf_in_lds": bool(out[3] & 1),
+                "level_search": bool(out[3] & 2)}
 
     def close(self):
         if self.h:

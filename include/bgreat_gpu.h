@@ -151,8 +151,8 @@ int bgr_aligner_reset_counters(bgr_aligner* a);
  * last reset: number of launches and their summed duration in milliseconds.  Synchronises the stream. */
 int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms);
 int bgr_aligner_reset_kernel_time(bgr_aligner* a);
-/* Launch geometry of the last mapping kernel (for logs): blocks, threads per block, dynamic LDS bytes, and
- * whether the MPHF cascade was staged in LDS. */
+/* Launch geometry of the last mapping kernel (for logs): blocks, threads per block, dynamic LDS bytes, and flags:
+ * bit 0 = the MPHF cascade was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first). */
 int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
 /* Tuning knobs (0 keeps the default): waves per workgroup, workgroups per CU, force MPHF LDS staging
  * (0 auto, 1 off, 2 on). */
