@@ -30,7 +30,10 @@ SYMBOLS = [
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup",
+    "bgr_aligner_set_knob",
 ]
+KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP = 1, 2, 3, 4
+SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
 
 
 class _Borrowed(np.ndarray):
@@ -129,6 +132,7 @@ def lib():
     L.bgr_aligner_reset_kernel_time.argtypes = [vp]
     L.bgr_aligner_launch_info.argtypes = [vp, vp]
     L.bgr_aligner_configure.argtypes = [vp, u32, u32, u32]
+    L.bgr_aligner_set_knob.argtypes = [vp, u32, u64]
     L.bgr_readset_load.argtypes = [C.c_char_p, i32, u32, C.POINTER(vp)]
     L.bgr_readset_load_parallel.argtypes = [C.c_char_p, i32, u32, u32, u64, C.POINTER(vp)]
     L.bgr_align_all.argtypes = [vp, C.POINTER(Params), C.POINTER(RunOptions), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_double)]
@@ -243,6 +247,10 @@ class Aligner:
 
     def configure(self, waves_per_block=0, blocks_per_cu=0, lds_mphf=0):
         _check(lib().bgr_aligner_configure(self.h, waves_per_block, blocks_per_cu, lds_mphf))
+
+    def set_knob(self, knob, value):
+        """Test / diagnostic hooks (KNOB_*), see include/bgreat_gpu.h."""
+        _check(lib().bgr_aligner_set_knob(self.h, knob, int(value)))
 
     def align(self, reads, offsets, m=2, effort=2, mode=MODE_GREEDY, partial=False):
         """-> (paths int32[], path_offsets uint64[n+1], status uint8[n]) in input order."""

@@ -68,6 +68,9 @@ struct bgr_aligner {
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
+    // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
+    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0;
+    uint64_t knob_split_limit = 0;
     int num_cus = 0;
     size_t lds_per_cu = 0;
     hipEvent_t ev_start[kTimerRing], ev_stop[kTimerRing];
@@ -224,9 +227,10 @@ int bgr_graph_adopt_device_blob(int device, const void* dev_blob, uint64_t bytes
     bgr_graph* g = new bgr_graph();
     hipError_t e = hipMemcpy(&g->header, dev_blob, sizeof(BgrBlobHeader), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete g; return fail(BGR_E_HIP, std::string("header D2H: ") + hipGetErrorString(e)); }
-    if (g->header.magic != BGR_MAGIC || g->header.version != BGR_BLOB_VERSION || g->header.blob_bytes != bytes || g->header.n_levels > BGR_MAX_LEVELS) {
+    std::string verr;  // the same checks as for a host blob: the kernels index HBM with these numbers
+    if (!bgr::validate_blob_header(&g->header, bytes, verr)) {
         delete g;
-        return fail(BGR_E_ARG, "bgr_graph_adopt_device_blob: not a graph blob of that size");
+        return fail(BGR_E_ARG, "bgr_graph_adopt_device_blob: " + verr);
     }
     g->dev[device] = {const_cast<void*>(dev_blob), false};
     *out = g;
@@ -287,6 +291,18 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
     return BGR_OK;
 }
 
+int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
+    if (!a) return fail(BGR_E_ARG, "bgr_aligner_set_knob: null aligner");
+    switch (knob) {
+        case BGR_KNOB_EXH_FRAME_CAP: a->knob_frame_cap = (uint32_t)std::min<uint64_t>(value, 1u << 20); return BGR_OK;
+        case BGR_KNOB_EXH_SEARCH: if (value > 2) break; a->knob_search = (uint32_t)value; return BGR_OK;
+        case BGR_KNOB_BATCH_SPLIT_LIMIT: a->knob_split_limit = value; return BGR_OK;
+        case BGR_KNOB_DEBUG_STOP: a->knob_debug_stop = (uint32_t)value; return BGR_OK;
+        default: break;
+    }
+    return fail(BGR_E_ARG, "bgr_aligner_set_knob: unknown knob or value out of range");
+}
+
 int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
                      uint64_t total_bases, uint32_t max_read_len) {
     if (!a || !p) return fail(BGR_E_ARG, "bgr_align_device: null argument");
@@ -306,28 +322,27 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     // so that many waves fit a CU; the rare read whose search goes deeper is listed and mapped by pass 2, which
     // keeps the worst-case search state in HBM.  Reads too long for pass 1's LDS layout all go through pass 2's
     // kernel directly.  Greedy mode is one pass.
-    const char* fc_env = getenv("BGR_EXH_FRAME_CAP");  // tests shrink it to push most reads through pass 2
-    const uint32_t kExhFrameCap = fc_env ? (uint32_t)std::max(2, atoi(fc_env)) : 24;
+    const bool fc_set = a->knob_frame_cap != 0;  // BGR_KNOB_EXH_FRAME_CAP: tests shrink it to push most reads through pass 2
+    const uint32_t kExhFrameCap = fc_set ? std::max<uint32_t>(2, a->knob_frame_cap) : 24;
     uint32_t words = 0, path_cap = 0, frames = 0, frames_deep = 0;
     uint64_t deep_stride = 0;
     const uint32_t lmode = p->mode == BGR_MODE_EXHAUSTIVE ? 1u : 0u;  // anchors mode uses the greedy per-wave layout
     bgr::lds_bytes_per_wave(lmode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep, 0, &deep_stride);
     const uint32_t per_wave_deep = bgr::deep_lds_bytes_per_wave(max_read_len);
     const bool exhaustive = p->mode == BGR_MODE_EXHAUSTIVE;
-    // pass 1 of exhaustive mode runs the level-by-level search (exh_dp) unless BGR_EXH_DP=0 asks for the depth-first one
+    // pass 1 of exhaustive mode runs the level-by-level search (exh_dp) or the depth-first one (BGR_KNOB_EXH_SEARCH forces either).
     // Which one is faster depends on how much the walks branch within the mismatch budget: the depth-first search wins
     // on a graph with an occasional 2-way bubble (about 1.2x), the level search where a read crosses many multi-way
     // sites (3.6x at 4 alleles every ~36 bp, m=5).  Estimate: (extra candidates per record) x (m+1) x (unitigs per read).
-    const char* dp_env = getenv("BGR_EXH_DP");
     bool level_search = false;
     if (exhaustive) {
         const BgrBlobHeader& gh = a->graph->header;
         const double mean_ext = std::max(1.0, (double)gh.total_bases / (2.0 * (double)std::max<uint64_t>(1, gh.n_unitigs)) - (double)(gh.k - 1));
         const double branching = (gh.slot_fill_x100 / 100.0 - 1.0) * (double)(p->max_mismatch + 1) * ((double)max_read_len / mean_ext);
-        level_search = dp_env ? atoi(dp_env) != 0 : branching >= 15.0;
+        level_search = a->knob_search ? a->knob_search == 2 : branching >= 15.0;
     }
     // level search: a level is one unitig of the walk; 16 levels cover 250 bp reads on a graph that branches every ~36 bp
-    const uint32_t level_cap = fc_env ? kExhFrameCap : std::max<uint32_t>(16, (max_read_len / 64) * 4);
+    const uint32_t level_cap = fc_set ? kExhFrameCap : std::max<uint32_t>(16, (max_read_len / 64) * 4);
     const uint32_t per_wave = bgr::lds_bytes_per_wave(level_search ? 2u : lmode, a->dg.k, max_read_len, &words, &path_cap, &frames,
                                                       level_search ? level_cap : kExhFrameCap);
     bool two_pass = exhaustive && (frames < frames_deep || level_search);  // the level search can also overflow on a wide level
@@ -339,14 +354,14 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     // grid of exactly CUs x b workgroups avoids a partial last round.
     const uint32_t cap = std::max<uint32_t>(4, bgr::resident_waves_per_cu(level_search ? 3u : p->mode));  // 3: the level-search kernel
     const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
-    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bgr::LaunchCfg& cfg) -> bool {
+    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bool allow_stage, bgr::LaunchCfg& cfg) -> bool {
         uint32_t waves = 0, bpc = 0;
         bool stage = false;
         auto fits = [&](uint32_t b, uint32_t w, bool st) {
             return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 7) / 8) * 8 : 0) + (uint64_t)w * pw) <= lds_fit;
         };
         if (allow_tuning && (a->cfg_waves || a->cfg_blocks_per_cu)) {  // explicit tuning through bgr_aligner_configure
-            stage = p->mode != BGR_MODE_ANCHORS && (a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true)));
+            stage = allow_stage && p->mode != BGR_MODE_ANCHORS && (a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true)));
             waves = a->cfg_waves ? a->cfg_waves : (stage ? 12 : 4);
             bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
             while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
@@ -354,7 +369,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
         } else {
             uint32_t best_res = 0;
-            if (a->cfg_lds_mphf != 1 && p->mode != BGR_MODE_ANCHORS && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
+            if (allow_stage && a->cfg_lds_mphf != 1 && p->mode != BGR_MODE_ANCHORS && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
                 const uint32_t bs[] = {1, 2, 3, 4, 6};
                 for (uint32_t b : bs) {
                     uint32_t w = std::min<uint32_t>(16, cap / b);
@@ -380,7 +395,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             // one wave per SIMD and workgroup schedules best (8-wave workgroups measured 87 vs 123 Mreads/s at 24 vs 20
             // resident waves): take that grouping unless it gives up more than a fifth of the resident waves
             if (w4 == 4 && b4 * w4 * 5 >= res_n * 4) { res_n = b4 * w4; wn = w4; bn = b4; }
-            if (a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
+            if (!allow_stage || a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
             if (best_res == 0) waves = 0;
         }
         if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return false;
@@ -397,12 +412,12 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     uint32_t frames_mid = 0;
     const uint32_t per_wave_mid = bgr::lds_bytes_per_wave(1u, a->dg.k, max_read_len, nullptr, nullptr, &frames_mid, kExhFrameCap);
     bool mid_pass = false;
-    if (!geometry(per_wave, n_reads, true, cfg)) {
+    if (!geometry(per_wave, n_reads, true, true, cfg)) {
         if (!exhaustive) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
         deep_only = two_pass = true;
     }
     if (two_pass) {
-        if (!geometry(per_wave_deep, n_reads, false, cfg_deep))
+        if (!geometry(per_wave_deep, n_reads, false, false, cfg_deep))  // the HBM-stack kernel never stages the cascade
             return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~160 kb)");
         // the HBM search state is sized for the worst case per wave: bound the grid by a 2 GiB scratch budget
         const uint64_t wave_bytes = deep_stride * 4;
@@ -415,7 +430,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         if (deep_stride > 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: read too long");
         HIP_TRY(a->deep.ensure((uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * wave_bytes));
         if (deep_only) cfg = cfg_deep;
-        mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, cfg_mid);
+        mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, true, cfg_mid);
     }
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
@@ -458,8 +473,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.results = static_cast<uint2*>(a->results.p);
     io.arena = static_cast<int32_t*>(a->arena.p);
     io.cursor = static_cast<uint32_t*>(a->small.p);
-    const char* dbg = getenv("BGR_DEBUG_STOP");
-    bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, dbg ? (uint32_t)atoi(dbg) : 0u};
+    bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, a->knob_debug_stop};
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 16, a->stream));
     HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
@@ -555,8 +569,8 @@ int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, cons
     HIP_TRY(hipSetDevice(a->device));
     const uint64_t base = read_offsets[0], total = read_offsets[n] - base;
     // One launch addresses its path arena with 32 bits: a batch beyond that (~13 M reads of 150 bp) is mapped in pieces.
-    const char* lim_env = getenv("BGR_BATCH_SPLIT_LIMIT");  // tests lower it to walk this path with small inputs
-    const uint64_t lim = lim_env ? std::max<uint64_t>(4096, strtoull(lim_env, nullptr, 10)) : 0xFFFFFFFFull - (256ull << 20);
+    // (BGR_KNOB_BATCH_SPLIT_LIMIT: tests lower the limit to walk this path with small inputs)
+    const uint64_t lim = a->knob_split_limit ? std::max<uint64_t>(4096, a->knob_split_limit) : 0xFFFFFFFFull - (256ull << 20);
     if (n > 1 && (2 * (total + 8 * n) >= lim || n >= 0x7FFFFFFFull)) {
         uint64_t w = 0;
         for (uint64_t i0 = 0; i0 < n;) {

@@ -98,6 +98,7 @@ inline void push(ParsedChunk& out, const Slice& h, const char* s, uint64_t sn, b
         r.s = s;
     }
     out.recs.push_back(r);
+    if (out.track_iters) out.rec_iter.push_back((uint32_t)(out.iters - 1));  // the iteration in progress
     out.seq_bytes += sn;
     out.hdr_bytes += h.n;
 }
@@ -123,6 +124,7 @@ void parse_fasta_chunk(const char* data, uint64_t begin, uint64_t end, uint32_t 
         Slice header, read, inter;  // one getReads() call: its locals start empty
         bool returned = false;
         for (unsigned i = 0; i < kBatch && !returned; ++i) {
+            ++out.iters;
             cur.getline(header);
             // Fast path for the shape nearly every record has: the stream is good, the sequence line ends with a
             // newline and the next line starts with '>'.  Exactly what the general machine below does for it
@@ -209,6 +211,7 @@ bool FastqPlan::parse_chunk(size_t c, ParsedChunk& out) {  // pass 2: chunk c ow
         if (line % 4 == 0) {
             const uint64_t rec = line / 4;
             if (rec >= par_records_) { tail_start_[c] = pos; return false; }
+            ++out.iters;  // record `rec` is this chunk's iteration number out.iters - 1
             const char* h = data + pos;
             const char* hq = static_cast<const char*>(memchr(h, '\n', (size_t)(size - pos)));
             const char* s = hq + 1;  // complete record: all four newlines exist
@@ -262,6 +265,7 @@ static void parse_fastq_range(const char* data, uint64_t begin, uint64_t size, P
     while (!cur.eofbit) {
         Slice header, read;  // one getReads() call: its locals start empty
         for (unsigned i = 0; i < kBatch; ++i) {
+            ++out.iters;
             cur.getline(header);
             cur.getline(read);  // untouched (== previous record's sequence) once the stream has failed
             if (read.n > 2 && valid_chars(read.p, read.n)) push(out, header, read.p, read.n, false, none);

@@ -30,6 +30,13 @@ struct ParsedChunk {
     std::string joined;          // storage of multi-line sequences; recs[].s of those are OFFSETS until fixup()
     std::vector<uint32_t> joined_idx;  // indices of recs whose s is an offset into `joined`
     uint64_t seq_bytes = 0, hdr_bytes = 0;
+    // getReads() loop iterations (aligner.cpp:51,70: one per record ATTEMPT, accepted or not) this chunk consumed, and,
+    // when track_iters is set, the iteration each accepted record came from (chunk-relative).  The reference's
+    // 10000-iteration calls are what its exhaustive worker counts for the periodic stdout block
+    // (alignerExhaustive.cpp:306-316); calls of a file = ceil(iterations / 10000).
+    uint64_t iters = 0;
+    bool track_iters = false;
+    std::vector<uint32_t> rec_iter;
     void fixup() {  // turn offsets into pointers once `joined` no longer grows
         for (uint32_t i : joined_idx) recs[i].s = joined.data() + reinterpret_cast<uintptr_t>(recs[i].s);
         joined_idx.clear();

@@ -5,6 +5,7 @@
 #include "graph_build.h"
 #include "anchor_index.h"
 #include "host_parallel.h"
+#include "file_image.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -182,27 +183,52 @@ void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGr
     dg.units_bytes = (uint32_t)(h->n_units * 16);
 }
 
-bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {
+// Everything the kernels later trust about a blob can be checked on its header alone (section extents, level table):
+// a truncated or foreign blob -- read from a file, or received from a rank running another version -- must be refused
+// here, because the kernels index HBM with these numbers unchecked.
+bool validate_blob_header(const BgrBlobHeader* h, uint64_t bytes, std::string& err) {
     if (bytes < sizeof(BgrBlobHeader)) { err = "blob smaller than its header"; return false; }
-    const BgrBlobHeader* h = static_cast<const BgrBlobHeader*>(blob);
     if (h->magic != BGR_MAGIC || h->version != BGR_BLOB_VERSION) { err = "not a bgreat graph blob (magic/version)"; return false; }
     if (h->blob_bytes != bytes) { err = "blob size does not match its header"; return false; }
     if (h->n_levels > BGR_MAX_LEVELS || h->k < 2 || h->k > 32) { err = "corrupt blob header"; return false; }
-    uint64_t ends[] = {h->off_units + h->n_units * 16, h->off_keys + h->n_keys * 8, h->off_recs + h->n_keys * sizeof(BgrSlot) * 8,
-                       h->off_meta + (h->n_unitigs + 1) * sizeof(BgrUnitigMeta), h->off_seq + h->seq_words * 8,
-                       h->off_fallback + h->n_fallback * 8};
-    for (uint64_t e : ends) if (e > bytes) { err = "blob section outside the blob"; return false; }
+    // off + count * size <= bytes without overflow; sections start behind the header, 256-byte aligned
+    auto inside = [&](uint64_t off, uint64_t count, uint64_t size) {
+        if (off < sizeof(BgrBlobHeader) || off > bytes || (off & 255u)) return false;
+        return count <= (bytes - off) / size;
+    };
+    if (h->n_keys > 0x10000000ull || h->n_unitigs > 0x40000000ull || h->n_units > 0xFFFFFFFFull / 16) { err = "corrupt blob header (counts)"; return false; }
+    if (!inside(h->off_units, h->n_units, 16) || !inside(h->off_keys, h->n_keys, 8) || !inside(h->off_recs, h->n_keys, sizeof(BgrSlot) * 8) ||
+        !inside(h->off_meta, h->n_unitigs + 1, sizeof(BgrUnitigMeta)) || !inside(h->off_seq, h->seq_words, 8)) { err = "blob section outside the blob"; return false; }
+    if (h->n_fallback && !inside(h->off_fallback, h->n_fallback, 8)) { err = "blob section outside the blob"; return false; }
+    if (h->n_placed > h->n_keys || h->n_fallback > h->n_keys || h->n_placed + h->n_fallback != h->n_keys) { err = "corrupt blob header (key counts)"; return false; }
+    if (h->seq_words < 2 || h->total_bases > (h->seq_words - 2) * 32 || h->seq_words * 8 >= (1ull << 32)) { err = "corrupt blob header (sequence store)"; return false; }
+    if (h->has_exc) {  // one bit per base, read 64 bits at a time one word past the addressed one
+        const uint64_t plane_words = (h->total_bases + 63) / 64 + 2;
+        if (!inside(h->off_exc, plane_words, 8) || !inside(h->off_excn, plane_words, 8)) { err = "blob exception planes outside the blob"; return false; }
+    }
+    uint64_t units = 0;
+    for (uint32_t i = 0; i < h->n_levels; ++i) {  // levels tile the unit array in order
+        const BgrLevel& lv = h->levels[i];
+        if (lv.units == 0 || lv.base != units || lv.units > h->n_units - units) { err = "corrupt MPHF level table"; return false; }
+        units += lv.units;
+    }
+    if (units != h->n_units) { err = "corrupt MPHF level table"; return false; }
     if (h->anc_n) {
-        uint64_t aends[] = {h->off_anc_bits + h->anc_words * 8, h->off_anc_ranks + h->anc_rank_words * 8,
-                            h->off_anc_final + h->anc_n_final * 16, h->off_anc_pos + h->anc_n * 8};
-        for (uint64_t e : aends) if (e > bytes) { err = "blob section outside the blob"; return false; }
+        if (!inside(h->off_anc_bits, h->anc_words, 8) || !inside(h->off_anc_ranks, h->anc_rank_words, 8) ||
+            (h->anc_n_final && !inside(h->off_anc_final, h->anc_n_final, 16)) || !inside(h->off_anc_pos, h->anc_n, 8)) { err = "blob section outside the blob"; return false; }
         for (int i = 0; i < BGR_ANC_LEVELS; ++i) {
             const BgrAncLevel& lv = h->anc_levels[i];
-            if (lv.domain == 0 || lv.word_base + 1 + lv.domain / 64 > h->anc_words) { err = "corrupt anchors index"; return false; }
+            if (lv.domain == 0 || lv.word_base > h->anc_words || 1 + lv.domain / 64 > h->anc_words - lv.word_base) { err = "corrupt anchors index"; return false; }
+            if (lv.rank_base > h->anc_rank_words || (1 + lv.domain / 64 + 7) / 8 > h->anc_rank_words - lv.rank_base) { err = "corrupt anchors index"; return false; }
         }
         if (h->anc_active_levels >= BGR_ANC_LEVELS) { err = "corrupt anchors index"; return false; }
     }
     return true;
+}
+
+bool validate_blob(const void* blob, uint64_t bytes, std::string& err) {
+    if (bytes < sizeof(BgrBlobHeader)) { err = "blob smaller than its header"; return false; }
+    return validate_blob_header(static_cast<const BgrBlobHeader*>(blob), bytes, err);
 }
 
 bool ZeroPages::reset(uint64_t words) {
@@ -228,19 +254,13 @@ unsigned build_threads() {
 }
 
 bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& seqs, std::vector<uint64_t>& offs, std::string& err) {
-    int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) { err = "cannot open unitig file " + path; return false; }
-    struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); err = "cannot stat unitig file " + path; return false; }
+    FileImage img;  // mmap, or read-until-EOF for a FIFO / process substitution
+    if (!img.open(path, err)) { err = "unitig file: " + err; return false; }
     seqs.clear();
     offs.assign(1, 0);
-    uint64_t size = (uint64_t)st.st_size;
-    if (size == 0) { close(fd); return true; }
-    void* mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (mp == MAP_FAILED) { err = "cannot map unitig file " + path; return false; }
-    madvise(mp, size, MADV_SEQUENTIAL);
-    const char* d = static_cast<const char*>(mp);
+    const uint64_t size = img.size;
+    if (size == 0) return true;
+    const char* d = img.data;
     // aligner.cpp:415-420: two getline per record (header ignored, a missing line reads as empty), stop at the
     // first sequence shorter than k.  Pass 1 finds the record extents, pass 2 copies them in parallel.
     struct Ext { uint64_t b; uint32_t len; };
@@ -253,7 +273,7 @@ bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& s
         const char* nl2 = sb < size ? static_cast<const char*>(memchr(d + sb, '\n', size - sb)) : nullptr;
         uint64_t se = nl2 ? (uint64_t)(nl2 - d) : size;
         if (se - sb < k) break;
-        if (se - sb > 0xFFFFFFFFull) { munmap(mp, size); err = "unitig longer than 2^32-1 bases"; return false; }
+        if (se - sb > 0xFFFFFFFFull) { err = "unitig longer than 2^32-1 bases"; return false; }
         ext.push_back({sb, (uint32_t)(se - sb)});
         total += se - sb;
         p = se + 1;
@@ -266,7 +286,6 @@ bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& s
     parallel_ranges(build_threads(), ext.size(), [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t i = b; i < e; ++i) memcpy(seqs.data() + offs[i], d + ext[i].b, ext[i].len);
     });
-    munmap(mp, size);
     return true;
 }
 

@@ -58,6 +58,9 @@ uint32_t host_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key);
 // Fill a BgrDeviceGraph whose pointers are `base` + section offsets (base may be a device address).
 void resolve_device_graph(const BgrBlobHeader* h, const void* base, BgrDeviceGraph& dg);
 
+// A blob is trusted only after this: magic/version, every section inside `bytes` (overflow-checked), the MPHF level table
+// tiling the unit array, key counts consistent.  validate_blob_header needs the header only (a blob that lives in HBM).
+bool validate_blob_header(const BgrBlobHeader* h, uint64_t bytes, std::string& err);
 bool validate_blob(const void* blob, uint64_t bytes, std::string& err);
 
 }  // namespace bgr

@@ -33,6 +33,7 @@
 
 #include "../../include/bgreat_gpu.h"
 #include "fastx.h"
+#include "file_image.h"
 
 namespace bgr {
 int set_error(int code, const std::string& msg);  // capi.hip
@@ -43,42 +44,7 @@ namespace {
 using bgr::ParsedChunk;
 using bgr::RecSlice;
 
-struct MappedFile {
-    const char* data = nullptr;
-    uint64_t size = 0;
-    int fd = -1;
-    bool mapped = false;
-    std::vector<char> fallback;
-    bool open(const std::string& path, std::string& err) {
-        fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) { err = "cannot open read file " + path; return false; }
-        struct stat st;
-        if (fstat(fd, &st) != 0) { err = "cannot stat " + path; return false; }
-        size = (uint64_t)st.st_size;
-        if (size == 0) { data = ""; return true; }
-        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (p != MAP_FAILED) {
-            data = static_cast<const char*>(p);
-            mapped = true;
-            madvise(p, size, MADV_SEQUENTIAL);
-            return true;
-        }
-        fallback.resize(size);  // pipes etc.: read it
-        uint64_t got = 0;
-        while (got < size) {
-            ssize_t r = ::read(fd, fallback.data() + got, size - got);
-            if (r <= 0) break;
-            got += (uint64_t)r;
-        }
-        size = got;
-        data = fallback.data();
-        return true;
-    }
-    ~MappedFile() {
-        if (mapped) munmap(const_cast<char*>(data), size);
-        if (fd >= 0) ::close(fd);
-    }
-};
+using MappedFile = bgr::FileImage;  // mmap for regular files, read-until-EOF for FIFOs and other streams
 
 // Persistent workers shared by the parse, gather and format stages (a batch is a few hundred thousand reads: spawning
 // threads per stage and batch cost more than the work).  run(n, fn): fn(0..n-1) on the workers and the calling
@@ -170,8 +136,18 @@ struct Pinned {  // the page-locked buffers of one batch in flight: sources / ta
     HostBuf reads{true}, offs{true}, paths{true}, poffs{true}, status{true};
 };
 
+// Something the reference prints to stdout between two reads of the input order: a file name (aligner.cpp:559,576) or, in
+// exhaustive mode, the block its worker prints after every tenth getReads() call (alignerExhaustive.cpp:306-316).  A
+// mark sits in front of read `pos` of its batch; the ordered writer prints it when it gets there.
+struct Mark {
+    uint64_t pos;
+    int kind;          // 0 = progress block, 1 = line of text
+    std::string text;
+};
+
 struct Batch {
     uint64_t index = 0;
+    std::vector<Mark> marks;                              // ascending pos
     std::shared_ptr<MappedFile> file;                     // keeps header/sequence slices valid
     std::vector<std::unique_ptr<ParsedChunk>> chunks;
     std::vector<std::pair<const ParsedChunk*, std::pair<uint32_t, uint32_t>>> spans;  // chunk, [first, last) records
@@ -223,6 +199,36 @@ private:
     std::deque<T> q_;
     size_t cap_;
     bool closed_ = false;
+};
+
+const uint64_t kRefBatch = 10000;  // records per getReads() call (alignerExhaustive.cpp:270)
+
+// Where the reference's exhaustive worker prints its periodic block at -t 1: `iter` starts at 1 (aligner.h:103) and
+// `iter++ % 10 == 0` is tested after every getReads() call, over all input files, so the block follows calls 10, 20, ...
+// A call is 10000 loop iterations of getReads (record attempts, accepted or not); the parser counts them per chunk.
+struct ProgressMarker {
+    bool on = false;
+    uint64_t calls_before = 0;  // calls made for earlier files
+    uint64_t next_fc = 10;      // the next call of the current file (1-based) that is followed by a block
+    void begin_file() { next_fc = 10 - calls_before % 10; }
+    // Chunk `ch` holds iterations [base_iter, base_iter + ch.iters) of the file: indices (chunk-relative, ascending) of the
+    // records in front of which a block is due; ch.recs.size() = behind its last record.
+    void chunk(const ParsedChunk& ch, uint64_t base_iter, std::vector<uint64_t>& idx_out) {
+        idx_out.clear();
+        while (on && next_fc * kRefBatch < base_iter + ch.iters) {
+            const uint64_t rel = next_fc * kRefBatch - base_iter;  // first iteration of the call after the block
+            idx_out.push_back((uint64_t)(std::lower_bound(ch.rec_iter.begin(), ch.rec_iter.end(), rel) - ch.rec_iter.begin()));
+            next_fc += 10;
+        }
+    }
+    // End of a file of `total_iters` iterations (>= 1: even an empty file costs one call): blocks still due.
+    unsigned end_file(uint64_t total_iters) {
+        const uint64_t calls = (total_iters + kRefBatch - 1) / kRefBatch;
+        unsigned due = 0;
+        while (on && next_fc <= calls) { ++due; next_fc += 10; }
+        calls_before += calls;
+        return due;
+    }
 };
 
 inline char* put_int(char* o, int32_t v) {  // to_string(v) + '.'  (aligner.cpp:600-609)
@@ -463,23 +469,43 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     });
 
     // ---- stage 1: parse + gather -----------------------------------------------------------------------
+    const bool progress_blocks = opt->echo_files && prm->mode == BGR_MODE_EXHAUSTIVE;
     std::thread producer([&]() {
         uint64_t next_index = 0;
         std::string list(reads_csv);
         size_t last = 0;
+        ProgressMarker marker;
+        marker.on = progress_blocks;
+        std::vector<Mark> pending;      // marks waiting for the next batch (they go in front of its first read)
+        std::vector<uint64_t> mark_idx;
+        auto open_batch = [&](std::unique_ptr<Batch>& b, const std::shared_ptr<MappedFile>& mf) {
+            if (!take_batch(b)) return false;
+            b->file = mf;
+            b->marks.clear();
+            for (auto& m : pending) { m.pos = 0; b->marks.push_back(std::move(m)); }
+            pending.clear();
+            return true;
+        };
         auto emit = [&](std::unique_ptr<Batch> b) {  // number the batch in input order and hand it to the gatherer
             b->index = next_index++;
             b->n = b->recs.size();
             return to_gather.push(std::move(b));
         };
-        for (size_t i = 0; i <= list.size() && !failed; ++i) {  // aligner.cpp:552-586: comma-separated list
+        auto drop = [&](std::unique_ptr<Batch> b) {  // an opened batch that got neither reads nor marks
+            b->chunks.clear(); b->file.reset(); b->recs.clear();
+            free_batches.push(std::move(b));
+        };
+        bool ok = true;
+        for (size_t i = 0; i <= list.size() && !failed && ok; ++i) {  // aligner.cpp:552-586: comma-separated list
             if (i != list.size() && list[i] != ',') continue;
             std::string file = list.substr(last, i - last);
             last = i + 1;
-            if (opt->echo_files) std::cout << file << std::endl;  // aligner.cpp:559,576
+            if (opt->echo_files) pending.push_back({0, 1, file});  // aligner.cpp:559,576  cout<<file<<endl
             auto mf = std::make_shared<MappedFile>();
             std::string err;
-            if (!mf->open(file, err)) { fail(BGR_E_IO, err); break; }
+            if (!mf->open(file, err)) { fail(BGR_E_IO, "read file: " + err); break; }
+            marker.begin_file();
+            uint64_t file_iters = 0;  // getReads() iterations of this file handed on so far
             if (opt->fastq) {
                 // FASTQ: newline counts first (they fix which line of a record every chunk starts in), then the chunks
                 // group by group, so that the later stages already work on the first batches while the rest is parsed
@@ -490,15 +516,21 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 plan.finish_counts();
                 us_parse += now_us() - tp0;
                 std::unique_ptr<Batch> b;
-                bool ok = true;
-                auto feed = [&](const std::vector<RecSlice>& rs) {  // slices point into the file image only (no joined storage)
-                    size_t lo = 0;
+                auto feed = [&](const ParsedChunk& ch) {  // slices point into the file image only (no joined storage)
+                    const std::vector<RecSlice>& rs = ch.recs;
+                    marker.chunk(ch, file_iters, mark_idx);
+                    file_iters += ch.iters;
+                    size_t lo = 0, mi = 0;
                     while (lo < rs.size() && ok) {
-                        if (!b) { if (!take_batch(b)) { ok = false; break; } b->file = mf; }
-                        size_t take = std::min<size_t>(rs.size() - lo, (size_t)batch_reads - b->recs.size());
+                        if (!b && !open_batch(b, mf)) { ok = false; break; }
+                        const size_t take = std::min<size_t>(rs.size() - lo, (size_t)batch_reads - b->recs.size());
+                        for (; mi < mark_idx.size() && mark_idx[mi] < lo + take; ++mi) b->marks.push_back({b->recs.size() + (mark_idx[mi] - lo), 0, ""});
                         b->recs.insert(b->recs.end(), rs.begin() + lo, rs.begin() + lo + take);
                         lo += take;
                         if (b->recs.size() >= batch_reads) ok = emit(std::move(b));
+                    }
+                    for (; mi < mark_idx.size(); ++mi) {  // due behind the chunk's last record
+                        if (b) b->marks.push_back({b->recs.size(), 0, ""}); else pending.push_back({0, 0, ""});
                     }
                 };
                 const size_t group = std::max<size_t>(threads, (size_t)((batch_reads * 330) / chunk_bytes));
@@ -506,38 +538,43 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 for (size_t c = 0; c < nc && !tail && ok && !failed; c += group) {
                     const size_t c_end = std::min(nc, c + group);
                     std::vector<ParsedChunk> fq(c_end - c);
+                    for (auto& ch : fq) ch.track_iters = marker.on;
                     std::vector<char> done(c_end - c, 1);
                     tp0 = now_us();
                     pool.run(c_end - c, [&](size_t j) { done[j] = plan.parse_chunk(c + j, fq[j]) ? 1 : 0; });
                     us_parse += now_us() - tp0;
                     for (size_t j = 0; j < fq.size() && ok; ++j) {
-                        feed(fq[j].recs);
+                        feed(fq[j]);
                         if (!done[j]) { tail = true; break; }  // this chunk ran into the sequential tail: nothing after it is parsed here
                     }
                 }
                 if (ok && !failed) {
-                    ParsedChunk last;
+                    ParsedChunk tl;
+                    tl.track_iters = marker.on;
                     tp0 = now_us();
-                    plan.parse_tail(last);
+                    plan.parse_tail(tl);
                     us_parse += now_us() - tp0;
-                    feed(last.recs);
+                    feed(tl);
                 }
-                if (ok && b && !b->recs.empty()) ok = emit(std::move(b));
-                else if (b) { b->file.reset(); b->recs.clear(); free_batches.push(std::move(b)); }
-                if (!ok) break;
+                for (unsigned d = marker.end_file(std::max<uint64_t>(1, file_iters)); d; --d) {
+                    if (b) b->marks.push_back({b->recs.size(), 0, ""}); else pending.push_back({0, 0, ""});
+                }
+                if (b) {
+                    if (ok && (!b->recs.empty() || !b->marks.empty())) ok = emit(std::move(b));
+                    else drop(std::move(b));
+                }
                 continue;
             }
             std::vector<uint64_t> starts = bgr::split_fasta(mf->data, mf->size, chunk_bytes);
             size_t c = 0;
-            while (c < starts.size() && !failed) {
+            while (c < starts.size() && !failed && ok) {
                 // as many chunks as it takes to reach ~batch_reads (estimated from bytes), at least `threads`
                 size_t group = std::max<size_t>(threads, (size_t)((batch_reads * 170) / chunk_bytes));
                 size_t c_end = std::min(starts.size(), c + group);
                 std::unique_ptr<Batch> b;
-                if (!take_batch(b)) break;
-                b->file = mf;
+                if (!open_batch(b, mf)) { ok = false; break; }
                 b->chunks.resize(c_end - c);
-                for (auto& ch : b->chunks) ch = std::make_unique<ParsedChunk>();
+                for (auto& ch : b->chunks) { ch = std::make_unique<ParsedChunk>(); ch->track_iters = marker.on; }
                 Batch* bp = b.get();
                 const uint64_t tp0 = now_us();
                 pool.run(c_end - c, [&](size_t j) {
@@ -547,46 +584,61 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 size_t total = 0;
                 for (auto& ch : b->chunks) total += ch->recs.size();
                 b->recs.reserve(total);
-                for (auto& ch : b->chunks) b->recs.insert(b->recs.end(), ch->recs.begin(), ch->recs.end());
+                for (auto& ch : b->chunks) {
+                    marker.chunk(*ch, file_iters, mark_idx);
+                    file_iters += ch->iters;
+                    for (uint64_t mi : mark_idx) b->marks.push_back({b->recs.size() + mi, 0, ""});
+                    b->recs.insert(b->recs.end(), ch->recs.begin(), ch->recs.end());
+                }
                 us_parse += now_us() - tp0;
                 c = c_end;
-                if (b->recs.empty()) { b->chunks.clear(); b->file.reset(); free_batches.push(std::move(b)); continue; }
-                if (!emit(std::move(b))) break;
+                if (c >= starts.size())
+                    for (unsigned d = marker.end_file(std::max<uint64_t>(1, file_iters)); d; --d) b->marks.push_back({b->recs.size(), 0, ""});
+                if (b->recs.empty() && b->marks.empty()) { drop(std::move(b)); continue; }
+                ok = emit(std::move(b));
             }
+        }
+        if (ok && !failed && !pending.empty()) {  // what is printed after the last read: an empty batch carries it to the writer
+            std::unique_ptr<Batch> b;
+            if (open_batch(b, nullptr)) emit(std::move(b));
         }
         to_gather.close();
     });
 
     // ---- stage 1b: gather the sequences of a batch into (pooled) pinned memory ---------------------------
     std::thread gatherer([&]() {
-        auto gather = [&](std::unique_ptr<Batch> b) {
+        // false = the batch could not be staged (the error is recorded); it still travels on, so that the writer sees every
+        // index and recycles every batch (a dropped batch would leave the producer waiting for a free one for ever)
+        auto gather = [&](Batch& b) {
             uint64_t bases = 0;
-            if (!free_pins.pop(b->pin)) return false;
+            if (!free_pins.pop(b.pin)) { fail(BGR_E_INTERNAL, "pinned buffer pool closed"); return false; }
             const uint64_t tg0 = now_us();
-            if (!b->pin->offs.ensure((b->n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            uint64_t* offs = static_cast<uint64_t*>(b->pin->offs.p);
-            for (uint64_t i = 0; i < b->n; ++i) { offs[i] = bases; bases += b->recs[i].sl; }
-            offs[b->n] = bases;
-            b->bases = bases;
-            b->path_cap = 8 * b->n + 4096;  // typical paths are a handful of ints; the worker retries with the full bound if not
-            if (!b->pin->reads.ensure(bases + 16) || !b->pin->paths.ensure(b->path_cap * 4) || !b->pin->poffs.ensure((b->n + 1) * 8) ||
-                !b->pin->status.ensure(b->n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            char* dst = static_cast<char*>(b->pin->reads.p);
+            if (!b.pin->offs.ensure((b.n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            uint64_t* offs = static_cast<uint64_t*>(b.pin->offs.p);
+            for (uint64_t i = 0; i < b.n; ++i) { offs[i] = bases; bases += b.recs[i].sl; }
+            offs[b.n] = bases;
+            b.bases = bases;
+            // typical paths are a handful of ints; the worker fetches again with the full bound if not.  A batch large enough
+            // for bgr_align_batch to map it in pieces gets the full bound at once (there is no single result to fetch again).
+            b.path_cap = 2 * (bases + 8 * b.n) >= (1ull << 31) ? bases + 8 * b.n + 8 : 8 * b.n + 4096;
+            if (!b.pin->reads.ensure(bases + 16) || !b.pin->paths.ensure(b.path_cap * 4) || !b.pin->poffs.ensure((b.n + 1) * 8) ||
+                !b.pin->status.ensure(b.n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            char* dst = static_cast<char*>(b.pin->reads.p);
             us_alloc += now_us() - tg0;
             const uint64_t tg1 = now_us();
-            const uint64_t per = (b->n + threads - 1) / threads;
-            Batch* bp = b.get();
+            const uint64_t per = (b.n + threads - 1) / threads;
+            Batch* bp = &b;
             pool.run(threads, [&](size_t t) {
                 uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
                 for (uint64_t i = lo; i < hi; ++i) memcpy(dst + offs[i], bp->recs[i].s, bp->recs[i].sl);
             });
             us_gather += now_us() - tg1;
-            return to_gpu.push(std::move(b));
+            return true;
         };
         std::unique_ptr<Batch> b;
         while (to_gather.pop(b)) {
-            if (failed) { to_out.push(std::move(b)); continue; }
-            if (!gather(std::move(b))) break;
+            if (failed || !gather(*b)) { if (!to_out.push(std::move(b))) break; continue; }
+            if (!to_gpu.push(std::move(b))) break;
         }
         to_gather.close();  // (after a failure: unblock the producer)
         to_gpu.close();
@@ -652,6 +704,31 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         std::unique_ptr<Batch> b;
         std::vector<char> okv(threads, 1);
         std::vector<std::string> bugv(threads);
+        // aligner.h:68 counters as the reference's single worker has them when it prints (atomic<uint>: 32-bit wrap-around)
+        uint32_t c_reads = 0, c_aligned = 0, c_failed = 0, c_noov = 0, c_overlaps = 0;
+        const uint32_t K1 = gi.k - 1;
+        auto count_reads = [&](const Batch& bt, uint64_t lo, uint64_t hi) {  // exhaustive mode: alignerExhaustive.cpp:35-58
+            const uint8_t* st = static_cast<const uint8_t*>(bt.pin->status.p);
+            for (uint64_t i = lo; i < hi; ++i) {
+                ++c_reads;
+                if ((st[i] & BGR_ST_MASK) == BGR_ST_ALIGNED) ++c_aligned; else ++c_failed;
+                const uint32_t L = bt.recs[i].sl;
+                c_overlaps += L >= K1 ? L - K1 + 1 : 1;  // overlaps += listOverlap.size(): every position (aligner.cpp:318-342)
+            }
+        };
+        auto print_block = [&]() {  // alignerExhaustive.cpp:306-316
+            const uint32_t got = c_aligned + c_failed;
+            std::cout << "Read : " << c_reads << std::endl;
+            std::cout << "No Overlap : " << c_noov << " Percent : " << (100 * float(c_noov)) / c_reads << std::endl;
+            std::cout << "Got Overlap : " << got << " Percent : " << (100 * float(got)) / c_reads << std::endl;
+            std::cout << "Overlap and Aligned : " << c_aligned << " Percent : " << (100 * float(c_aligned)) / got << std::endl;
+            std::cout << "Overlap but no aligne: " << c_failed << " Percent : " << (100 * float(c_failed)) / got << std::endl;
+            const auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count();
+            std::cout << "Reads/seconds : " << c_reads / (uint64_t)(secs + 1) << std::endl;
+            // (the reference divides by zero here -- and dies -- when no read has been counted yet)
+            std::cout << "Overlap per reads : " << (got ? c_overlaps / got : 0u) << std::endl;
+            std::cout << std::endl;
+        };
         while (to_out.pop(b)) {
             pending[b->index] = std::move(b);
             while (!pending.empty() && pending.begin()->first == want) {
@@ -660,9 +737,17 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 ++want;
                 struct Recycle {  // hand the batch (and its pinned buffers) back to the producer
                     Channel<std::unique_ptr<Batch>>& ch; Channel<std::unique_ptr<Pinned>>& pins; std::unique_ptr<Batch>& b;
-                    ~Recycle() { if (b->pin) pins.push(std::move(b->pin)); b->recs.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
+                    ~Recycle() { if (b->pin) pins.push(std::move(b->pin)); b->recs.clear(); b->marks.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
                 } recycle{free_batches, free_pins, cur};
-                if ((failed && !stop_writing_after_this) || !writes || wrote_last) continue;
+                if (!failed) {  // what the reference prints between reads, in input order
+                    uint64_t at = 0;
+                    for (const Mark& mk : cur->marks) {
+                        if (progress_blocks) { count_reads(*cur, at, mk.pos); at = mk.pos; }
+                        if (mk.kind == 1) std::cout << mk.text << std::endl; else print_block();
+                    }
+                    if (progress_blocks) count_reads(*cur, at, cur->n);
+                }
+                if ((failed && !stop_writing_after_this) || !writes || wrote_last || cur->n == 0) continue;
                 std::unique_ptr<OutBufs> o;
                 if (!free_bufs.pop(o)) continue;
                 std::vector<std::string>&pb = o->pb, &nb = o->nb, &ob = o->ob;

@@ -158,6 +158,18 @@ int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
  * (0 auto, 1 off, 2 on). */
 int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blocks_per_cu, uint32_t lds_mphf);
 
+/* Test / diagnostic hooks, set once per aligner (they used to be environment variables read on every launch):
+ *   BGR_KNOB_EXH_FRAME_CAP     exhaustive pass 1: search frames (depth-first) or levels (level search) per wave, 0 = default;
+ *                              a tiny cap pushes most reads through the later passes
+ *   BGR_KNOB_EXH_SEARCH        0 = choose per graph and budget, 1 = depth-first search, 2 = level search
+ *   BGR_KNOB_BATCH_SPLIT_LIMIT bgr_align_batch maps a batch in pieces beyond this many path-arena ints, 0 = default (~2^32)
+ *   BGR_KNOB_DEBUG_STOP        diagnostic builds (-DBGR_PHASE_TIMING) only: 1 = stop after packing, 2 = after the position scan */
+#define BGR_KNOB_EXH_FRAME_CAP 1u
+#define BGR_KNOB_EXH_SEARCH 2u
+#define BGR_KNOB_BATCH_SPLIT_LIMIT 3u
+#define BGR_KNOB_DEBUG_STOP 4u
+int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value);
+
 /* ---- read files (host) ----------------------------------------------------------------------------
  * Replaces Aligner::getReads (aligner.cpp:46-117) for a whole file: the accepted (header, read) records
  * in file order with the reference's drop rules (characters outside ACGTN, size <= 2, FASTA size <= k,

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iostream>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -113,6 +114,82 @@ int main(int argc, char** argv) {
             }
         }
         printf("%s ok\n", c.file);
+    }
+    // ---- what the reference prints while it maps (file names; in exhaustive mode the block after every tenth getReads()
+    // call, alignerExhaustive.cpp:306-316): it must come out of the ordered writer between the right reads, whatever the
+    // batch and chunk sizes.  Expected text: the sequential parser's iteration count per record, walked in input order.
+    {
+        const char* al = "ACGT";
+        for (int variant = 0; variant < 2; ++variant) {  // FASTA with dropped records, FASTQ
+            const bool fq = variant == 1;
+            const std::string f1 = tmp + (fq ? "/prog1.fq" : "/prog1.fa"), f2 = tmp + (fq ? "/prog2.fq" : "/prog2.fa");
+            for (int fi = 0; fi < 2; ++fi) {
+                std::ofstream o(fi ? f2 : f1, std::ios::binary);
+                const int n = fi ? 61000 : 137003;   // calls: 14 + 7 (FASTA), so blocks fall after calls 10 and 20 (the 6th of file 2)
+                for (int i = 0; i < n; ++i) {
+                    std::string r;
+                    for (int j = 0; j < 8 + i % 5; ++j) r += al[(i * 5 + j * 11 + (j * j) % 7) & 3];
+                    if (i % 97 == 5) r[3] = 'x';     // dropped: still one getReads() iteration
+                    if (fq) o << "@q" << i << "\n" << r << "\n+\n" << std::string(r.size(), 'I') << "\n";
+                    else o << ">r" << i << "\n" << r << "\n";
+                }
+            }
+            std::string expect;
+            {
+                uint32_t reads = 0, alig = 0, fail_ = 0, ov = 0;
+                uint64_t calls_before = 0;
+                bgr_graph g{5u};
+                auto block = [&]() {
+                    std::ostringstream b;
+                    const uint32_t got = alig + fail_;
+                    b << "Read : " << reads << "\nNo Overlap : 0 Percent : " << (100 * float(0)) / reads << "\nGot Overlap : " << got << " Percent : " << (100 * float(got)) / reads
+                      << "\nOverlap and Aligned : " << alig << " Percent : " << (100 * float(alig)) / got << "\nOverlap but no aligne: " << fail_ << " Percent : " << (100 * float(fail_)) / got
+                      << "\nReads/seconds : X\nOverlap per reads : " << (got ? ov / got : 0u) << "\n\n";
+                    expect += b.str();
+                };
+                for (const std::string& f : {f1, f2}) {
+                    expect += f + "\n";
+                    const std::string d = slurp(f);
+                    bgr::ParsedChunk pc;
+                    pc.track_iters = true;
+                    if (fq) bgr::parse_fastq_image(d.data(), d.size(), pc); else bgr::parse_fasta_chunk(d.data(), 0, d.size(), g.k, pc);
+                    const uint64_t calls = (pc.iters + 9999) / 10000;
+                    size_t r = 0;
+                    for (uint64_t c = 1; c <= calls; ++c) {  // call c of this file covers iterations [(c-1)*10000, c*10000)
+                        for (; r < pc.recs.size() && pc.rec_iter[r] < c * 10000; ++r) {
+                            ++reads;
+                            if (pc.recs[r].sl & 1) ++alig; else ++fail_;
+                            ov += pc.recs[r].sl >= g.k - 1 ? pc.recs[r].sl - (g.k - 1) + 1 : 1;
+                        }
+                        if ((calls_before + c) % 10 == 0) block();
+                    }
+                    calls_before += calls;
+                }
+            }
+            for (unsigned threads : {1u, 5u}) {
+                for (uint64_t batch : {911ull, 20000ull, 1000000ull}) {
+                    bgr_graph g{5u};
+                    bgr_params prm = {BGR_MODE_EXHAUSTIVE, 2, 2, 0};
+                    bgr_run_options opt;
+                    memset(&opt, 0, sizeof(opt));
+                    opt.n_gpus = 2; opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 30000; opt.fastq = fq; opt.echo_files = 1;
+                    uint64_t tot[5]; double secs;
+                    std::ostringstream cap;
+                    std::streambuf* old = std::cout.rdbuf(cap.rdbuf());
+                    const int rc = bgr_align_all(&g, &prm, &opt, (f1 + "," + f2).c_str(), (tmp + "/p").c_str(), (tmp + "/n").c_str(), tot, &secs);
+                    std::cout.rdbuf(old);
+                    if (rc != BGR_OK) { printf("FAIL progress run: %s\n", bgr_last_error()); return 1; }
+                    std::string got;  // blank the time-dependent line
+                    { std::istringstream ss(cap.str()); std::string line;
+                      while (std::getline(ss, line)) got += (line.rfind("Reads/seconds : ", 0) == 0 ? std::string("Reads/seconds : X") : line) + "\n"; }
+                    if (got != expect) {
+                        printf("FAIL progress blocks %s threads=%u batch=%llu\n--- got\n%s--- expected\n%s", fq ? "fastq" : "fasta", threads, (unsigned long long)batch, got.c_str(), expect.c_str());
+                        return 1;
+                    }
+                }
+            }
+        }
+        printf("progress blocks ok\n");
     }
     return 0;
 }

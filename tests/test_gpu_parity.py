@@ -57,12 +57,10 @@ def graphs():
 
 
 @pytest.mark.parametrize("case", GREEDY + EXH, ids=["%02d-%s" % (c["id"], c["group"]) for c in GREEDY + EXH])
-def test_gpu_matches_reference_golden(case, graphs, monkeypatch):
+def test_gpu_matches_reference_golden(case, graphs):
     """Greedy cases: bytes of the unmodified reference.  Exhaustive (-b) cases: counters of the unmodified reference,
     bytes of what it computes but does not write (tests/golden/README.md)."""
     args = case["args"]
-    if "-b" in args:   # alternate between the two formulations of the exhaustive search over the cases
-        monkeypatch.setenv("BGR_EXH_DP", str(case["id"] & 1))
     k = int(_argval(args, "-k", "30"))
     m = int(_argval(args, "-m", "2"))
     e = int(_argval(args, "-e", "2"))
@@ -70,6 +68,8 @@ def test_gpu_matches_reference_golden(case, graphs, monkeypatch):
     mode = B.MODE_EXHAUSTIVE if "-b" in args else (B.MODE_ANCHORS if "-G" in args else B.MODE_GREEDY)   # -b wins over -G
     g, al = graphs(os.path.join(GOLD, _argval(args, "-g", None)), k, mode == B.MODE_ANCHORS)
     al.reset_counters()
+    # alternate between the two formulations of the exhaustive search over the -b cases
+    al.set_knob(B.KNOB_EXH_SEARCH, (B.SEARCH_BY_LEVEL if case["id"] & 1 else B.SEARCH_DEPTH_FIRST) if "-b" in args else B.SEARCH_AUTO)
     pbytes, nbytes = b"", b""
     for f in _argval(args, "-r", None).split(","):
         reads, roffs, heads, hoffs = B.load_reads(os.path.join(GOLD, f), k, fastq)
@@ -234,13 +234,79 @@ def test_cli_exhaustive_writes_nothing_unless_asked():
     check_against_golden(case, out, paths, na)
 
 
+@pytest.mark.parametrize("fastq", [False, True])
+def test_cli_exhaustive_stdout_against_reference_binary(oracle_bins, fastq, tmp_path):
+    """-b: stdout is all the reference shows, including the block its worker prints after every tenth
+    getReads() call (alignerExhaustive.cpp:306-316; `iter` starts at 1, aligner.h:103, and runs on over the files).  At
+    -t 1 every line of it but Reads/seconds is deterministic: the CLI prints the same lines in the same places, whatever
+    its threads, batch and chunk sizes.  A call is 10 000 record ATTEMPTS, so the files carry dropped records too."""
+    ref = oracle_bins["ref"]
+    if not ref:
+        pytest.skip("needs the compiled reference (oracle/_ref/bgreat)")
+    s = Synth(200000, 100, 3, 31, 808)
+    s.write_unitigs(str(tmp_path / "u.fa"))
+    rng = np.random.default_rng(5 + fastq)
+    files = []
+    for fi, n in enumerate((127003, 40000, 36000)):   # calls 13 + 4 + 4: blocks after calls 10 and 20 (file 3), none at a file end
+        good, goffs = s.reads(fi * 200000, n, 64, 3, 809 + fi)
+        out = []
+        for i in range(n):
+            rd = good[int(goffs[i]):int(goffs[i + 1])].tobytes()
+            r = int(rng.integers(0, 50))
+            if r == 0:
+                rd = rd[:20].lower() + rd[20:]                 # dropped (characters), still an iteration
+            elif r == 1 and not fastq:
+                rd = rd[:25]                                   # FASTA: dropped (size <= k)
+            elif r == 2 and not fastq:
+                rd = rd[:30] + b"\n" + rd[30:]                 # multi-line record: one iteration
+            out.append((b"@" if fastq else b">") + b"f%d_%d\n" % (fi, i) + rd + (b"\n+\n" + b"I" * len(rd) if fastq else b"") + b"\n")
+        f = str(tmp_path / ("p%d.%s" % (fi, "fq" if fastq else "fa")))
+        open(f, "wb").write(b"".join(out))
+        files.append(f)
+    args = ["-r", ",".join(files), "-k", "31", "-g", str(tmp_path / "u.fa"), "-m", "3", "-b"] + (["-q"] if fastq else [])
+    o1, p1, n1 = run_cli(ref, args + ["-t", "1"])
+    def timeless(o):
+        return [ln for ln in o.splitlines() if "seconds" not in ln]
+    assert sum(ln.startswith("Read : ") for ln in o1.splitlines()) == 2
+    for extra in (["-t", "6", "--batch", "7001", "--chunk-bytes", "40000"], ["-t", "2"]):
+        o2, p2, n2 = run_cli(B.CLI_PATH, args + extra)
+        assert timeless(o1) == timeless(o2), extra
+        assert p2 == b"" and n2 == b""
+
+
+def test_cli_reads_and_unitigs_through_fifos(tmp_path):
+    """Inputs that are not regular files (FIFOs, process substitution: st_size is 0 and mmap is impossible) are read to
+    the end like the reference's ifstream does; same bytes as from the files."""
+    import threading
+    s = Synth(150000, 90, 2, 31, 31)
+    ufa, rfa = str(tmp_path / "u.fa"), str(tmp_path / "r.fa")
+    s.write_unitigs(ufa)
+    s.write_reads(rfa, 0, 30000, 120, 2, 32)
+    args = ["-k", "31", "-m", "2", "-t", "3"]
+    o1, p1, n1 = run_cli(B.CLI_PATH, ["-r", rfa, "-g", ufa] + args)
+    ufifo, rfifo = str(tmp_path / "u.fifo"), str(tmp_path / "r.fifo")
+    os.mkfifo(ufifo)
+    os.mkfifo(rfifo)
+    def feed(src, dst):
+        with open(dst, "wb") as o, open(src, "rb") as i:
+            o.write(i.read())
+    ts = [threading.Thread(target=feed, args=(ufa, ufifo)), threading.Thread(target=feed, args=(rfa, rfifo))]
+    for t in ts:
+        t.start()
+    o2, p2, n2 = run_cli(B.CLI_PATH, ["-r", rfifo, "-g", ufifo] + args)
+    for t in ts:
+        t.join()
+    from util import parse_counters
+    assert parse_counters(o1) == parse_counters(o2) and parse_counters(o1)["aligned"] > 20000
+    assert p1 == p2 and n1 == n2
+
+
 @pytest.mark.parametrize("seed,k,L,m,partial,nfrac,d,alleles", [
     (1, 31, 150, 2, False, 0.0, 75, 2), (2, 31, 250, 5, False, 0.0, 40, 4), (3, 31, 200, 5, True, 0.002, 45, 4),
     (4, 21, 120, 3, False, 0.004, 50, 3), (5, 8, 60, 4, False, 0.0, 20, 4), (6, 31, 150, 0, True, 0.0, 140, 2), (7, 32, 100, 6, False, 0.01, 60, 4)])
 @pytest.mark.parametrize("search", ["depth-first", "by-level"])
-def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, alleles, search, monkeypatch):
+def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, alleles, search):
     """Both formulations of the exhaustive search (exh_search, exh_dp; the library picks one per graph and budget)."""
-    monkeypatch.setenv("BGR_EXH_DP", "1" if search == "by-level" else "0")
     s = Synth(100000, d, alleles, k, 9000 + seed)
     seqs, offs = s.unitigs()
     reads, roffs = s.reads(0, 8000, L, m + 1, 9500 + seed)
@@ -248,6 +314,7 @@ def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, 
         reads = _inject_n(reads, np.random.default_rng(seed), nfrac)
     g = B.Graph.build(k, seqs, offs)
     al = B.Aligner(g, 0)
+    al.set_knob(B.KNOB_EXH_SEARCH, B.SEARCH_BY_LEVEL if search == "by-level" else B.SEARCH_DEPTH_FIRST)
     o = oracle_py.Oracle(k, seqs, offs)
     p1, po1, st1 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE, partial=partial)
     p2, po2, st2 = o.align(reads, roffs, m=m, mode=1, partial=partial)
@@ -259,16 +326,16 @@ def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, 
 
 @pytest.mark.parametrize("cap", ["2", "3", "5"])
 @pytest.mark.parametrize("search", ["depth-first", "by-level"])
-def test_exhaustive_deep_stack_second_pass(cap, search, monkeypatch):
+def test_exhaustive_deep_stack_second_pass(cap, search):
     """Pass 1 of the exhaustive kernel has a shallow stack (depth-first search) or few levels (level search); reads that
     need more go through pass 2.  With a tiny cap nearly every mapped read takes the second pass; results must not change."""
-    monkeypatch.setenv("BGR_EXH_FRAME_CAP", cap)
-    monkeypatch.setenv("BGR_EXH_DP", "1" if search == "by-level" else "0")
     s = Synth(60000, 30, 4, 12, 606)
     seqs, offs = s.unitigs()
     reads, roffs = s.reads(0, 6000, 120, 4, 607)
     g = B.Graph.build(12, seqs, offs)
     al = B.Aligner(g, 0)
+    al.set_knob(B.KNOB_EXH_FRAME_CAP, int(cap))
+    al.set_knob(B.KNOB_EXH_SEARCH, B.SEARCH_BY_LEVEL if search == "by-level" else B.SEARCH_DEPTH_FIRST)
     o = oracle_py.Oracle(12, seqs, offs)
     p1, po1, st1 = al.align(reads, roffs, m=3, mode=B.MODE_EXHAUSTIVE)
     p2, po2, st2 = o.align(reads, roffs, m=3, mode=1)
@@ -405,7 +472,7 @@ def test_full_size_batch_properties():
         assert np.array_equal(p1[int(po1[i]): int(po1[i + 1])], ps[int(pos[j]): int(pos[j + 1])])
 
 
-def test_oversized_batch_is_mapped_in_pieces(monkeypatch):
+def test_oversized_batch_is_mapped_in_pieces():
     """bgr_align_batch splits a batch whose path arena would not fit 32-bit addressing; with the limit lowered the split
     path runs on a small batch and must give the rows of the unsplit call."""
     s = Synth(300000, 90, 2, 31, 4)
@@ -414,11 +481,11 @@ def test_oversized_batch_is_mapped_in_pieces(monkeypatch):
     reads, roffs = s.reads(0, 50000, 150, 2, 5)
     p1, po1, st1 = al.align(reads, roffs)
     al.reset_counters()
-    monkeypatch.setenv("BGR_BATCH_SPLIT_LIMIT", str(3_000_000))   # pieces of ~4 600 reads
+    al.set_knob(B.KNOB_BATCH_SPLIT_LIMIT, 3_000_000)   # pieces of ~4 600 reads
     p2, po2, st2 = al.align(reads, roffs)
     assert np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2)
     assert al.counters()["reads"] == 50000
-    monkeypatch.setenv("BGR_BATCH_SPLIT_LIMIT", "4096")           # one read per piece
+    al.set_knob(B.KNOB_BATCH_SPLIT_LIMIT, 4096)        # one read per piece
     p3, po3, st3 = al.align(reads[: 300 * 150], roffs[:301])
     assert np.array_equal(p3, p1[: int(po1[300])]) and np.array_equal(po3, po1[:301]) and np.array_equal(st3, st1[:300])
 

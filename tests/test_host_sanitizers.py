@@ -30,7 +30,8 @@ def test_host_parser_and_index_builder_are_sanitizer_clean(flags, tmp_path):
 def test_host_pipeline_is_sanitizer_clean(flags, tmp_path):
     """bgr_align_all's threads (producer, gatherer, 2 stream workers per device x 2 devices, formatter, writers, worker
     pool, page-locked ring) over golden files with 1..100000-read batches, against a stand-in for the GPU calls
-    (tests/sanitize_pipeline.cpp): every record once, in input order, in the right file."""
+    (tests/sanitize_pipeline.cpp): every record once, in input order, in the right file; and what the reference prints to
+    stdout while it maps (file names, the exhaustive worker's periodic block) between the right reads."""
     exe = str(tmp_path / "sanitize_pipeline")
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", flags, "-I" + SRC, "-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "sanitize_pipeline.cpp"), os.path.join(SRC, "pipeline.cpp"), os.path.join(SRC, "fastx.cpp"),
@@ -41,5 +42,5 @@ def test_host_pipeline_is_sanitizer_clean(flags, tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
     p = subprocess.run([exe, GOLD, str(out)], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert p.stdout.count(" ok") == 5 and "FAIL" not in p.stdout
+    assert p.stdout.count(" ok") == 6 and "FAIL" not in p.stdout
     assert "ERROR: " not in p.stderr and "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-4000:]

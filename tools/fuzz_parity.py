@@ -1,13 +1,14 @@
 """Randomised parity campaign against the oracle (written for the exhaustive level search, exh_dp; also greedy / anchors): 60 random (k, site spacing, alleles,
 read length, m, -i, N rate, level cap) configurations per seed, N in unitigs now and then, small caps to push reads through
-the depth-first and HBM-stack passes.  Run on a GPU box: python tools/fuzz_parity.py [seed] [exhaustive|greedy|anchors].
+the depth-first and HBM-stack passes.  Run on a GPU box: python tools/fuzz_parity.py [seed] [exhaustive|greedy|anchors] [by-level|depth-first|auto].
 (Test infrastructure.)"""
 import os, sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tools")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import bgreat_amd as B, oracle_py
 from synth import Synth
-os.environ["BGR_EXH_DP"] = "1"
+SEARCH = {"by-level": 2, "depth-first": 1, "auto": 0}[sys.argv[3] if len(sys.argv) > 3 else "by-level"]
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)
 MODE = sys.argv[2] if len(sys.argv) > 2 else "exhaustive"   # exhaustive | greedy | anchors
 bad = 0
@@ -31,8 +32,9 @@ for it in range(60):
     anc = MODE == "anchors"
     g = B.Graph.build(k, seqs, offs, anchors=anc); al = B.Aligner(g, 0); o = oracle_py.Oracle(k, seqs, offs, anchors=anc)
     effort = int(rng.choice([0, 1, 2, 2, 3, 8]))
-    cap = str(int(rng.choice([3, 6, 16, 24])))
-    os.environ["BGR_EXH_FRAME_CAP"] = cap
+    cap = int(rng.choice([3, 6, 16, 24]))
+    al.set_knob(B.KNOB_EXH_FRAME_CAP, cap)
+    al.set_knob(B.KNOB_EXH_SEARCH, SEARCH)
     if MODE == "exhaustive":
         p1, po1, st1 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE, partial=partial)
         p2, po2, st2 = o.align(reads, roffs, m=m, mode=1, partial=partial)

@@ -1,59 +1,119 @@
-// tools/ubench/valu_rates.hip -- issue cost of the integer VALU ops the mapping kernels lean on (gfx950).
-// One wave per SIMD would under-fill the pipe, so 8 waves per SIMD run the same dependent-free streams;
-// prints cycles per wave-instruction per SIMD.   hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
+// tools/ubench/valu_rates.hip -- issue cost of the VALU instructions the mapping kernels lean on (gfx950), as a function
+// of how many waves share a SIMD.  Inline assembly, so the instruction stream is exactly what is named: every wave runs
+// REP iterations of 32 instructions of ONE kind over 8 independent register chains (no dependent back-to-back pair closer
+// than 8 instructions).  Prints cycles per wave-instruction per SIMD = (event time x 2.4 GHz) / (instructions per SIMD).
+//   hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates && ./valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#define REP 4096
+#define REP 2048
+#define R4(x) x x x x
+// 8 chains on 32-bit registers: ins dst, src0, src1 with dst = chain register
+#define BODY32(ins) \
+    asm volatile(R4(ins " %0, %8, %0\n" ins " %1, %8, %1\n" ins " %2, %8, %2\n" ins " %3, %8, %3\n" \
+                    ins " %4, %8, %4\n" ins " %5, %8, %5\n" ins " %6, %8, %6\n" ins " %7, %8, %7\n") \
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(s))
+#define BODY32_3(ins) /* three-operand: dst = f(chain, s, chain) */ \
+    asm volatile(R4(ins " %0, %0, %8, %0\n" ins " %1, %1, %8, %1\n" ins " %2, %2, %8, %2\n" ins " %3, %3, %8, %3\n" \
+                    ins " %4, %4, %8, %4\n" ins " %5, %5, %8, %5\n" ins " %6, %6, %8, %6\n" ins " %7, %7, %8, %7\n") \
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(s))
+#define BODY32_1(ins) /* one source */ \
+    asm volatile(R4(ins " %0, %0\n" ins " %1, %1\n" ins " %2, %2\n" ins " %3, %3\n" ins " %4, %4\n" ins " %5, %5\n" ins " %6, %6\n" ins " %7, %7\n") \
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]))
+#define BODY64(ins) /* 64-bit shift: dst pair, shift amount, src pair */ \
+    asm volatile(R4(ins " %0, %8, %0\n" ins " %1, %8, %1\n" ins " %2, %8, %2\n" ins " %3, %8, %3\n" \
+                    ins " %4, %8, %4\n" ins " %5, %8, %5\n" ins " %6, %8, %6\n" ins " %7, %8, %7\n") \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(s))
+#define BODYDPP(ins) \
+    asm volatile(R4(ins " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" ins " %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" \
+                    ins " %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n" ins " %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n" \
+                    ins " %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n" ins " %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n" \
+                    ins " %6, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n" ins " %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf\n") \
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]))
+#define BODYRL /* v_readlane_b32 into 8 SGPRs (then nothing: the scalar results are dead but asm volatile keeps them) */ \
+    asm volatile(R4("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5\n v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %3, 9\n" \
+                    "v_readlane_b32 s24, %4, 11\n v_readlane_b32 s25, %5, 13\n v_readlane_b32 s26, %6, 15\n v_readlane_b32 s27, %7, 17\n") \
+                 : : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27")
+#define BODYSALU /* scalar ALU for comparison */ \
+    asm volatile(R4("s_add_u32 s20, s20, s28\n s_add_u32 s21, s21, s28\n s_lshl_b32 s22, s22, 1\n s_and_b32 s23, s23, s28\n" \
+                    "s_add_u32 s24, s24, s28\n s_xor_b32 s25, s25, s28\n s_lshr_b32 s26, s26, 1\n s_or_b32 s27, s27, s28\n") \
+                 : : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "scc")
 template <int OP>
-__global__ void k(uint64_t* out, uint64_t seed) {
-    uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;
-    uint32_t b0 = (uint32_t)a0, b1 = (uint32_t)a1, b2 = (uint32_t)a2, b3 = (uint32_t)a3;
-    uint32_t s = (uint32_t)(seed & 31) + 1;
+__global__ void __launch_bounds__(256) k(uint64_t* out, uint32_t seed) {
+    uint32_t b[8];
+    uint64_t a[8];
+    for (int i = 0; i < 8; ++i) { b[i] = seed * (2 * i + 1) + threadIdx.x; a[i] = (uint64_t)b[i] * 0x9E3779B97F4A7C15ULL; }
+    uint32_t s = (seed & 15) + 1;
     for (int i = 0; i < REP; ++i) {
-        if (OP == 0) { b0 = b0 + s; b1 = b1 + s; b2 = b2 + s; b3 = b3 + s; }                          // v_add_u32
-        if (OP == 1) { a0 = a0 << s; a1 = a1 << s; a2 = a2 << s; a3 = a3 << s; a0 |= 1; a1 |= 1; a2 |= 1; a3 |= 1; }  // v_lshlrev_b64 + or
-        if (OP == 2) { b0 = b0 << s | 1; b1 = b1 << s | 1; b2 = b2 << s | 1; b3 = b3 << s | 1; }      // v_lshl_or_b32
-        if (OP == 3) { b0 = b0 * 0x9E3779B1u + 1; b1 = b1 * 0x9E3779B1u + 1; b2 = b2 * 0x9E3779B1u + 1; b3 = b3 * 0x9E3779B1u + 1; }  // v_mul_lo_u32
-        if (OP == 4) { b0 = __umulhi(b0, 0x9E3779B1u) + s; b1 = __umulhi(b1, 0x9E3779B1u) + s; b2 = __umulhi(b2, 0x9E3779B1u) + s; b3 = __umulhi(b3, 0x9E3779B1u) + s; }
-        if (OP == 5) { b0 = __popc(b0) + s * b0; b1 = __popc(b1) + b1; b2 = __popc(b2) + b2; b3 = __popc(b3) + b3; }  // v_bcnt
-        if (OP == 6) { a0 = a0 * 0xBF58476D1CE4E5B9ULL + 1; a1 = a1 * 0xBF58476D1CE4E5B9ULL + 1; a2 = a2 * 0xBF58476D1CE4E5B9ULL + 1; a3 = a3 * 0xBF58476D1CE4E5B9ULL + 1; }  // 64x64 mul
-        if (OP == 7) { a0 = a0 + a1; a1 = a1 + a2; a2 = a2 + a3; a3 = a3 + a0; }                      // 64-bit add
-        if (OP == 8) { b0 = __builtin_amdgcn_alignbit(b0, b1, s); b1 = __builtin_amdgcn_alignbit(b1, b2, s); b2 = __builtin_amdgcn_alignbit(b2, b3, s); b3 = __builtin_amdgcn_alignbit(b3, b0, s); }
-        if (OP == 9) { a0 = a0 >> s | 1ULL << 63; a1 = a1 >> s | 1ULL << 63; a2 = a2 >> s | 1ULL << 63; a3 = a3 >> s | 1ULL << 63; }  // v_lshrrev_b64
-        if (OP == 10) { b0 = (b0 & 0xFFFF) * 48 + b0; b1 = (b1 & 0xFFFF) * 48 + b1; b2 = (b2 & 0xFFFF) * 48 + b2; b3 = (b3 & 0xFFFF) * 48 + b3; }  // v_mad_u32_u24
+        if (OP == 0) BODY32("v_add_u32");
+        if (OP == 1) BODY32("v_xor_b32");
+        if (OP == 2) BODY32("v_lshlrev_b32");
+        if (OP == 3) BODY32_3("v_lshl_or_b32");
+        if (OP == 4) BODY32_3("v_alignbit_b32");
+        if (OP == 5) BODY32_1("v_bfrev_b32");
+        if (OP == 6) BODY32("v_bcnt_u32_b32");
+        if (OP == 7) BODY32("v_mul_lo_u32");
+        if (OP == 8) BODY32("v_mul_hi_u32");
+        if (OP == 9) BODY32_3("v_mad_u32_u24");
+        if (OP == 10) BODY64("v_lshlrev_b64");
+        if (OP == 11) BODY64("v_lshrrev_b64");
+        if (OP == 12) BODYDPP("v_add_u32_dpp");
+        if (OP == 13) BODYRL;
+        if (OP == 14) BODY32("v_min_u32");
+        if (OP == 15) BODY32_3("v_and_or_b32");
+        if (OP == 16) BODY32_3("v_xad_u32");
+        if (OP == 17) BODYSALU;
+        if (OP == 18) BODY32_3("v_bfe_u32");
+        if (OP == 19) BODY32_3("v_add3_u32");
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ b0 ^ b1 ^ b2 ^ b3;
+    uint64_t x = 0;
+    for (int i = 0; i < 8; ++i) x ^= a[i] ^ b[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
 }
 template <int OP>
-void run(const char* name, int ops_per_iter, uint64_t* d) {
+void run(const char* name, uint64_t* d) {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    const int blocks = 256 * 8, threads = 256;   // 8 waves per SIMD on every CU
-    k<OP><<<blocks, threads>>>(d, 12345);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) k<OP><<<blocks, threads>>>(d, 12345 + r);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double wave_instr = 5.0 * blocks * (threads / 64) * (double)REP * ops_per_iter;   // total wave-instructions
-    double per_simd = wave_instr / 1024.0;                                            // 1024 SIMDs
-    double ns = ms * 1e6 / per_simd;
-    printf("%-28s %.3f ns per wave-instruction per SIMD  (= %.2f cycles at 2.1 GHz, %.2f at 2.4)\n", name, ns, ns * 2.1, ns * 2.4);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    printf("%-18s", name);
+    for (int wps : {1, 2, 4, 6, 8}) {              // waves per SIMD: 256 CUs x wps workgroups of 4 waves
+        const int blocks = 256 * wps, threads = 256;
+        k<OP><<<blocks, threads>>>(d, 12345);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) k<OP><<<blocks, threads>>>(d, 12345 + r);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double wave_instr = 5.0 * blocks * (threads / 64) * (double)REP * 32;
+        const double ns = ms * 1e6 / (wave_instr / 1024.0);
+        printf("  w%d: %5.2f cyc", wps, ns * 2.4);
+    }
+    printf("\n");
 }
 int main() {
-    uint64_t* d; hipMalloc(&d, 256 * 8 * 256 * 8);
-    run<0>("v_add_u32", 4, d);
-    run<2>("v_lshl_or_b32", 4, d);
-    run<8>("v_alignbit_b32", 4, d);
-    run<10>("v_and + v_mad_u32_u24", 8, d);
-    run<5>("v_bcnt_u32 (+mul/add)", 9, d);
-    run<3>("v_mul_lo_u32 + add", 8, d);
-    run<4>("v_mul_hi_u32 + add", 8, d);
-    run<7>("64-bit add (2 ops)", 8, d);
-    run<1>("v_lshlrev_b64 + v_or", 8, d);
-    run<9>("v_lshrrev_b64 + v_or", 8, d);
-    run<6>("64x64->64 mul + add", 4, d);
+    uint64_t* d; (void)hipMalloc(&d, 256 * 8 * 256 * 8);
+    int clk_khz = 0; (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
+    printf("device clock attribute %d kHz; cycles below = event time x 2.4 GHz / wave-instructions per SIMD (1024 SIMDs)\n", clk_khz);
+    printf("columns: waves resident per SIMD (w1 = one wave alone)\n");
+    run<0>("v_add_u32", d);
+    run<1>("v_xor_b32", d);
+    run<2>("v_lshlrev_b32", d);
+    run<14>("v_min_u32", d);
+    run<3>("v_lshl_or_b32", d);
+    run<15>("v_and_or_b32", d);
+    run<16>("v_xad_u32", d);
+    run<19>("v_add3_u32", d);
+    run<18>("v_bfe_u32", d);
+    run<4>("v_alignbit_b32", d);
+    run<5>("v_bfrev_b32", d);
+    run<6>("v_bcnt_u32_b32", d);
+    run<9>("v_mad_u32_u24", d);
+    run<7>("v_mul_lo_u32", d);
+    run<8>("v_mul_hi_u32", d);
+    run<10>("v_lshlrev_b64", d);
+    run<11>("v_lshrrev_b64", d);
+    run<12>("v_add_u32_dpp", d);
+    run<13>("v_readlane_b32", d);
+    run<17>("SALU mix", d);
     return 0;
 }
