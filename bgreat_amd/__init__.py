@@ -32,7 +32,7 @@ SYMBOLS = [
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup",
     "bgr_aligner_set_knob",
 ]
-KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP = 1, 2, 3, 4
+KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST = 1, 2, 3, 4, 5
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
 
 
@@ -300,7 +300,7 @@ class Aligner:
         out = np.zeros(4, dtype=np.uint32)
         _check(lib().bgr_aligner_launch_info(self.h, out.ctypes.data))
         return {"blocks": int(out[0]), "threads": int(out[1]), "lds_bytes": int(out[2]), "mphf_in_lds": bool(out[3] & 1),
-                "level_search": bool(out[3] & 2)}
+                "level_search": bool(out[3] & 2), "four_reads_per_wave": bool(out[3] & 4)}
 
     def close(self):
         if self.h:

@@ -10,8 +10,10 @@
 namespace bgr {
 
 struct BatchIO {
-    const uint8_t* reads;        // concatenated ASCII reads
-    const uint64_t* read_offs;   // n+1
+    const uint64_t* fw3;         // 2-bit plane of the batch (bgr_pack_reads_kernel / host packer): read r at word (read_offs[r] >> 5) + r
+    const uint64_t* nmw;         // N-mask plane, same addressing; valid only for reads whose bit is set in hasn
+    const uint32_t* hasn;        // bitmap: read holds an N
+    const uint64_t* read_offs;   // n+1 base offsets of the reads (lengths; packed-plane addressing)
     uint2* results;              // n: x = path offset in the arena, y = path length | status << 24
     int32_t* arena;
     uint32_t* cursor;            // [0] ints used, [1] overflow flag; counters (5 x u64) start at cursor + 16
@@ -26,6 +28,7 @@ struct BatchIO {
     uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
+    uint32_t greedy4;            // greedy mode: launch the four-reads-per-wave kernel (it lists what it does not settle on ovf_list)
     uint32_t subset_ctr, ovf_ctr; // which words of `cursor` count the reads of `subset` / collect the reads put on `ovf_list`
 };
 
@@ -73,13 +76,18 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
 }
 
 // Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive depth-first,
-// 2 anchors, 3 exhaustive level search).
+// 2 anchors, 3 exhaustive level search, 4 greedy four-reads-per-wave).
 uint32_t resident_waves_per_cu(uint32_t mode);
 
 // (results, arena) of the last mapping launch -> input-ordered CSR on the device.  phase 0: block_sums[ceil(n/4096)] and
 // *total (all path ints); phase 1: path_offsets[n+1], paths[total] (nothing is stored past paths_cap), status[n].
 hipError_t launch_csr(const uint2* results, const int32_t* arena, uint32_t n, uint32_t* block_sums, unsigned long long* total,
                       unsigned long long* path_offsets, int32_t* paths, uint8_t* status, uint32_t paths_cap, int phase, hipStream_t stream);
+
+// ASCII reads (ACGTN) -> the 2-bit planes the mapping kernels read.  `hasn` (ceil(n/32) words) must be zero on entry;
+// planes need (total_bytes >> 5) + n + 2 words each.
+hipError_t launch_pack_reads(const uint8_t* reads, const uint64_t* read_offs, uint32_t n, uint64_t total_bytes, uint64_t* fw3, uint64_t* nmw,
+                             uint32_t* hasn, hipStream_t stream);
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);
 

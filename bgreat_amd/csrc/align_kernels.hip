@@ -157,10 +157,28 @@ __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, const uint
     return idx;
 }
 
-// ---- stage A + the two derived streams -------------------------------------------------------------------
+// ---- stage A: the read's 2-bit words, from the planes the pre-pass (bgr_pack_reads_kernel) or the host packer wrote ----
 // FW3: str2num codes (N->3).  NM: 3 on every N.  RCW: reverseComplements(read) (utils.cpp:66-73, non-ACG -> 'A').
 // FWQ: what the rolling `num` of getNOverlap/getListOverlap holds: str2num codes inside the first window,
 //      nuc2int codes (N->0) for bases entered by update() (aligner.cpp:305-309, utils.cpp:132-140).
+// Read r of a batch owns words [woff, woff + ceil(L/32)) of both planes, woff = (read_offs[r] >> 5) + r: computable from the
+// ASCII offsets alone (no scan), never overlapping, at most one spare word per read.  The N plane of a read is valid
+// only if its bit in `hasn` is set.
+__device__ __forceinline__ uint32_t packed_word_offset(u64 off, uint32_t r) { return (uint32_t)(off >> 5) + r; }
+
+__device__ __forceinline__ bool load_packed(const BatchIO& io, uint32_t r, u64 off, uint32_t L, uint32_t W, u64* FW3, u64* NM, int lane) {
+    const uint32_t woff = packed_word_offset(off, r), Wr = (L + 31) >> 5;
+    const bool hasN = (io.hasn[r >> 5] >> (r & 31)) & 1u;
+    for (uint32_t j = lane; j < W; j += 64) {
+        u64 f = 0, m = 0;
+        if (j < Wr) { f = io.fw3[woff + j]; if (hasN) m = io.nmw[woff + j]; }
+        FW3[j] = f;
+        NM[j] = m;
+    }
+    wave_sync();
+    return hasN;
+}
+
 // 4 ASCII bases starting at byte 4*bi of the read as one dword (first base in the low byte), 0 past the end
 __device__ __forceinline__ uint32_t load4(const uint8_t* rd, uint32_t L, uint32_t bi) {
     const uint32_t b0 = bi * 4;
@@ -178,28 +196,50 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* rd, uint32_t L, uint32_
     return x;
 }
 
-// x0 = load4(rd, L, lane)
-__device__ __forceinline__ bool pack_read(uint32_t x0, const uint8_t* rd, uint32_t L, uint32_t W, u64* FW3, u64* NM, int lane) {
-    unsigned char* FW3b = reinterpret_cast<unsigned char*>(FW3);
-    unsigned char* NMb = reinterpret_cast<unsigned char*>(NM);
-    bool sawN = false;
-    for (uint32_t bi = lane; bi < 8 * W; bi += 64) {
-        const uint32_t x = bi < 64 ? x0 : load4(rd, L, bi);
-        // SWAR over 4 bytes: A0 C1 G2 T3 = ((c>>1)^(c>>2))&3; 'N' -> 3 + mask; a zero byte (past the end) -> 0
-        uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
-        const uint32_t t = x ^ 0x4E4E4E4Eu;                                 // zero byte <=> 'N'
-        const uint32_t isn = ((t - 0x01010101u) & ~t & 0x80808080u) >> 7;  // 0x01 per 'N' byte (exact for the alphabet ACGTN the parser admits)
-        const uint32_t n3 = isn * 3u;
-        c |= n3;
-        const uint32_t code = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
-        const uint32_t nmask = ((n3 << 6) | (n3 >> 4) | (n3 >> 14) | (n3 >> 24)) & 0xFFu;
-        FW3b[bi ^ 7] = (unsigned char)code;
-        NMb[bi ^ 7] = (unsigned char)nmask;
-        sawN |= nmask != 0;
+// 4 ASCII bases (one dword, first base in the low byte; a zero byte = past the end) -> one byte of 2-bit codes, first base
+// in the top two bits, and the same for the N mask (3 on 'N').  A0 C1 G2 T3 = ((c>>1)^(c>>2))&3; exact for the
+// alphabet ACGTN the parser admits (aligner.cpp:56-61).
+__device__ __forceinline__ void pack4(uint32_t x, uint32_t* code, uint32_t* nmask) {
+    uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    const uint32_t t = x ^ 0x4E4E4E4Eu;                                 // zero byte <=> 'N'
+    const uint32_t isn = ((t - 0x01010101u) & ~t & 0x80808080u) >> 7;  // 0x01 per 'N' byte
+    const uint32_t n3 = isn * 3u;
+    c |= n3;
+    *code = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
+    *nmask = ((n3 << 6) | (n3 >> 4) | (n3 >> 14) | (n3 >> 24)) & 0xFFu;
+}
+
+// 32 bases [32j, 32j+32) of a read -> its FW3 word (first base most significant) and N-mask word
+__device__ __forceinline__ void pack32(const uint8_t* rd, uint32_t L, uint32_t j, u64 abs_end_ok, u64* fw, u64* nm) {
+    uint32_t xs[8];
+    if (abs_end_ok) {  // all 32 bytes lie inside the batch buffer: two (unaligned) 16-byte loads, bytes past the read masked off
+        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
+        const u32x4_unaligned v0 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j);
+        const u32x4_unaligned v1 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j + 16);
+        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+        const uint32_t valid = L - 32 * j;  // >= 1
+        if (valid < 32) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t lo = 4u * d;
+                if (valid <= lo) xs[d] = 0;
+                else if (valid < lo + 4) xs[d] &= 0xFFFFFFFFu >> (8 * (lo + 4 - valid));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) xs[d] = load4(rd, L, 8 * j + d);
     }
-    const bool hasN = __any(sawN);
-    wave_sync();
-    return hasN;
+    u64 w = 0, n = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        uint32_t c, m;
+        pack4(xs[d], &c, &m);
+        w = (w << 8) | c;
+        n = (n << 8) | m;
+    }
+    *fw = w;
+    *nm = n;
 }
 
 // RCW (reverse-complement stream) and FWQ (rolling-update quirk stream) from FW3/NM.  Only needed when the read
@@ -832,6 +872,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;
     const uint32_t K1 = g.k - 1;
+    // as the second pass behind bgr_align_greedy4_kernel it maps only the reads that kernel listed (count in cursor[subset_ctr])
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
+    if ((uint32_t)(blockIdx.x * waves) >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
     uint2* LV;
     uint32_t mphf_words;
     const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
@@ -847,11 +890,12 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
     // getNOverlap(read, 0) still looks at position 0 before testing the count (aligner.cpp:349-368)
     const uint32_t effort = prm.effort ? prm.effort : 1;
 
-    for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
+    for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
         // (prefetching the next read one iteration ahead was measured: no gain at 24 waves/CU, it only added spills)
-        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
         bool derived = false;
 
         // ---- passes: forward read, then its reverse complement (alignerGreedy.cpp:54) -----------
@@ -924,6 +968,250 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
         if (lane == BGR_ST_NOANCHOR && c_lane) atomicAdd(&counters[1], (unsigned long long)c_lane);
         if (lane == BGR_ST_ALIGNED && c_lane) atomicAdd(&counters[2], (unsigned long long)c_lane);
         if (lane == BGR_ST_FAILED && c_lane) atomicAdd(&counters[3], (unsigned long long)c_lane);
+    }
+}
+
+// ================================= greedy, four reads per wavefront ====================================
+// bgr_align_greedy_kernel above walks one read per wave: a walk step is two dependent loads (slot, bases) scored by at
+// most 4 candidates x a few 32-base chunks, i.e. a handful of the 64 lanes, and per read there are ~4 such steps in a row.
+// Here a wave takes FOUR reads: their position scans still run one after the other on all 64 lanes (a scan is lane-
+// efficient: one (k-1)-mer per lane), then the four extensions run side by side, 16 lanes each (4 candidates x 4 chunk
+// lanes = 128 bases per step), so four slot/base load chains are in flight per wave and every wave instruction of a walk
+// step serves four reads.  Path ints stay in registers (lane j of a group holds int j of each direction).
+// The kernel settles the common case only -- no N in the read, first anchor extends within the budget (or there is
+// no anchor at all), at most G4_PATH ints per direction.  Every other read (N, failed first anchor: the reference then
+// tries further anchors and the reverse complement, alignerGreedy.cpp:41-56; long paths) is put on a list and mapped by
+// bgr_align_greedy_kernel right behind, so results are the reference's for every read.
+#ifndef BGR_G4_OCC
+#define BGR_G4_OCC 8
+#endif
+#define G4_PATH 16
+
+__device__ __forceinline__ uint32_t row_ror4(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x124, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t row_ror8(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+
+// One extension step for up to four walks (one per 16-lane group; `act` = this lane's group takes part).
+// DIR 0: left step.  DIR 1: right step; `first` = the group's first right step (checkEndGreedy: the read slice starts
+// behind the k-1 overlap), else mapOnRightEndGreedy (slice includes the overlap).  alignerGreedy.cpp:167-364.
+// Outputs are uniform within a group: found; w1 = next record | next canonical << 28 | fits << 29; miss; ext; sid.
+template <int DIR>
+__device__ __forceinline__ void g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, bool act, uint32_t rec, bool canon,
+                                        uint32_t pos, bool first, uint32_t budget, int lane, bool* found, uint32_t* w1, uint32_t* miss,
+                                        uint32_t* ext_o, int32_t* sid_o) {
+    const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u;
+    const bool useR = (DIR == 0) ? canon : !canon;
+    const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
+    uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
+    if (act && rec != BGR_NONE) {
+        const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + (useR ? 4u : 0u) + c) * 2;
+        sl = sp[0];
+        m0 = sp[1];
+    }
+    const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+    const u64 zmask = __ballot(id == 0);  // (all lanes of a candidate agree; a group that sits out reads as "no candidate")
+    const uint32_t nb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
+    const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+    const bool valid = c < first_zero;
+    const bool fwd = (sl.x & fbit) != 0;
+    const uint32_t len = sl.y;
+    const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+    const uint32_t ext = len - K1;
+    bool fits, ncanon;
+    uint32_t n, ustart, rstart, nrec;
+    if (DIR == 0) {
+        fits = ext >= pos;
+        n = fits ? pos : ext;
+        ustart = fits ? ext - pos : 0;
+        rstart = fits ? 0 : pos - ext;
+        nrec = fwd ? m0.y : m0.z;
+        ncanon = (m0.x & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
+    } else {
+        const uint32_t kk = first ? K1 : 0u;
+        const uint32_t rl = L - pos - kk;
+        fits = ext >= rl;
+        const uint32_t span = ext + K1 - kk;  // first step: the unitig behind the overlap; later: the whole unitig (clipped at |read|)
+        n = fits ? rl : (span < rl ? span : rl);
+        ustart = kk;
+        rstart = pos + kk;
+        nrec = fwd ? m0.z : m0.y;
+        ncanon = (m0.x & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
+    }
+    if (!valid) n = 0;
+    uint32_t cnt = 0;
+    for (uint32_t b = q * 32; __any(b < n); b += 128)
+        if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
+    cnt += quad_xor1(cnt);
+    cnt += quad_xor2(cnt);
+    // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
+    uint32_t key = valid ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
+    uint32_t o = row_ror4(key);
+    key = o < key ? o : key;
+    o = row_ror8(key);
+    key = o < key ? o : key;
+    const uint32_t src = ((uint32_t)lane & 48u) | ((key & 3u) << 2);
+    const uint32_t pk = nrec | (ncanon ? 1u << 28 : 0u) | (fits ? 1u << 29 : 0u);
+    *w1 = lane_get(pk, src);
+    *ext_o = lane_get(ext, src);
+    *sid_o = (int32_t)lane_get(fwd ? id : 0u - id, src);
+    *miss = key >> 2;
+    *found = act && (key >> 2) <= budget;  // an empty record gives key 0xFFFFFFFF: not found
+}
+
+template <bool STAGE>
+__global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;  // <= 16 (checked by the host): one lane per word of a read
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    u64* RD = lds + 64 + mphf_words + (u64)wave * (4 * W);  // the four reads of this wave, W words each
+    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
+    const u64* FW = RD + grp * W;
+    const uint32_t m = prm.max_mismatch;
+
+    uint32_t c_noov = 0, c_al = 0;          // wave-uniform counts of the reads settled here
+    uint32_t chunk_pos = 0, chunk_end = 0;  // this wave's slice of the path arena
+
+    for (uint32_t rbase = (blockIdx.x * waves + wave) * 4; rbase < io.n_reads; rbase += gridDim.x * waves * 4) {
+        const uint32_t r = rbase + grp;
+        const bool have = r < io.n_reads;
+        u64 off = 0;
+        uint32_t L = 0;
+        bool hasN = false;
+        if (have) {
+            off = io.read_offs[r];
+            L = (uint32_t)(io.read_offs[r + 1] - off);
+            hasN = (io.hasn[r >> 5] >> (r & 31)) & 1u;
+        }
+        const uint32_t Wr = (L + 31) >> 5;
+        const bool fast = have && !hasN;
+        {   // stage the 2-bit words: lane `sub` of a group brings word `sub` of its read
+            u64 f = 0;
+            if (fast && sub < Wr) f = io.fw3[packed_word_offset(off, r) + sub];
+            if (sub < W) RD[grp * W + sub] = f;
+        }
+        wave_sync();
+
+        // ---- anchors (getNOverlap, aligner.cpp:345-378): the first overlap (k-1)-mer of each read, 64 positions at a time
+        uint32_t a_pos = 0, a_rec = BGR_NONE;
+        bool a_canon = false;
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (!rl32(fast ? 1u : 0u, (int)(16 * q))) continue;
+            const uint32_t Lq = rl32(L, (int)(16 * q));
+            const u64* A = RD + q * W;
+            uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
+            if (!prm.effort && npos > 1) npos = 1;  // getNOverlap(read, 0) still looks at position 0 (aligner.cpp:349-368)
+            for (uint32_t base = 0; base < npos; base += 64) {
+                const uint32_t i = base + (uint32_t)lane;
+                const bool valid = i < npos;
+                u64 num = 0;
+                if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
+                const uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
+                const u64 mask = __ballot(idx != BGR_NONE);
+                if (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    const uint32_t h_rec = rl32(idx, src);
+                    const bool h_canon = rl32(num <= rcn ? 1u : 0u, src) != 0;
+                    if (grp == q) { a_pos = base + (uint32_t)src; a_rec = h_rec; a_canon = h_canon; }
+                    break;
+                }
+            }
+        }
+
+        // ---- extension from the first anchor (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast ----
+        const bool anchored = fast && a_rec != BGR_NONE;
+        uint32_t nl = 0, nr = 0, budget = m;
+        int32_t pl = 0, pr = 0;  // lane `sub` keeps path int number `sub` of the left walk (near -> far, offset last) / right walk
+        bool bad = false;        // walk failed or path too long for the registers: the general kernel takes the read
+        {   // left walk: checkBeginGreedy / mapOnLeftEndGreedy
+            uint32_t pos = a_pos, rec = a_rec;
+            bool canon = a_canon, act = anchored;
+            for (;;) {
+                if (act && pos == 0) { if (sub == nl) pl = 0; ++nl; act = false; }
+                if (act && nl > G4_PATH - 2) { bad = true; act = false; }
+                if (!__any(act)) break;
+                bool found;
+                uint32_t w1, miss, ext;
+                int32_t sid;
+                g4_step<0>(g, FW, L, K1, act, rec, canon, pos, false, budget, lane, &found, &w1, &miss, &ext, &sid);
+                if (act) {
+                    if (!found) { bad = true; act = false; }
+                    else {
+                        if (sub == nl) pl = sid;
+                        ++nl;
+                        budget -= miss;
+                        if (w1 & (1u << 29)) { if (sub == nl) pl = (int32_t)(ext - pos); ++nl; act = false; }
+                        else { pos -= ext; rec = w1 & 0x0FFFFFFFu; canon = (w1 >> 28) & 1u; }
+                    }
+                }
+            }
+        }
+        {   // right walk: checkEndGreedy, then mapOnRightEndGreedy
+            uint32_t pos = a_pos, rec = a_rec;
+            bool canon = a_canon, act = anchored && !bad, first = true;
+            for (;;) {
+                if (act && (first ? (L - pos - K1 == 0) : (L - pos < K1 + 1))) act = false;
+                if (act && nr > G4_PATH - 1) { bad = true; act = false; }
+                if (!__any(act)) break;
+                bool found;
+                uint32_t w1, miss, ext;
+                int32_t sid;
+                g4_step<1>(g, FW, L, K1, act, rec, canon, pos, first, budget, lane, &found, &w1, &miss, &ext, &sid);
+                if (act) {
+                    if (!found) { bad = true; act = false; }
+                    else {
+                        if (sub == nr) pr = sid;
+                        ++nr;
+                        budget -= miss;
+                        if (w1 & (1u << 29)) act = false;
+                        else { pos += ext; rec = w1 & 0x0FFFFFFFu; canon = (w1 >> 28) & 1u; first = false; }
+                    }
+                }
+            }
+        }
+
+        // ---- publish: reverse(left) ++ right into the arena; what is not settled goes on the list -----------------------
+        const bool aligned = anchored && !bad;
+        const bool settled = fast && (aligned || a_rec == BGR_NONE);
+        const uint32_t p_n = aligned ? nl + nr : 0;
+        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        if (tot > chunk_end - chunk_pos) {  // one global atomic per ~50 reads (see publish_path)
+            const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(io.cursor, want);
+            chunk_pos = rl32(got, 0);
+            chunk_end = chunk_pos + want;
+        }
+        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const bool room = chunk_pos + tot <= io.arena_cap;
+        chunk_pos += tot;
+#pragma unroll
+        for (uint32_t jj = 0; jj < 2; ++jj) {
+            const uint32_t j = sub + 16 * jj;
+            const uint32_t vl = lane_get((uint32_t)pl, ((uint32_t)lane & 48u) | ((nl - 1 - j) & 15u));
+            const uint32_t vr = lane_get((uint32_t)pr, ((uint32_t)lane & 48u) | ((j - nl) & 15u));
+            if (j < p_n && room) io.arena[gbase + j] = (int32_t)(j < nl ? vl : vr);
+        }
+        if (!room && lane == 0 && tot) io.cursor[1] = 1;  // overflow: reported by the host as an error
+        if (sub == 0 && have) {
+            if (settled) io.results[r] = make_uint2(aligned ? gbase : 0u, p_n | ((uint32_t)(aligned ? BGR_ST_ALIGNED : BGR_ST_NOANCHOR) << 24));
+            else io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+        }
+        c_al += (uint32_t)__popcll(__ballot(sub == 0 && aligned));
+        c_noov += (uint32_t)__popcll(__ballot(sub == 0 && settled && !aligned));
+        wave_sync();
+    }
+    if (lane == 0 && (c_al | c_noov)) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov));
+        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
     }
 }
 
@@ -1030,7 +1318,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC_OCC) bgr_align_anchors_kernel(Bg
     for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
         bool derived = false;
         uint32_t status = BGR_ST_NOANCHOR, p_lo = 0, p_n = 0;
         const uint32_t dk = L < K ? L : K;                       // read.substr(0, k) of a shorter read is the whole read
@@ -1193,7 +1481,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
         const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
         if (hasN) derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane);
         const u64* ROLL = hasN ? FWQ : FW3;  // the rolling `num` stream
         uint32_t p_n = 0;
@@ -1286,7 +1574,7 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
         const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
-        const bool hasN = pack_read(load4(io.reads + off, L, lane), io.reads + off, L, W, FW3, NM, lane);
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
         if (hasN) derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane);
         const u64* ROLL = hasN ? FWQ : FW3;  // the rolling `num` stream
         uint32_t p_n = 0;
@@ -1356,6 +1644,51 @@ hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, cons
 }
 
 }  // namespace
+
+// ======================================= pre-pass: ASCII reads -> 2-bit planes ================================
+// Streaming kernel in front of every mapping launch that is handed ASCII reads (what getReads yields, aligner.cpp:46-117):
+// str2num codes (utils.cpp:117-129: A0 C1 G2, anything else 3) 32 bases per u64, first base most significant, plus
+// the N mask for the few reads that hold an N (their bit is set in `hasn`, which the caller zeroes).  8 lanes per read,
+// 32 bases per lane and step.  ~150 B in + 48 B out per 150 bp read: HBM-streaming bound.
+__global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* reads, const u64* read_offs, uint32_t n, u64 total_bytes, u64* fw3,
+                                                             u64* nmw, uint32_t* hasn) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = t >> 3, j0 = t & 7;
+    const int lane = threadIdx.x & 63;
+    bool sawN = false;
+    u64 off = 0;
+    uint32_t L = 0, Wr = 0, woff = 0;
+    if (r < n) {
+        off = read_offs[r];
+        L = (uint32_t)(read_offs[r + 1] - off);
+        Wr = (L + 31) >> 5;
+        woff = packed_word_offset(off, r);
+        for (uint32_t j = j0; j < Wr; j += 8) {
+            u64 w, nm;
+            pack32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, &w, &nm);
+            fw3[woff + j] = w;
+            sawN |= nm != 0;
+        }
+    }
+    // a read with an N: all its N-plane words are written (the mapping kernels read the plane only for such reads)
+    const u64 any = __ballot(sawN);
+    if ((any >> (lane & ~7)) & 0xFFu) {
+        for (uint32_t j = j0; j < Wr; j += 8) {
+            u64 w, nm;
+            pack32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, &w, &nm);
+            nmw[woff + j] = nm;
+        }
+        if (j0 == 0) atomicOr(&hasn[r >> 5], 1u << (r & 31));
+    }
+}
+
+hipError_t launch_pack_reads(const uint8_t* reads, const uint64_t* read_offs, uint32_t n, uint64_t total_bytes, uint64_t* fw3, uint64_t* nmw,
+                             uint32_t* hasn, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)(((uint64_t)n * 8 + 255) / 256);
+    hipLaunchKernelGGL(bgr_pack_reads_kernel, dim3(blocks), dim3(256), 0, stream, reads, read_offs, n, total_bytes, fw3, nmw, hasn);
+    return hipGetLastError();
+}
 
 // ======================================= results -> CSR, on the device =======================================
 // The mapping kernels leave every path where its wave found room in the arena.  These three small kernels turn
@@ -1460,18 +1793,21 @@ uint32_t resident_waves_per_cu(uint32_t mode) {
     const void* fn = mode == 0 ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)
                    : mode == 2 ? reinterpret_cast<const void*>(&bgr_align_anchors_kernel)
                    : mode == 3 ? reinterpret_cast<const void*>(&bgr_align_exhaustive_dp_kernel<false>)
+                   : mode == 4 ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true>)
                                : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
     // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;
     // the kernels use ~106 SGPRs, which caps a SIMD at 6 waves (800 / (7*16 + 16)); compiling for 7 (72 VGPRs,
     // spills) measured 381 vs 532 Mreads/s greedy, 28 vs 37 exhaustive.
     const uint32_t alloc = ((uint32_t)fa.numRegs + 7) / 8 * 8;
-    return 4 * std::min<uint32_t>(6, 512 / alloc);
+    return 4 * std::min<uint32_t>(mode == 4 ? 8 : 6, 512 / alloc);
 }
 
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     if (io.n_reads == 0) return hipSuccess;
     if (p.mode == 0) {
+        if (io.greedy4) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true>, g, io, p, cfg, stream)
+                                              : launch_one(bgr_align_greedy4_kernel<false>, g, io, p, cfg, stream);
         return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
                               : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
     }

@@ -64,12 +64,12 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, results, arena, ovf, ovf2, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
-    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0;
+    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0;
     uint64_t knob_split_limit = 0;
     int num_cus = 0;
     size_t lds_per_cu = 0;
@@ -275,7 +275,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->deep.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->deep.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -298,6 +298,7 @@ int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
         case BGR_KNOB_EXH_SEARCH: if (value > 2) break; a->knob_search = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_BATCH_SPLIT_LIMIT: a->knob_split_limit = value; return BGR_OK;
         case BGR_KNOB_DEBUG_STOP: a->knob_debug_stop = (uint32_t)value; return BGR_OK;
+        case BGR_KNOB_GREEDY_FAST: if (value > 1) break; a->knob_greedy_fast = (uint32_t)value; return BGR_OK;
         default: break;
     }
     return fail(BGR_E_ARG, "bgr_aligner_set_knob: unknown knob or value out of range");
@@ -352,9 +353,10 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     // `b` workgroups per CU of `w` waves each, every staged workgroup holding its own copy of the MPHF cascade.
     // More resident waves hide more of the walk's dependent-load latency (measured 16 -> 24 waves/CU: +18 %), and a
     // grid of exactly CUs x b workgroups avoids a partial last round.
-    const uint32_t cap = std::max<uint32_t>(4, bgr::resident_waves_per_cu(level_search ? 3u : p->mode));  // 3: the level-search kernel
+    const uint32_t cap_default = std::max<uint32_t>(4, bgr::resident_waves_per_cu(level_search ? 3u : p->mode));  // 3: the level-search kernel
     const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
-    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bool allow_stage, bgr::LaunchCfg& cfg) -> bool {
+    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bool allow_stage, bgr::LaunchCfg& cfg, uint32_t cap_override = 0) -> bool {
+        const uint32_t cap = cap_override ? cap_override : cap_default;
         uint32_t waves = 0, bpc = 0;
         bool stage = false;
         auto fits = [&](uint32_t b, uint32_t w, bool st) {
@@ -432,6 +434,11 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         if (deep_only) cfg = cfg_deep;
         mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, true, cfg_mid);
     }
+    // Greedy mode, first pass: four reads per wave (bgr_align_greedy4_kernel) when a read fits one lane per word and the graph
+    // has no exception planes; what it does not settle is listed and mapped by the general kernel (cfg) right behind.
+    bgr::LaunchCfg cfg_fast;
+    const bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && words <= 16 && !a->graph->header.has_exc &&
+                           geometry(4 * 8 * words, (n_reads + 3) / 4, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
@@ -439,13 +446,23 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
     const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
                                (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0) +
-                               (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0);
+                               (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0) +
+                               (fast_pass ? (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk : 0);
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
-    a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf | (level_search && !deep_only ? 2u : 0u);
+    a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf | (level_search && !deep_only ? 2u : 0u) | (fast_pass ? 4u : 0u);
+    if (fast_pass) { a->last_launch[0] = cfg_fast.blocks; a->last_launch[1] = cfg_fast.waves_per_block * 64; a->last_launch[2] = cfg_fast.lds_bytes; a->last_launch[3] = cfg_fast.stage_mphf | 4u; }
 
+    // the reads as 2-bit planes (streaming pre-pass over the ASCII bytes; the mapping kernels only see the planes)
+    const uint64_t plane_words = (total_bases >> 5) + n_reads + 4;
+    if (plane_words >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large; split it");
+    HIP_TRY(a->pk_fw3.ensure(plane_words * 8));
+    HIP_TRY(a->pk_nm.ensure(plane_words * 8));
+    HIP_TRY(a->pk_hasn.ensure((n_reads + 31) / 32 * 4 + 4));
     bgr::BatchIO io;
-    io.reads = static_cast<const uint8_t*>(d_reads);
+    io.fw3 = static_cast<const uint64_t*>(a->pk_fw3.p);
+    io.nmw = static_cast<const uint64_t*>(a->pk_nm.p);
+    io.hasn = static_cast<const uint32_t*>(a->pk_hasn.p);
     io.read_offs = static_cast<const uint64_t*>(d_read_offsets);
     io.n_reads = (uint32_t)n_reads;
     io.words_per_read = words;
@@ -458,8 +475,10 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.deep_scratch = nullptr;
     io.deep_stride = (uint32_t)deep_stride;
     io.level_search = level_search ? 1u : 0u;
+    io.greedy4 = 0;
     io.subset_ctr = 2;
     io.ovf_ctr = 2;
+    if (fast_pass) HIP_TRY(a->ovf.ensure(n_reads * 4));
     if (two_pass && !deep_only) {
         HIP_TRY(a->ovf.ensure(n_reads * 4));
         io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
@@ -477,7 +496,21 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 16, a->stream));
     HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
-    hipError_t e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
+    HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, (n_reads + 31) / 32 * 4, a->stream));
+    hipError_t e = bgr::launch_pack_reads(static_cast<const uint8_t*>(d_reads), io.read_offs, io.n_reads, total_bases, static_cast<uint64_t*>(a->pk_fw3.p),
+                                          static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("pre-pass launch: ") + hipGetErrorString(e));
+    if (fast_pass) {  // the general kernel then maps only the listed reads (always enqueued: with an empty list its waves exit at once)
+        bgr::BatchIO iof = io;
+        iof.greedy4 = 1;
+        iof.ovf_list = static_cast<uint32_t*>(a->ovf.p);
+        iof.ovf_ctr = 2;
+        e = bgr::launch_align(a->dg, iof, kp, cfg_fast, a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (four-reads-per-wave pass): ") + hipGetErrorString(e));
+        io.subset = iof.ovf_list;
+        io.subset_ctr = 2;
+    }
+    e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (two_pass && !deep_only) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
         const uint32_t* pending = io.ovf_list;

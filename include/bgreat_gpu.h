@@ -152,7 +152,8 @@ int bgr_aligner_reset_counters(bgr_aligner* a);
 int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms);
 int bgr_aligner_reset_kernel_time(bgr_aligner* a);
 /* Launch geometry of the last mapping kernel (for logs): blocks, threads per block, dynamic LDS bytes, and flags:
- * bit 0 = the MPHF cascade was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first). */
+ * bit 0 = the MPHF cascade was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first),
+ * bit 2 = greedy mode ran its four-reads-per-wave first pass (the numbers then describe that launch). */
 int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
 /* Tuning knobs (0 keeps the default): waves per workgroup, workgroups per CU, force MPHF LDS staging
  * (0 auto, 1 off, 2 on). */
@@ -168,6 +169,7 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
 #define BGR_KNOB_EXH_SEARCH 2u
 #define BGR_KNOB_BATCH_SPLIT_LIMIT 3u
 #define BGR_KNOB_DEBUG_STOP 4u
+#define BGR_KNOB_GREEDY_FAST 5u /* greedy mode: 0 = four-reads-per-wave first pass + general kernel for the rest (default), 1 = general kernel only */
 int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value);
 
 /* ---- read files (host) ----------------------------------------------------------------------------

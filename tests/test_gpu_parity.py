@@ -383,6 +383,36 @@ def test_gpu_matches_oracle_random(seed, k, L, m, e, nfrac, d, alleles):
     assert al.counters() == {**o.counters(), "overlaps": 0}
 
 
+@pytest.mark.parametrize("seed,k,L,m,e,nfrac,d,alleles", [
+    (1, 31, 150, 2, 2, 0.0, 140, 2), (2, 31, 100, 2, 2, 0.003, 75, 2), (3, 21, 250, 5, 1, 0.0, 40, 4), (4, 8, 90, 3, 3, 0.0, 12, 3),
+    (5, 31, 150, 0, 0, 0.0, 100, 2), (6, 32, 440, 4, 2, 0.001, 60, 4), (7, 12, 64, 1, 8, 0.0, 20, 2), (8, 31, 33, 2, 2, 0.0, 90, 2)])
+def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m, e, nfrac, d, alleles):
+    """Greedy mode maps with bgr_align_greedy4_kernel (four reads per wave, first anchor only) and hands what that does not
+    settle -- N reads, failed first anchors, long paths (small k: many short unitigs) -- to the general kernel.  Both
+    routes and the oracle must agree row for row, counters included; batch sizes that leave 1..3 reads in the last wave."""
+    s = Synth(150000, d, alleles, k, 7100 + seed)
+    seqs, offs = s.unitigs()
+    n = 20003 - seed
+    reads, roffs = s.reads(0, n, L, m + 1, 7200 + seed)
+    if nfrac:
+        reads = _inject_n(reads, np.random.default_rng(seed), nfrac)
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs)
+    p2, po2, st2 = o.align(reads, roffs, m=m, effort=e)
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=e)
+    assert al.launch_info()["four_reads_per_wave"]
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    assert al.counters() == o.counters()
+    al.reset_counters()
+    al.set_knob(B.KNOB_GREEDY_FAST, 1)   # general kernel only
+    p3, po3, st3 = al.align(reads, roffs, m=m, effort=e)
+    assert not al.launch_info()["four_reads_per_wave"]
+    assert np.array_equal(st3, st2) and np.array_equal(po3, po2) and np.array_equal(p3, p2)
+    assert al.counters() == o.counters()
+
+
 def test_ragged_and_empty_batches():
     s = Synth(60000, 75, 2, 31, 77)
     seqs, offs = s.unitigs()
