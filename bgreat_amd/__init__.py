@@ -30,7 +30,7 @@ SYMBOLS = [
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup",
-    "bgr_aligner_set_knob",
+    "bgr_aligner_set_knob", "bgr_aligner_pass_counts",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST = 1, 2, 3, 4, 5
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
@@ -133,6 +133,7 @@ def lib():
     L.bgr_aligner_launch_info.argtypes = [vp, vp]
     L.bgr_aligner_configure.argtypes = [vp, u32, u32, u32]
     L.bgr_aligner_set_knob.argtypes = [vp, u32, u64]
+    L.bgr_aligner_pass_counts.argtypes = [vp, vp]
     L.bgr_readset_load.argtypes = [C.c_char_p, i32, u32, C.POINTER(vp)]
     L.bgr_readset_load_parallel.argtypes = [C.c_char_p, i32, u32, u32, u64, C.POINTER(vp)]
     L.bgr_align_all.argtypes = [vp, C.POINTER(Params), C.POINTER(RunOptions), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_double)]
@@ -301,6 +302,12 @@ class Aligner:
         _check(lib().bgr_aligner_launch_info(self.h, out.ctypes.data))
         return {"blocks": int(out[0]), "threads": int(out[1]), "lds_bytes": int(out[2]), "mphf_in_lds": bool(out[3] & 1),
                 "level_search": bool(out[3] & 2), "four_reads_per_wave": bool(out[3] & 4)}
+
+    def pass_counts(self):
+        """Reads each pass of the last launch handed on (see bgr_aligner_pass_counts): 4 ints."""
+        out = np.zeros(4, dtype=np.uint32)
+        _check(lib().bgr_aligner_pass_counts(self.h, out.ctypes.data))
+        return tuple(int(x) for x in out)
 
     def close(self):
         if self.h:

@@ -28,7 +28,13 @@ struct BatchIO {
     uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
-    uint32_t greedy4;            // greedy mode: launch the four-reads-per-wave kernel (it lists what it does not settle on ovf_list)
+    uint32_t greedy4;            // greedy mode: launch the four-reads-per-wave kernel; reads it cannot finish in this launch go on ovf_list
+                                 // (with their state in g4_state, for its next pass) or on gen_list (for the general kernel)
+    uint32_t* g4_state;          // n words: where a listed read's mapping stands (strand, anchors tried, scan position)
+    uint32_t* gen_list;          // reads for the general kernel (count at cursor[gen_ctr])
+    uint32_t gen_ctr;
+    uint32_t list_chunk;         // entries of ovf_list a wave reserves per global atomic (4..16; the unused ones become holes = BGR_NONE)
+    uint32_t g4_last;            // last pass of the four-reads-per-wave kernel: everything unfinished goes on gen_list
     uint32_t subset_ctr, ovf_ctr; // which words of `cursor` count the reads of `subset` / collect the reads put on `ovf_list`
 };
 

@@ -991,20 +991,23 @@ __device__ __forceinline__ uint32_t row_ror4(uint32_t x) { return (uint32_t)__bu
 __device__ __forceinline__ uint32_t row_ror8(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 
-// One extension step for up to four walks (one per 16-lane group; `act` = this lane's group takes part).
-// DIR 0: left step.  DIR 1: right step; `first` = the group's first right step (checkEndGreedy: the read slice starts
-// behind the k-1 overlap), else mapOnRightEndGreedy (slice includes the overlap).  alignerGreedy.cpp:167-364.
-// Outputs are uniform within a group: found; w1 = next record | next canonical << 28 | fits << 29; miss; ext; sid.
-template <int DIR>
-__device__ __forceinline__ void g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, bool act, uint32_t rec, bool canon,
-                                        uint32_t pos, bool first, uint32_t budget, int lane, bool* found, uint32_t* w1, uint32_t* miss,
-                                        uint32_t* ext_o, int32_t* sid_o) {
+// One extension step for up to four walks, one per 16-lane group.  `phase` (uniform within a group): 0 = the group sits
+// out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
+// behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
+// Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
+#define G4_REC_MASK 0x0FFFFFFFu
+#define G4_CANON (1u << 28)
+#define G4_FITS (1u << 29)
+#define G4_FOUND (1u << 30)
+__device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t phase, uint32_t rec, uint32_t canon,
+                                            uint32_t pos, uint32_t budget, int lane, uint32_t* miss, uint32_t* ext_o, int32_t* sid_o) {
     const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u;
-    const bool useR = (DIR == 0) ? canon : !canon;
-    const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
+    const uint32_t left = phase == 1 ? 1u : 0u;
+    // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
+    const uint32_t useR = canon == left ? 1u : 0u;
     uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
-    if (act && rec != BGR_NONE) {
-        const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + (useR ? 4u : 0u) + c) * 2;
+    if (phase != 0 && rec != G4_REC_MASK) {
+        const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + useR * 4u + c) * 2;
         sl = sp[0];
         m0 = sp[1];
     }
@@ -1012,51 +1015,47 @@ __device__ __forceinline__ void g4_step(const BgrDeviceGraph& g, const u64* FW, 
     const u64 zmask = __ballot(id == 0);  // (all lanes of a candidate agree; a group that sits out reads as "no candidate")
     const uint32_t nb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
     const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
-    const bool valid = c < first_zero;
-    const bool fwd = (sl.x & fbit) != 0;
+    const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
     const uint32_t len = sl.y;
     const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
     const uint32_t ext = len - K1;
-    bool fits, ncanon;
-    uint32_t n, ustart, rstart, nrec;
-    if (DIR == 0) {
-        fits = ext >= pos;
-        n = fits ? pos : ext;
-        ustart = fits ? ext - pos : 0;
-        rstart = fits ? 0 : pos - ext;
-        nrec = fwd ? m0.y : m0.z;
-        ncanon = (m0.x & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
-    } else {
-        const uint32_t kk = first ? K1 : 0u;
-        const uint32_t rl = L - pos - kk;
-        fits = ext >= rl;
-        const uint32_t span = ext + K1 - kk;  // first step: the unitig behind the overlap; later: the whole unitig (clipped at |read|)
-        n = fits ? rl : (span < rl ? span : rl);
-        ustart = kk;
-        rstart = pos + kk;
-        nrec = fwd ? m0.z : m0.y;
-        ncanon = (m0.x & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
-    }
-    if (!valid) n = 0;
+    // left: `rl` bases of the read lie left of the overlap; right: behind it (first step) / from its start (later steps)
+    const uint32_t kk = phase == 2 ? K1 : 0u;
+    const uint32_t rl = left ? pos : L - pos - kk;
+    const uint32_t fits = ext >= rl ? 1u : 0u;
+    const uint32_t span = left ? ext : ext + K1 - kk;  // what is compared when the walk goes on: the unitig beyond the overlap, or all of it
+    uint32_t n = fits ? rl : (span < rl ? span : rl);  // (later right steps: read.substr(pos, |u|) is clipped at |read|)
+    const uint32_t ustart = left ? ext - n : kk;
+    const uint32_t rstart = left ? rl - n : pos + kk;
+    const uint32_t nrec = fwd == left ? m0.y : m0.z;
+    const uint32_t cbit = left ? (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND) : (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
+    if (c >= first_zero) n = 0;
     uint32_t cnt = 0;
     for (uint32_t b = q * 32; __any(b < n); b += 128)
         if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
     cnt += quad_xor1(cnt);
     cnt += quad_xor2(cnt);
     // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
-    uint32_t key = valid ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
+    uint32_t key = c < first_zero ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
     uint32_t o = row_ror4(key);
     key = o < key ? o : key;
     o = row_ror8(key);
     key = o < key ? o : key;
     const uint32_t src = ((uint32_t)lane & 48u) | ((key & 3u) << 2);
-    const uint32_t pk = nrec | (ncanon ? 1u << 28 : 0u) | (fits ? 1u << 29 : 0u);
-    *w1 = lane_get(pk, src);
+    const uint32_t pk = nrec | ((m0.x & cbit) ? G4_CANON : 0u) | (fits ? G4_FITS : 0u);
+    const uint32_t w1 = lane_get(pk, src);
     *ext_o = lane_get(ext, src);
     *sid_o = (int32_t)lane_get(fwd ? id : 0u - id, src);
     *miss = key >> 2;
-    *found = act && (key >> 2) <= budget;  // an empty record gives key 0xFFFFFFFF: not found
+    return (key >> 2) <= budget ? w1 | G4_FOUND : 0u;  // an empty record gives key 0xFFFFFFFF: not found
 }
+
+// A read the kernel cannot finish in this launch is listed with where to go on: which strand (the reference maps the
+// reverse complement once every forward anchor has failed, alignerGreedy.cpp:54), how many anchors of that strand have
+// been tried (getNOverlap hands out the first `effort` of them) and the position the scan resumes from.
+#define G4_ST_RC (1u << 31)
+#define G4_ST_TRIED_SHIFT 20
+#define G4_ST_POS_MASK 0xFFFFFu
 
 template <bool STAGE>
 __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
@@ -1065,119 +1064,169 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host): one lane per word of a read
     const uint32_t K1 = g.k - 1;
+    // later passes map the reads an earlier pass listed (count in cursor[subset_ctr]), from the state it left in g4_state
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
+    if ((uint32_t)(blockIdx.x * waves) * 4u >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
     uint2* LV;
     uint32_t mphf_words;
     const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
-    u64* RD = lds + 64 + mphf_words + (u64)wave * (4 * W);  // the four reads of this wave, W words each
+    u64* RD = lds + 64 + mphf_words + (u64)wave * (8 * W);  // the four reads of this wave: forward words | reverse-complement words
     const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
-    const u64* FW = RD + grp * W;
     const uint32_t m = prm.max_mismatch;
+    const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
 
-    uint32_t c_noov = 0, c_al = 0;          // wave-uniform counts of the reads settled here
-    uint32_t chunk_pos = 0, chunk_end = 0;  // this wave's slice of the path arena
+    uint32_t c_noov = 0, c_al = 0, c_na = 0;  // wave-uniform counts of the reads settled here
+    uint32_t chunk_pos = 0, chunk_end = 0;    // this wave's slice of the path arena
+    uint32_t lst_pos = 0, lst_end = 0;        // this wave's slice of the list for the next pass (reserved io.list_chunk entries at a
+                                              // time: one single-address atomic per listed read caps a launch near 300 M/s)
 
-    for (uint32_t rbase = (blockIdx.x * waves + wave) * 4; rbase < io.n_reads; rbase += gridDim.x * waves * 4) {
-        const uint32_t r = rbase + grp;
-        const bool have = r < io.n_reads;
+    // (per-lane flags are kept as 0/1 words in VGPRs on purpose: as `bool`s they become 64-bit lane masks in SGPRs, and this
+    // kernel is short of SGPRs, not of VGPRs)
+    for (uint32_t ibase = (blockIdx.x * waves + wave) * 4; ibase < total; ibase += gridDim.x * waves * 4) {
+        const uint32_t it = ibase + grp;
+        uint32_t have = it < total ? 1u : 0u;
+        uint32_t r = 0, st = 0;
         u64 off = 0;
-        uint32_t L = 0;
-        bool hasN = false;
+        uint32_t L = 0, fast = 0;
+        if (have && io.subset) {
+            r = io.subset[it];
+            if (r == BGR_NONE) have = 0;  // a hole: the unused tail of some wave's chunk of the list
+            else st = io.g4_state[r];
+        } else {
+            r = it;
+        }
         if (have) {
             off = io.read_offs[r];
             L = (uint32_t)(io.read_offs[r + 1] - off);
-            hasN = (io.hasn[r >> 5] >> (r & 31)) & 1u;
+            fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
         }
-        const uint32_t Wr = (L + 31) >> 5;
-        const bool fast = have && !hasN;
+        const uint32_t rc = st >> 31;
+        uint32_t tried = (st >> G4_ST_TRIED_SHIFT) & 0x7FFu;
+        const uint32_t s_from = st & G4_ST_POS_MASK;
+        u64* F = RD + grp * (2 * W);
         {   // stage the 2-bit words: lane `sub` of a group brings word `sub` of its read
             u64 f = 0;
-            if (fast && sub < Wr) f = io.fw3[packed_word_offset(off, r) + sub];
-            if (sub < W) RD[grp * W + sub] = f;
+            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
+            if (sub < W) F[sub] = f;
         }
         wave_sync();
+        if (__any(rc != 0)) {  // reverseComplements(read) (utils.cpp:66-73) of the groups that are on their second strand
+            if (rc && sub < W) {
+                const long long p = (long long)L - 32 * ((long long)sub + 1);
+                u64 w = 0;
+                if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
+                else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                F[W + sub] = w;
+            }
+            wave_sync();
+        }
+        const u64* FW = F + (rc ? W : 0);  // the strand this pass maps
 
-        // ---- anchors (getNOverlap, aligner.cpp:345-378): the first overlap (k-1)-mer of each read, 64 positions at a time
-        uint32_t a_pos = 0, a_rec = BGR_NONE;
-        bool a_canon = false;
+        // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each read from where its scan stands and,
+        // when it lies in the same 64 positions, the one after it; record | canonical << 28
+        uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
         for (uint32_t q = 0; q < 4; ++q) {
-            if (!rl32(fast ? 1u : 0u, (int)(16 * q))) continue;
+            if (!rl32(fast, (int)(16 * q))) continue;
             const uint32_t Lq = rl32(L, (int)(16 * q));
-            const u64* A = RD + q * W;
+            const u64* A = RD + q * (2 * W) + (rl32(rc, (int)(16 * q)) ? W : 0);
+            const uint32_t left_q = eff - rl32(tried, (int)(16 * q));  // anchors this strand may still try (>= 1)
             uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
-            if (!prm.effort && npos > 1) npos = 1;  // getNOverlap(read, 0) still looks at position 0 (aligner.cpp:349-368)
-            for (uint32_t base = 0; base < npos; base += 64) {
+            if (!prm.effort && npos > 1) npos = 1;
+            for (uint32_t base = rl32(s_from, (int)(16 * q)); base < npos; base += 64) {
                 const uint32_t i = base + (uint32_t)lane;
                 const bool valid = i < npos;
                 u64 num = 0;
                 if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
-                const uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
+                uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {
-                    const int src = __ffsll((long long)mask) - 1;
-                    const uint32_t h_rec = rl32(idx, src);
-                    const bool h_canon = rl32(num <= rcn ? 1u : 0u, src) != 0;
-                    if (grp == q) { a_pos = base + (uint32_t)src; a_rec = h_rec; a_canon = h_canon; }
+                    if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
+                    const int s1 = __ffsll((long long)mask) - 1;
+                    const u64 mask2 = mask & (mask - 1);
+                    const uint32_t h1 = rl32(idx, s1);
+                    uint32_t h2 = BGR_NONE, p2 = 0;
+                    if (mask2 && left_q >= 2) {  // a second anchor is tried when the first fails
+                        const int s2 = __ffsll((long long)mask2) - 1;
+                        h2 = rl32(idx, s2);
+                        p2 = base + (uint32_t)s2;
+                    }
+                    if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
                     break;
                 }
             }
         }
 
-        // ---- extension from the first anchor (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast ----
-        const bool anchored = fast && a_rec != BGR_NONE;
-        uint32_t nl = 0, nr = 0, budget = m;
+        // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast; a group whose anchor fails
+        // starts over from the next one, if the scan has seen it, while the others go on ----
+        uint32_t phase = (fast && a_rec != BGR_NONE) ? 1u : 0u;
+        uint32_t pos = a_pos, rec = a_rec & G4_REC_MASK, canon = (a_rec >> 28) & 1u, budget = m;
+        uint32_t nl = 0, nr = 0, bad = 0, failed = 0;
         int32_t pl = 0, pr = 0;  // lane `sub` keeps path int number `sub` of the left walk (near -> far, offset last) / right walk
-        bool bad = false;        // walk failed or path too long for the registers: the general kernel takes the read
-        {   // left walk: checkBeginGreedy / mapOnLeftEndGreedy
-            uint32_t pos = a_pos, rec = a_rec;
-            bool canon = a_canon, act = anchored;
-            for (;;) {
-                if (act && pos == 0) { if (sub == nl) pl = 0; ++nl; act = false; }
-                if (act && nl > G4_PATH - 2) { bad = true; act = false; }
-                if (!__any(act)) break;
-                bool found;
-                uint32_t w1, miss, ext;
-                int32_t sid;
-                g4_step<0>(g, FW, L, K1, act, rec, canon, pos, false, budget, lane, &found, &w1, &miss, &ext, &sid);
-                if (act) {
-                    if (!found) { bad = true; act = false; }
-                    else {
-                        if (sub == nl) pl = sid;
-                        ++nl;
-                        budget -= miss;
-                        if (w1 & (1u << 29)) { if (sub == nl) pl = (int32_t)(ext - pos); ++nl; act = false; }
-                        else { pos -= ext; rec = w1 & 0x0FFFFFFFu; canon = (w1 >> 28) & 1u; }
-                    }
-                }
+        for (;;) {
+            if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
+                if (sub == nl) pl = 0;
+                ++nl;
+                phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
             }
-        }
-        {   // right walk: checkEndGreedy, then mapOnRightEndGreedy
-            uint32_t pos = a_pos, rec = a_rec;
-            bool canon = a_canon, act = anchored && !bad, first = true;
-            for (;;) {
-                if (act && (first ? (L - pos - K1 == 0) : (L - pos < K1 + 1))) act = false;
-                if (act && nr > G4_PATH - 1) { bad = true; act = false; }
-                if (!__any(act)) break;
-                bool found;
-                uint32_t w1, miss, ext;
-                int32_t sid;
-                g4_step<1>(g, FW, L, K1, act, rec, canon, pos, first, budget, lane, &found, &w1, &miss, &ext, &sid);
-                if (act) {
-                    if (!found) { bad = true; act = false; }
-                    else {
-                        if (sub == nr) pr = sid;
-                        ++nr;
-                        budget -= miss;
-                        if (w1 & (1u << 29)) act = false;
-                        else { pos += ext; rec = w1 & 0x0FFFFFFFu; canon = (w1 >> 28) & 1u; first = false; }
-                    }
+            if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
+            if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
+            if ((phase == 1 && nl > G4_PATH - 2) || (phase >= 2 && nr > G4_PATH - 1)) { bad = 1; phase = 0; }  // path too long for the registers
+            if (!__any(phase != 0)) break;
+            uint32_t miss, ext;
+            int32_t sid;
+            const uint32_t w1 = g4_step(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+            if (phase != 0) {
+                if (!(w1 & G4_FOUND)) {
+                    ++tried;
+                    if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
+                        a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
+                        nl = 0; nr = 0; budget = m;
+                        phase = 1; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                    } else { failed = 1; phase = 0; }
+                } else if (phase == 1) {
+                    if (sub == nl) pl = sid;
+                    ++nl;
+                    budget -= miss;
+                    if (w1 & G4_FITS) {
+                        if (sub == nl) pl = (int32_t)(ext - pos);
+                        ++nl;
+                        phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                    } else { pos -= ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; }
+                } else {
+                    if (sub == nr) pr = sid;
+                    ++nr;
+                    budget -= miss;
+                    if (w1 & G4_FITS) phase = 0;
+                    else { pos += ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; phase = 3; }
                 }
             }
         }
 
-        // ---- publish: reverse(left) ++ right into the arena; what is not settled goes on the list -----------------------
-        const bool aligned = anchored && !bad;
-        const bool settled = fast && (aligned || a_rec == BGR_NONE);
+        // ---- what became of each read (alignerGreedy.cpp:35-57) ---------------------------------------------------------------
+        // 0 = aligned, 1 = no anchor on this strand and none tried before (++noOverlapRead), 2 = not aligned (both strands done),
+        // 3 = goes on in a later pass with `nst`, 4 = general kernel (N in the read, path too long for the registers)
+        uint32_t outcome, nst = 0;
+        {
+            const uint32_t npos_g = (L >= K1 ? L - K1 + 1 : 0);
+            const uint32_t npos_e = (!prm.effort && npos_g > 1) ? 1u : npos_g;
+            if (!fast || bad) outcome = 4;
+            else if (a_rec != BGR_NONE && !failed) outcome = 0;
+            else if (a_rec == BGR_NONE && tried == 0) outcome = 1;
+            else {
+                // the strand's anchors are used up when `effort` of them have been tried or the scan has passed the last position
+                const uint32_t resume = a_pos + 1;  // (a_pos = the anchor tried last; unused when the scan found none)
+                const uint32_t used_up = (a_rec == BGR_NONE || tried >= eff || resume >= npos_e) ? 1u : 0u;
+                if (!used_up) { outcome = 3; nst = (rc << 31) | (tried << G4_ST_TRIED_SHIFT) | resume; }
+                else if (!rc) { outcome = 3; nst = G4_ST_RC; }  // the reverse complement, from its first position
+                else outcome = 2;
+                if (tried > 0x7FFu) outcome = 4;
+            }
+            if (outcome == 3 && io.g4_last) outcome = 4;  // no further pass of this kernel: the general kernel maps the read from scratch
+        }
+
+        // ---- publish: reverse(left) ++ right into the arena ----------------------------------------------------------------------
+        const uint32_t aligned = outcome == 0 ? 1u : 0u;
         const uint32_t p_n = aligned ? nl + nr : 0;
         const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
         const uint32_t tot = n0 + n1 + n2 + n3;
@@ -1200,18 +1249,42 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
         }
         if (!room && lane == 0 && tot) io.cursor[1] = 1;  // overflow: reported by the host as an error
         if (sub == 0 && have) {
-            if (settled) io.results[r] = make_uint2(aligned ? gbase : 0u, p_n | ((uint32_t)(aligned ? BGR_ST_ALIGNED : BGR_ST_NOANCHOR) << 24));
-            else io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+            if (outcome <= 2) {
+                const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc ? BGR_ST_RC : 0u);
+                io.results[r] = make_uint2(aligned ? gbase : 0u, p_n | (code << 24));
+            } else if (outcome == 3) {
+                io.g4_state[r] = nst;
+            } else {
+                io.gen_list[atomicAdd(io.cursor + io.gen_ctr, 1u)] = r;
+            }
         }
-        c_al += (uint32_t)__popcll(__ballot(sub == 0 && aligned));
-        c_noov += (uint32_t)__popcll(__ballot(sub == 0 && settled && !aligned));
+        {   // the reads that go on in the next pass: appended to this wave's slice of the list
+            const u64 lm = __ballot(sub == 0 && have && outcome == 3);
+            if (lm) {
+                const uint32_t cnt = (uint32_t)__popcll(lm);
+                if (cnt > lst_end - lst_pos) {  // what is left of the old slice becomes holes
+                    for (uint32_t j = lst_pos + (uint32_t)lane; j < lst_end; j += 64) io.ovf_list[j] = BGR_NONE;
+                    uint32_t got = 0;
+                    if (lane == 0) got = atomicAdd(io.cursor + io.ovf_ctr, io.list_chunk);
+                    lst_pos = rl32(got, 0);
+                    lst_end = lst_pos + io.list_chunk;
+                }
+                if (sub == 0 && have && outcome == 3) io.ovf_list[lst_pos + (uint32_t)__popcll(lm & ((1ULL << lane) - 1))] = r;
+                lst_pos += cnt;
+            }
+        }
+        c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
+        c_noov += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 1));
+        c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
         wave_sync();
     }
-    if (lane == 0 && (c_al | c_noov)) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead
+    for (uint32_t j = lst_pos + (uint32_t)lane; j < lst_end; j += 64) io.ovf_list[j] = BGR_NONE;
+    if (lane == 0 && (c_al | c_noov | c_na)) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov));
+        atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov + c_na));
         if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
         if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
     }
 }
 

@@ -64,7 +64,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, ovf3, g4st, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -275,7 +275,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->deep.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->ovf3.release(); a->g4st.release(); a->deep.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
         for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
         if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -438,7 +438,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     // has no exception planes; what it does not settle is listed and mapped by the general kernel (cfg) right behind.
     bgr::LaunchCfg cfg_fast;
     const bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && words <= 16 && !a->graph->header.has_exc &&
-                           geometry(4 * 8 * words, (n_reads + 3) / 4, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
+                           geometry(8 * 8 * words, (n_reads + 3) / 4, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
@@ -476,9 +476,21 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.deep_stride = (uint32_t)deep_stride;
     io.level_search = level_search ? 1u : 0u;
     io.greedy4 = 0;
+    io.g4_state = nullptr;
+    io.gen_list = nullptr;
+    io.gen_ctr = 8;
+    io.g4_last = 0;
+    io.list_chunk = 16;
     io.subset_ctr = 2;
     io.ovf_ctr = 2;
-    if (fast_pass) HIP_TRY(a->ovf.ensure(n_reads * 4));
+    if (fast_pass) {
+        // the lists between the passes are written in per-wave slices of 16 entries (bgr::kG4ListChunk): room for the holes
+        const uint64_t list_cap = n_reads + n_reads / 4 + (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 2 * 16 + 64;  // <= 3 holes per 16 at a slice change, <= 15 at a wave's end
+        HIP_TRY(a->ovf.ensure(list_cap * 4));
+        HIP_TRY(a->ovf2.ensure(n_reads * 4));
+        HIP_TRY(a->ovf3.ensure(list_cap * 4));
+        HIP_TRY(a->g4st.ensure(n_reads * 4));
+    }
     if (two_pass && !deep_only) {
         HIP_TRY(a->ovf.ensure(n_reads * 4));
         io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
@@ -494,21 +506,38 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     io.cursor = static_cast<uint32_t*>(a->small.p);
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, a->knob_debug_stop};
 
-    HIP_TRY(hipMemsetAsync(a->small.p, 0, 16, a->stream));
+    HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters
     HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
     HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, (n_reads + 31) / 32 * 4, a->stream));
     hipError_t e = bgr::launch_pack_reads(static_cast<const uint8_t*>(d_reads), io.read_offs, io.n_reads, total_bases, static_cast<uint64_t*>(a->pk_fw3.p),
                                           static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("pre-pass launch: ") + hipGetErrorString(e));
-    if (fast_pass) {  // the general kernel then maps only the listed reads (always enqueued: with an empty list its waves exit at once)
-        bgr::BatchIO iof = io;
-        iof.greedy4 = 1;
-        iof.ovf_list = static_cast<uint32_t*>(a->ovf.p);
-        iof.ovf_ctr = 2;
-        e = bgr::launch_align(a->dg, iof, kp, cfg_fast, a->stream);
-        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (four-reads-per-wave pass): ") + hipGetErrorString(e));
-        io.subset = iof.ovf_list;
-        io.subset_ctr = 2;
+    if (fast_pass) {
+        // Three launches of the four-reads-per-wave kernel: all reads; then twice what the launch before could not finish (the
+        // next anchors of a read whose first ones failed, then its reverse complement), densely packed four to a wave again.
+        // What is left after that -- and reads the kernel does not take at all (N, very long paths) -- is mapped from scratch
+        // by the general kernel.  All enqueued back to back: with an empty list a launch's workgroups exit at once.
+        uint32_t* lists[2] = {static_cast<uint32_t*>(a->ovf.p), static_cast<uint32_t*>(a->ovf3.p)};
+        const int kFastPasses = 3;
+        for (int ps = 0; ps < kFastPasses; ++ps) {
+            bgr::BatchIO iof = io;
+            iof.greedy4 = 1;
+            iof.g4_state = static_cast<uint32_t*>(a->g4st.p);
+            iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
+            iof.gen_ctr = 8;
+            iof.g4_last = ps == kFastPasses - 1 ? 1u : 0u;
+            // slices of 16 list entries per atomic for big batches (a single-address atomic per read caps a launch near 300 M/s),
+            // of 4 for small ones (every wave leaves the unused tail of its last slice as holes)
+            iof.list_chunk = n_reads >= (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 256 ? 16u : 4u;
+            iof.subset = ps ? lists[(ps - 1) & 1] : nullptr;
+            iof.subset_ctr = 2 + (uint32_t)ps - 1;
+            iof.ovf_list = lists[ps & 1];
+            iof.ovf_ctr = 2 + (uint32_t)ps;
+            e = bgr::launch_align(a->dg, iof, kp, cfg_fast, a->stream);
+            if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (four-reads-per-wave pass): ") + hipGetErrorString(e));
+        }
+        io.subset = static_cast<uint32_t*>(a->ovf2.p);
+        io.subset_ctr = 8;
     }
     e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -681,6 +710,16 @@ int bgr_aligner_reset_kernel_time(bgr_aligner* a) {
 int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]) {
     if (!a || !out) return fail(BGR_E_ARG, "bgr_aligner_launch_info: null argument");
     memcpy(out, a->last_launch, sizeof(a->last_launch));
+    return BGR_OK;
+}
+
+int bgr_aligner_pass_counts(bgr_aligner* a, uint32_t out[4]) {
+    if (!a || !out) return fail(BGR_E_ARG, "bgr_aligner_pass_counts: null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    uint32_t cur[16];
+    HIP_TRY(hipMemcpy(cur, a->small.p, sizeof(cur), hipMemcpyDeviceToHost));
+    out[0] = cur[2]; out[1] = cur[3]; out[2] = cur[4]; out[3] = cur[8];
     return BGR_OK;
 }
 

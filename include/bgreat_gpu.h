@@ -155,6 +155,12 @@ int bgr_aligner_reset_kernel_time(bgr_aligner* a);
  * bit 0 = the MPHF cascade was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first),
  * bit 2 = greedy mode ran its four-reads-per-wave first pass (the numbers then describe that launch). */
 int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
+/* How the last mapping launch went through its passes.  Greedy mode: out[0..2] = reads the first / second / third launch of
+ * the four-reads-per-wave kernel handed on to the next one, counted in list entries (lists are written in per-wave slices,
+ * so the figure includes a few unused entries; out[2] is 0: the third launch hands everything to the general kernel),
+ * out[3] = reads mapped by the general kernel.  Exhaustive mode: out[0] = reads listed by the first pass, out[1] = by the
+ * second.  Synchronises the stream. */
+int bgr_aligner_pass_counts(bgr_aligner* a, uint32_t out[4]);
 /* Tuning knobs (0 keeps the default): waves per workgroup, workgroups per CU, force MPHF LDS staging
  * (0 auto, 1 off, 2 on). */
 int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blocks_per_cu, uint32_t lds_mphf);
