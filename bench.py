@@ -4,20 +4,32 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one launch of the mapping kernel over one batch of synthetic reads that is already resident in HBM
-(ASCII reads + offsets, as the C-ABI's bgr_align_device takes them).  Workload = BASELINE.json configs[2]
-("Synthetic 50M x 150 bp reads, k=31, m=2, E.coli-scale graph (~100k unitigs), greedy"): with the defaults
-(10 steps x 5M reads) one run maps exactly that read set on one GPU.  With N>1 every rank maps its own
-equally sized shard (weak scaling); the read-only graph blob is built on rank 0 and broadcast once over RCCL.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+A step = one mapping launch (bgr_align_device of the C-ABI) over one batch of synthetic reads that is already resident
+in HBM as ASCII (what the reference's getReads hands over): the pre-pass that packs the reads to 2 bits and the passes of
+the mapping kernels, enqueued back to back on one stream.  Workload = BASELINE.json configs[2] ("Synthetic 50M x 150 bp
+reads, k=31, m=2, E.coli-scale graph (~100k unitigs), greedy"): with the defaults (10 steps x 5M reads) one run maps
+exactly that read set on one GPU.  With N>1 every rank maps its own equally sized shard (weak scaling); the read-only
+graph blob is built on rank 0 and broadcast once over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Besides `value` (device-resident) it carries
+  roofline       algorithmic bytes (SURVEY 8d formula, oracle counter mode) / launch time, plus what bounds the launch in
+                 fact: HBM traffic measured in this run (rocprofv3 PMC passes over a short child run of this script) and
+                 the VALU issue fraction
+  pcie_inclusive pinned host buffers -> bgr_align_batch (H2D + launch + CSR + D2H), same batch size
+  e2e            bgr_align_all: read file -> paths / notAligned.fa (parse, pack, GPU, format, write; index build excluded)
+  cpu_baseline   the compiled reference (oracle/_ref/bgreat -t cores) on a bounded sample, rank 0, N=1 only
 """
 import argparse
+import csv
+import ctypes
+import glob
 import json
 import os
 import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -26,14 +38,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_GHZ = 2.4         # hipDeviceAttributeClockRate on the box; profiles/r02_valu_rates.txt is priced at it
+N_SIMD = 1024           # 256 CUs x 4
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -50,7 +64,7 @@ def main():
     ap.add_argument("--alg-sample", type=int, default=20_000, help="reads used to count ALGORITHMIC bytes/read with the oracle")
     ap.add_argument("--lds-mphf", type=int, default=0, help="0 auto, 1 HBM/L2 only, 2 force LDS staging")
     ap.add_argument("--waves", type=int, default=0)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for input generation, the e2e leg and the CPU baseline")
     ap.add_argument("--workload", default="ecoli", choices=["ecoli", "small", "chr1", "branchy"],
                     help="ecoli = BASELINE configs[2] (default, the metric's config); small = configs[1]; chr1 = configs[3] graph scale; "
                          "branchy = configs[4] (exhaustive, m=5, 250 bp)")
@@ -58,8 +72,13 @@ def main():
     ap.add_argument("--anchors", action="store_true", help="-G: greedy mapping from k-mer anchors (diagnostic; not the headline metric)")
     ap.add_argument("--gamma", type=float, default=0.0, help="MPHF positions per key and level (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the four-reads-per-wave passes (diagnostic)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and valu_issue_frac become null)")
+    ap.add_argument("--pmc-steps", type=int, default=3)
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end leg per GPU (0 disables)")
+    ap.add_argument("--pcie-steps", type=int, default=3, help="timed bgr_align_batch calls of the PCIe-inclusive leg (0 disables)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-
     presets = {  # SURVEY.md 8d synthetic inputs; explicit flags given on the command line win over the preset
         "small": dict(genome=250_000, site_spacing=75, alleles=2, read_len=100, reads_per_step=1_000_000),
         "chr1": dict(genome=230_000_000, site_spacing=175, alleles=2),
@@ -68,15 +87,76 @@ def main():
     for key, val in presets.get(args.workload, {}).items():
         if getattr(args, key) == ap.get_default(key):
             setattr(args, key, val)
+    return args
+
+
+# ---- HBM traffic and instruction counters of one step, measured in this run ------------------------------------------------
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
+              ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]),
+              ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"]))
+
+
+def run_pmc_passes(args):
+    """rocprofv3 --pmc over short child runs of this script (same workload, same launch geometry, `pmc_steps` launches and
+    nothing else on the GPU), one pass per counter group as MI355X_MICROARCH.md prescribes.  Runs BEFORE this process
+    touches the GPU.  -> {counter: mean per mapping launch, summed over the kernels of the launch}, or {"error": ...}."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    fwd = ["--pmc-child", "--steps", str(args.pmc_steps), "--warmup", "0", "--workload", args.workload, "--reads-per-step", str(args.reads_per_step),
+           "--read-len", str(args.read_len), "--k", str(args.k), "--mismatch", str(args.mismatch), "--effort", str(args.effort),
+           "--genome", str(args.genome), "--site-spacing", str(args.site_spacing), "--alleles", str(args.alleles), "--lds-mphf", str(args.lds_mphf),
+           "--waves", str(args.waves), "--blocks-per-cu", str(args.blocks_per_cu), "--gamma", str(args.gamma), "--cpu-threads", str(args.cpu_threads)]
+    for flag in ("exhaustive", "anchors", "general_kernel_only"):
+        if getattr(args, flag):
+            fwd.append("--" + flag.replace("_", "-"))
+    totals, per_kernel = {}, {}
+    t0 = time.time()
+    for tag, counters in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix="bgr_pmc_%s_" % tag, dir="/tmp")
+        try:
+            cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + fwd
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return {"error": "rocprofv3 pass '%s' failed (rc %d): %s" % (tag, p.returncode, (p.stderr or "")[-300:])}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    kn = row.get("Kernel_Name", "")
+                    if "bgr_" not in kn:
+                        continue
+                    v = float(row["Counter_Value"])
+                    totals[row["Counter_Name"]] = totals.get(row["Counter_Name"], 0.0) + v
+                    short = kn[kn.find("bgr_"):].split("(")[0]
+                    per_kernel.setdefault(short, {})
+                    per_kernel[short][row["Counter_Name"]] = per_kernel[short].get(row["Counter_Name"], 0.0) + v
+        except Exception as ex:  # the counters are a diagnostic: never fail the bench over them
+            return {"error": "%s: %s" % (type(ex).__name__, ex)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    n = float(args.pmc_steps)
+    out = {k: v / n for k, v in totals.items()}
+    out["_per_kernel"] = {k: {c: v / n for c, v in d.items()} for k, d in per_kernel.items()}
+    out["_seconds"] = round(time.time() - t0, 1)
+    return out
+
+
+def main():
+    args = parse_args()
     mode = 1 if args.exhaustive else (2 if args.anchors else 0)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    pmc = None
+    if not args.pmc_child and not args.no_pmc and world == 1:
+        pmc = run_pmc_passes(args)   # child processes; this process has not initialised the GPU yet
+        log("pmc passes:", {k: v for k, v in pmc.items() if not k.startswith("_per")} if pmc else None)
 
     import torch
     import bgreat_amd as B
     from tools.synth import Synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
@@ -116,25 +196,27 @@ def main():
         g = B.Graph.build(args.k, seqs, offs, args.gamma, anchors=(mode == 2))
         graph_info = g.info()
         log("index build: %.2fs on the host (%d unitigs)" % (time.time() - tb, graph_info["n_unitigs"]))
-    blob_keepalive = None
     if world > 1:
         from bgreat_amd import dist as D
-        g, blob_keepalive = D.broadcast_graph(g, dist, device=coll_dev)  # C1: the only data-path collective; reads never move
+        g, _blob_keepalive = D.broadcast_graph(g, dist, device=coll_dev)  # C1: the only data-path collective; reads never move
     al = B.Aligner(g, dev)
     al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
+    if args.general_kernel_only:
+        al.set_knob(B.KNOB_GREEDY_FAST, 1)
     if rank == 0:
         log("graph: %s  (%.1fs)" % (graph_info, time.time() - t0))
 
     # ---- reads: rank r owns global reads [r*K*R, (r+1)*K*R); generated on the host, parked in HBM -----------
     t0 = time.time()
-    ncpu = min(len(os.sched_getaffinity(0)), args.cpu_threads)  # the GPU box gives one GPU a 16-core share
+    ncpu_all = len(os.sched_getaffinity(0))
+    ncpu = max(1, min(ncpu_all // max(1, world) if world > 1 else ncpu_all, args.cpu_threads))  # the GPU box gives one GPU a 16-core share
     offs_np = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
     offs_t = torch.from_numpy(offs_np.view(np.int64)).to("cuda")
     batches = []
     first_host = None
     for s in range(K):
-        arr, _ = syn.reads((rank * K + s) * R, R, L, args.mismatch, seed_reads, threads=max(1, ncpu // max(1, min(world, 8))))
-        if s == 0 and rank == 0:
+        arr, _ = syn.reads((rank * K + s) * R, R, L, args.mismatch, seed_reads, threads=ncpu)
+        if s == 0 and rank == 0 and not args.pmc_child:
             first_host = arr[: max(args.cpu_sample, args.alg_sample) * L].copy()
         batches.append(torch.from_numpy(arr).to("cuda"))
         del arr
@@ -162,12 +244,21 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    if args.pmc_child:
+        return
     if dist is not None:
         elapsed = D.max_over_ranks(elapsed, dist, device=coll_dev)
     launches, kernel_ms = al.kernel_time()
+    _, slots = al.kernel_times()
     counters = al.counters()
+    pass_counts = al.pass_counts()
     if dist is not None:  # C2: sum the aligner.h:68 counters over ranks
         counters = D.reduce_counters(counters, dist, device=coll_dev)
+
+    # ---- end to end: file in -> paths / notAligned.fa out (every rank its own shard file and GPU) ---------------
+    e2e = None
+    if args.e2e_reads > 0 and mode == 0:
+        e2e = run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D if dist is not None else None, coll_dev, seed_reads)
 
     if rank != 0:
         if dist is not None:
@@ -177,7 +268,7 @@ def main():
 
     total_reads = world * K * R
     value = total_reads / elapsed / 1e6
-    avg_kernel_ms = kernel_ms / max(1, launches)
+    avg_launch_ms = kernel_ms / max(1, launches)
 
     # ---- ALGORITHMIC bytes per read: SURVEY.md 8d formula, counted by the oracle on a sample of this workload ----
     import oracle_py
@@ -192,81 +283,69 @@ def main():
     # parity of the same sample through the GPU path (outside the timed region)
     p1, po1, st1 = al.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
     parity_ok = bool(np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2))
-    achieved = alg_bytes_per_read * R / (avg_kernel_ms / 1e3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("reads_per_launch") == R and tj.get("read_len") == L and tj.get("workload") == args.workload and mode == 0:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    achieved = alg_bytes_per_read * R / (avg_launch_ms / 1e3) / 1e9
+    kernels_ms = [{"kernel": nm, "avg_ms": round(ms / max(1, launches), 4)} for nm, ms in slots]
+    dominant = max(slots, key=lambda x: x[1])[0] if slots else None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "kernel": ("bgr_align_greedy_kernel", "bgr_align_exhaustive_dp_kernel" if al.launch_info().get("level_search") else "bgr_align_exhaustive_kernel", "bgr_align_anchors_kernel")[mode], "avg_launch_ms": round(avg_kernel_ms, 4), "launches": launches,
+                "traffic": None,
+                "definition": "achieved = ALGORITHMIC bytes of the REFERENCE's control flow (SURVEY 8d: gamma-10 BooPHF probes, rank words, 24-B records, "
+                              "compared bases, path ints; oracle counter mode) x reads per launch / launch time.  This implementation moves far fewer "
+                              "bytes (own cascade probed in LDS): `traffic` is what HBM saw, `limiter` what bounds the launch",
+                "launch": "pre-pass + mapping passes of one batch, enqueued back to back on one stream (HIP events around the sequence)",
+                "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "kernels_ms": kernels_ms, "dominant_kernel": dominant,
                 "alg_bytes_per_read": round(alg_bytes_per_read, 1), "reads_per_launch": R}
+    if pmc and "error" not in pmc:
+        fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
+        if fetch_kb is not None and write_kb is not None:
+            raw = (fetch_kb + write_kb) * 1024.0
+            corrected = (2.0 * fetch_kb + write_kb) * 1024.0  # gfx950: FETCH_SIZE tallies 128-B requests of wide reads at 64 B (upper bound for small gathers)
+            roofline["traffic"] = round(corrected, 1)
+            roofline["traffic_raw"] = round(raw, 1)
+            roofline["traffic_note"] = ("HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc in separate passes over a %d-launch child run of "
+                                        "this script in this run; raw = without the gfx950 x2 on FETCH_SIZE" % args.pmc_steps)
+            roofline["traffic_frac"] = round(corrected / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+            roofline["traffic_bytes_per_read"] = round(corrected / R, 1)
+        if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
+            roofline["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
+        if pmc.get("SQ_INSTS_VALU") is not None:
+            simd_cycles = N_SIMD * (avg_launch_ms / 1e3) * CLOCK_GHZ * 1e9
+            roofline["limiter"] = "valu_issue"
+            roofline["valu_insts_per_read"] = round(pmc["SQ_INSTS_VALU"] / R, 1)
+            roofline["salu_insts_per_read"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / R, 1)
+            # profiles/r02_valu_rates.txt: ~4.1 cycles per wave64 instruction for shifts/min/popcount/mul/DPP/readlane, ~2.2 for plain
+            # add/logic; SQ_ACTIVE_INST_VALU counts the busy time of the vector ALUs in units of 4 cycles
+            if pmc.get("SQ_ACTIVE_INST_VALU") is not None:
+                roofline["valu_issue_frac"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, 4)
+            roofline["valu_issue_frac_at_4_cycles"] = round(pmc["SQ_INSTS_VALU"] * 4.0 / simd_cycles, 4)
+            roofline["salu_issue_frac"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / (N_SIMD / 4 * (avg_launch_ms / 1e3) * CLOCK_GHZ * 1e9), 4)  # one scalar unit per CU
+            roofline["issue_note"] = ("instructions per launch from rocprofv3 SQ counters (same child runs); VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x launch time "
+                                      "x %.1f GHz); SALU = SQ_INSTS_SALU / (256 CUs x cycles): one scalar instruction per cycle and CU" % CLOCK_GHZ)
+        roofline["pmc_seconds"] = pmc.get("_seconds")
+        roofline["pmc_per_kernel"] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in pmc.get("_per_kernel", {}).items()}
+    elif pmc:
+        roofline["traffic_note"] = "not measured in this run: " + pmc["error"]
+
+    # ---- PCIe inclusive: pinned host buffers through bgr_align_batch (H2D + launch + CSR + D2H), N=1 only ---------
+    pcie = None
+    if world == 1 and args.pcie_steps > 0 and mode == 0:
+        pcie = run_pcie(args, B, g, al, syn, seed_reads, ncpu, dev)
 
     # ---- CPU baseline: the compiled reference (oracle/_ref/bgreat -t cores) on a bounded sample, N=1 only -------
     cpu = None
     if world == 1 and args.cpu_sample > 0 and mode == 0:
-        nc = min(args.cpu_sample, R)
-        ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
-        d = tempfile.mkdtemp(prefix="bgr_cpu_")
-        try:
-            syn.write_unitigs(os.path.join(d, "u.fa"))
-            syn.write_reads(os.path.join(d, "r.fa"), 0, nc, L, args.mismatch, seed_reads)
-            cores = min(ncpu, 255)
-            if os.path.exists(ref):
-                cmd, kind = [ref], "reference"
-            else:
-                cmd, kind = [os.path.join(ROOT, "oracle", "bgreat_oracle")], "port"
-            cmd += ["-r", os.path.join(d, "r.fa"), "-k", str(args.k), "-g", os.path.join(d, "u.fa"), "-m", str(args.mismatch), "-e", str(args.effort), "-t", str(cores)]
-            t1 = time.perf_counter()
-            subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL)
-            wall = time.perf_counter() - t1
-            # index-only run (empty read file) to subtract the one-off indexing from the mapping time
-            open(os.path.join(d, "empty.fa"), "w").close()
-            cmd_i = list(cmd)
-            cmd_i[cmd_i.index("-r") + 1] = os.path.join(d, "empty.fa")
-            d2 = os.path.join(d, "idx")
-            os.makedirs(d2)
-            t1 = time.perf_counter()
-            subprocess.run(cmd_i, cwd=d2, check=True, stdout=subprocess.DEVNULL)
-            wall_idx = time.perf_counter() - t1
-            map_s = max(1e-6, wall - wall_idx)
-            # parity at scale: GPU records == reference records as a multiset (-t N interleaves records)
-            ref_paths = open(os.path.join(d, "paths"), "rb").read().split(b"\n")
-            c_reads = first_host[: nc * L]
-            c_offs = np.arange(nc + 1, dtype=np.uint64) * np.uint64(L)
-            gp, gpo, gst = al.align(c_reads, c_offs, m=args.mismatch, effort=args.effort)
-            ref_map = {}
-            for h, p in zip(ref_paths[0::2], ref_paths[1::2]):
-                ref_map[h] = p
-            n_al = int((gpo[1:] > gpo[:-1]).sum())
-            ok = n_al == len(ref_map)
-            if ok:
-                idx = np.nonzero(gpo[1:] > gpo[:-1])[0]
-                for i in idx[:: max(1, len(idx) // 200000)]:
-                    want = ref_map.get(b">r%d" % i)
-                    got = b"".join(b"%d." % v for v in gp[int(gpo[i]): int(gpo[i + 1])])
-                    if want != got:
-                        ok = False
-                        break
-            cpu = {"value": round(nc / map_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind,
-                   "sample": "first %d reads of step 0 of this workload, %s -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(cmd[0]), cores, wall, wall_idx),
-                   "gpu_matches_cpu_records": bool(ok)}
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+        cpu = run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads)
 
     out = {
         "metric": "Mreads/s aligned (k=%d, %dbp, m=%d)" % (args.k, L, args.mismatch), "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%s: synthetic %.1fM x %d bp reads per GPU (%d steps x %d), k=%d, m=%d, effort=%d, %s, graph of %d unitigs (genome %d bp, %d alleles every ~%d bp)"
+        "config": {"workload": "%s: synthetic %.1fM x %d bp reads per GPU (%d steps x %d), k=%d, m=%d, effort=%d, %s, graph of %d unitigs (genome %d bp, %d alleles every ~%d bp); "
+                               "reads resident in HBM as ASCII before the timed region, results left in HBM"
                    % ({"ecoli": "BASELINE configs[2]", "small": "BASELINE configs[1]", "chr1": "BASELINE configs[3] graph scale, one GPU's share", "branchy": "BASELINE configs[4] graph, one GPU's share"}[args.workload],
                       K * R / 1e6, L, K, R, args.k, args.mismatch, args.effort, ("greedy", "exhaustive", "greedy from k-mer anchors (-G)")[mode], graph_info["n_unitigs"], args.genome, args.alleles, args.site_spacing),
                    "reads_per_step_per_gpu": R, "read_len": L, "k": args.k, "m": args.mismatch, "effort": args.effort,
-                   "parallelism": "reads sharded over %d GPU(s); graph blob broadcast once" % world, "launch": al.launch_info()},
-        "roofline": roofline, "cpu_baseline": cpu,
+                   "parallelism": "reads sharded over %d GPU(s); graph blob broadcast once" % world, "launch": al.launch_info(),
+                   "pass_counts_last_launch": pass_counts},
+        "roofline": roofline, "pcie_inclusive": pcie, "e2e": e2e, "cpu_baseline": cpu,
         "counters": counters, "parity_sample": {"reads": ns, "gpu_equals_oracle": parity_ok},
         "oracle_work_per_read": {k: round(v / ns, 2) for k, v in work.items() if k not in ("reads",)},
     }
@@ -274,6 +353,168 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_reads):
+    """bgr_align_all on a FASTA file written just before (so it is read from the page cache): mmap + chunk-parallel parse +
+    gather into pinned batches + H2D + launch + CSR + D2H + format + write, `ncpu` host threads per GPU.  Index build excluded."""
+    n, L = args.e2e_reads, args.read_len
+    d = tempfile.mkdtemp(prefix="bgr_e2e_r%d_" % rank)
+    try:
+        f = os.path.join(d, "reads.fa")
+        syn.write_reads(f, (world + rank) * 1_000_000_000, n, L, args.mismatch, seed_reads, threads=ncpu)
+        fsize = os.path.getsize(f)
+        best = None
+        for rep in range(2):  # the second run has its device buffers and the pinned pool warm
+            if dist is not None:
+                dist.barrier()
+            t1 = time.perf_counter()
+            cnt, secs = B.align_all(g, f, os.path.join(d, "paths"), os.path.join(d, "notAligned.fa"), m=args.mismatch, effort=args.effort,
+                                    threads=ncpu, n_gpus=1, first_device=dev)
+            if dist is not None:
+                dist.barrier()
+            wall = time.perf_counter() - t1
+            if dist is not None:
+                wall = D.max_over_ranks(wall, dist, device=coll_dev)
+            if best is None or wall < best:
+                best = wall
+        out_bytes = os.path.getsize(os.path.join(d, "paths")) + os.path.getsize(os.path.join(d, "notAligned.fa"))
+        return {"value": round(world * n / best / 1e6, 3), "unit": "Mreads/s", "reads_per_gpu": n, "n_gpus": world, "host_threads_per_gpu": ncpu, "seconds": round(best, 4),
+                "input": "FASTA, %d bytes per GPU, written just before the run: page cache" % fsize, "input_GB_per_s": round(world * fsize / best / 1e9, 2),
+                "output_bytes_per_gpu": out_bytes, "aligned": cnt["aligned"], "what": "bgr_align_all (the CLI's mapping phase): file -> paths + notAligned.fa; best of 2 runs; index build excluded"}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def run_pcie(args, B, g, al, syn, seed_reads, ncpu, dev):
+    """Page-locked host buffers -> bgr_align_batch: H2D of the ASCII reads + offsets, the mapping launch, CSR on the device,
+    D2H of paths / offsets / status.  One blocking stream, then two aligners (streams) on two host threads, as the CLI's
+    pipeline drives them."""
+    try:
+        R, L = args.reads_per_step, args.read_len
+        lib = B.lib()
+
+        def pinned(nbytes, dtype):
+            p = ctypes.c_void_p()
+            B._check(lib.bgr_host_alloc(nbytes, ctypes.byref(p)))
+            return p, np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,)).view(dtype)
+
+        def buffers(n):
+            cap = 8 * n + 4096
+            hr, reads = pinned(n * L, np.uint8)
+            ho, offs = pinned((n + 1) * 8, np.uint64)
+            hp, paths = pinned(cap * 4, np.int32)
+            hq, poffs = pinned((n + 1) * 8, np.uint64)
+            hs, status = pinned(n + 8, np.uint8)
+            offs[:] = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+            return dict(h=(hr, ho, hp, hq, hs), reads=reads, offs=offs, paths=paths, poffs=poffs, status=status, cap=cap, n=n)
+
+        def call(a, b):
+            p = B.Params(B.MODE_GREEDY, args.mismatch, args.effort, 0)
+            B._check(lib.bgr_align_batch(a.h, ctypes.byref(p), b["reads"].ctypes.data, b["offs"].ctypes.data, b["n"], b["paths"].ctypes.data, b["cap"],
+                                         b["poffs"].ctypes.data, b["status"].ctypes.data))
+
+        t0 = time.time()
+        arr, _ = syn.reads(3_000_000_000, R, L, args.mismatch, seed_reads, threads=ncpu)
+        one = buffers(R)
+        one["reads"][:] = arr
+        call(al, one)  # warm-up: device buffers of this size
+        t1 = time.perf_counter()
+        for _ in range(args.pcie_steps):
+            call(al, one)
+        t_one = (time.perf_counter() - t1) / args.pcie_steps
+        h2d = R * L + (R + 1) * 8
+        d2h = int(one["poffs"][R]) * 4 + (R + 1) * 8 + R
+        # two streams: two aligners, each with its own half-size pinned batch, driven from two host threads
+        half = R // 2
+        al2 = B.Aligner(g, dev)
+        hb = [buffers(half), buffers(half)]
+        hb[0]["reads"][:] = arr[: half * L]
+        hb[1]["reads"][:] = arr[half * L: 2 * half * L]
+        als = [al, al2]
+        for i in range(2):
+            call(als[i], hb[i])
+
+        def worker(i):
+            for _ in range(args.pcie_steps * 2):
+                call(als[i], hb[i])
+
+        t1 = time.perf_counter()
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        t_two = time.perf_counter() - t1
+        out = {"value": round(R / t_one / 1e6, 3), "unit": "Mreads/s", "reads_per_call": R, "ms_per_call": round(t_one * 1e3, 3),
+               "two_streams": {"value": round(2 * half * args.pcie_steps * 2 / t_two / 1e6, 3), "unit": "Mreads/s", "reads_per_call": half},
+               "h2d_bytes_per_read": round(h2d / R, 1), "d2h_bytes_per_read": round(d2h / R, 1),
+               "what": "bgr_align_batch on page-locked host buffers: H2D (ASCII reads + offsets) + pre-pass + mapping passes + CSR on the device + D2H (paths, offsets, status); "
+                       "mean of %d blocking calls on one stream; two_streams = two aligners on two host threads (how the CLI's pipeline overlaps copies and kernels)" % args.pcie_steps}
+        al2.close()
+        for b in [one] + hb:
+            for h in b["h"]:
+                lib.bgr_host_free(h)
+        log("pcie leg: %.1fs" % (time.time() - t0))
+        return out
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+
+def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
+    R, L = args.reads_per_step, args.read_len
+    nc = min(args.cpu_sample, R)
+    ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
+    d = tempfile.mkdtemp(prefix="bgr_cpu_")
+    try:
+        syn.write_unitigs(os.path.join(d, "u.fa"))
+        syn.write_reads(os.path.join(d, "r.fa"), 0, nc, L, args.mismatch, seed_reads)
+        cores = min(ncpu, 255)
+        if os.path.exists(ref):
+            cmd, kind = [ref], "reference"
+        else:
+            cmd, kind = [os.path.join(ROOT, "oracle", "bgreat_oracle")], "port"
+        cmd += ["-r", os.path.join(d, "r.fa"), "-k", str(args.k), "-g", os.path.join(d, "u.fa"), "-m", str(args.mismatch), "-e", str(args.effort), "-t", str(cores)]
+        t1 = time.perf_counter()
+        subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL)
+        wall = time.perf_counter() - t1
+        # index-only run (empty read file) to subtract the one-off indexing from the mapping time
+        open(os.path.join(d, "empty.fa"), "w").close()
+        cmd_i = list(cmd)
+        cmd_i[cmd_i.index("-r") + 1] = os.path.join(d, "empty.fa")
+        d2 = os.path.join(d, "idx")
+        os.makedirs(d2)
+        t1 = time.perf_counter()
+        subprocess.run(cmd_i, cwd=d2, check=True, stdout=subprocess.DEVNULL)
+        wall_idx = time.perf_counter() - t1
+        map_s = max(1e-6, wall - wall_idx)
+        # parity at scale: GPU records == reference records as a multiset (-t N interleaves records, SURVEY fact 0.6)
+        ref_paths = open(os.path.join(d, "paths"), "rb").read().split(b"\n")
+        c_reads = first_host[: nc * L]
+        c_offs = np.arange(nc + 1, dtype=np.uint64) * np.uint64(L)
+        gp, gpo, gst = al.align(c_reads, c_offs, m=args.mismatch, effort=args.effort)
+        ref_map = {}
+        for h, p in zip(ref_paths[0::2], ref_paths[1::2]):
+            ref_map[h] = p
+        n_al = int((gpo[1:] > gpo[:-1]).sum())
+        ok = n_al == len(ref_map)
+        if ok:
+            idx = np.nonzero(gpo[1:] > gpo[:-1])[0]
+            for i in idx[:: max(1, len(idx) // 200000)]:
+                want = ref_map.get(b">r%d" % i)
+                got = b"".join(b"%d." % v for v in gp[int(gpo[i]): int(gpo[i + 1])])
+                if want != got:
+                    ok = False
+                    break
+        return {"value": round(nc / map_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind,
+                "sample": "first %d reads of step 0 of this workload, %s -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(cmd[0]), cores, wall, wall_idx),
+                "gpu_matches_cpu_records": bool(ok)}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ SYMBOLS = [
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup",
-    "bgr_aligner_set_knob", "bgr_aligner_pass_counts",
+    "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST = 1, 2, 3, 4, 5
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
@@ -52,7 +52,7 @@ class Params(C.Structure):
 class RunOptions(C.Structure):
     _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
                 ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("correction", C.c_uint32),
-                ("no_overlap_file", C.c_char_p)]
+                ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):
@@ -130,6 +130,7 @@ def lib():
     L.bgr_aligner_reset_counters.argtypes = [vp]
     L.bgr_aligner_kernel_time.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double)]
     L.bgr_aligner_reset_kernel_time.argtypes = [vp]
+    L.bgr_aligner_kernel_times.argtypes = [vp, C.POINTER(u64), vp, vp]
     L.bgr_aligner_launch_info.argtypes = [vp, vp]
     L.bgr_aligner_configure.argtypes = [vp, u32, u32, u32]
     L.bgr_aligner_set_knob.argtypes = [vp, u32, u64]
@@ -294,6 +295,14 @@ class Aligner:
         _check(lib().bgr_aligner_kernel_time(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def kernel_times(self):
+        """-> (launches, [(kernel name, summed ms), ...]) per kernel of a launch, in launch order."""
+        n = C.c_uint64()
+        ms = (C.c_double * 8)()
+        names = (C.c_char_p * 8)()
+        _check(lib().bgr_aligner_kernel_times(self.h, C.byref(n), ms, names))
+        return n.value, [(names[i].decode(), ms[i]) for i in range(8) if names[i]]
+
     def reset_kernel_time(self):
         _check(lib().bgr_aligner_reset_kernel_time(self.h))
 
@@ -322,11 +331,11 @@ class Aligner:
 
 
 def align_all(graph, reads_csv, paths_file, notaligned_file, m=2, effort=2, mode=MODE_GREEDY, partial=False, n_gpus=1, threads=1,
-              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False, correction=False, no_overlap_file=None):
+              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False, correction=False, no_overlap_file=None, first_device=0):
     """Aligner::alignAll (aligner.cpp:550-597) as one call -> (counters dict, mapping seconds)."""
     p = Params(mode, m, effort, int(partial))
     o = RunOptions(n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, int(correction),
-                   no_overlap_file.encode() if no_overlap_file else None)
+                   no_overlap_file.encode() if no_overlap_file else None, first_device)
     out = np.zeros(5, dtype=np.uint64)
     secs = C.c_double()
     _check(lib().bgr_align_all(graph.h, C.byref(p), C.byref(o), reads_csv.encode(), paths_file.encode(), notaligned_file.encode(),

@@ -28,7 +28,8 @@ int fail(int code, const std::string& msg) { tl_err = msg; return code; }
     } while (0)
 
 const uint32_t kLdsFixed = 512;  // level descriptors at the start of the dynamic LDS
-const int kTimerRing = 256;
+const int kTimerRing = 64;   // launches between two drains of the timers
+const int kTimerSlots = 8;   // kernels of one launch timed separately (pre-pass, passes)
 
 }  // namespace
 
@@ -73,10 +74,12 @@ struct bgr_aligner {
     uint64_t knob_split_limit = 0;
     int num_cus = 0;
     size_t lds_per_cu = 0;
-    hipEvent_t ev_start[kTimerRing], ev_stop[kTimerRing];
+    hipEvent_t ev[kTimerRing][kTimerSlots + 1];  // ev[i][0] = start of launch i, ev[i][j] = behind its j-th kernel
+    int ev_marks[kTimerRing];                    // kernels timed in launch i
     int ev_used = 0;
     uint64_t t_launches = 0;
-    double t_ms = 0;
+    double t_ms = 0, t_slot_ms[kTimerSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const char* t_slot_name[kTimerSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -86,8 +89,12 @@ int drain_timers(bgr_aligner* a) {
     HIP_TRY(hipStreamSynchronize(a->stream));
     for (int i = 0; i < a->ev_used; ++i) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, a->ev_start[i], a->ev_stop[i]));
+        HIP_TRY(hipEventElapsedTime(&ms, a->ev[i][0], a->ev[i][a->ev_marks[i]]));
         a->t_ms += ms;
+        for (int j = 0; j < a->ev_marks[i]; ++j) {
+            HIP_TRY(hipEventElapsedTime(&ms, a->ev[i][j], a->ev[i][j + 1]));
+            a->t_slot_ms[j] += ms;
+        }
         ++a->t_launches;
     }
     a->ev_used = 0;
@@ -258,9 +265,11 @@ int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out) {
     e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete a; return fail(BGR_E_HIP, hipGetErrorString(e)); }
     for (int i = 0; i < kTimerRing; ++i) {
-        if (hipEventCreate(&a->ev_start[i]) != hipSuccess || hipEventCreate(&a->ev_stop[i]) != hipSuccess) {
-            delete a;
-            return fail(BGR_E_HIP, "hipEventCreate failed");
+        for (int j = 0; j <= kTimerSlots; ++j) {
+            if (hipEventCreate(&a->ev[i][j]) != hipSuccess) {
+                delete a;
+                return fail(BGR_E_HIP, "hipEventCreate failed");
+            }
         }
     }
     bgr::resolve_device_graph(&g->header, g->dev[device].ptr, a->dg);
@@ -277,7 +286,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
         a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->ovf3.release(); a->g4st.release(); a->deep.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
-        for (int i = 0; i < kTimerRing; ++i) { (void)hipEventDestroy(a->ev_start[i]); (void)hipEventDestroy(a->ev_stop[i]); }
+        for (int i = 0; i < kTimerRing; ++i) for (int j = 0; j <= kTimerSlots; ++j) (void)hipEventDestroy(a->ev[i][j]);
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
     delete a;
@@ -507,11 +516,19 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, a->knob_debug_stop};
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters
-    HIP_TRY(hipEventRecord(a->ev_start[a->ev_used], a->stream));
+    // HIP events on the aligner's stream: one in front of the launch, one behind every kernel of it (bgr_aligner_kernel_times)
+    int marks = 0;
+    auto mark = [&](const char* name) -> hipError_t {
+        if (marks >= kTimerSlots) return hipSuccess;
+        a->t_slot_name[marks] = name;
+        return hipEventRecord(a->ev[a->ev_used][++marks], a->stream);
+    };
+    HIP_TRY(hipEventRecord(a->ev[a->ev_used][0], a->stream));
     HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, (n_reads + 31) / 32 * 4, a->stream));
     hipError_t e = bgr::launch_pack_reads(static_cast<const uint8_t*>(d_reads), io.read_offs, io.n_reads, total_bases, static_cast<uint64_t*>(a->pk_fw3.p),
                                           static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("pre-pass launch: ") + hipGetErrorString(e));
+    HIP_TRY(mark("bgr_pack_reads_kernel"));
     if (fast_pass) {
         // Three launches of the four-reads-per-wave kernel: all reads; then twice what the launch before could not finish (the
         // next anchors of a read whose first ones failed, then its reverse complement), densely packed four to a wave again.
@@ -535,12 +552,16 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             iof.ovf_ctr = 2 + (uint32_t)ps;
             e = bgr::launch_align(a->dg, iof, kp, cfg_fast, a->stream);
             if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (four-reads-per-wave pass): ") + hipGetErrorString(e));
+            HIP_TRY(mark(ps == 0 ? "bgr_align_greedy4_kernel pass 1 (all reads)" : ps == 1 ? "bgr_align_greedy4_kernel pass 2 (listed reads)" : "bgr_align_greedy4_kernel pass 3 (listed reads)"));
         }
         io.subset = static_cast<uint32_t*>(a->ovf2.p);
         io.subset_ctr = 8;
     }
     e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(mark(p->mode == BGR_MODE_GREEDY ? (fast_pass ? "bgr_align_greedy_kernel (listed reads)" : "bgr_align_greedy_kernel")
+                 : p->mode == BGR_MODE_ANCHORS ? "bgr_align_anchors_kernel"
+                 : deep_only ? "bgr_align_exhaustive_kernel (HBM stack)" : level_search ? "bgr_align_exhaustive_dp_kernel" : "bgr_align_exhaustive_kernel"));
     if (two_pass && !deep_only) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
         const uint32_t* pending = io.ovf_list;
         uint32_t pending_ctr = 2;
@@ -554,6 +575,7 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
             iom.ovf_ctr = 3;
             e = bgr::launch_align(a->dg, iom, kp, cfg_mid, a->stream);
             if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (depth-first pass): ") + hipGetErrorString(e));
+            HIP_TRY(mark("bgr_align_exhaustive_kernel (listed reads)"));
             pending = iom.ovf_list;
             pending_ctr = 3;
         }
@@ -566,8 +588,9 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         io2.level_search = 0;
         e = bgr::launch_align(a->dg, io2, kp, cfg_deep, a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (deep pass): ") + hipGetErrorString(e));
+        HIP_TRY(mark("bgr_align_exhaustive_kernel (HBM stack, listed reads)"));
     }
-    HIP_TRY(hipEventRecord(a->ev_stop[a->ev_used], a->stream));
+    a->ev_marks[a->ev_used] = marks;
     ++a->ev_used;
     return BGR_OK;
 }
@@ -697,6 +720,19 @@ int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms
     return BGR_OK;
 }
 
+int bgr_aligner_kernel_times(bgr_aligner* a, uint64_t* launches, double slot_ms[8], const char* slot_names[8]) {
+    if (!a || !slot_ms) return fail(BGR_E_ARG, "bgr_aligner_kernel_times: null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    int rc = drain_timers(a);
+    if (rc != BGR_OK) return rc;
+    if (launches) *launches = a->t_launches;
+    for (int j = 0; j < kTimerSlots; ++j) {
+        slot_ms[j] = a->t_slot_ms[j];
+        if (slot_names) slot_names[j] = a->t_slot_ms[j] > 0 ? a->t_slot_name[j] : nullptr;
+    }
+    return BGR_OK;
+}
+
 int bgr_aligner_reset_kernel_time(bgr_aligner* a) {
     if (!a) return fail(BGR_E_ARG, "bgr_aligner_reset_kernel_time: null aligner");
     HIP_TRY(hipSetDevice(a->device));
@@ -704,6 +740,7 @@ int bgr_aligner_reset_kernel_time(bgr_aligner* a) {
     if (rc != BGR_OK) return rc;
     a->t_launches = 0;
     a->t_ms = 0;
+    for (double& x : a->t_slot_ms) x = 0;
     return BGR_OK;
 }
 

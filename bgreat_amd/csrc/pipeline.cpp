@@ -404,7 +404,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     for (unsigned g = 0; g < n_gpus; ++g) {
         for (unsigned j = 0; j < per_dev; ++j) {
             bgr_aligner* a = nullptr;
-            int rc = bgr_aligner_create(graph, (int)g, &a);
+            int rc = bgr_aligner_create(graph, (int)(opt->first_device + g), &a);
             if (rc != BGR_OK) {
                 for (auto* x : aligners) bgr_aligner_destroy(x);
                 fclose(pathF); fclose(notF);

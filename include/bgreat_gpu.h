@@ -151,6 +151,10 @@ int bgr_aligner_reset_counters(bgr_aligner* a);
  * last reset: number of launches and their summed duration in milliseconds.  Synchronises the stream. */
 int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms);
 int bgr_aligner_reset_kernel_time(bgr_aligner* a);
+/* The same per kernel of a launch, in launch order (a mapping launch is a short sequence on one stream: the pre-pass that
+ * packs the reads, then the passes of the mode): summed milliseconds per position and the kernel's name (static strings;
+ * NULL behind the last).  Launches of different modes since the last reset share positions. */
+int bgr_aligner_kernel_times(bgr_aligner* a, uint64_t* launches, double slot_ms[8], const char* slot_names[8]);
 /* Launch geometry of the last mapping kernel (for logs): blocks, threads per block, dynamic LDS bytes, and flags:
  * bit 0 = the MPHF cascade was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first),
  * bit 2 = greedy mode ran its four-reads-per-wave first pass (the numbers then describe that launch). */
@@ -209,12 +213,16 @@ typedef struct {
     uint64_t chunk_bytes;      /* parser chunk size (0 = default 8 MiB)                                         */
     uint32_t fastq;            /* -q                                                                            */
     uint32_t write_exhaustive; /* exhaustive mode writes nothing in the reference; 1 = write  */
-    uint32_t echo_files;       /* print each file name to stdout before mapping it (aligner.cpp:559,576)        */
+    uint32_t echo_files;       /* print what the reference's workers print to stdout while mapping, in its -t 1 order: each file
+                                  name (aligner.cpp:559,576) and, in exhaustive mode, the block after every tenth getReads()
+                                  call (alignerExhaustive.cpp:306-316)                                              */
     uint32_t correction;       /* -c: write header + the read as spelled by its path (recoverPath, aligner.cpp:270-290,
                                   alignerGreedy.cpp:394-404) instead of the path; greedy mode only                 */
     const char* no_overlap_file; /* optional third output (NULL = the reference's behaviour): reads WITHOUT any anchor go
                                   here instead of notAligned.fa -- the split README.md:47-52 documents and
                                   alignerGreedy.cpp:414-419 disables                                               */
+    uint32_t first_device;     /* devices first_device .. first_device + n_gpus - 1 (one process per GPU under a launcher
+                                  that does not hide the others: first_device = the rank's local index, n_gpus = 1)   */
 } bgr_run_options;
 int bgr_align_all(bgr_graph* g, const bgr_params* p, const bgr_run_options* o, const char* reads_csv, const char* paths_file,
                   const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds);
