@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the four-reads-per-wave passes (diagnostic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and valu_issue_frac become null)")
     ap.add_argument("--pmc-steps", type=int, default=3)
-    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end leg per GPU (0 disables)")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end leg per GPU (0 disables)")
     ap.add_argument("--pcie-steps", type=int, default=3, help="timed bgr_align_batch calls of the PCIe-inclusive leg (0 disables)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbgreat_gpu.so")
+LIB_PATH = os.environ.get("BGR_LIB_PATH") or os.path.join(_HERE, "lib", "libbgreat_gpu.so")  # (the override: A/B builds of the kernels, tools only)
 CLI_PATH = os.path.join(_HERE, "bin", "bgreat")
 
 MODE_GREEDY, MODE_EXHAUSTIVE, MODE_ANCHORS = 0, 1, 2
