@@ -513,7 +513,8 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 #define BGR_ANC_OCC 4 /* 128 VGPRs, no spills: 220 vs 200 Mreads/s at 6 */
 #endif
 #ifndef BGR_DP_OCC
-#define BGR_DP_OCC 6
+#define BGR_DP_OCC 5 /* 96 VGPRs: at 6 (80 VGPRs) the level search spills 38 VGPRs into scratch inside its loops (3.4 KB written per
+                        read, round 1); at 5 three registers are parked once per kernel.  14.4 vs 14.7 ms per 2 M reads; at 4: 16.5 */
 #endif
 #ifndef BGR_EXH_OCC
 #define BGR_EXH_OCC 6 /* waves per SIMD the exhaustive kernel is compiled for */
