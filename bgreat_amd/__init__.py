@@ -30,7 +30,7 @@ SYMBOLS = [
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup",
-    "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times",
+    "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST = 1, 2, 3, 4, 5
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
@@ -53,6 +53,11 @@ class RunOptions(C.Structure):
     _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
                 ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("correction", C.c_uint32),
                 ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32)]
+
+
+class PackedReads(C.Structure):
+    _fields_ = [("read_offsets", C.c_void_p), ("fw3", C.c_void_p), ("hasn", C.c_void_p), ("nm_index", C.c_void_p), ("nm_value", C.c_void_p),
+                ("nm_count", C.c_uint64), ("max_read_len", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):
@@ -118,11 +123,18 @@ def lib():
     L.bgr_graph_device_blob.restype = vp
     L.bgr_graph_device_blob.argtypes = [vp, i32]
     L.bgr_graph_adopt_device_blob.argtypes = [i32, vp, u64, C.POINTER(vp)]
+    L.bgr_devices_init.argtypes = [vp, i32, u32, u32]
+    L.bgr_devices_method.argtypes = [vp]
+    L.bgr_devices_method.restype = u32
     L.bgr_aligner_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.bgr_aligner_destroy.argtypes = [vp]
     L.bgr_aligner_destroy.restype = None
     L.bgr_align_batch.argtypes = [vp, C.POINTER(Params), vp, vp, u64, vp, u64, vp, vp]
     L.bgr_align_device.argtypes = [vp, C.POINTER(Params), vp, vp, u64, u64, u32]
+    L.bgr_packed_plane_words.argtypes = [u64, u64]
+    L.bgr_packed_plane_words.restype = u64
+    L.bgr_pack_reads.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u32)]
+    L.bgr_align_batch_packed.argtypes = [vp, C.POINTER(Params), C.POINTER(PackedReads), u64, vp, u64, vp, vp]
     L.bgr_aligner_sync.argtypes = [vp]
     L.bgr_aligner_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.bgr_aligner_fetch.argtypes = [vp, u64, vp, u64, vp, vp]
@@ -163,6 +175,26 @@ def _as_u8(a):
     if isinstance(a, (bytes, bytearray)):
         a = np.frombuffer(a, dtype=np.uint8)
     return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def pack_reads(reads, offsets):
+    """ASCII reads -> the 2-bit planes of bgr_align_batch_packed (host side; bgr_pack_reads).  -> dict of arrays."""
+    reads = _as_u8(reads)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    rel = offsets - offsets[0]
+    total = int(rel[n])
+    words = lib().bgr_packed_plane_words(n, total)
+    fw3 = np.zeros(words, dtype=np.uint64)
+    hasn = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
+    cap = max(64, total // 16 + 64)
+    nm_index = np.zeros(cap, dtype=np.uint32)
+    nm_value = np.zeros(cap, dtype=np.uint64)
+    cnt, mx = C.c_uint64(), C.c_uint32()
+    _check(lib().bgr_pack_reads(reads.ctypes.data, offsets.ctypes.data, n, fw3.ctypes.data, hasn.ctypes.data, nm_index.ctypes.data,
+                                nm_value.ctypes.data, cap, C.byref(cnt), C.byref(mx)))
+    return {"read_offsets": rel, "fw3": fw3, "hasn": hasn, "nm_index": nm_index[: cnt.value].copy(), "nm_value": nm_value[: cnt.value].copy(),
+            "max_read_len": mx.value, "n": n}
 
 
 class Graph:
@@ -224,6 +256,11 @@ class Graph:
     def upload(self, device=0):
         _check(lib().bgr_graph_upload(self.h, device))
 
+    def devices_init(self, first_device=0, n_devices=1, how=0):
+        """Graph resident on n devices: one upload, then RCCL broadcast / xGMI peer copies (bgr_devices_init) -> method used."""
+        _check(lib().bgr_devices_init(self.h, first_device, n_devices, how))
+        return lib().bgr_devices_method(self.h)
+
     def device_blob(self, device=0):
         return lib().bgr_graph_device_blob(self.h, device)
 
@@ -266,6 +303,20 @@ class Aligner:
         p = Params(mode, m, effort, int(partial))
         _check(lib().bgr_align_batch(self.h, C.byref(p), reads.ctypes.data, offsets.ctypes.data, n, paths.ctypes.data, cap,
                                      poffs.ctypes.data, status.ctypes.data))
+        return paths[: int(poffs[n])].copy(), poffs, status[:n]
+
+    def align_packed(self, pk, m=2, effort=2, mode=MODE_GREEDY, partial=False, out=None):
+        """bgr_align_batch_packed on the dict pack_reads() returns -> (paths, path_offsets, status)."""
+        n = pk["n"]
+        cap = int(pk["read_offsets"][n]) + 8 * n + 8
+        paths = np.empty(cap, dtype=np.int32)
+        poffs = np.empty(n + 1, dtype=np.uint64)
+        status = np.empty(max(n, 1), dtype=np.uint8)
+        s = PackedReads(pk["read_offsets"].ctypes.data, pk["fw3"].ctypes.data, pk["hasn"].ctypes.data,
+                        pk["nm_index"].ctypes.data if len(pk["nm_index"]) else None, pk["nm_value"].ctypes.data if len(pk["nm_value"]) else None,
+                        len(pk["nm_index"]), pk["max_read_len"])
+        p = Params(mode, m, effort, int(partial))
+        _check(lib().bgr_align_batch_packed(self.h, C.byref(p), C.byref(s), n, paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
         return paths[: int(poffs[n])].copy(), poffs, status[:n]
 
     def align_device(self, d_reads_ptr, d_offsets_ptr, n, total_bases, max_len, m=2, effort=2, mode=MODE_GREEDY, partial=False):

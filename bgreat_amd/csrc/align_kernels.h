@@ -95,6 +95,8 @@ hipError_t launch_csr(const uint2* results, const int32_t* arena, uint32_t n, ui
 hipError_t launch_pack_reads(const uint8_t* reads, const uint64_t* read_offs, uint32_t n, uint64_t total_bytes, uint64_t* fw3, uint64_t* nmw,
                              uint32_t* hasn, hipStream_t stream);
 
+hipError_t launch_scatter_words(const uint32_t* index, const uint64_t* value, uint64_t n, uint64_t* plane, uint64_t plane_words, hipStream_t stream);
+
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);
 
 }  // namespace bgr

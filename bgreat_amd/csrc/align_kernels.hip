@@ -1764,6 +1764,17 @@ hipError_t launch_pack_reads(const uint8_t* reads, const uint64_t* read_offs, ui
     return hipGetLastError();
 }
 
+// plane[index[i]] = value[i]: the N-mask words of a host-packed batch (bgr_align_batch_packed)
+__global__ void __launch_bounds__(256) bgr_scatter_words_kernel(const uint32_t* index, const u64* value, uint64_t n, u64* plane, uint64_t plane_words) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && index[i] < plane_words) plane[index[i]] = value[i];
+}
+hipError_t launch_scatter_words(const uint32_t* index, const uint64_t* value, uint64_t n, uint64_t* plane, uint64_t plane_words, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bgr_scatter_words_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, index, value, n, plane, plane_words);
+    return hipGetLastError();
+}
+
 // ======================================= results -> CSR, on the device =======================================
 // The mapping kernels leave every path where its wave found room in the arena.  These three small kernels turn
 // (results, arena) into what the C-ABI hands out -- input-ordered path_offsets[n+1], dense paths, status bytes -- so

@@ -2,6 +2,7 @@
 // and stream management, launch geometry; the algorithm lives in graph_build.cpp (index) and
 // align_kernels.hip (mapping).  There is no CPU mapping path in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include "fastx.h"
 #include "anchor_index.h"
 #include "graph_build.h"
+#include "read_pack.h"
 
 namespace {
 
@@ -44,6 +46,7 @@ struct bgr_graph {
     BgrBlobHeader header;
     struct Dev { void* ptr; bool owned; };
     std::map<int, Dev> dev;
+    uint32_t fanout_method = 0;  // how bgr_devices_init moved the blob between devices last time
 };
 
 struct DevBuf {
@@ -222,6 +225,136 @@ int bgr_graph_upload(bgr_graph* g, int device) {
     return BGR_OK;
 }
 
+// ---- one-off distribution of the graph over the GPUs of one process -------------------------------------------------------
+// The blob goes from the host to the first device once and from there device to device over xGMI: as ONE RCCL broadcast
+// (a communicator per device from ncclCommInitAll; librccl is looked up at run time, so the library has no link-time
+// dependency on it), or, when RCCL is not available or refuses, as peer copies in a doubling schedule (1 -> 2 -> 4 -> 8
+// holders: every round uses disjoint point-to-point links).
+namespace {
+
+struct Rccl {
+    typedef int (*CommInitAll_t)(void** comms, int n, const int* devs);
+    typedef int (*Group_t)(void);
+    typedef int (*Broadcast_t)(const void* send, void* recv, size_t count, int dtype, int root, void* comm, hipStream_t stream);
+    typedef int (*CommDestroy_t)(void* comm);
+    void* lib = nullptr;
+    CommInitAll_t CommInitAll = nullptr;
+    Group_t GroupStart = nullptr, GroupEnd = nullptr;
+    Broadcast_t Broadcast = nullptr;
+    CommDestroy_t CommDestroy = nullptr;
+    bool load() {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = reinterpret_cast<CommInitAll_t>(dlsym(lib, "ncclCommInitAll"));
+        GroupStart = reinterpret_cast<Group_t>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<Group_t>(dlsym(lib, "ncclGroupEnd"));
+        Broadcast = reinterpret_cast<Broadcast_t>(dlsym(lib, "ncclBroadcast"));
+        CommDestroy = reinterpret_cast<CommDestroy_t>(dlsym(lib, "ncclCommDestroy"));
+        return CommInitAll && GroupStart && GroupEnd && Broadcast && CommDestroy;
+    }
+};
+
+// ptr[i] on device devs[i]; ptr[0] holds the blob.  false = RCCL not usable here (nothing has been copied, or partly:
+// the caller then overwrites with peer copies).
+bool fanout_rccl(const std::vector<int>& devs, const std::vector<void*>& ptr, uint64_t bytes, std::string& why) {
+    Rccl r;
+    if (!r.load()) { why = "librccl not loadable"; return false; }
+    const int n = (int)devs.size();
+    std::vector<void*> comms(n, nullptr);
+    if (r.CommInitAll(comms.data(), n, devs.data()) != 0) { why = "ncclCommInitAll failed"; return false; }
+    std::vector<hipStream_t> streams(n, nullptr);
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) ok = hipSetDevice(devs[i]) == hipSuccess && hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) == hipSuccess;
+    if (ok) {
+        ok = r.GroupStart() == 0;
+        for (int i = 0; i < n && ok; ++i) {
+            ok = hipSetDevice(devs[i]) == hipSuccess &&
+                 r.Broadcast(ptr[i], ptr[i], (size_t)bytes, /*ncclChar*/ 0, /*root rank*/ 0, comms[i], streams[i]) == 0;
+        }
+        ok = r.GroupEnd() == 0 && ok;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (streams[i]) { if (hipSetDevice(devs[i]) == hipSuccess) { ok = hipStreamSynchronize(streams[i]) == hipSuccess && ok; (void)hipStreamDestroy(streams[i]); } }
+    }
+    for (void* c : comms) if (c) (void)r.CommDestroy(c);
+    if (!ok) why = "RCCL broadcast failed";
+    return ok;
+}
+
+int fanout_peer(const std::vector<int>& devs, const std::vector<void*>& ptr, uint64_t bytes) {
+    const size_t n = devs.size();
+    for (size_t have = 1; have < n; have *= 2) {  // holders 0..have-1 each feed device i + have
+        std::vector<hipStream_t> streams;
+        std::vector<int> sdev;
+        for (size_t i = 0; i < have && i + have < n; ++i) {
+            const int src = devs[i], dst = devs[i + have];
+            HIP_TRY(hipSetDevice(src));
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, src, dst) == hipSuccess && can) {
+                hipError_t pe = hipDeviceEnablePeerAccess(dst, 0);  // direct xGMI path; without it the runtime stages through the host
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+            hipStream_t st = nullptr;
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            streams.push_back(st);
+            sdev.push_back(src);
+            HIP_TRY(hipMemcpyPeerAsync(ptr[i + have], dst, ptr[i], src, bytes, st));
+        }
+        for (size_t j = 0; j < streams.size(); ++j) {
+            HIP_TRY(hipSetDevice(sdev[j]));
+            HIP_TRY(hipStreamSynchronize(streams[j]));
+            HIP_TRY(hipStreamDestroy(streams[j]));
+        }
+    }
+    return BGR_OK;
+}
+
+}  // namespace
+
+int bgr_devices_init(bgr_graph* g, int first_device, uint32_t n_devices, uint32_t how) {
+    if (!g) return fail(BGR_E_ARG, "bgr_devices_init: null graph");
+    if (n_devices == 0) n_devices = 1;
+    if (how > BGR_FANOUT_PEER) return fail(BGR_E_ARG, "bgr_devices_init: unknown distribution method");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return fail(BGR_E_HIP, "no HIP device available");
+    if (first_device < 0 || (uint64_t)first_device + n_devices > (uint64_t)nd) return fail(BGR_E_ARG, "bgr_devices_init: device range outside the visible devices");
+    int rc = bgr_graph_upload(g, first_device);  // host -> first device (idempotent)
+    if (rc != BGR_OK) return rc;
+    std::vector<int> devs(1, first_device);
+    std::vector<void*> ptr(1, g->dev[first_device].ptr);
+    for (uint32_t i = 1; i < n_devices; ++i) {
+        const int d = first_device + (int)i;
+        if (g->dev.count(d)) continue;  // already resident there
+        HIP_TRY(hipSetDevice(d));
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, g->header.blob_bytes));
+        g->dev[d] = {p, true};
+        devs.push_back(d);
+        ptr.push_back(p);
+    }
+    g->fanout_method = 0;
+    std::string why;
+    if (devs.size() == 1) {
+        // nothing to distribute.  Asked for RCCL explicitly, the call still goes through a one-rank communicator and an in-place
+        // broadcast, so that the run-time lookup of librccl and the call sequence can be checked on a single-GPU machine.
+        if (how == BGR_FANOUT_RCCL) {
+            if (!fanout_rccl(devs, ptr, g->header.blob_bytes, why)) return fail(BGR_E_HIP, "bgr_devices_init: " + why);
+            g->fanout_method = BGR_FANOUT_RCCL;
+        }
+        return BGR_OK;
+    }
+    if (how != BGR_FANOUT_PEER && fanout_rccl(devs, ptr, g->header.blob_bytes, why)) { g->fanout_method = BGR_FANOUT_RCCL; return BGR_OK; }
+    if (how == BGR_FANOUT_RCCL) return fail(BGR_E_HIP, "bgr_devices_init: " + why);
+    rc = fanout_peer(devs, ptr, g->header.blob_bytes);
+    if (rc == BGR_OK) g->fanout_method = BGR_FANOUT_PEER;
+    return rc;
+}
+
+uint32_t bgr_devices_method(const bgr_graph* g) { return g ? g->fanout_method : 0; }
+
 const void* bgr_graph_device_blob(const bgr_graph* g, int device) {
     if (!g) return nullptr;
     auto it = g->dev.find(device);
@@ -313,15 +446,17 @@ int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
     return fail(BGR_E_ARG, "bgr_aligner_set_knob: unknown knob or value out of range");
 }
 
-int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
-                     uint64_t total_bases, uint32_t max_read_len) {
+// The mapping launch of one batch.  planes_ready: the aligner's 2-bit planes (pk_fw3 / pk_nm / pk_hasn) already hold the batch
+// (bgr_align_batch_packed copied them in); else they are made from the ASCII reads at d_reads by the pre-pass.
+static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
+                             uint64_t total_bases, uint32_t max_read_len, bool planes_ready) {
     if (!a || !p) return fail(BGR_E_ARG, "bgr_align_device: null argument");
     if (p->mode > BGR_MODE_ANCHORS) return fail(BGR_E_ARG, "bgr_align_device: unknown mode");
     if (p->mode == BGR_MODE_ANCHORS && !a->graph->header.anc_n)
         return fail(BGR_E_ARG, "bgr_align_device: BGR_MODE_ANCHORS needs a graph built with BGR_BUILD_ANCHORS");
     a->last_n = n_reads;
     if (n_reads == 0) return BGR_OK;
-    if (!d_reads || !d_read_offsets) return fail(BGR_E_ARG, "bgr_align_device: null device buffer");
+    if ((!d_reads && !planes_ready) || !d_read_offsets) return fail(BGR_E_ARG, "bgr_align_device: null device buffer");
     if (n_reads >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: more than 2^32-2 reads in one batch");
     HIP_TRY(hipSetDevice(a->device));
     if (a->ev_used == kTimerRing) { int rc = drain_timers(a); if (rc != BGR_OK) return rc; }
@@ -524,11 +659,14 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
         return hipEventRecord(a->ev[a->ev_used][++marks], a->stream);
     };
     HIP_TRY(hipEventRecord(a->ev[a->ev_used][0], a->stream));
-    HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, (n_reads + 31) / 32 * 4, a->stream));
-    hipError_t e = bgr::launch_pack_reads(static_cast<const uint8_t*>(d_reads), io.read_offs, io.n_reads, total_bases, static_cast<uint64_t*>(a->pk_fw3.p),
-                                          static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
-    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("pre-pass launch: ") + hipGetErrorString(e));
-    HIP_TRY(mark("bgr_pack_reads_kernel"));
+    hipError_t e = hipSuccess;
+    if (!planes_ready) {
+        HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, (n_reads + 31) / 32 * 4, a->stream));
+        e = bgr::launch_pack_reads(static_cast<const uint8_t*>(d_reads), io.read_offs, io.n_reads, total_bases, static_cast<uint64_t*>(a->pk_fw3.p),
+                                   static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("pre-pass launch: ") + hipGetErrorString(e));
+        HIP_TRY(mark("bgr_pack_reads_kernel"));
+    }
     if (fast_pass) {
         // Three launches of the four-reads-per-wave kernel: all reads; then twice what the launch before could not finish (the
         // next anchors of a read whose first ones failed, then its reverse complement), densely packed four to a wave again.
@@ -593,6 +731,81 @@ int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, c
     a->ev_marks[a->ev_used] = marks;
     ++a->ev_used;
     return BGR_OK;
+}
+
+int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
+                     uint64_t total_bases, uint32_t max_read_len) {
+    return align_device_impl(a, p, d_reads, d_read_offsets, n_reads, total_bases, max_read_len, false);
+}
+
+uint64_t bgr_packed_plane_words(uint64_t n_reads, uint64_t total_bases) { return bgr::packed_plane_words(n_reads, total_bases); }
+
+int bgr_pack_reads(const char* reads, const uint64_t* read_offsets, uint64_t n, uint64_t* fw3, uint32_t* hasn, uint32_t* nm_index, uint64_t* nm_value,
+                   uint64_t nm_cap, uint64_t* nm_count, uint32_t* max_read_len) {
+    if (!read_offsets || !fw3 || !hasn || !nm_count || (n && !reads)) return fail(BGR_E_ARG, "bgr_pack_reads: null argument");
+    const uint64_t base = read_offsets[0];
+    memset(hasn, 0, ((n + 31) / 32) * 4);
+    uint64_t cnt = 0;
+    uint32_t longest = 0;
+    std::vector<uint64_t> nm;
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint64_t off = read_offsets[r] - base, len64 = read_offsets[r + 1] - read_offsets[r];
+        if (len64 > 0x7FFFFFFFull) return fail(BGR_E_ARG, "bgr_pack_reads: read longer than 2^31 bases");
+        const uint32_t len = (uint32_t)len64, words = (len + 31) >> 5;
+        longest = std::max(longest, len);
+        if (nm.size() < words) nm.resize(words);
+        const uint64_t w0 = bgr::packed_word_offset(off, r);
+        if (bgr::pack_read(reads + read_offsets[r], len, fw3 + w0, nm.data())) {
+            hasn[r >> 5] |= 1u << (r & 31);
+            if (cnt + words > nm_cap || !nm_index || !nm_value) return fail(BGR_E_CAPACITY, "bgr_pack_reads: N-mask list too small");
+            for (uint32_t j = 0; j < words; ++j) { nm_index[cnt] = (uint32_t)(w0 + j); nm_value[cnt] = nm[j]; ++cnt; }
+        }
+    }
+    *nm_count = cnt;
+    if (max_read_len) *max_read_len = longest;
+    return BGR_OK;
+}
+
+int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed_reads* pk, uint64_t n, int32_t* paths_out, uint64_t paths_cap,
+                           uint64_t* path_offsets, uint8_t* status) {
+    if (!a || !p || !pk || !path_offsets || (n && (!pk->read_offsets || !pk->fw3 || !pk->hasn || !status))) return fail(BGR_E_ARG, "bgr_align_batch_packed: null argument");
+    if (pk->nm_count && (!pk->nm_index || !pk->nm_value)) return fail(BGR_E_ARG, "bgr_align_batch_packed: null N-mask list");
+    path_offsets[0] = 0;
+    a->last_n = 0;
+    if (n == 0) return BGR_OK;
+    if (pk->read_offsets[0] != 0) return fail(BGR_E_ARG, "bgr_align_batch_packed: read_offsets must start at 0 (they address the planes)");
+    const uint64_t total = pk->read_offsets[n];
+    if (n >= 0x7FFFFFFFull || 2 * (total + 8 * n) >= 0xFFFFFFFFull - (256ull << 20))
+        return fail(BGR_E_ARG, "bgr_align_batch_packed: batch too large for one launch (2*(bases + 8*reads) must stay below 2^32); pack it in pieces");
+    HIP_TRY(hipSetDevice(a->device));
+    const uint64_t plane_words = bgr::packed_plane_words(n, total);
+    HIP_TRY(a->in_offs.ensure((n + 1) * 8));
+    HIP_TRY(a->pk_fw3.ensure(plane_words * 8));
+    HIP_TRY(a->pk_nm.ensure(plane_words * 8));
+    HIP_TRY(a->pk_hasn.ensure((n + 31) / 32 * 4 + 4));
+    HIP_TRY(hipMemcpyAsync(a->in_offs.p, pk->read_offsets, (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
+    HIP_TRY(hipMemcpyAsync(a->pk_fw3.p, pk->fw3, ((total >> 5) + n + 1) * 8, hipMemcpyHostToDevice, a->stream));
+    HIP_TRY(hipMemcpyAsync(a->pk_hasn.p, pk->hasn, (n + 31) / 32 * 4, hipMemcpyHostToDevice, a->stream));
+    if (pk->nm_count) {  // the N-mask words of the few reads that hold an N: a sparse list, scattered into the plane on the device
+        HIP_TRY(a->in_reads.ensure(pk->nm_count * 12 + 16));
+        char* d = static_cast<char*>(a->in_reads.p);
+        const uint64_t voff = (pk->nm_count * 4 + 7) & ~7ull;
+        HIP_TRY(a->in_reads.ensure(voff + pk->nm_count * 8));
+        d = static_cast<char*>(a->in_reads.p);
+        HIP_TRY(hipMemcpyAsync(d, pk->nm_index, pk->nm_count * 4, hipMemcpyHostToDevice, a->stream));
+        HIP_TRY(hipMemcpyAsync(d + voff, pk->nm_value, pk->nm_count * 8, hipMemcpyHostToDevice, a->stream));
+        hipError_t e = bgr::launch_scatter_words(reinterpret_cast<const uint32_t*>(d), reinterpret_cast<const uint64_t*>(d + voff), pk->nm_count,
+                                                 static_cast<uint64_t*>(a->pk_nm.p), plane_words, a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("N-mask scatter launch: ") + hipGetErrorString(e));
+    }
+    uint32_t max_len = pk->max_read_len;
+    if (!max_len) {
+        for (uint64_t i = 0; i < n; ++i) max_len = std::max<uint32_t>(max_len, (uint32_t)std::min<uint64_t>(pk->read_offsets[i + 1] - pk->read_offsets[i], 0x7FFFFFFFull));
+    }
+    // (the host buffers may be reused once the copies are done: bgr_aligner_fetch below synchronises the stream)
+    int rc = align_device_impl(a, p, nullptr, a->in_offs.p, n, total, max_len, true);
+    if (rc != BGR_OK) return rc;
+    return bgr_aligner_fetch(a, n, paths_out, paths_cap, path_offsets, status);
 }
 
 int bgr_aligner_sync(bgr_aligner* a) {

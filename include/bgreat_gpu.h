@@ -109,6 +109,16 @@ void bgr_graph_destroy(bgr_graph* g);
  * broadcast from rank 0); the memory stays owned by the caller and must outlive the graph. */
 int bgr_graph_upload(bgr_graph* g, int device);
 const void* bgr_graph_device_blob(const bgr_graph* g, int device); /* NULL if not resident there */
+/* Several GPUs in one process (replaces the thread fan-out of aligner.cpp:577-586 on the device side): makes the graph
+ * resident on devices first_device .. first_device + n_devices - 1.  One host -> device copy to the first, then device to
+ * device over xGMI: `how` = BGR_FANOUT_AUTO (one RCCL broadcast when librccl can be loaded at run time, else peer copies),
+ * BGR_FANOUT_RCCL (ncclCommInitAll + ncclBroadcast, fail if unavailable), BGR_FANOUT_PEER (hipMemcpyPeerAsync in a doubling
+ * schedule 1 -> 2 -> 4 -> 8 holders).  bgr_devices_method: what the last call used (0 = nothing to distribute). */
+#define BGR_FANOUT_AUTO 0u
+#define BGR_FANOUT_RCCL 1u
+#define BGR_FANOUT_PEER 2u
+int bgr_devices_init(bgr_graph* g, int first_device, uint32_t n_devices, uint32_t how);
+uint32_t bgr_devices_method(const bgr_graph* g);
 int bgr_graph_adopt_device_blob(int device, const void* dev_blob, uint64_t bytes, bgr_graph** out);
 
 /* ---- mapping --------------------------------------------------------------------------------------
@@ -127,6 +137,28 @@ void bgr_aligner_destroy(bgr_aligner* a);
  * addresses its path arena with 32 bits (about 13 M reads of 150 bp); a larger batch is mapped in pieces.     */
 int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
                     int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
+
+/* The same with the reads already packed on the host into the 2-bit planes the kernels read (what bgr_align_device's pre-pass
+ * makes on the device): a batch then crosses PCIe at ~0.3 byte per base instead of 1.  Layout: str2num codes (utils.cpp:117-129:
+ * A0 C1 G2, else 3), 32 bases per uint64, first base most significant, zero beyond a read's end; read r owns words
+ * [(read_offsets[r] >> 5) + r, ... + ceil(len/32)) of `fw3` (bgr_packed_plane_words() words in all; read_offsets[0] must be 0).
+ * Reads that hold an N have their bit set in `hasn` and one N-mask word (3 on every N) per word of theirs in the sparse list
+ * nm_index[] (plane word index) / nm_value[].  bgr_pack_reads fills all of it from ASCII reads (single thread; ranges of a
+ * batch can be packed concurrently with the helpers of bgreat_amd/csrc/read_pack.h, as the CLI's pipeline does). */
+typedef struct {
+    const uint64_t* read_offsets; /* n+1 base offsets, starting at 0 */
+    const uint64_t* fw3;
+    const uint32_t* hasn;         /* (n + 31) / 32 words */
+    const uint32_t* nm_index;
+    const uint64_t* nm_value;
+    uint64_t nm_count;
+    uint32_t max_read_len;        /* longest read of the batch (0 = have it computed) */
+} bgr_packed_reads;
+uint64_t bgr_packed_plane_words(uint64_t n_reads, uint64_t total_bases);
+int bgr_pack_reads(const char* reads, const uint64_t* read_offsets, uint64_t n_reads, uint64_t* fw3, uint32_t* hasn, uint32_t* nm_index,
+                   uint64_t* nm_value, uint64_t nm_cap, uint64_t* nm_count, uint32_t* max_read_len);
+int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed_reads* reads, uint64_t n_reads, int32_t* paths_out,
+                           uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
 
 /* Device-resident form: inputs already in this device's HBM (d_reads bytes, d_read_offsets uint64[n+1]);
  * results stay in aligner-owned device buffers (bgr_aligner_device_results).  Asynchronous on the

@@ -413,6 +413,28 @@ def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m
     assert al.counters() == o.counters()
 
 
+def test_devices_init_on_one_gpu():
+    """bgr_devices_init (graph resident on the GPUs of one process: one upload, then RCCL broadcast / xGMI peer copies).  A
+    one-GPU box can only check the single-device paths: nothing to distribute, the forced RCCL path through a one-rank
+    communicator (run-time lookup of librccl, ncclCommInitAll, in-place ncclBroadcast), argument errors."""
+    s = Synth(120000, 90, 2, 31, 17)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(31, seqs, offs)
+    assert g.devices_init(0, 1) == 0 and g.device_blob(0)
+    assert g.devices_init(0, 1, how=2) == 0
+    assert g.devices_init(0, 1, how=1) == 1       # BGR_FANOUT_RCCL
+    with pytest.raises(B.BgrError):
+        g.devices_init(0, B.device_count() + 1)
+    with pytest.raises(B.BgrError):
+        g.devices_init(0, 1, how=7)
+    al = B.Aligner(g, 0)
+    reads, roffs = s.reads(0, 3000, 150, 2, 18)
+    o = oracle_py.Oracle(31, seqs, offs)
+    p1, po1, st1 = al.align(reads, roffs)
+    p2, po2, st2 = o.align(reads, roffs)
+    assert np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2)   # the blob survived the in-place broadcast
+
+
 def test_ragged_and_empty_batches():
     s = Synth(60000, 75, 2, 31, 77)
     seqs, offs = s.unitigs()
