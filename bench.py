@@ -448,11 +448,37 @@ def run_pcie(args, B, g, al, syn, seed_reads, ncpu, dev):
         for t in ts:
             t.join()
         t_two = time.perf_counter() - t1
+        # the same with the reads packed to 2 bits on the host beforehand (what the CLI's gather stage does on its host threads)
+        pk = B.pack_reads(arr, np.arange(R + 1, dtype=np.uint64) * np.uint64(L))
+        hp = {}
+        keep = []
+        for key in ("read_offsets", "fw3", "hasn"):
+            h, view = pinned(pk[key].nbytes, pk[key].dtype)
+            view[:] = pk[key]
+            hp[key] = view
+            keep.append(h)
+        spk = B.PackedReads(hp["read_offsets"].ctypes.data, hp["fw3"].ctypes.data, hp["hasn"].ctypes.data, None, None, 0, L)
+
+        def call_packed(a, b):
+            p = B.Params(B.MODE_GREEDY, args.mismatch, args.effort, 0)
+            B._check(lib.bgr_align_batch_packed(a.h, ctypes.byref(p), ctypes.byref(spk), R, b["paths"].ctypes.data, b["cap"], b["poffs"].ctypes.data, b["status"].ctypes.data))
+
+        call_packed(al, one)
+        t1 = time.perf_counter()
+        for _ in range(args.pcie_steps):
+            call_packed(al, one)
+        t_pk = (time.perf_counter() - t1) / args.pcie_steps
+        h2d_pk = pk["fw3"].nbytes + (R + 1) * 8 + pk["hasn"].nbytes
         out = {"value": round(R / t_one / 1e6, 3), "unit": "Mreads/s", "reads_per_call": R, "ms_per_call": round(t_one * 1e3, 3),
                "two_streams": {"value": round(2 * half * args.pcie_steps * 2 / t_two / 1e6, 3), "unit": "Mreads/s", "reads_per_call": half},
+               "host_packed": {"value": round(R / t_pk / 1e6, 3), "unit": "Mreads/s", "ms_per_call": round(t_pk * 1e3, 3), "h2d_bytes_per_read": round(h2d_pk / R, 1),
+                               "what": "bgr_align_batch_packed: the reads cross PCIe as 2-bit planes packed on the host beforehand (packing not timed: the CLI does it in its "
+                                       "gather stage instead of a memcpy); one blocking stream"},
                "h2d_bytes_per_read": round(h2d / R, 1), "d2h_bytes_per_read": round(d2h / R, 1),
                "what": "bgr_align_batch on page-locked host buffers: H2D (ASCII reads + offsets) + pre-pass + mapping passes + CSR on the device + D2H (paths, offsets, status); "
                        "mean of %d blocking calls on one stream; two_streams = two aligners on two host threads (how the CLI's pipeline overlaps copies and kernels)" % args.pcie_steps}
+        for h in keep:
+            lib.bgr_host_free(h)
         al2.close()
         for b in [one] + hb:
             for h in b["h"]:

@@ -34,6 +34,7 @@
 #include "../../include/bgreat_gpu.h"
 #include "fastx.h"
 #include "file_image.h"
+#include "read_pack.h"
 
 namespace bgr {
 int set_error(int code, const std::string& msg);  // capi.hip
@@ -133,7 +134,10 @@ struct HostBuf {  // grow-only host buffer; `pinned` = page-locked (20 GB/s to a
 };
 
 struct Pinned {  // the page-locked buffers of one batch in flight: sources / targets of the async copies
-    HostBuf reads{true}, offs{true}, paths{true}, poffs{true}, status{true};
+    // reads travel as 2-bit planes (read_pack.h): fw3 words, N bitmap, and the N-mask words of the few reads with an N
+    HostBuf fw3{true}, hasn{true}, nm_idx{true}, nm_val{true}, offs{true}, paths{true}, poffs{true}, status{true};
+    uint64_t nm_count = 0;
+    uint32_t max_len = 0;
 };
 
 // Something the reference prints to stdout between two reads of the input order: a file name (aligner.cpp:559,576) or, in
@@ -369,7 +373,9 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     const unsigned threads = std::max<uint32_t>(1, opt->threads);
     // Defaults: 128k reads per batch keeps the page-locked staging small (it costs ~0.2 s per GB to allocate) and the
     // pipeline fine-grained; the parser chunk is a thread's share of a batch.
-    const uint64_t batch_reads = opt->batch_reads ? opt->batch_reads : (1ull << 17);
+    // (one launch addresses its path arena with 32 bits: a batch stays below 4 M reads and ~1 G bases)
+    const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (1ull << 17), 4ull << 20);
+    const uint64_t batch_bases_cap = 1ull << 30;
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes
                                                   : std::min<uint64_t>(8ull << 20, std::max<uint64_t>(256ull << 10, batch_reads * 170 / threads));
     const bool writes = prm->mode != BGR_MODE_EXHAUSTIVE || opt->write_exhaustive;
@@ -460,8 +466,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         for (size_t i = 0; i < n_pins; ++i) {
             auto pn = std::make_unique<Pinned>();
             if (i < need) {  // best effort: the stages grow what turns out too small
-                (void)(pn->reads.ensure(est_bytes + 16) && pn->offs.ensure((est_n + 1) * 8) && pn->paths.ensure((8 * est_n + 4096) * 4) &&
-                       pn->poffs.ensure((est_n + 1) * 8) && pn->status.ensure(est_n + 1));
+                (void)(pn->fw3.ensure(bgr::packed_plane_words(est_n, est_bytes) * 8) && pn->hasn.ensure((est_n / 32 + 2) * 4) && pn->offs.ensure((est_n + 1) * 8) &&
+                       pn->paths.ensure((8 * est_n + 4096) * 4) && pn->poffs.ensure((est_n + 1) * 8) && pn->status.ensure(est_n + 1));
             }
             if (!free_pins.push(std::move(pn))) break;
         }
@@ -481,6 +487,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         auto open_batch = [&](std::unique_ptr<Batch>& b, const std::shared_ptr<MappedFile>& mf) {
             if (!take_batch(b)) return false;
             b->file = mf;
+            b->bases = 0;
             b->marks.clear();
             for (auto& m : pending) { m.pos = 0; b->marks.push_back(std::move(m)); }
             pending.clear();
@@ -523,11 +530,17 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     size_t lo = 0, mi = 0;
                     while (lo < rs.size() && ok) {
                         if (!b && !open_batch(b, mf)) { ok = false; break; }
-                        const size_t take = std::min<size_t>(rs.size() - lo, (size_t)batch_reads - b->recs.size());
+                        size_t take = std::min<size_t>(rs.size() - lo, (size_t)batch_reads - b->recs.size());
+                        uint64_t acc = b->bases;
+                        for (size_t j = 0; j < take; ++j) {  // long reads: close the batch at ~1 G bases
+                            acc += rs[lo + j].sl;
+                            if (acc >= batch_bases_cap) { take = j + 1; break; }
+                        }
+                        b->bases = acc;
                         for (; mi < mark_idx.size() && mark_idx[mi] < lo + take; ++mi) b->marks.push_back({b->recs.size() + (mark_idx[mi] - lo), 0, ""});
                         b->recs.insert(b->recs.end(), rs.begin() + lo, rs.begin() + lo + take);
                         lo += take;
-                        if (b->recs.size() >= batch_reads) ok = emit(std::move(b));
+                        if (b->recs.size() >= batch_reads || b->bases >= batch_bases_cap) ok = emit(std::move(b));
                     }
                     for (; mi < mark_idx.size(); ++mi) {  // due behind the chunk's last record
                         if (b) b->marks.push_back({b->recs.size(), 0, ""}); else pending.push_back({0, 0, ""});
@@ -621,17 +634,48 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             // typical paths are a handful of ints; the worker fetches again with the full bound if not.  A batch large enough
             // for bgr_align_batch to map it in pieces gets the full bound at once (there is no single result to fetch again).
             b.path_cap = 2 * (bases + 8 * b.n) >= (1ull << 31) ? bases + 8 * b.n + 8 : 8 * b.n + 4096;
-            if (!b.pin->reads.ensure(bases + 16) || !b.pin->paths.ensure(b.path_cap * 4) || !b.pin->poffs.ensure((b.n + 1) * 8) ||
-                !b.pin->status.ensure(b.n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            char* dst = static_cast<char*>(b.pin->reads.p);
+            if (!b.pin->fw3.ensure(bgr::packed_plane_words(b.n, bases) * 8) || !b.pin->hasn.ensure((b.n / 32 + 2) * 4) || !b.pin->paths.ensure(b.path_cap * 4) ||
+                !b.pin->poffs.ensure((b.n + 1) * 8) || !b.pin->status.ensure(b.n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            uint64_t* fw3 = static_cast<uint64_t*>(b.pin->fw3.p);
+            uint32_t* hasn = static_cast<uint32_t*>(b.pin->hasn.p);
             us_alloc += now_us() - tg0;
             const uint64_t tg1 = now_us();
-            const uint64_t per = (b.n + threads - 1) / threads;
+            // pack (instead of copy) the sequences into the page-locked plane: every thread a range of whole bitmap words
+            const uint64_t per = (((b.n + threads - 1) / threads) + 31) & ~31ull;
             Batch* bp = &b;
+            struct Part { std::vector<uint32_t> idx; std::vector<uint64_t> val; uint32_t max_len = 0; };
+            std::vector<Part> parts(threads);
             pool.run(threads, [&](size_t t) {
-                uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
-                for (uint64_t i = lo; i < hi; ++i) memcpy(dst + offs[i], bp->recs[i].s, bp->recs[i].sl);
+                const uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
+                if (lo >= hi) return;
+                Part& pt = parts[t];
+                std::vector<uint64_t> nm;
+                memset(hasn + lo / 32, 0, ((hi - lo + 31) / 32) * 4);
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const uint32_t len = bp->recs[i].sl, words = (len + 31) >> 5;
+                    if (nm.size() < words) nm.resize(words);
+                    const uint64_t w0 = bgr::packed_word_offset(offs[i], i);
+                    pt.max_len = std::max(pt.max_len, len);
+                    if (bgr::pack_read(bp->recs[i].s, len, fw3 + w0, nm.data())) {
+                        hasn[i >> 5] |= 1u << (i & 31);
+                        for (uint32_t j = 0; j < words; ++j) { pt.idx.push_back((uint32_t)(w0 + j)); pt.val.push_back(nm[j]); }
+                    }
+                }
             });
+            uint64_t nmc = 0;
+            b.pin->max_len = 0;
+            for (const Part& pt : parts) { nmc += pt.idx.size(); b.pin->max_len = std::max(b.pin->max_len, pt.max_len); }
+            b.pin->nm_count = nmc;
+            if (nmc) {
+                if (!b.pin->nm_idx.ensure(nmc * 4) || !b.pin->nm_val.ensure(nmc * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+                uint64_t at = 0;
+                for (const Part& pt : parts) {
+                    if (pt.idx.empty()) continue;
+                    memcpy(static_cast<uint32_t*>(b.pin->nm_idx.p) + at, pt.idx.data(), pt.idx.size() * 4);
+                    memcpy(static_cast<uint64_t*>(b.pin->nm_val.p) + at, pt.val.data(), pt.val.size() * 8);
+                    at += pt.idx.size();
+                }
+            }
             us_gather += now_us() - tg1;
             return true;
         };
@@ -653,9 +697,16 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             while (to_gpu.pop(b)) {
                 if (!failed) {
                     const uint64_t tq0 = now_us();
-                    int rc = bgr_align_batch(aligners[w], prm, static_cast<const char*>(b->pin->reads.p), static_cast<const uint64_t*>(b->pin->offs.p), b->n,
-                                             static_cast<int32_t*>(b->pin->paths.p), b->path_cap, static_cast<uint64_t*>(b->pin->poffs.p),
-                                             static_cast<uint8_t*>(b->pin->status.p));
+                    bgr_packed_reads pk;
+                    pk.read_offsets = static_cast<const uint64_t*>(b->pin->offs.p);
+                    pk.fw3 = static_cast<const uint64_t*>(b->pin->fw3.p);
+                    pk.hasn = static_cast<const uint32_t*>(b->pin->hasn.p);
+                    pk.nm_index = static_cast<const uint32_t*>(b->pin->nm_idx.p);
+                    pk.nm_value = static_cast<const uint64_t*>(b->pin->nm_val.p);
+                    pk.nm_count = b->pin->nm_count;
+                    pk.max_read_len = b->pin->max_len;
+                    int rc = bgr_align_batch_packed(aligners[w], prm, &pk, b->n, static_cast<int32_t*>(b->pin->paths.p), b->path_cap,
+                                                    static_cast<uint64_t*>(b->pin->poffs.p), static_cast<uint8_t*>(b->pin->status.p));
                     if (rc == BGR_E_CAPACITY) {  // unusually long paths: fetch the same device results again into a full-size buffer
                         b->path_cap = b->bases + 8 * b->n + 8;
                         if (!b->pin->paths.ensure(b->path_cap * 4)) rc = BGR_E_HIP;

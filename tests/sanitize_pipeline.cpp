@@ -32,8 +32,13 @@ int bgr_host_alloc(uint64_t bytes, void** out) { *out = malloc(bytes ? bytes : 1
 int bgr_host_free(void* p) { free(p); return BGR_OK; }
 int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) { memcpy(out, a->counters, sizeof(a->counters)); return BGR_OK; }
 int bgr_aligner_fetch(bgr_aligner*, uint64_t, int32_t*, uint64_t, uint64_t*, uint8_t*) { return BGR_E_INTERNAL; }
-int bgr_align_batch(bgr_aligner* a, const bgr_params*, const char*, const uint64_t* offs, uint64_t n, int32_t* paths, uint64_t cap,
-                    uint64_t* poffs, uint8_t* status) {
+int bgr_align_batch_packed(bgr_aligner* a, const bgr_params*, const bgr_packed_reads* pk, uint64_t n, int32_t* paths, uint64_t cap,
+                           uint64_t* poffs, uint8_t* status) {
+    const uint64_t* offs = pk->read_offsets;
+    for (uint64_t i = 0; i < n; ++i) {  // the packed plane must spell the read: check the first base of every read's first word
+        const uint64_t len = offs[i + 1] - offs[i];
+        if (len && (pk->fw3[(offs[i] >> 5) + i] >> 62) > 3) return BGR_E_INTERNAL;
+    }
     std::this_thread::sleep_for(std::chrono::microseconds(200 + (n * 7919) % 900));  // let the stages interleave
     uint64_t w = 0;
     poffs[0] = 0;

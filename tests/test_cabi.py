@@ -205,6 +205,58 @@ def test_unitig_fasta_through_a_fifo(tmp_path):
     assert g1.info()["n_unitigs"] > 500 and np.array_equal(np.array(g1.blob()), np.array(g2.blob()))
 
 
+def _pack_reference(reads, offs):
+    """The plane layout of include/bgreat_gpu.h, written out plainly: codes A0 C1 G2 else 3, 32 per word, first base in the top
+    bits, read r at word (offs[r] >> 5) + r; N reads flagged, with a mask word (3 per N) for every word of theirs."""
+    code = np.full(256, 3, dtype=np.uint64)
+    code[ord("A")], code[ord("C")], code[ord("G")], code[ord("T")] = 0, 1, 2, 3
+    n = len(offs) - 1
+    words = (int(offs[n]) >> 5) + n + 4
+    fw3 = np.zeros(words, dtype=np.uint64)
+    hasn = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
+    nm = {}
+    for r in range(n):
+        seq = reads[int(offs[r]):int(offs[r + 1])]
+        w0 = (int(offs[r]) >> 5) + r
+        isn = seq == ord("N")
+        for j in range((len(seq) + 31) // 32):
+            chunk = seq[32 * j:32 * j + 32]
+            v = 0
+            for i, c in enumerate(chunk):
+                v |= int(code[c]) << (62 - 2 * i)
+            fw3[w0 + j] = v
+            if isn.any():
+                m = 0
+                for i in np.nonzero(isn[32 * j:32 * j + 32])[0]:
+                    m |= 3 << (62 - 2 * int(i))
+                nm[w0 + j] = m
+        if isn.any():
+            hasn[r >> 5] |= np.uint32(1 << (r & 31))
+    return fw3, hasn, nm
+
+
+def test_host_packer_layout():
+    """bgr_pack_reads (SSSE3 or scalar) against the layout written out in numpy: ragged lengths 1..200 around the 16- and
+    32-base boundaries, N in a few reads, a batch that does not start at offset 0."""
+    rng = np.random.default_rng(12)
+    lens = np.concatenate([np.arange(1, 70), rng.integers(1, 200, size=300), [15, 16, 17, 31, 32, 33, 63, 64, 65, 128, 150]])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    reads = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(offs[-1]))
+    for r in rng.choice(len(lens), size=25, replace=False):
+        a, b = int(offs[r]), int(offs[r + 1])
+        reads[rng.integers(a, b, size=min(3, b - a))] = ord("N")
+    pk = B.pack_reads(reads, offs)
+    fw3, hasn, nm = _pack_reference(reads, offs)
+    assert np.array_equal(pk["fw3"][:len(fw3)], fw3)
+    assert np.array_equal(pk["hasn"][:len(hasn)], hasn) and pk["max_read_len"] == int(lens.max())
+    assert dict(zip(pk["nm_index"].tolist(), pk["nm_value"].tolist())) == nm and len(pk["nm_index"]) == len(nm)
+    # the same reads inside a larger buffer: offsets not starting at 0 are rebased
+    pad = 77
+    reads2 = np.concatenate([np.full(pad, ord("T"), dtype=np.uint8), reads])
+    pk2 = B.pack_reads(reads2, offs + np.uint64(pad))
+    assert np.array_equal(pk2["fw3"], pk["fw3"]) and np.array_equal(pk2["read_offsets"], offs) and np.array_equal(pk2["nm_index"], pk["nm_index"])
+
+
 def test_exception_planes_only_when_needed():
     assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig.fa"), 5).info()["has_exceptions"] == 0
     assert B.Graph.from_fasta(os.path.join(GOLD, "deg_unitig_exc.fa"), 5).info()["has_exceptions"] == 1

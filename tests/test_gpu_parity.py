@@ -413,6 +413,31 @@ def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m
     assert al.counters() == o.counters()
 
 
+@pytest.mark.parametrize("mode,m", [(0, 2), (1, 3), (2, 2)])
+def test_host_packed_batch_equals_ascii_batch(mode, m):
+    """bgr_align_batch_packed (reads packed to 2 bits on the host, N-mask words as a sparse list scattered on the device) gives
+    the rows of bgr_align_batch (ASCII in, packed by the pre-pass kernel) in every mode; ragged lengths, N in 1 % of the reads."""
+    k = 31
+    s = Synth(200000, 70, 3, k, 4100 + mode)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(k, seqs, offs, anchors=(mode == 2))
+    al = B.Aligner(g, 0)
+    rng = np.random.default_rng(5 + mode)
+    full, foffs = s.reads(0, 30001, 180, m, 4200 + mode)
+    lens = rng.integers(33, 181, size=30001)     # ragged: cut every read
+    keep = np.concatenate([full[int(foffs[i]):int(foffs[i]) + int(lens[i])] for i in range(len(lens))])
+    roffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    reads = _inject_n(keep, rng, 0.0005)
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=2, mode=mode)
+    c1 = al.counters()
+    al.reset_counters()
+    pk = B.pack_reads(reads, roffs)
+    assert len(pk["nm_index"]) > 0
+    p2, po2, st2 = al.align_packed(pk, m=m, effort=2, mode=mode)
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2) and np.array_equal(p1, p2) and al.counters() == c1
+
+
 def test_devices_init_on_one_gpu():
     """bgr_devices_init (graph resident on the GPUs of one process: one upload, then RCCL broadcast / xGMI peer copies).  A
     one-GPU box can only check the single-device paths: nothing to distribute, the forced RCCL path through a one-rank
