@@ -102,7 +102,7 @@ __device__ __forceinline__ u64 rcb_fast(u64 x, uint32_t n) { return (~rev2_fast(
 // until no lane is still on a "several keys here" position -- about 2-3 levels at gamma 2, because a lane
 // that lands on an empty position (most read positions are not overlaps) is rejected at once.
 // LV = level descriptors {units, base} staged in LDS.
-// SPEC (cascade in L2/HBM, not staged in LDS): the unit of level l+1 is requested together with level l's -- its
+// SPEC (cascade in L2/HBM, not staged in LDS): the state word of level l+1 is requested together with level l's -- its
 // address needs only the hash (double hashing), not level l's answer -- so two dependent-looking loads are in flight
 // at once; lanes that stop on level l simply drop it.
 template <bool SPEC, typename UP>
@@ -110,30 +110,53 @@ __device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const u
     u64 m = bgr_mix64(key);
     uint32_t hl = (uint32_t)m;
     const uint32_t hb = (uint32_t)(m >> 32) | 1u;
-    uint32_t res = BGR_NONE;
     const uint32_t nl = g.n_levels;
-    uint4 qn = make_uint4(0, 0, 0, 0);
-    if (SPEC && active && nl) { const uint2 lv = LV[0]; qn = reinterpret_cast<const uint4*>(units)[lv.y + __umulhi(hl, lv.x)]; }
-    for (uint32_t l = 0; l < nl; ++l) {
-        if (!__any(active)) break;
-        uint4 q;
-        if (SPEC) {
-            q = qn;
+    uint32_t res = BGR_NONE;
+    if (SPEC) {
+        // cascade in L2/HBM: one 16-byte unit per level answers membership candidate AND minimal index, the next level's unit
+        // requested ahead (a second dependent access for the rank would cost a full L2 round trip: measured 7.98 -> 9.63 ms)
+        uint4 qn = make_uint4(0, 0, 0, 0);
+        if (active && nl) { const uint2 lv = LV[0]; qn = reinterpret_cast<const uint4*>(units)[lv.y + __umulhi(hl, lv.x)]; }
+        for (uint32_t l = 0; l < nl; ++l) {
+            if (!__any(active)) break;
+            const uint4 q = qn;
             if (active && l + 1 < nl) { const uint2 lv1 = LV[l + 1]; qn = reinterpret_cast<const uint4*>(units)[lv1.y + __umulhi(hl + hb, lv1.x)]; }
-        } else {
-            const uint2 lv = LV[l];
-            q = reinterpret_cast<const uint4*>(units)[lv.y + __umulhi(hl, lv.x)];
+            const uint32_t p = bgr_level_pos(hl);
+            const uint32_t wi = p >> 4, sh = (p & 15) * 2;
+            const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
+            const uint32_t st = (w >> sh) & 3u;
+            uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
+            r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
+            r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
+            if (active && st == 1u) res = r;
+            active = active && st == 3u;
+            hl += hb;
         }
-        const uint32_t p = bgr_level_pos(hl);
-        const uint32_t wi = p >> 4, sh = (p & 15) * 2;
-        const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
-        const uint32_t st = (w >> sh) & 3u;
-        uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
-        r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
-        r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
-        if (active && st == 1u) res = r;
-        active = active && st == 3u;
-        hl += hb;
+    } else {
+        // cascade in LDS: per level only the state word that holds the position is read (a dword: a quarter of the unit); the
+        // position where the walk ends on state 1 is remembered (unit << 6 | position) and its rank worked out once, behind
+        // the loop (4.49 -> 4.09 ms per 5 M reads: the loop body halves)
+        uint32_t hit = BGR_NONE;
+        for (uint32_t l = 0; l < nl; ++l) {
+            if (!__any(active)) break;
+            const uint2 lv = LV[l];
+            const uint32_t u = lv.y + __umulhi(hl, lv.x);
+            const uint32_t p = bgr_level_pos(hl);
+            const uint32_t w = units[(size_t)u * 4 + (p >> 4)];
+            const uint32_t st = (w >> ((p & 15) * 2)) & 3u;
+            if (active && st == 1u) hit = u << 6 | p;
+            active = active && st == 3u;
+            hl += hb;
+        }
+        if (hit != BGR_NONE) {  // minimal index = rank of the position among the placed ones: the unit's running rank + the placed states before it
+            const uint4 q = reinterpret_cast<const uint4*>(units)[hit >> 6];
+            const uint32_t p = hit & 63u, wi = p >> 4, sh = (p & 15) * 2;
+            const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
+            uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
+            r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
+            r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
+            res = r;
+        }
     }
     if ((g.flags & BGR_GF_HAS_FALLBACK) && __any(active)) {
         if (active) {  // bisection in the (tiny) sorted fallback list; its location comes from the blob header
@@ -1576,12 +1599,20 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
                 const uint32_t a_rec = rl32(idx, src), a_pos = base + (uint32_t)src;
                 const u64 a_num = rl64(lds_win32(ROLL, a_pos) >> (64 - 2 * K1), 0);  // re-read (uniform) instead of keeping `num` live across the search
                 const bool a_canon = a_num <= rcb_fast(a_num, K1);
-                uint32_t nl = 0, nr = 0;
-                const uint32_t eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane);
-                if (eb == EXH_OVERFLOW) { overflow = true; break; }
-                if (eb > m) continue;
-                for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                uint32_t nl = 0, nr = 0, eb = 0;
+                if (a_pos == 0) {  // checkBeginExhaustive at position 0 is [0] at no cost (alignerExhaustive.cpp:159): no search
+                    if (lane == 0) OUT[0] = 0;
+                    nl = 1;
+                } else {
+                    eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane);
+                    if (eb == EXH_OVERFLOW) { overflow = true; break; }
+                    if (eb > m) continue;
+                    for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                }
                 wave_sync();
+                // position 0 is tried whatever its (k-1)-mer: when that is no overlap of the graph getBegin() is empty, and only an
+                // empty right side or -i can make the anchor succeed (alignerExhaustive.cpp:206-221): no search either
+                if (a_rec == BGR_NONE && !prm.partial && L - a_pos - K1 != 0) continue;
                 const uint32_t ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane);
                 if (ee == EXH_OVERFLOW) { overflow = true; break; }
                 if (ee > m - eb) continue;
@@ -1669,12 +1700,20 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
                 const uint32_t a_rec = rl32(idx, src), a_pos = base + (uint32_t)src;
                 const u64 a_num = rl64(lds_win32(ROLL, a_pos) >> (64 - 2 * K1), 0);  // re-read (uniform) instead of keeping `num` live across the search
                 const bool a_canon = a_num <= rcb_fast(a_num, K1);
-                uint32_t nl = 0, nr = 0;
-                const uint32_t eb = exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, T, io.frames_per_wave, BEST, &nl, lane);
-                if (eb == EXH_OVERFLOW) { overflow = true; break; }
-                if (eb > m) continue;
-                for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                uint32_t nl = 0, nr = 0, eb = 0;
+                if (a_pos == 0) {  // checkBeginExhaustive at position 0 is [0] at no cost (alignerExhaustive.cpp:159): no search
+                    if (lane == 0) OUT[0] = 0;
+                    nl = 1;
+                } else {
+                    eb = exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, T, io.frames_per_wave, BEST, &nl, lane);
+                    if (eb == EXH_OVERFLOW) { overflow = true; break; }
+                    if (eb > m) continue;
+                    for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                }
                 wave_sync();
+                // position 0 is tried whatever its (k-1)-mer: when that is no overlap of the graph getBegin() is empty, and only an
+                // empty right side or -i can make the anchor succeed (alignerExhaustive.cpp:206-221): no search either
+                if (a_rec == BGR_NONE && !prm.partial && L - a_pos - K1 != 0) continue;
                 const uint32_t ee = exh_dp<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, T, io.frames_per_wave, BEST, &nr, lane);
                 if (ee == EXH_OVERFLOW) { overflow = true; break; }
                 if (ee > m - eb) continue;
