@@ -1081,7 +1081,8 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
 #define G4_ST_TRIED_SHIFT 20
 #define G4_ST_POS_MASK 0xFFFFFu
 
-template <bool STAGE>
+// LIST: the launch maps the reads an earlier launch listed (io.subset) instead of all reads of the batch.
+template <bool STAGE, bool LIST>
 __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1089,7 +1090,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host): one lane per word of a read
     const uint32_t K1 = g.k - 1;
     // later passes map the reads an earlier pass listed (count in cursor[subset_ctr]), from the state it left in g4_state
-    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
+    const uint32_t total = LIST ? io.cursor[io.subset_ctr] : io.n_reads;
     if ((uint32_t)(blockIdx.x * waves) * 4u >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
     uint2* LV;
     uint32_t mphf_words;
@@ -1112,7 +1113,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
         uint32_t r = 0, st = 0;
         u64 off = 0;
         uint32_t L = 0, fast = 0;
-        if (have && io.subset) {
+        if (have && LIST) {
             r = io.subset[it];
             if (r == BGR_NONE) have = 0;  // a hole: the unused tail of some wave's chunk of the list
             else st = io.g4_state[r];
@@ -1124,9 +1125,9 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
             L = (uint32_t)(io.read_offs[r + 1] - off);
             fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
         }
-        const uint32_t rc = st >> 31;
+        uint32_t rc = st >> 31;
         uint32_t tried = (st >> G4_ST_TRIED_SHIFT) & 0x7FFu;
-        const uint32_t s_from = st & G4_ST_POS_MASK;
+        uint32_t s_from = st & G4_ST_POS_MASK;
         u64* F = RD + grp * (2 * W);
         {   // stage the 2-bit words: lane `sub` of a group brings word `sub` of its read
             u64 f = 0;
@@ -1134,120 +1135,134 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
             if (sub < W) F[sub] = f;
         }
         wave_sync();
-        if (__any(rc != 0)) {  // reverseComplements(read) (utils.cpp:66-73) of the groups that are on their second strand
-            if (rc && sub < W) {
-                const long long p = (long long)L - 32 * ((long long)sub + 1);
-                u64 w = 0;
-                if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
-                else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
-                F[W + sub] = w;
-            }
-            wave_sync();
-        }
-        const u64* FW = F + (rc ? W : 0);  // the strand this pass maps
-
-        // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each read from where its scan stands and,
-        // when it lies in the same 64 positions, the one after it; record | canonical << 28
-        uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
-        for (uint32_t q = 0; q < 4; ++q) {
-            if (!rl32(fast, (int)(16 * q))) continue;
-            const uint32_t Lq = rl32(L, (int)(16 * q));
-            const u64* A = RD + q * (2 * W) + (rl32(rc, (int)(16 * q)) ? W : 0);
-            const uint32_t left_q = eff - rl32(tried, (int)(16 * q));  // anchors this strand may still try (>= 1)
-            uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
-            if (!prm.effort && npos > 1) npos = 1;
-            for (uint32_t base = rl32(s_from, (int)(16 * q)); base < npos; base += 64) {
-                const uint32_t i = base + (uint32_t)lane;
-                const bool valid = i < npos;
-                u64 num = 0;
-                if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
-                const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
-                uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
-                const u64 mask = __ballot(idx != BGR_NONE);
-                if (mask) {
-                    if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
-                    const int s1 = __ffsll((long long)mask) - 1;
-                    const u64 mask2 = mask & (mask - 1);
-                    const uint32_t h1 = rl32(idx, s1);
-                    uint32_t h2 = BGR_NONE, p2 = 0;
-                    if (mask2 && left_q >= 2) {  // a second anchor is tried when the first fails
-                        const int s2 = __ffsll((long long)mask2) - 1;
-                        h2 = rl32(idx, s2);
-                        p2 = base + (uint32_t)s2;
-                    }
-                    if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
-                    break;
-                }
-            }
-        }
-
-        // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast; a group whose anchor fails
-        // starts over from the next one, if the scan has seen it, while the others go on ----
-        uint32_t phase = (fast && a_rec != BGR_NONE) ? 1u : 0u;
-        uint32_t pos = a_pos, rec = a_rec & G4_REC_MASK, canon = (a_rec >> 28) & 1u, budget = m;
-        uint32_t nl = 0, nr = 0, bad = 0, failed = 0;
+        uint32_t act = fast;                 // the group takes part in the current round
+        uint32_t outcome = 4, nst = 0, rc_out = rc;  // what became of the read (below); 4 = general kernel
+        uint32_t nl = 0, nr = 0;
         int32_t pl = 0, pr = 0;  // lane `sub` keeps path int number `sub` of the left walk (near -> far, offset last) / right walk
-        for (;;) {
-            if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
-                if (sub == nl) pl = 0;
-                ++nl;
-                phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+        for (uint32_t round = 0;; ++round) {
+            if (__any(act && rc)) {  // reverseComplements(read) (utils.cpp:66-73) of the groups that are on their second strand
+                if (act && rc && sub < W) {
+                    const long long p = (long long)L - 32 * ((long long)sub + 1);
+                    u64 w = 0;
+                    if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
+                    else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                    F[W + sub] = w;
+                }
+                wave_sync();
             }
-            if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
-            if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
-            if ((phase == 1 && nl > G4_PATH - 2) || (phase >= 2 && nr > G4_PATH - 1)) { bad = 1; phase = 0; }  // path too long for the registers
-            if (!__any(phase != 0)) break;
-            uint32_t miss, ext;
-            int32_t sid;
-            const uint32_t w1 = g4_step(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
-            if (phase != 0) {
-                if (!(w1 & G4_FOUND)) {
-                    ++tried;
-                    if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
-                        a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
-                        nl = 0; nr = 0; budget = m;
-                        phase = 1; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
-                    } else { failed = 1; phase = 0; }
-                } else if (phase == 1) {
-                    if (sub == nl) pl = sid;
-                    ++nl;
-                    budget -= miss;
-                    if (w1 & G4_FITS) {
-                        if (sub == nl) pl = (int32_t)(ext - pos);
-                        ++nl;
-                        phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
-                    } else { pos -= ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; }
-                } else {
-                    if (sub == nr) pr = sid;
-                    ++nr;
-                    budget -= miss;
-                    if (w1 & G4_FITS) phase = 0;
-                    else { pos += ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; phase = 3; }
+            const u64* FW = F + (rc ? W : 0);  // the strand this pass maps
+
+            // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each read from where its scan stands and,
+            // when it lies in the same 64 positions, the one after it; record | canonical << 28
+            uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
+            for (uint32_t q = 0; q < 4; ++q) {
+                if (!rl32(act, (int)(16 * q))) continue;
+                const uint32_t Lq = rl32(L, (int)(16 * q));
+                const u64* A = RD + q * (2 * W) + (rl32(rc, (int)(16 * q)) ? W : 0);
+                const uint32_t left_q = eff - rl32(tried, (int)(16 * q));  // anchors this strand may still try (>= 1)
+                uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
+                if (!prm.effort && npos > 1) npos = 1;
+                for (uint32_t base = rl32(s_from, (int)(16 * q)); base < npos; base += 64) {
+                    const uint32_t i = base + (uint32_t)lane;
+                    const bool valid = i < npos;
+                    u64 num = 0;
+                    if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                    const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
+                    uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
+                    const u64 mask = __ballot(idx != BGR_NONE);
+                    if (mask) {
+                        if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
+                        const int s1 = __ffsll((long long)mask) - 1;
+                        const u64 mask2 = mask & (mask - 1);
+                        const uint32_t h1 = rl32(idx, s1);
+                        uint32_t h2 = BGR_NONE, p2 = 0;
+                        if (mask2 && left_q >= 2) {  // a second anchor is tried when the first fails
+                            const int s2 = __ffsll((long long)mask2) - 1;
+                            h2 = rl32(idx, s2);
+                            p2 = base + (uint32_t)s2;
+                        }
+                        if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
+                        break;
+                    }
                 }
             }
-        }
 
-        // ---- what became of each read (alignerGreedy.cpp:35-57) ---------------------------------------------------------------
-        // 0 = aligned, 1 = no anchor on this strand and none tried before (++noOverlapRead), 2 = not aligned (both strands done),
-        // 3 = goes on in a later pass with `nst`, 4 = general kernel (N in the read, path too long for the registers)
-        uint32_t outcome, nst = 0;
-        {
-            const uint32_t npos_g = (L >= K1 ? L - K1 + 1 : 0);
-            const uint32_t npos_e = (!prm.effort && npos_g > 1) ? 1u : npos_g;
-            if (!fast || bad) outcome = 4;
-            else if (a_rec != BGR_NONE && !failed) outcome = 0;
-            else if (a_rec == BGR_NONE && tried == 0) outcome = 1;
-            else {
-                // the strand's anchors are used up when `effort` of them have been tried or the scan has passed the last position
-                const uint32_t resume = a_pos + 1;  // (a_pos = the anchor tried last; unused when the scan found none)
-                const uint32_t used_up = (a_rec == BGR_NONE || tried >= eff || resume >= npos_e) ? 1u : 0u;
-                if (!used_up) { outcome = 3; nst = (rc << 31) | (tried << G4_ST_TRIED_SHIFT) | resume; }
-                else if (!rc) { outcome = 3; nst = G4_ST_RC; }  // the reverse complement, from its first position
-                else outcome = 2;
-                if (tried > 0x7FFu) outcome = 4;
+            // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast; a group whose anchor fails
+            // starts over from the next one, if the scan has seen it, while the others go on ----
+            uint32_t phase = (act && a_rec != BGR_NONE) ? 1u : 0u;
+            uint32_t pos = a_pos, rec = a_rec & G4_REC_MASK, canon = (a_rec >> 28) & 1u, budget = m;
+            uint32_t bad = 0, failed = 0;
+            if (act) { nl = 0; nr = 0; }
+            for (;;) {
+                if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
+                    if (sub == nl) pl = 0;
+                    ++nl;
+                    phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                }
+                if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
+                if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
+                if ((phase == 1 && nl > G4_PATH - 2) || (phase >= 2 && nr > G4_PATH - 1)) { bad = 1; phase = 0; }  // path too long for the registers
+                if (!__any(phase != 0)) break;
+                uint32_t miss, ext;
+                int32_t sid;
+                const uint32_t w1 = g4_step(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+                if (phase != 0) {
+                    if (!(w1 & G4_FOUND)) {
+                        ++tried;
+                        if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
+                            a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
+                            nl = 0; nr = 0; budget = m;
+                            phase = 1; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                        } else { failed = 1; phase = 0; }
+                    } else if (phase == 1) {
+                        if (sub == nl) pl = sid;
+                        ++nl;
+                        budget -= miss;
+                        if (w1 & G4_FITS) {
+                            if (sub == nl) pl = (int32_t)(ext - pos);
+                            ++nl;
+                            phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                        } else { pos -= ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; }
+                    } else {
+                        if (sub == nr) pr = sid;
+                        ++nr;
+                        budget -= miss;
+                        if (w1 & G4_FITS) phase = 0;
+                        else { pos += ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; phase = 3; }
+                    }
+                }
             }
-            if (outcome == 3 && io.g4_last) outcome = 4;  // no further pass of this kernel: the general kernel maps the read from scratch
+
+            // ---- what became of each read (alignerGreedy.cpp:35-57) ---------------------------------------------------------------
+            // 0 = aligned, 1 = no anchor on this strand and none tried before (++noOverlapRead), 2 = not aligned (both strands done),
+            // 3 = goes on in a later pass with `nst`, 4 = general kernel (N in the read, path too long for the registers)
+            uint32_t o_now = 4, n_now = 0;
+            {
+                const uint32_t npos_g = (L >= K1 ? L - K1 + 1 : 0);
+                const uint32_t npos_e = (!prm.effort && npos_g > 1) ? 1u : npos_g;
+                if (bad) o_now = 4;
+                else if (a_rec != BGR_NONE && !failed) o_now = 0;
+                else if (a_rec == BGR_NONE && tried == 0) o_now = 1;
+                else {
+                    // the strand's anchors are used up when `effort` of them have been tried or the scan has passed the last position
+                    const uint32_t resume = a_pos + 1;  // (a_pos = the anchor tried last; unused when the scan found none)
+                    const uint32_t used_up = (a_rec == BGR_NONE || tried >= eff || resume >= npos_e) ? 1u : 0u;
+                    if (!used_up) { o_now = 3; n_now = (rc << 31) | (tried << G4_ST_TRIED_SHIFT) | resume; }
+                    else if (!rc) { o_now = 3; n_now = G4_ST_RC; }  // the reverse complement, from its first position
+                    else o_now = 2;
+                    if (tried > 0x7FFu) o_now = 4;
+                }
+            }
+            if (act) { outcome = o_now; nst = n_now; rc_out = rc; }
+            // A launch over a LIST goes straight on to the reverse complement of the reads whose forward anchors are used up now
+            // (most of such a launch's reads: a second round is as densely packed as the first); the launch over all reads leaves
+            // them to the next one (7 % of its reads: three of four groups would sit idle).
+            const uint32_t again = (LIST && round == 0 && act && o_now == 3 && n_now == G4_ST_RC) ? 1u : 0u;
+            if (!LIST) break;
+            if (!__any(again != 0)) break;
+            act = again; rc = 1; tried = 0; s_from = 0;
         }
+        if (outcome == 3 && io.g4_last) outcome = 4;  // no further pass of this kernel: the general kernel maps the read from scratch
 
         // ---- publish: reverse(left) ++ right into the arena ----------------------------------------------------------------------
         const uint32_t aligned = outcome == 0 ? 1u : 0u;
@@ -1274,7 +1289,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
         if (!room && lane == 0 && tot) io.cursor[1] = 1;  // overflow: reported by the host as an error
         if (sub == 0 && have) {
             if (outcome <= 2) {
-                const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc ? BGR_ST_RC : 0u);
+                const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc_out ? BGR_ST_RC : 0u);
                 io.results[r] = make_uint2(aligned ? gbase : 0u, p_n | (code << 24));
             } else if (outcome == 3) {
                 io.g4_state[r] = nst;
@@ -1917,7 +1932,7 @@ uint32_t resident_waves_per_cu(uint32_t mode) {
     const void* fn = mode == 0 ? reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>)
                    : mode == 2 ? reinterpret_cast<const void*>(&bgr_align_anchors_kernel)
                    : mode == 3 ? reinterpret_cast<const void*>(&bgr_align_exhaustive_dp_kernel<false>)
-                   : mode == 4 ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true>)
+                   : mode == 4 ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, true>)
                                : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
     // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;
@@ -1930,8 +1945,10 @@ uint32_t resident_waves_per_cu(uint32_t mode) {
 hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     if (io.n_reads == 0) return hipSuccess;
     if (p.mode == 0) {
-        if (io.greedy4) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true>, g, io, p, cfg, stream)
-                                              : launch_one(bgr_align_greedy4_kernel<false>, g, io, p, cfg, stream);
+        if (io.greedy4 && io.subset) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, true>, g, io, p, cfg, stream)
+                                                           : launch_one(bgr_align_greedy4_kernel<false, true>, g, io, p, cfg, stream);
+        if (io.greedy4) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, false>, g, io, p, cfg, stream)
+                                              : launch_one(bgr_align_greedy4_kernel<false, false>, g, io, p, cfg, stream);
         return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
                               : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
     }
