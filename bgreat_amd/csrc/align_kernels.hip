@@ -1660,6 +1660,313 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
     }
 }
 
+// ============================== exhaustive, four reads per wavefront ===================================
+// The level search (exh_dp) gives a wave ONE read, and after de-duplication a level of the walk rarely holds more than one
+// node: 4 candidate slots x 4 chunk lanes = 16 of the 64 lanes work.  Here a wave takes four reads, 16 lanes each, and runs
+// their searches side by side, for the shape nearly every read has: every level has exactly ONE node (all candidates that go
+// on lead to the same (record, position, strand): bubbles that close again), at most X4_LEVELS levels per side, no N, and
+// the first anchor that can succeed does.  Per side: a forward sweep scores the node's <= 4 candidates per level (kept:
+// id, offset, mismatches, fits, alive), a backward sweep settles cost(level) = first minimum over the slots of mismatches
+// [+ cost(level + 1) when the walk goes on] -- the value and the choice of the reference's recursion
+// (alignerExhaustive.cpp:61-259; see exh_dp) -- and the walk is read off.  Anything else (a level with two nodes, a failing
+// first anchor, N, -i) is listed for bgr_align_exhaustive_dp_kernel / the depth-first passes, which map it from scratch.
+#ifndef BGR_X4_OCC
+#define BGR_X4_OCC 6
+#endif
+#define X4_LEVELS 16
+#define X4_LV_WORDS 16  // per level: [0..3] sid, [4..7] aux (the path int a walk ending there emits), [8..11] miss | fits<<16 | alive<<17, [12] node flags, [13] chosen slot
+#define X4_END 1u
+#define X4_INF 0xFFFFu
+
+// One side of the search for up to four reads (act = the group takes part).  DIR 0: left of the anchor (exL), DIR 1: right
+// (exR).  On return, for the groups that took part: *cost = best total (X4_INF: none within the budget; the caller compares
+// with its budget), *n_out ints written to OUTG[o_off ...] in output order, *fb = the search left the shape this kernel
+// handles (the read goes on the list).
+template <int DIR>
+__device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t act, uint32_t a_rec, uint32_t a_canon,
+                                          uint32_t a_pos, uint32_t budget, uint32_t* LVT, int32_t* OUTG, uint32_t o_off, int lane, uint32_t* cost_o,
+                                          uint32_t* n_out, uint32_t* fb_o) {
+    const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u, sub = (uint32_t)lane & 15u;
+    uint32_t fwd = act, fb = 0, lvl = 0, nlev = 0, prefix = 0;
+    uint32_t pos = a_pos, rec = a_rec, canon = a_canon;
+    // ---- forward: one node per level ----
+    for (;;) {
+        if (fwd && lvl >= X4_LEVELS) { fb = 1; fwd = 0; }
+        const uint32_t end_here = (fwd && ((DIR == 0) ? (pos == 0) : (L - pos - K1 == 0))) ? 1u : 0u;
+        if (end_here) {  // left: the read's first base is reached; right: nothing is left of the read
+            if (sub == 0) LVT[lvl * X4_LV_WORDS + 12] = X4_END;
+            nlev = lvl + 1;
+            fwd = 0;
+        }
+        if (!__any(fwd != 0)) break;
+        const uint32_t useR = ((DIR == 0) ? canon : (canon ^ 1u));
+        uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
+        if (fwd && rec != G4_REC_MASK) {
+            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + useR * 4u + c) * 2;
+            sl = sp[0];
+            m0 = sp[1];
+        }
+        const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+        const u64 zmask = __ballot(id == 0);
+        const uint32_t zb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
+        const uint32_t first_zero = zb ? (uint32_t)(__ffs((int)zb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+        const uint32_t valid = c < first_zero ? 1u : 0u;
+        const uint32_t fwdu = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
+        const uint32_t len = sl.y;
+        const uint32_t fw = sl.z, fo = sl.w + (fwdu ? 0u : len);
+        const uint32_t ext = len - K1;
+        uint32_t fits, n, ustart, rstart, nrec, cbit, aux, npos;
+        if (DIR == 0) {
+            fits = ext >= pos ? 1u : 0u;
+            n = fits ? pos : ext;
+            ustart = fits ? ext - pos : 0;
+            rstart = fits ? 0 : pos - ext;
+            nrec = fwdu ? m0.y : m0.z;
+            cbit = fwdu ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND;
+            aux = ext - pos;   // offset in the last unitig (:126,:175)
+            npos = pos - ext;
+        } else {
+            const uint32_t rl = L - pos - K1;
+            fits = ext >= rl ? 1u : 0u;
+            n = fits ? rl : ext;
+            ustart = K1;
+            rstart = pos + K1;
+            nrec = fwdu ? m0.z : m0.y;
+            cbit = fwdu ? BGR_META_CANON_END : BGR_META_CANON_RCBEG;
+            aux = L - pos;     // |readLeft| + k-1 (:99,:231)
+            npos = pos + ext;
+        }
+        if (!valid) n = 0;
+        uint32_t cnt = 0;
+        for (uint32_t b = q * 32; __any(b < n); b += 128)
+            if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
+        cnt += quad_xor1(cnt);
+        cnt += quad_xor2(cnt);
+        const uint32_t miss = cnt > 0xFFFFu ? 0xFFFFu : cnt;
+        const uint32_t ptotal = prefix + miss;
+        const uint32_t alive = (valid && ptotal <= budget) ? 1u : 0u;  // a walk through here costs at least this much
+        const uint32_t need = (alive && !fits) ? 1u : 0u;
+        if (fwd && q == 0) {
+            uint32_t* R = LVT + lvl * X4_LV_WORDS;
+            R[c] = fwdu ? id : 0u - id;
+            R[4 + c] = aux;
+            R[8 + c] = miss | (fits << 16) | (alive << 17);
+            if (c == 0) R[12] = 0;
+        }
+        // the candidates that go on must all reach the same node
+        const u64 nmask = __ballot(need && q == 0 && fwd);
+        const uint32_t nb = (uint32_t)(nmask >> ((uint32_t)lane & 48u)) & 0x1111u;
+        const uint32_t src = ((uint32_t)lane & 48u) | (nb ? (uint32_t)(__ffs((int)nb) - 1) : 0u);
+        const uint32_t kpk = nrec | ((m0.x & cbit) ? G4_CANON : 0u);
+        const uint32_t k_rec = lane_get(kpk, src), k_pos = lane_get(npos, src);
+        const u64 dmask = __ballot(need && fwd && (kpk != k_rec || npos != k_pos));
+        uint32_t pmin = need ? ptotal : 0xFFFFFFFFu;
+        uint32_t o = row_ror4(pmin);
+        pmin = o < pmin ? o : pmin;
+        o = row_ror8(pmin);
+        pmin = o < pmin ? o : pmin;
+        if (fwd) {
+            nlev = lvl + 1;
+            if ((uint32_t)(dmask >> ((uint32_t)lane & 48u)) & 0xFFFFu) { fb = 1; fwd = 0; }  // a level with two nodes
+            else if (!nb) fwd = 0;                                                      // every candidate ends here or is too dear
+            else { prefix = pmin; pos = k_pos; rec = k_rec & G4_REC_MASK; canon = (k_rec >> 28) & 1u; ++lvl; }
+        }
+    }
+    wave_sync();
+    // ---- backward: cost of every level, first slot on ties ----
+    const uint32_t ok = (act && !fb) ? 1u : 0u;
+    const uint32_t n0 = rl32(ok ? nlev : 0u, 0), n1 = rl32(ok ? nlev : 0u, 16), n2 = rl32(ok ? nlev : 0u, 32), n3 = rl32(ok ? nlev : 0u, 48);
+    const uint32_t maxl = max(max(n0, n1), max(n2, n3));
+    uint32_t cnext = X4_INF;
+    for (int l = (int)maxl - 1; l >= 0; --l) {
+        const uint32_t in = (ok && (uint32_t)l < nlev) ? 1u : 0u;
+        uint32_t key = 0xFFFFFFFFu, flags = 0;
+        if (in) {
+            const uint32_t* R = LVT + (uint32_t)l * X4_LV_WORDS;
+            flags = R[12];
+            if (sub < 4) {
+                const uint32_t pk = R[8 + sub];
+                uint32_t total = X4_INF;
+                if (pk & (1u << 17)) {
+                    total = (pk & 0xFFFFu) + ((pk & (1u << 16)) ? 0u : cnext);
+                    if (total > X4_INF) total = X4_INF;
+                }
+                key = total << 2 | sub;
+            }
+        }
+        uint32_t o = quad_xor1(key);
+        key = o < key ? o : key;
+        o = quad_xor2(key);
+        key = o < key ? o : key;
+        key = lane_get(key, (uint32_t)lane & 48u);
+        if (in) {
+            cnext = (flags & X4_END) ? 0u : (key >> 2);
+            if (sub == 0) LVT[(uint32_t)l * X4_LV_WORDS + 13] = key & 3u;
+        }
+    }
+    wave_sync();
+    // ---- read the walk off: level j's chosen slot, down to the first level that ends the walk ----
+    uint32_t endj = 0, sid = 0, auxv = 0, isend = 0;
+    if (ok && sub < nlev) {
+        const uint32_t* R = LVT + sub * X4_LV_WORDS;
+        const uint32_t a = R[13];
+        isend = R[12] & X4_END;
+        const uint32_t pk = R[8 + a];
+        endj = (isend || (pk & (1u << 16))) ? 1u : 0u;
+        sid = R[a];
+        auxv = R[4 + a];
+    }
+    const u64 emask = __ballot(endj != 0);
+    const uint32_t eb16 = (uint32_t)(emask >> ((uint32_t)lane & 48u)) & 0xFFFFu;
+    const uint32_t d = eb16 ? (uint32_t)(__ffs((int)eb16) - 1) : 0u;           // depth of the level that ends the walk
+    const uint32_t d_end = lane_get(isend, ((uint32_t)lane & 48u) | d);       // ... by reaching the read's end (no unitig taken there)
+    uint32_t n = 0;
+    const uint32_t good = (ok && cnext <= budget && eb16) ? 1u : 0u;
+    if (good) {
+        int32_t* O = OUTG + o_off;
+        if (DIR == 0) {
+            // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); else [offset, farthest unitig, ..., nearest]
+            if (d_end) { n = d == 0 ? 1u : d; if (d == 0) { if (sub == 0) O[0] = 0; } else if (sub < d) O[d - 1 - sub] = (int32_t)sid; }
+            else { n = d + 2; if (sub == d) { O[0] = (int32_t)auxv; O[1] = (int32_t)sid; } else if (sub < d) O[1 + (d - sub)] = (int32_t)sid; }
+        } else {
+            // right: every depth pushes 0 at the read's end (:64,:210); else [nearest ... farthest unitig, end offset]
+            if (d_end) { n = d + 1; if (sub < d) O[sub] = (int32_t)sid; if (sub == d) O[d] = 0; }
+            else { n = d + 2; if (sub <= d) O[sub] = (int32_t)sid; if (sub == d) O[d + 1] = (int32_t)auxv; }
+        }
+    }
+    wave_sync();
+    *cost_o = good ? cnext : X4_INF;
+    *n_out = n;
+    *fb_o = fb;
+}
+
+template <bool STAGE>
+__global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    // per wave: 4 x { read words W | level table X4_LEVELS x X4_LV_WORDS u32 | out ints 2 x (X4_LEVELS + 2) }
+    const uint32_t out_ints = 2 * (X4_LEVELS + 2);
+    const uint32_t grp_words = W + (X4_LEVELS * X4_LV_WORDS + out_ints + 1) / 2;
+    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
+    u64* WV = lds + 64 + mphf_words + (u64)wave * (4 * grp_words);
+    u64* F = WV + grp * grp_words;
+    uint32_t* LVT = reinterpret_cast<uint32_t*>(F + W);
+    int32_t* OUTG = reinterpret_cast<int32_t*>(LVT + X4_LEVELS * X4_LV_WORDS);
+    const uint32_t m = prm.max_mismatch;
+
+    uint32_t c_al = 0, c_na = 0;
+    unsigned long long c_ov = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+
+    for (uint32_t rbase = (blockIdx.x * waves + wave) * 4; rbase < io.n_reads; rbase += gridDim.x * waves * 4) {
+        const uint32_t r = rbase + grp;
+        const uint32_t have = r < io.n_reads ? 1u : 0u;
+        u64 off = 0;
+        uint32_t L = 0, fast = 0;
+        if (have) {
+            off = io.read_offs[r];
+            L = (uint32_t)(io.read_offs[r + 1] - off);
+            fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;
+            if (L <= K1) fast = 0;  // (a read of k-1 bases or fewer: the general kernel)
+        }
+        {
+            u64 f = 0;
+            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
+            if (sub < W) F[sub] = f;
+        }
+        wave_sync();
+        // ---- the first position that can anchor the read (getListOverlap keeps every position, aligner.cpp:318-342; only
+        // position 0 and overlap (k-1)-mers of the graph can succeed): position 0 when its k-mer is an overlap, else the first hit
+        uint32_t a_pos = 0, a_rec = BGR_NONE;
+        for (uint32_t qq = 0; qq < 4; ++qq) {
+            if (!rl32(fast, (int)(16 * qq))) continue;
+            const uint32_t Lq = rl32(L, (int)(16 * qq));
+            const u64* A = WV + qq * grp_words;
+            const uint32_t npos = Lq - K1 + 1;
+            for (uint32_t base = 0; base < npos; base += 64) {
+                const uint32_t i = base + (uint32_t)lane;
+                const bool valid = i < npos;
+                u64 num = 0;
+                if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                const u64 rcn = rcb_fast(num, K1);
+                uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
+                const u64 mask = __ballot(idx != BGR_NONE);
+                if (mask) {
+                    if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
+                    const int s1 = __ffsll((long long)mask) - 1;
+                    const uint32_t h1 = rl32(idx, s1);
+                    if (grp == qq) { a_pos = base + (uint32_t)s1; a_rec = h1; }
+                    break;
+                }
+            }
+        }
+        const uint32_t npos_g = L >= K1 ? L - K1 + 1 : 0;
+        const uint32_t anchored = (fast && a_rec != BGR_NONE) ? 1u : 0u;
+        // left side: [0] at position 0 (no search), else the search with the whole budget
+        uint32_t eb = 0, nl = 0, fbl = 0;
+        {
+            const uint32_t actl = (anchored && a_pos != 0) ? 1u : 0u;
+            uint32_t cl = 0, nll = 0;
+            x4_search<0>(g, F, L, K1, actl, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, m, LVT, OUTG, 0, lane, &cl, &nll, &fbl);
+            if (actl) { eb = cl; nl = nll; }
+            else if (anchored) { if (sub == 0) OUTG[0] = 0; nl = 1; }
+        }
+        wave_sync();
+        uint32_t ee = 0, nr = 0, fbr = 0;
+        {
+            const uint32_t actr = (anchored && !fbl && eb <= m) ? 1u : 0u;
+            uint32_t cr = 0, nrr = 0;
+            x4_search<1>(g, F, L, K1, actr, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, actr ? m - eb : 0u, LVT, OUTG, nl, lane, &cr, &nrr, &fbr);
+            if (actr) { ee = cr; nr = nrr; } else ee = X4_INF;
+        }
+        // 0 = aligned; 2 = not aligned for sure (no overlap (k-1)-mer anywhere in the read: every position fails); 4 = the list
+        uint32_t outcome = 4;
+        if (fast && !anchored) outcome = 2;
+        else if (anchored && !fbl && !fbr && eb <= m && ee != X4_INF && eb + ee <= m) outcome = 0;
+        const uint32_t aligned = outcome == 0 ? 1u : 0u;
+        const uint32_t p_n = aligned ? nl + nr : 0;
+        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        if (tot > chunk_end - chunk_pos) {
+            const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(io.cursor, want);
+            chunk_pos = rl32(got, 0);
+            chunk_end = chunk_pos + want;
+        }
+        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const bool room = chunk_pos + tot <= io.arena_cap;
+        chunk_pos += tot;
+        for (uint32_t j = sub; j < p_n; j += 16)
+            if (room) io.arena[gbase + j] = OUTG[j];
+        if (!room && lane == 0 && tot) io.cursor[1] = 1;
+        if (sub == 0 && have) {
+            if (outcome == 0) io.results[r] = make_uint2(gbase, p_n | ((uint32_t)BGR_ST_ALIGNED << 24));
+            else if (outcome == 2) io.results[r] = make_uint2(0u, (uint32_t)BGR_ST_FAILED << 24);
+            else io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+        }
+        const u64 fin = __ballot(sub == 0 && have && outcome != 4);
+        c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
+        c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
+        for (int gq = 0; gq < 4; ++gq)
+            if ((fin >> (16 * gq)) & 1) c_ov += rl32(npos_g, 16 * gq);  // overlaps += listOverlap.size() (alignerExhaustive.cpp:38)
+        wave_sync();
+    }
+    if (lane == 0 && (c_al | c_na)) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)(c_al + c_na));
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        atomicAdd(&counters[4], c_ov);
+    }
+}
+
 // Pass 1 of exhaustive mode with the level-by-level search (exh_dp); what it cannot hold goes to the overflow list and
 // through bgr_align_exhaustive_kernel<false, true>.
 template <bool STAGE>
@@ -1933,6 +2240,7 @@ uint32_t resident_waves_per_cu(uint32_t mode) {
                    : mode == 2 ? reinterpret_cast<const void*>(&bgr_align_anchors_kernel)
                    : mode == 3 ? reinterpret_cast<const void*>(&bgr_align_exhaustive_dp_kernel<false>)
                    : mode == 4 ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, true>)
+                   : mode == 5 ? reinterpret_cast<const void*>(&bgr_align_exhaustive4_kernel<false>)
                                : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return 16;
     // MI355X_MICROARCH.md "Register files": 512 VGPRs per SIMD lane, allocation granule 8, at most 8 waves per SIMD;
@@ -1953,6 +2261,8 @@ hipError_t launch_align(const BgrDeviceGraph& g, const BatchIO& io, const Kernel
                               : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
     }
     if (p.mode == 2) return launch_one(bgr_align_anchors_kernel, g, io, p, cfg, stream);
+    if (io.exh4) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive4_kernel<true>, g, io, p, cfg, stream)
+                                       : launch_one(bgr_align_exhaustive4_kernel<false>, g, io, p, cfg, stream);
     if (io.deep_scratch) return launch_one(bgr_align_exhaustive_kernel<false, true>, g, io, p, cfg, stream);
     if (io.level_search) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_dp_kernel<true>, g, io, p, cfg, stream)
                                                : launch_one(bgr_align_exhaustive_dp_kernel<false>, g, io, p, cfg, stream);

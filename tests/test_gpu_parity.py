@@ -324,6 +324,38 @@ def test_gpu_exhaustive_matches_oracle_random(seed, k, L, m, partial, nfrac, d, 
     assert al.counters() == o.counters()
 
 
+@pytest.mark.parametrize("seed,k,L,m,d,alleles,nfrac", [(1, 31, 250, 5, 36, 4, 0.0), (2, 31, 150, 2, 140, 2, 0.001), (3, 15, 120, 4, 25, 3, 0.0),
+                                                      (4, 31, 440, 6, 60, 4, 0.0), (5, 9, 80, 3, 12, 4, 0.0), (6, 32, 100, 0, 50, 2, 0.0)])
+def test_exhaustive_four_reads_per_wave_pass_equals_level_search_and_oracle(seed, k, L, m, d, alleles, nfrac):
+    """-b maps with bgr_align_exhaustive4_kernel first (four reads per wave; one node per level, first anchor) and leaves the
+    rest -- levels with two nodes, failing first anchors, N, long walks (small k) -- to the level / depth-first passes.  With and
+    without that first pass, and the oracle, must agree row for row, counters included."""
+    s = Synth(150000, d, alleles, k, 8100 + seed)
+    seqs, offs = s.unitigs()
+    n = 12003 - seed
+    reads, roffs = s.reads(0, n, L, m + 1, 8200 + seed)
+    if nfrac:
+        reads = _inject_n(reads, np.random.default_rng(seed), nfrac)
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs)
+    p2, po2, st2 = o.align(reads, roffs, m=m, mode=1)
+    p1, po1, st1 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE)
+    assert al.launch_info()["four_reads_per_wave"]
+    left = al.pass_counts()[2]
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    assert al.counters() == o.counters()
+    if k == 31 and not nfrac:
+        assert left < 0.2 * n, (left, n)   # the fast pass settles most reads on graphs of isolated bubbles
+    al.reset_counters()
+    al.set_knob(B.KNOB_EXH_FAST, 1)
+    p3, po3, st3 = al.align(reads, roffs, m=m, mode=B.MODE_EXHAUSTIVE)
+    assert not al.launch_info()["four_reads_per_wave"]
+    assert np.array_equal(st3, st2) and np.array_equal(po3, po2) and np.array_equal(p3, p2)
+    assert al.counters() == o.counters()
+
+
 @pytest.mark.parametrize("cap", ["2", "3", "5"])
 @pytest.mark.parametrize("search", ["depth-first", "by-level"])
 def test_exhaustive_deep_stack_second_pass(cap, search):
