@@ -6,6 +6,7 @@ else included (mmap + parse + H2D + kernel + D2H + format + write).  Prints one 
 """
 import argparse
 import hashlib
+import resource
 import json
 import os
 import shutil
@@ -57,15 +58,18 @@ def main():
             rd = os.path.join(d, "run%d" % rep)
             os.makedirs(rd)
             t0 = time.time()
+            ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
             p = subprocess.run([cli] + base, cwd=rd, env=env, capture_output=True, text=True, check=True)
             wall = time.time() - t0
+            ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
             line = [l for l in p.stderr.splitlines() if l.startswith("bgreat: mapping")][-1]
             secs = float(line.split()[2])
             stages = [l for l in p.stderr.splitlines() if "stage busy" in l]
             if stages:
                 print(stages[-1], file=sys.stderr)
             out["run%d" % rep] = {"wall_s": round(wall, 3), "mapping_s": secs, "mreads_per_s": round(args.reads / secs / 1e6, 3),
-                                  "input_GB_per_s": round(fsize / secs / 1e9, 3)}
+                                  "input_GB_per_s": round(fsize / secs / 1e9, 3),
+                                  "cpu_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "cpu_sys_s": round(ru1.ru_stime - ru0.ru_stime, 2)}
         res = {"reads": args.reads, "read_len": args.read_len, "threads": args.threads, "gpus": args.gpus, "input_bytes": fsize,
                "generate_s": round(gen_s, 1), **out}
         if args.check and os.path.exists(ref):
