@@ -116,7 +116,7 @@ def run_pmc_passes(args):
         d = tempfile.mkdtemp(prefix="bgr_pmc_%s_" % tag, dir="/tmp")
         try:
             cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + fwd
-            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return {"error": "rocprofv3 pass '%s' failed (rc %d): %s" % (tag, p.returncode, (p.stderr or "")[-300:])}

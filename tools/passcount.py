@@ -1,3 +1,5 @@
+"""How many reads each pass of a greedy mapping launch hands on (bgr_aligner_pass_counts), effort 2 and 1, on the default
+E. coli-scale workload: python tools/passcount.py (GPU box).  Diagnostic."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 import numpy as np, bgreat_amd as B
