@@ -810,11 +810,9 @@ int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed
     HIP_TRY(hipMemcpyAsync(a->pk_fw3.p, pk->fw3, ((total >> 5) + n + 1) * 8, hipMemcpyHostToDevice, a->stream));
     HIP_TRY(hipMemcpyAsync(a->pk_hasn.p, pk->hasn, (n + 31) / 32 * 4, hipMemcpyHostToDevice, a->stream));
     if (pk->nm_count) {  // the N-mask words of the few reads that hold an N: a sparse list, scattered into the plane on the device
-        HIP_TRY(a->in_reads.ensure(pk->nm_count * 12 + 16));
-        char* d = static_cast<char*>(a->in_reads.p);
-        const uint64_t voff = (pk->nm_count * 4 + 7) & ~7ull;
+        const uint64_t voff = (pk->nm_count * 4 + 7) & ~7ull;  // indices, then the values 8-byte aligned, in the ASCII staging buffer (unused here)
         HIP_TRY(a->in_reads.ensure(voff + pk->nm_count * 8));
-        d = static_cast<char*>(a->in_reads.p);
+        char* d = static_cast<char*>(a->in_reads.p);
         HIP_TRY(hipMemcpyAsync(d, pk->nm_index, pk->nm_count * 4, hipMemcpyHostToDevice, a->stream));
         HIP_TRY(hipMemcpyAsync(d + voff, pk->nm_value, pk->nm_count * 8, hipMemcpyHostToDevice, a->stream));
         hipError_t e = bgr::launch_scatter_words(reinterpret_cast<const uint32_t*>(d), reinterpret_cast<const uint64_t*>(d + voff), pk->nm_count,

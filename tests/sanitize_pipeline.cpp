@@ -177,7 +177,8 @@ int main(int argc, char** argv) {
                     bgr_params prm = {BGR_MODE_EXHAUSTIVE, 2, 2, 0};
                     bgr_run_options opt;
                     memset(&opt, 0, sizeof(opt));
-                    opt.n_gpus = 2; opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 30000; opt.fastq = fq; opt.echo_files = 1;
+                    opt.n_gpus = batch == 911ull ? 8 : (threads == 1 ? 1 : 2);  // 16 / 1 / 4 stream workers over the stand-in devices
+                    opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 30000; opt.fastq = fq; opt.echo_files = 1;
                     uint64_t tot[5]; double secs;
                     std::ostringstream cap;
                     std::streambuf* old = std::cout.rdbuf(cap.rdbuf());
