@@ -196,7 +196,7 @@ bool validate_blob_header(const BgrBlobHeader* h, uint64_t bytes, std::string& e
         if (off < sizeof(BgrBlobHeader) || off > bytes || (off & 255u)) return false;
         return count <= (bytes - off) / size;
     };
-    if (h->n_keys > 0x10000000ull || h->n_unitigs > 0x40000000ull || h->n_units >= (1ull << 26)) { err = "corrupt blob header (counts)"; return false; }
+    if (h->n_keys >= 0x0FFFFFFFull || h->n_unitigs > 0x40000000ull || h->n_units >= (1ull << 26)) { err = "corrupt blob header (counts)"; return false; }
     if (!inside(h->off_units, h->n_units, 16) || !inside(h->off_keys, h->n_keys, 8) || !inside(h->off_recs, h->n_keys, sizeof(BgrSlot) * 8) ||
         !inside(h->off_meta, h->n_unitigs + 1, sizeof(BgrUnitigMeta)) || !inside(h->off_seq, h->seq_words, 8)) { err = "blob section outside the blob"; return false; }
     if (h->n_fallback && !inside(h->off_fallback, h->n_fallback, 8)) { err = "blob section outside the blob"; return false; }
