@@ -1,4 +1,5 @@
-// align_kernels.h -- launch interface between the C-ABI (capi.hip) and the gfx950 kernels (align_kernels.hip).
+// align_kernels.h -- launch interface between the C-ABI (capi.hip) and the gfx950 kernels (greedy_kernels.hip,
+// exhaustive_kernels.hip, anchors_kernel.hip, batch_kernels.hip; shared device code in device_common.h).
 #ifndef BGREAT_AMD_ALIGN_KERNELS_H
 #define BGREAT_AMD_ALIGN_KERNELS_H
 

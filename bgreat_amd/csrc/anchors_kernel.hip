@@ -1,0 +1,240 @@
+// anchors_kernel.hip -- anchors mode (-G: getNAnchors + alignReadGreedyAnchors, aligner.cpp:381-405, alignerGreedy.cpp:60-164).
+#include "device_common.h"
+
+namespace bgr {
+namespace {
+
+// ======================================== anchors mode (-G) ==========================================
+// alignReadGreedyAnchors (alignerGreedy.cpp:60-164) over getNAnchors (aligner.cpp:381-405).  The k-mer anchors come
+// from BooPHF's exact structure (graph_layout.h "anchors index"): the reference takes whatever lookup() answers,
+// key or not, so the lookup below is boomphf::mphf::lookup (BooPHF.h:783-818) instruction for instruction in its
+// arithmetic: hash64 with the two seeds, xorshift128+ for the later levels, `% domain`, the 512-bit rank blocks.
+struct AncView {
+    const u64* bits;
+    const u64* ranks;
+    const u64* fin;
+    const u64* pos;
+    u64 n_final, last_rank;
+    u64 lv_domain, lv_word_base, lv_rank_base, lv_magic;  // lane l < n_active holds level l
+    uint32_t n_active;                                    // levels that hold set bits (the rest cannot answer)
+};
+
+__device__ __forceinline__ AncView anc_view(const BgrDeviceGraph& g, int lane) {
+    AncView a;
+    const BgrBlobHeader* h = g.hdr;
+    const char* base = reinterpret_cast<const char*>(h);
+    a.bits = reinterpret_cast<const u64*>(base + h->off_anc_bits);
+    a.ranks = reinterpret_cast<const u64*>(base + h->off_anc_ranks);
+    a.fin = reinterpret_cast<const u64*>(base + h->off_anc_final);
+    a.pos = reinterpret_cast<const u64*>(base + h->off_anc_pos);
+    a.n_final = h->anc_n_final;
+    a.last_rank = h->anc_last_rank;
+    a.n_active = (uint32_t)h->anc_active_levels;
+    const int l = lane < (int)a.n_active ? lane : 0;
+    a.lv_domain = h->anc_levels[l].domain;
+    a.lv_word_base = h->anc_levels[l].word_base;
+    a.lv_rank_base = h->anc_levels[l].rank_base;
+    a.lv_magic = h->anc_levels[l].magic;
+    return a;
+}
+
+// wave-uniform key -> index or ~0.  Lane l probes level l; the first level whose bit is set answers with its rank.
+__device__ __forceinline__ u64 anc_lookup(const AncView& a, u64 key, int lane) {
+    u64 s0 = bgr_boo_hash64(key, BGR_BOO_SEED0), s1 = bgr_boo_hash64(key, BGR_BOO_SEED1);
+    u64 hv = lane == 0 ? s0 : s1;
+    for (int i = 2; i < (int)a.n_active; ++i) {  // BooPHF.h:336-356: the level hashes are a sequence, walked in step
+        const u64 v = bgr_boo_next(&s0, &s1);
+        if (lane == i) hv = v;
+    }
+    bool hit = false;
+    u64 pos = 0;
+    if (lane < (int)a.n_active) {
+        pos = bgr_mod_magic(hv, a.lv_domain, a.lv_magic);
+        hit = (a.bits[a.lv_word_base + (pos >> 6)] >> (pos & 63)) & 1;
+    }
+    const u64 mask = __ballot(hit);
+    if (mask) {  // BooPHF.h:609-622 rank: sample of the 512-bit block + popcount of the words before the bit
+        const int f = __ffsll((long long)mask) - 1;
+        const u64 fpos = rl64(pos, f), wb = rl64(a.lv_word_base, f), rb = rl64(a.lv_rank_base, f);
+        const u64 widx = fpos >> 6, blk = fpos >> 9;
+        uint32_t cnt = 0;
+        if (lane < 8) {
+            const u64 wi = blk * 8 + (u64)lane;
+            if (wi < widx) cnt = (uint32_t)__popcll(a.bits[wb + wi]);
+            else if (wi == widx) cnt = (uint32_t)__popcll(a.bits[wb + wi] & ((1ULL << (fpos & 63)) - 1));
+        }
+        cnt = rl32(row16_sum(cnt), 0);
+        return a.ranks[rb + blk] + cnt;
+    }
+    u64 lo = 0, hi = a.n_final;  // what 24 levels could not place (repeated k-mers): exact, sorted {key, index}
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (a.fin[2 * mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo < a.n_final && a.fin[2 * lo] == key) return a.last_rank + a.fin[2 * lo + 1];
+    return ~0ULL;
+}
+
+// Hamming distance of read[rb, rb+n) against the packed store from base `ub` after word `fw` (one strand of one
+// unitig), whole wave: lane l takes bases [32l, 32l+32) of every 2048.
+__device__ __forceinline__ uint32_t ham_span(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t fw, uint32_t ub,
+                                             uint32_t rb, uint32_t n, int lane) {
+    uint32_t cnt = 0;
+    for (uint32_t b = (uint32_t)lane * 32; b < n; b += 2048) cnt += ham_chunk(g, CMP, NM, useN, fw, ub + b, rb + b, n - b);
+    cnt = row16_sum(cnt);
+    return rl32(cnt, 0) + rl32(cnt, 16) + rl32(cnt, 32) + rl32(cnt, 48);
+}
+
+__global__ void __launch_bounds__(1024, BGR_ANC_OCC) bgr_align_anchors_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;
+    const uint32_t K = g.k, K1 = g.k - 1;
+    const uint32_t per_wave_words = 4 * W + io.path_cap / 2;
+    u64* FW3 = lds + 64 + (u64)wave * per_wave_words;  // same per-wave layout as the greedy kernel, no MPHF staging
+    u64* FWQ = FW3 + W;
+    u64* RCW = FWQ + W;
+    u64* NM = RCW + W;
+    int32_t* PATH = reinterpret_cast<int32_t*>(NM + W);
+    const AncView av = anc_view(g, lane);
+    const u64 km1_mask = (1ULL << (2 * K1)) - 1;  // offsetUpdate - 1 (aligner.h:101-102): update() keeps k-1 digits
+
+    uint32_t c_reads = 0, c_noov = 0, c_al = 0, c_na = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+    const uint32_t effort = prm.effort ? prm.effort : 1;  // getNAnchors(read, 0) still takes a hit at position 0
+
+    for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
+        const u64 off = io.read_offs[r];
+        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
+        bool derived = false;
+        uint32_t status = BGR_ST_NOANCHOR, p_lo = 0, p_n = 0;
+        const uint32_t dk = L < K ? L : K;                       // read.substr(0, k) of a shorter read is the whole read
+        const uint32_t last_i = !prm.effort ? 0 : (L > K ? L - K : 0);  // the loop leaves after position i when i + k >= |read|
+        for (int pass = 0; pass < 2 && L > 0; ++pass) {
+            if (pass == 1 && !derived) { derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane); derived = true; }
+            const u64* S = pass ? RCW : FW3;        // the characters of this pass's read (reverseComplements: N -> 'A')
+            const bool useN = (pass == 0) && hasN;
+            // getNAnchors (aligner.cpp:381-405): the first k-mer by str2num, then the (k-1)-mer rolling updates applied to it
+            u64 num = lds_win32(S, 0) >> (64 - 2 * dk);
+            u64 rcnum = rcb_fast(num, K);
+            uint32_t tried = 0;
+            bool done = false;
+            for (uint32_t i = 0;; ++i) {
+                const u64 rep = num < rcnum ? num : rcnum;
+                const u64 idx = anc_lookup(av, rep, lane);
+                if (idx != ~0ULL) {
+                    ++tried;
+                    // ---- alignReadGreedyAnchors loop body for this anchor (alignerGreedy.cpp:68-161) ------------
+                    const u64 pv = av.pos[idx];
+                    const uint32_t un = (uint32_t)(pv >> 32);
+                    uint32_t pU = (uint32_t)pv;
+                    const uint32_t pR = i;
+                    const BgrUnitigMeta mt = g.meta[un];
+                    const uint32_t len = mt.len;
+                    if (len >= K) {  // :72-75 (an index nobody wrote holds unitig 0, the empty string)
+                        const uint32_t fw = (uint32_t)(mt.F >> 5);
+                        uint32_t fo = (uint32_t)(mt.F & 31);
+                        const u64 ukm = seq_win32(g.seq, fw, fo + pU) >> (64 - 2 * K);
+                        const uint32_t rdk = L - pR < K ? L - pR : K;
+                        const u64 rkm = lds_win32(S, pR) >> (64 - 2 * rdk);
+                        const bool returned = ukm != rkm;  // :76-83: any difference means "take the reverse complement"
+                        if (returned) { fo += len; pU = len - K - pU; }
+                        const int32_t uid = returned ? -(int32_t)un : (int32_t)un;
+                        // the oriented unitig's end (k-1)-mers as neighbour records (what str2num + getEnd/getBegin find)
+                        const uint32_t rec_b = returned ? mt.rec_end : mt.rec_beg, rec_e = returned ? mt.rec_beg : mt.rec_end;
+                        const bool can_b = (mt.flags & (returned ? BGR_META_CANON_RCEND : BGR_META_CANON_BEG)) != 0;
+                        const bool can_e = (mt.flags & (returned ? BGR_META_CANON_RCBEG : BGR_META_CANON_END)) != 0;
+                        const uint32_t m = prm.max_mismatch;
+                        if (pR >= pU) {
+                            const uint32_t start = pR - pU;  // read position of the unitig's first base
+                            if (L - pR >= len - pU) {
+                                // CASE 1: unitig inside the read (:87-110)
+                                const uint32_t errors = ham_span(g, S, NM, useN, fw, fo, start, len, lane);
+                                if (errors <= m) {
+                                    uint32_t budget = m - errors, nl = 0, nr = 0;
+                                    const uint32_t mid = start + 2;
+                                    if (walk_left(g, S, NM, useN, L, K1, rec_b, can_b, start, &budget, PATH, mid, &nl, lane)) {
+                                        if (lane == 0) PATH[mid] = uid;
+                                        if (walk_right(g, S, NM, useN, L, K1, rec_e, can_e, start + len - K1, &budget, PATH, mid + 1, &nr, lane)) {
+                                            p_lo = mid - nl; p_n = nl + 1 + nr; done = true;
+                                        }
+                                    }
+                                }
+                            } else {
+                                // CASE 2: the unitig runs past the read's end (:111-130)
+                                const uint32_t errors = ham_span(g, S, NM, useN, fw, fo, start, L - start, lane);
+                                if (errors <= m) {
+                                    uint32_t budget = m - errors, nl = 0;
+                                    const uint32_t mid = start + 2;
+                                    if (walk_left(g, S, NM, useN, L, K1, rec_b, can_b, start, &budget, PATH, mid, &nl, lane)) {
+                                        if (lane == 0) PATH[mid] = uid;
+                                        p_lo = mid - nl; p_n = nl + 1; done = true;
+                                    }
+                                }
+                            }
+                        } else {
+                            const uint32_t uoff = pU - pR;  // unitig position of the read's first base
+                            if (L - pR >= len - pU) {
+                                // CASE 3: the read starts inside the unitig and runs past its end (:133-148)
+                                const uint32_t errors = ham_span(g, S, NM, useN, fw, fo + uoff, 0, len - uoff, lane);
+                                if (errors <= m) {
+                                    uint32_t budget = m - errors, nr = 0;
+                                    if (lane == 0) { PATH[0] = (int32_t)uoff; PATH[1] = uid; }
+                                    if (walk_right(g, S, NM, useN, L, K1, rec_e, can_e, len - uoff - K1, &budget, PATH, 2, &nr, lane)) {
+                                        p_lo = 0; p_n = 2 + nr; done = true;
+                                    }
+                                }
+                            } else {
+                                // CASE 4: read inside the unitig (:149-160)
+                                const uint32_t errors = ham_span(g, S, NM, useN, fw, fo + uoff, 0, L, lane);
+                                if (errors <= m) {
+                                    if (lane == 0) { PATH[0] = (int32_t)uoff; PATH[1] = uid; }
+                                    p_lo = 0; p_n = 2; done = true;
+                                }
+                            }
+                        }
+                    }
+                    if (done || tried >= effort) break;
+                }
+                if (i >= last_i) break;
+                // update() / updateRC() (aligner.cpp:305-315) with read[i + k]
+                const uint32_t d = (uint32_t)(lds_win32(S, i + K) >> 62);
+                const bool isn = useN && (lds_win32(NM, i + K) >> 62) != 0;
+                const u64 fwd_code = isn ? 0 : d, rc_code = isn ? 0 : 3 - d;  // nuc2int / nuc2intrc (utils.cpp:132-151)
+                num = ((num << 2) + fwd_code) & km1_mask;
+                rcnum = (rcnum >> 2) + (rc_code << (2 * K - 4));
+            }
+            if (done) { status = BGR_ST_ALIGNED | (pass ? BGR_ST_RC : 0); break; }
+            if (tried == 0) { status = BGR_ST_NOANCHOR | (pass ? BGR_ST_RC : 0); break; }  // ++noOverlapRead, no retry
+            status = BGR_ST_FAILED | BGR_ST_RC;  // every anchor failed: once more on the reverse complement (:162)
+        }
+        wave_sync();
+        uint32_t abase = 0;
+        if ((status & BGR_ST_MASK) == BGR_ST_ALIGNED) abase = publish_path(io, PATH, p_lo, p_n, &chunk_pos, &chunk_end, lane);
+        else p_n = 0;
+        if (lane == 0) io.results[r] = make_uint2(abase, p_n | (status << 24));
+        ++c_reads;
+        c_noov += (status & BGR_ST_MASK) == BGR_ST_NOANCHOR;
+        c_al += (status & BGR_ST_MASK) == BGR_ST_ALIGNED;
+        c_na += (status & BGR_ST_MASK) == BGR_ST_FAILED;
+        wave_sync();
+    }
+    if (lane == 0 && c_reads) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)c_reads);
+        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_anchors(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
+    return launch_one(bgr_align_anchors_kernel, g, io, p, cfg, stream);
+}
+const void* anchors_kernel_fn() { return reinterpret_cast<const void*>(&bgr_align_anchors_kernel); }
+
+}  // namespace bgr

@@ -1,6 +1,6 @@
 // capi.hip -- implementation of the C-ABI declared in include/bgreat_gpu.h.  Thin: argument checks, HIP memory
 // and stream management, launch geometry; the algorithm lives in graph_build.cpp (index) and
-// align_kernels.hip (mapping).  There is no CPU mapping path in this library.
+// the *_kernels.hip files (mapping; launch interface align_kernels.h).  There is no CPU mapping path in this library.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 

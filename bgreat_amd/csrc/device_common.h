@@ -1,0 +1,581 @@
+// device_common.h -- device helpers shared by the mapping kernels of the BGREAT path (gfx950; included by the .hip files of
+// this directory only): wave primitives, 2-bit window reads, the MPHF cascade lookup, the read planes, candidate scoring
+// (missmatchNumber over 2-bit words), the greedy step / walks, workgroup prologue (cascade staging), path arena.
+// Integer/byte work only: no MFMA anywhere (there is no dense contraction on this path).
+#ifndef BGREAT_AMD_DEVICE_COMMON_H
+#define BGREAT_AMD_DEVICE_COMMON_H
+
+#include <algorithm>
+
+#include "../../include/bgreat_gpu.h"
+#include "align_kernels.h"
+
+namespace bgr {
+namespace {
+
+typedef uint64_t u64;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+#define EVEN_BITS 0x5555555555555555ULL
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t rl32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ u64 rl64(u64 v, int lane) {
+    return ((u64)rl32((uint32_t)(v >> 32), lane) << 32) | rl32((uint32_t)v, lane);
+}
+// 32 bases starting at base p of a first-base-most-significant packed array (needs A[p/32 + 1] readable)
+// Branch-free funnel shift: both words are always loaded (side by side: one 16-byte access), and the low word's
+// contribution vanishes by itself when the window is word aligned.
+template <typename P>
+__device__ __forceinline__ u64 win32(P A, u64 p) {
+    const u64 w = p >> 5;
+    const uint32_t s = (uint32_t)(p & 31) * 2;
+    const u64 hi = A[w], lo = A[w + 1];
+    return (hi << s) | ((lo >> 1) >> (63 - s));
+}
+// the same for the per-wave LDS streams, whose base positions fit 32 bits
+__device__ __forceinline__ u64 lds_win32(const u64* A, uint32_t p) {
+    const uint32_t s = (p & 31) * 2;
+    const u64 hi = A[p >> 5], lo = A[(p >> 5) + 1];
+    return (hi << s) | ((lo >> 1) >> (63 - s));
+}
+// 32 BITS starting at bit q of a 1-bit-per-base plane, most significant first
+__device__ __forceinline__ uint32_t plane32(const u64* P, u64 q) {
+    u64 w = q >> 6;
+    uint32_t s = (uint32_t)(q & 63);
+    u64 hi = P[w], lo = P[w + 1];
+    u64 x = s ? (hi << s) | (lo >> (64 - s)) : hi;
+    return (uint32_t)(x >> 32);
+}
+// keep the even-position bits of x (bit 62-2j -> bit 31-j)
+__device__ __forceinline__ uint32_t compress_even(u64 x) {
+    x &= EVEN_BITS;
+    x = (x | (x >> 1)) & 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
+    return (uint32_t)x;
+}
+// Sum over each aligned group of 16 lanes (a DPP "row"), result in every lane of the group: four v_add_u32_dpp,
+// no LDS round trip (ds_bpermute shuffles cost ~7 instructions + an LDS wait each).
+__device__ __forceinline__ uint32_t row16_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]  (lane ^ 1)
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]  (lane ^ 2)
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of the half row
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, true);  // row_mirror: the other half of the row
+    return x;
+}
+
+// reverse the order of the 32 two-bit digits of x: full bit reversal (v_bfrev_b32 x2), then swap the bits of each pair
+__device__ __forceinline__ u64 rev2_fast(u64 x) {
+    u64 y = __builtin_bitreverse64(x);
+    return ((y >> 1) & EVEN_BITS) | ((y & EVEN_BITS) << 1);
+}
+__device__ __forceinline__ u64 rcb_fast(u64 x, uint32_t n) { return (~rev2_fast(x)) >> (64 - 2 * n); }
+
+// MPHF cascade walk for one key per lane (graph_layout.h: 2-bit position states).  Returns the minimal index
+// or BGR_NONE; the caller compares keys[idx].  Straight-line body, wave-uniform trip count: the loop runs
+// until no lane is still on a "several keys here" position -- about 2-3 levels at gamma 2, because a lane
+// that lands on an empty position (most read positions are not overlaps) is rejected at once.
+// LV = level descriptors {units, base} staged in LDS.
+// SPEC (cascade in L2/HBM, not staged in LDS): the state word of level l+1 is requested together with level l's -- its
+// address needs only the hash (double hashing), not level l's answer -- so two dependent-looking loads are in flight
+// at once; lanes that stop on level l simply drop it.
+template <bool SPEC, typename UP>
+__device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
+    u64 m = bgr_mix64(key);
+    uint32_t hl = (uint32_t)m;
+    const uint32_t hb = (uint32_t)(m >> 32) | 1u;
+    const uint32_t nl = g.n_levels;
+    uint32_t res = BGR_NONE;
+    if (SPEC) {
+        // cascade in L2/HBM: one 16-byte unit per level answers membership candidate AND minimal index, the next level's unit
+        // requested ahead (a second dependent access for the rank would cost a full L2 round trip: measured 7.98 -> 9.63 ms)
+        uint4 qn = make_uint4(0, 0, 0, 0);
+        if (active && nl) { const uint2 lv = LV[0]; qn = reinterpret_cast<const uint4*>(units)[lv.y + __umulhi(hl, lv.x)]; }
+        for (uint32_t l = 0; l < nl; ++l) {
+            if (!__any(active)) break;
+            const uint4 q = qn;
+            if (active && l + 1 < nl) { const uint2 lv1 = LV[l + 1]; qn = reinterpret_cast<const uint4*>(units)[lv1.y + __umulhi(hl + hb, lv1.x)]; }
+            const uint32_t p = bgr_level_pos(hl);
+            const uint32_t wi = p >> 4, sh = (p & 15) * 2;
+            const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
+            const uint32_t st = (w >> sh) & 3u;
+            uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
+            r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
+            r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
+            if (active && st == 1u) res = r;
+            active = active && st == 3u;
+            hl += hb;
+        }
+    } else {
+        // cascade in LDS: per level only the state word that holds the position is read (a dword: a quarter of the unit); the
+        // position where the walk ends on state 1 is remembered (unit << 6 | position) and its rank worked out once, behind
+        // the loop (4.49 -> 4.09 ms per 5 M reads: the loop body halves)
+        uint32_t hit = BGR_NONE;
+        for (uint32_t l = 0; l < nl; ++l) {
+            if (!__any(active)) break;
+            const uint2 lv = LV[l];
+            const uint32_t u = lv.y + __umulhi(hl, lv.x);
+            const uint32_t p = bgr_level_pos(hl);
+            const uint32_t w = units[(size_t)u * 4 + (p >> 4)];
+            const uint32_t st = (w >> ((p & 15) * 2)) & 3u;
+            if (active && st == 1u) hit = u << 6 | p;
+            active = active && st == 3u;
+            hl += hb;
+        }
+        if (hit != BGR_NONE) {  // minimal index = rank of the position among the placed ones: the unit's running rank + the placed states before it
+            const uint4 q = reinterpret_cast<const uint4*>(units)[hit >> 6];
+            const uint32_t p = hit & 63u, wi = p >> 4, sh = (p & 15) * 2;
+            const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
+            uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
+            r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
+            r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
+            res = r;
+        }
+    }
+    if ((g.flags & BGR_GF_HAS_FALLBACK) && __any(active)) {
+        if (active) {  // bisection in the (tiny) sorted fallback list; its location comes from the blob header
+            const uint32_t nfb = (uint32_t)g.hdr->n_fallback;
+            const u64* fb = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_fallback);
+            uint32_t lo = 0, hi = nfb;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (fb[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nfb && fb[lo] == key) res = (uint32_t)g.hdr->n_placed + lo;
+        }
+    }
+    return res;
+}
+// membership: MPHF index of key if key is an overlap of the graph, else BGR_NONE (aligner.cpp:158,219,353,361)
+template <bool SPEC, typename UP>
+__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
+    uint32_t idx = mphf_lookup<SPEC>(g, LV, units, key, active);
+    if (idx != BGR_NONE && g.keys[idx] != key) idx = BGR_NONE;
+    return idx;
+}
+
+// ---- stage A: the read's 2-bit words, from the planes the pre-pass (bgr_pack_reads_kernel) or the host packer wrote ----
+// FW3: str2num codes (N->3).  NM: 3 on every N.  RCW: reverseComplements(read) (utils.cpp:66-73, non-ACG -> 'A').
+// FWQ: what the rolling `num` of getNOverlap/getListOverlap holds: str2num codes inside the first window,
+//      nuc2int codes (N->0) for bases entered by update() (aligner.cpp:305-309, utils.cpp:132-140).
+// Read r of a batch owns words [woff, woff + ceil(L/32)) of both planes, woff = (read_offs[r] >> 5) + r: computable from the
+// ASCII offsets alone (no scan), never overlapping, at most one spare word per read.  The N plane of a read is valid
+// only if its bit in `hasn` is set.
+__device__ __forceinline__ uint32_t packed_word_offset(u64 off, uint32_t r) { return (uint32_t)(off >> 5) + r; }
+
+__device__ __forceinline__ bool load_packed(const BatchIO& io, uint32_t r, u64 off, uint32_t L, uint32_t W, u64* FW3, u64* NM, int lane) {
+    const uint32_t woff = packed_word_offset(off, r), Wr = (L + 31) >> 5;
+    const bool hasN = (io.hasn[r >> 5] >> (r & 31)) & 1u;
+    for (uint32_t j = lane; j < W; j += 64) {
+        u64 f = 0, m = 0;
+        if (j < Wr) { f = io.fw3[woff + j]; if (hasN) m = io.nmw[woff + j]; }
+        FW3[j] = f;
+        NM[j] = m;
+    }
+    wave_sync();
+    return hasN;
+}
+
+// 4 ASCII bases starting at byte 4*bi of the read as one dword (first base in the low byte), 0 past the end
+__device__ __forceinline__ uint32_t load4(const uint8_t* rd, uint32_t L, uint32_t bi) {
+    const uint32_t b0 = bi * 4;
+    uint32_t x = 0;
+    if (b0 < L) {
+        const uint32_t nb = L - b0;
+        if (nb >= 4) {
+            x = *reinterpret_cast<const u32_unaligned*>(rd + b0);  // possibly unaligned dword
+        } else {  // the last 1..3 bases: never touch bytes past the read (they may be past the buffer)
+            x = rd[b0];
+            if (nb > 1) x |= (uint32_t)rd[b0 + 1] << 8;
+            if (nb > 2) x |= (uint32_t)rd[b0 + 2] << 16;
+        }
+    }
+    return x;
+}
+
+// 4 ASCII bases (one dword, first base in the low byte; a zero byte = past the end) -> one byte of 2-bit codes, first base
+// in the top two bits, and the same for the N mask (3 on 'N').  A0 C1 G2 T3 = ((c>>1)^(c>>2))&3; exact for the
+// alphabet ACGTN the parser admits (aligner.cpp:56-61).
+__device__ __forceinline__ void pack4(uint32_t x, uint32_t* code, uint32_t* nmask) {
+    uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    const uint32_t t = x ^ 0x4E4E4E4Eu;                                 // zero byte <=> 'N'
+    const uint32_t isn = ((t - 0x01010101u) & ~t & 0x80808080u) >> 7;  // 0x01 per 'N' byte
+    const uint32_t n3 = isn * 3u;
+    c |= n3;
+    *code = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
+    *nmask = ((n3 << 6) | (n3 >> 4) | (n3 >> 14) | (n3 >> 24)) & 0xFFu;
+}
+
+// 32 bases [32j, 32j+32) of a read -> its FW3 word (first base most significant) and N-mask word
+__device__ __forceinline__ void pack32(const uint8_t* rd, uint32_t L, uint32_t j, u64 abs_end_ok, u64* fw, u64* nm) {
+    uint32_t xs[8];
+    if (abs_end_ok) {  // all 32 bytes lie inside the batch buffer: two (unaligned) 16-byte loads, bytes past the read masked off
+        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
+        const u32x4_unaligned v0 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j);
+        const u32x4_unaligned v1 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j + 16);
+        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+        const uint32_t valid = L - 32 * j;  // >= 1
+        if (valid < 32) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t lo = 4u * d;
+                if (valid <= lo) xs[d] = 0;
+                else if (valid < lo + 4) xs[d] &= 0xFFFFFFFFu >> (8 * (lo + 4 - valid));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) xs[d] = load4(rd, L, 8 * j + d);
+    }
+    u64 w = 0, n = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        uint32_t c, m;
+        pack4(xs[d], &c, &m);
+        w = (w << 8) | c;
+        n = (n << 8) | m;
+    }
+    *fw = w;
+    *nm = n;
+}
+
+// RCW (reverse-complement stream) and FWQ (rolling-update quirk stream) from FW3/NM.  Only needed when the read
+// contains N (the rolling k-mers then differ from plain windows) or for the reverse-complement retry; a read
+// without N maps from FW3 alone (FWQ == FW3, and the reverse k-mer of a window is rcb of its forward k-mer).
+__device__ __forceinline__ void derive_streams(uint32_t L, uint32_t W, uint32_t K1, const u64* FW3, u64* FWQ, u64* RCW, const u64* NM, int lane) {
+    for (uint32_t w = lane; w < W; w += 64) {
+        long long p = (long long)L - 32 * ((long long)w + 1);
+        u64 rcw = 0;
+        if (p >= 0) {
+            rcw = ~rev2_fast(lds_win32(FW3, (uint32_t)p));
+        } else if (p > -32) {
+            uint32_t v = (uint32_t)(32 + p);  // valid bases
+            u64 x = FW3[0] >> (64 - 2 * v);
+            rcw = (~rev2_fast(x)) & (~0ULL << (64 - 2 * v));
+        }
+        RCW[w] = rcw;
+        u64 ge;
+        if (32 * w >= K1) ge = ~0ULL;
+        else if (32 * (w + 1) <= K1) ge = 0;
+        else ge = ~0ULL >> (2 * (K1 - 32 * w));
+        FWQ[w] = FW3[w] & ~(NM[w] & ge);
+    }
+    wave_sync();
+}
+
+// ---- candidate scoring shared by the greedy and the exhaustive extension -------------------------------
+// The <=4 slots of the neighbour record (getEnd / getBegin, aligner.cpp:147-267) are scored 16 lanes each.
+// DIR 0: left step (alignerGreedy.cpp:167-218,268-319; alignerExhaustive.cpp:109-203)
+// DIR 1: right step whose read slice starts AFTER the k-1 overlap (checkEndGreedy :322-364; every exhaustive
+//        right step, alignerExhaustive.cpp:61-106,206-259)
+// DIR 2: later greedy right steps, whose slice INCLUDES the overlap (mapOnRightEndGreedy :221-265)
+struct Scored {        // per lane; lanes 16c..16c+15 describe candidate c
+    uint32_t cnt;      // Hamming distance over the compared window (full count, not clipped)
+    int32_t sid;       // +id forward, -id reversed (what the reference pushes on the path)
+    uint32_t ext;      // len - (k-1)
+    uint32_t nrec;     // neighbour record at the far end of this unitig in walking direction
+    uint32_t info;     // bit 0: the walk ends inside this unitig ("fits"), bit 1: the far-end k-mer is canonical
+    int first_zero;    // number of candidates (the reference's nested ifs stop at the first empty slot)
+};
+
+// 32 bases of the packed unitig store starting `ub` bases after the start of seq word `fw` (32-bit arithmetic)
+__device__ __forceinline__ u64 seq_win32(const u64* seq, uint32_t fw, uint32_t ub) {
+    const uint32_t boff = (fw + (ub >> 5)) << 3;  // byte offset < 4 GiB (checked when the graph is built)
+    const u64* q = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(seq) + boff);
+    const uint32_t s = (ub & 31) * 2;
+    const u64 hi = q[0], lo = q[1];
+    return (hi << s) | ((lo >> 1) >> (63 - s));
+}
+
+// mismatches of one 32-base chunk (v = valid bases in it, 1..32)
+__device__ __forceinline__ uint32_t ham_chunk(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t fw, uint32_t ub,
+                                              uint32_t rb, uint32_t v) {
+    const u64 x = seq_win32(g.seq, fw, ub) ^ lds_win32(CMP, rb);
+    u64 mm = (x | (x >> 1)) & EVEN_BITS;
+    u64 nm = 0;
+    if (useN) { nm = lds_win32(NM, rb) & EVEN_BITS; mm |= nm; }
+    if (g.flags & BGR_GF_HAS_EXC) {  // forward-strand unitig bases outside ACGT: never equal, except N == N
+        const u64 abs_base = (u64)fw * 32 + ub;
+        const u64* exc = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_exc);
+        const uint32_t e = plane32(exc, abs_base);
+        if (e) {
+            const u64* excn = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_excn);
+            const uint32_t en = plane32(excn, abs_base);
+            uint32_t m1 = compress_even(mm) | e;
+            m1 &= ~(en & compress_even(nm));
+            if (v < 32) m1 &= ~(0xFFFFFFFFu >> v);
+            return __popc(m1);
+        }
+    }
+    if (v < 32) mm &= ~(~0ULL >> (2 * v));
+    return __popcll(mm);
+}
+
+template <int DIR>
+__device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
+                                                   uint32_t K1, uint32_t rec, bool canon, uint32_t pos, int lane) {
+    Scored sc;
+    const int c = lane >> 4, sub = lane & 15;
+    // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
+    const bool useR = (DIR == 0) ? canon : !canon;
+    const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
+    // one 32-byte slot per candidate (graph_layout.h BgrSlot): id + orientation bits, length, sequence address |
+    // the unitig's flags and end records (what the NEXT step needs)
+    const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + (useR ? 4u : 0u) + (uint32_t)c) * 2;
+    const uint4 sl = sp[0];
+    const uint4 m0 = sp[1];  // x = BGR_META_* flags, y = rec_beg, z = rec_end
+    const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+    const u64 zmask = __ballot(id == 0);
+    sc.first_zero = zmask ? (__ffsll((long long)zmask) - 1) >> 4 : 4;
+    const bool valid = c < sc.first_zero;
+    const bool fwd = (sl.x & fbit) != 0;
+    const uint32_t len = valid ? sl.y : 0;
+    // oriented strand start: forward at (Fw, Fo), reverse complement `len` bases further
+    const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+    sc.sid = fwd ? (int32_t)id : -(int32_t)id;
+    sc.ext = len - K1;
+    bool fits;
+    uint32_t n, ustart, rstart;
+    if (DIR == 0) {
+        fits = sc.ext >= pos;
+        n = fits ? pos : sc.ext;
+        ustart = fits ? sc.ext - pos : 0;
+        rstart = fits ? 0 : pos - sc.ext;
+        sc.nrec = fwd ? m0.y : m0.z;
+        sc.info = (fits ? 1u : 0u) | ((m0.x & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) ? 2u : 0u);
+    } else {
+        if (DIR == 1) {
+            const uint32_t rl = L - pos - K1;
+            fits = sc.ext >= rl;
+            n = fits ? rl : sc.ext;
+            ustart = K1;
+            rstart = pos + K1;
+        } else {
+            const uint32_t rl = L - pos;
+            fits = sc.ext >= rl;
+            n = fits ? rl : (len < rl ? len : rl);  // read.substr(pos, |u|) is clipped at |read|
+            ustart = 0;
+            rstart = pos;
+        }
+        sc.nrec = fwd ? m0.z : m0.y;
+        sc.info = (fits ? 1u : 0u) | ((m0.x & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) ? 2u : 0u);
+    }
+    if (!valid) n = 0;
+    // (requesting the next step's slot line here, ahead of the choice, was measured: 1-4 % slower on all workloads)
+    // lane `sub` of the candidate's 16 compares bases [32*sub, 32*sub+32); windows longer than 512 bases loop on
+    uint32_t cnt = 0;
+    const uint32_t b0 = (uint32_t)sub * 32;
+    if (b0 < n) cnt = ham_chunk(g, CMP, NM, useN, fw, fo + ustart + b0, rstart + b0, n - b0);
+    if (__any(n > 512)) {
+        for (uint32_t b = b0 + 512; b < n; b += 512) cnt += ham_chunk(g, CMP, NM, useN, fw, fo + ustart + b, rstart + b, n - b);
+    }
+    sc.cnt = row16_sum(cnt);
+    return sc;
+}
+
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t row_ror4(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x124, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t row_ror8(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+
+// record index | canonical << 28 (| fits << 29 | found << 30 in a step result) as the four-reads-per-wave kernels pass it around
+#define G4_REC_MASK 0x0FFFFFFFu
+#define G4_CANON (1u << 28)
+#define G4_FITS (1u << 29)
+#define G4_FOUND (1u << 30)
+// ============================================== greedy ================================================
+struct Step {  // wave-uniform result of one extension step
+    bool found, fits;
+    int32_t sid;
+    uint32_t miss, ext, next_rec;
+    bool next_canon;
+};
+
+template <int DIR>
+__device__ __forceinline__ Step greedy_step(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
+                                            uint32_t K1, uint32_t rec, bool canon, uint32_t pos, uint32_t budget, int lane) {
+    Step out;
+    out.found = false; out.fits = false; out.sid = 0; out.miss = 0; out.ext = 0; out.next_rec = BGR_NONE; out.next_canon = false;
+    if (rec == BGR_NONE) return out;  // key not in the table: getBegin/getEnd return an empty list
+    const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, rec, canon, pos, lane);
+    // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min"):
+    // the minimum of (miss << 2 | slot) over the candidates
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const uint32_t kc = (rl32(sc.cnt, cc * 16) << 2) | (uint32_t)cc;
+        if (cc < sc.first_zero && kc < key) key = kc;
+    }
+    if ((key >> 2) > budget) return out;  // includes "no candidate"
+    const int bl = (int)(key & 3u) * 16;
+    const uint32_t info = rl32(sc.info, bl);
+    out.found = true;
+    out.fits = (info & 1u) != 0;
+    out.next_canon = (info & 2u) != 0;
+    out.sid = (int32_t)rl32((uint32_t)sc.sid, bl);
+    out.miss = key >> 2;
+    out.ext = rl32(sc.ext, bl);
+    out.next_rec = rl32(sc.nrec, bl);
+    return out;
+}
+
+// Left walk (checkBeginGreedy / mapOnLeftEndGreedy, alignerGreedy.cpp:268-319,167-218) from the (k-1)-mer `rec` at
+// read position `pos`: ints are stored downwards from PATH[mid-1] (near -> far, offset last), *nl counts them.
+// Returns false when a step has no candidate within the budget; the budget is reduced by what the walk spent.
+__device__ __forceinline__ bool walk_left(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
+                                          uint32_t rec, bool canon, uint32_t pos, uint32_t* budget, int32_t* PATH, uint32_t mid,
+                                          uint32_t* nl_out, int lane) {
+    uint32_t nl = 0;
+    for (;;) {
+        if (pos == 0) { if (lane == 0) PATH[mid - 1 - nl] = 0; ++nl; break; }
+        Step s = greedy_step<0>(g, CMP, NM, useN, L, K1, rec, canon, pos, *budget, lane);
+        if (!s.found) return false;
+        if (lane == 0) PATH[mid - 1 - nl] = s.sid;
+        ++nl;
+        *budget -= s.miss;
+        if (s.fits) { if (lane == 0) PATH[mid - 1 - nl] = (int32_t)(s.ext - pos); ++nl; break; }
+        pos -= s.ext; rec = s.next_rec; canon = s.next_canon;
+    }
+    *nl_out = nl;
+    return true;
+}
+// Right walk (checkEndGreedy, then mapOnRightEndGreedy: alignerGreedy.cpp:322-364,221-265): ints stored upwards from
+// PATH[at], *nr counts them.
+__device__ __forceinline__ bool walk_right(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
+                                           uint32_t rec, bool canon, uint32_t pos, uint32_t* budget, int32_t* PATH, uint32_t at,
+                                           uint32_t* nr_out, int lane) {
+    uint32_t nr = 0;
+    bool first = true;
+    for (;;) {
+        if (first) { if (L - pos - K1 == 0) break; } else { if (L - pos < K1 + 1) break; }
+        Step s = first ? greedy_step<1>(g, CMP, NM, useN, L, K1, rec, canon, pos, *budget, lane)
+                       : greedy_step<2>(g, CMP, NM, useN, L, K1, rec, canon, pos, *budget, lane);
+        if (!s.found) return false;
+        if (lane == 0) PATH[at + nr] = s.sid;
+        ++nr;
+        *budget -= s.miss;
+        if (s.fits) break;
+        pos += s.ext; rec = s.next_rec; canon = s.next_canon;
+        first = false;
+    }
+    *nr_out = nr;
+    return true;
+}
+
+// Greedy extension from one anchor (alignReadGreedy's loop body, alignerGreedy.cpp:41-52).  On success the
+// path sits in PATH[*p_lo .. *p_lo + *p_n).
+__device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
+                                                   uint32_t K1, uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t m,
+                                                   int32_t* PATH, uint32_t* p_lo, uint32_t* p_n, int lane) {
+    // (the two loops are walk_left / walk_right written out: sharing them through out-parameters cost this kernel two
+    // spilled registers)
+    const uint32_t mid = a_pos + 2;  // left pushes grow downwards from mid-1 (at most a_pos+1 of them), right upwards from mid
+    uint32_t nl = 0, nr = 0, budget = m;
+    uint32_t pos = a_pos, rec = a_rec;
+    bool canon = a_canon;
+    for (;;) {  // left walk
+        if (pos == 0) { if (lane == 0) PATH[mid - 1 - nl] = 0; ++nl; break; }
+        Step s = greedy_step<0>(g, CMP, NM, useN, L, K1, rec, canon, pos, budget, lane);
+        if (!s.found) return false;
+        if (lane == 0) PATH[mid - 1 - nl] = s.sid;
+        ++nl;
+        budget -= s.miss;
+        if (s.fits) { if (lane == 0) PATH[mid - 1 - nl] = (int32_t)(s.ext - pos); ++nl; break; }
+        pos -= s.ext; rec = s.next_rec; canon = s.next_canon;
+    }
+    pos = a_pos; rec = a_rec; canon = a_canon;
+    bool first = true;
+    for (;;) {  // right walk
+        if (first) { if (L - pos - K1 == 0) break; } else { if (L - pos < K1 + 1) break; }
+        Step s = first ? greedy_step<1>(g, CMP, NM, useN, L, K1, rec, canon, pos, budget, lane)
+                       : greedy_step<2>(g, CMP, NM, useN, L, K1, rec, canon, pos, budget, lane);
+        if (!s.found) return false;
+        if (lane == 0) PATH[mid + nr] = s.sid;
+        ++nr;
+        budget -= s.miss;
+        if (s.fits) break;
+        pos += s.ext; rec = s.next_rec; canon = s.next_canon;
+        first = false;
+    }
+    *p_lo = mid - nl;
+    *p_n = nl + nr;
+    return true;
+}
+
+// waves per SIMD the kernels are compiled for (__launch_bounds__)
+#ifndef BGR_GREEDY_OCC
+#define BGR_GREEDY_OCC 6
+#endif
+#ifndef BGR_ANC_OCC
+#define BGR_ANC_OCC 4 /* 128 VGPRs, no spills: 220 vs 200 Mreads/s at 6 */
+#endif
+#ifndef BGR_DP_OCC
+#define BGR_DP_OCC 5 /* 96 VGPRs: at 6 (80 VGPRs) the level search spills 38 VGPRs into scratch inside its loops (3.4 KB written per
+                        read, round 1); at 5 three registers are parked once per kernel.  14.4 vs 14.7 ms per 2 M reads; at 4: 16.5 */
+#endif
+#ifndef BGR_EXH_OCC
+#define BGR_EXH_OCC 6 /* waves per SIMD the exhaustive kernel is compiled for */
+#endif
+
+// ================================================ kernels ===============================================
+template <bool STAGE>
+__device__ __forceinline__ const uint32_t* block_prologue(const BgrDeviceGraph& g, u64* lds, uint2** LVout, uint32_t* mphf_words) {
+    // LDS: [level descriptors 512 B][optional MPHF copy][per-wave regions]
+    uint2* LV = reinterpret_cast<uint2*>(lds);
+    if (threadIdx.x < BGR_MAX_LEVELS) LV[threadIdx.x] = make_uint2(g.hdr->levels[threadIdx.x].units, g.hdr->levels[threadIdx.x].base);
+    *mphf_words = STAGE ? (g.units_bytes + 7) / 8 : 0;
+    const uint32_t* units = g.units;
+    if (STAGE) {
+        const uint4* src = reinterpret_cast<const uint4*>(g.units);
+        uint4* dst = reinterpret_cast<uint4*>(lds + 64);
+        for (uint32_t i = threadIdx.x; i < g.units_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        units = reinterpret_cast<const uint32_t*>(lds + 64);
+    }
+    __syncthreads();
+    *LVout = LV;
+    return units;
+}
+
+// Arena space comes in per-wave chunks: ONE global atomic per ~50 reads instead of one per read (a
+// single-address atomic saturates near 90 M/s chip-wide, MI355X_MICROARCH.md "dequeue").
+__device__ __forceinline__ uint32_t publish_path(const BatchIO& io, const int32_t* PATH, uint32_t p_lo, uint32_t p_n,
+                                                 uint32_t* chunk_pos, uint32_t* chunk_end, int lane) {
+    if (p_n > *chunk_end - *chunk_pos) {
+        const uint32_t want = p_n > io.arena_chunk ? p_n : io.arena_chunk;
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(io.cursor, want);
+        *chunk_pos = rl32(got, 0);
+        *chunk_end = *chunk_pos + want;
+    }
+    const uint32_t abase = *chunk_pos;
+    *chunk_pos += p_n;
+    if (abase + p_n <= io.arena_cap) {
+        for (uint32_t j = lane; j < p_n; j += 64) io.arena[abase + j] = PATH[p_lo + j];
+    } else if (lane == 0) {
+        io.cursor[1] = 1;  // overflow: reported by the host as an error
+    }
+    return abase;
+}
+
+template <typename K>
+hipError_t launch_one(K kernel, const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
+    if (cfg.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(cfg.blocks), dim3(cfg.waves_per_block * 64), cfg.lds_bytes, stream, g, io, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+}  // namespace bgr
+
+#endif

@@ -1,0 +1,857 @@
+// exhaustive_kernels.hip -- exhaustive mode (-b: alignReadExhaustive, alignerExhaustive.cpp:35-259) on gfx950.
+//   bgr_align_exhaustive4_kernel    four reads per wavefront, one node per level of the walk (x4_search)
+//   bgr_align_exhaustive_dp_kernel  the level search (exh_dp): all nodes of a level at once, backward cost pass
+//   bgr_align_exhaustive_kernel     depth-first search in slot order (exh_search); DEEP: search state in HBM
+#include "device_common.h"
+
+namespace bgr {
+namespace {
+
+// ============================================ exhaustive ==============================================
+// alignerExhaustive.cpp:61-259.  The reference recursion explores a candidate only if its own mismatches are
+// below the best total found so far in that call, adds the best total of the rest of the walk, and keeps the
+// first candidate (slot order) on ties.  That is exactly: among all complete walks of cost <= budget, the
+// one of minimal total cost, ties broken by slot order at the shallowest differing step -- i.e. what a
+// depth-first search in slot order with ONE running best and strict `<` acceptance returns.  Pruning with the
+// running best only skips walks that could not be accepted anyway.
+//
+// Frame (20 u32, in LDS): [0] rec  [1] pos  [2] cost so far  [3] cursor | ncand<<8 | scored<<16 | canon<<17
+//                         [4+4c..] candidate c: sid, next_rec, aux (non-fitting: ext; fitting: the path int
+//                                               emitted when the walk ends there), miss | fits<<16 | next_canon<<17
+#define FR_WORDS 20
+#define EXH_OVERFLOW 0xFFFFFFFFu
+
+template <int DIR>
+__device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
+                                               uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t budget, bool partial,
+                                               uint32_t* FR, uint32_t max_frames, int32_t* CUR, int32_t* BEST, uint32_t* best_n, int lane) {
+    // returns the best total (budget+1 if none; EXH_OVERFLOW if the search needs more than max_frames frames);
+    // the best walk's ints are BEST[0..*best_n) in output order
+    uint32_t best = budget + 1;
+    *best_n = 0;
+    int depth = 0;
+    if (lane == 0) { FR[0] = a_rec; FR[1] = a_pos; FR[2] = 0; FR[3] = a_canon ? (1u << 17) : 0u; }
+    wave_sync();
+    while (depth >= 0) {
+        uint32_t* F = FR + (uint32_t)depth * FR_WORDS;
+        const uint32_t rec = F[0], pos = F[1], cost = F[2];
+        uint32_t ctl = F[3];
+        if (!((ctl >> 16) & 1u)) {
+            // ---- first visit: base cases, then score the candidates once --------------------------
+            const bool end_here = (DIR == 0) ? (pos == 0) : (L - pos - K1 == 0);
+            if (end_here) {
+                // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); right: every depth pushes 0 (:64,:210)
+                if (cost < best) {
+                    best = cost;
+                    if (DIR == 0) {
+                        for (int j = lane; j < depth; j += 64) BEST[j] = CUR[depth - 1 - j];  // far -> near
+                        *best_n = (uint32_t)depth;
+                        if (depth == 0) { if (lane == 0) BEST[0] = 0; *best_n = 1; }
+                    } else {
+                        for (int j = lane; j < depth; j += 64) BEST[j] = CUR[j];              // near -> far
+                        if (lane == 0) BEST[depth] = 0;
+                        *best_n = (uint32_t)depth + 1;
+                    }
+                }
+                wave_sync();
+                --depth;
+                continue;
+            }
+            uint32_t ncand = 0;
+            if (rec != BGR_NONE) {
+                const bool canon = (ctl >> 17) & 1u;
+                const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, rec, canon, pos, lane);
+                ncand = (uint32_t)sc.first_zero;
+                if ((lane & 15) == 0 && (lane >> 4) < sc.first_zero) {
+                    const int c = lane >> 4;
+                    const uint32_t miss = sc.cnt > 0xFFFFu ? 0xFFFFu : sc.cnt;
+                    const bool fits = (sc.info & 1u) != 0;
+                    // fitting: left emits the offset in the last unitig (ext-pos, :126,:175), right |readLeft|+k-1 (:99,:231)
+                    const uint32_t aux = fits ? ((DIR == 0) ? sc.ext - pos : L - pos) : sc.ext;
+                    F[4 + 4 * c] = (uint32_t)sc.sid;
+                    F[5 + 4 * c] = sc.nrec;
+                    F[6 + 4 * c] = aux;
+                    F[7 + 4 * c] = miss | (fits ? 1u << 16 : 0u) | ((sc.info & 2u) ? 1u << 17 : 0u);
+                }
+            }
+            if (DIR == 1 && depth == 0 && partial && ncand == 0) {  // alignerExhaustive.cpp:217-221 (-i)
+                *best_n = 0;
+                wave_sync();
+                return 0;
+            }
+            ctl = (ctl & (1u << 17)) | (1u << 16) | (ncand << 8);
+            if (lane == 0) F[3] = ctl;
+            wave_sync();
+        }
+        const uint32_t cur = ctl & 0xFFu, ncand = (ctl >> 8) & 0xFFu;
+        if (cur >= ncand) { --depth; continue; }
+        const uint32_t sid = F[4 + 4 * cur], nrec = F[5 + 4 * cur], aux = F[6 + 4 * cur], pk = F[7 + 4 * cur];
+        wave_sync();
+        if (lane == 0) F[3] = ctl + 1;
+        const uint32_t total = cost + (pk & 0xFFFFu);
+        if (total >= best) { wave_sync(); continue; }  // the reference explores a candidate only if miss < best so far
+        if ((pk >> 16) & 1u) {
+            // the walk ends inside this unitig: a complete solution, strictly better than the running best
+            best = total;
+            if (DIR == 0) {  // [offset, this (farthest) unitig, ..., nearest unitig]
+                for (int j = lane; j < depth; j += 64) BEST[2 + j] = CUR[depth - 1 - j];
+                if (lane == 0) { BEST[0] = (int32_t)aux; BEST[1] = (int32_t)sid; }
+            } else {         // [nearest ... this (farthest) unitig, end offset]
+                for (int j = lane; j < depth; j += 64) BEST[j] = CUR[j];
+                if (lane == 0) { BEST[depth] = (int32_t)sid; BEST[depth + 1] = (int32_t)aux; }
+            }
+            *best_n = (uint32_t)depth + 2;
+            wave_sync();
+            continue;
+        }
+        // descend
+        if ((uint32_t)depth + 1 >= max_frames) { wave_sync(); return EXH_OVERFLOW; }
+        if (lane == 0) {
+            CUR[depth] = (int32_t)sid;
+            uint32_t* N = F + FR_WORDS;
+            N[0] = nrec;
+            N[1] = (DIR == 0) ? pos - aux : pos + aux;
+            N[2] = total;
+            N[3] = ((pk >> 17) & 1u) ? (1u << 17) : 0u;
+        }
+        wave_sync();
+        ++depth;
+    }
+    return best;
+}
+
+// ---- the same search, level by level ------------------------------------------------------------------------
+// exh_search visits one (record, read position) node per loop iteration and comes back to it once per candidate.
+// A node's best continuation does not depend on how the walk got there, so the search can also run as a dynamic
+// programme over the levels of the walk (level = number of unitigs taken):
+//   forward   all nodes of a level at once -- up to 4 nodes x 4 slots = 16 candidates, 4 lanes each -- are scored;
+//             candidates within the budget that do not end inside their unitig give the next level's nodes, and
+//             candidates reaching the same (record, position, strand) share one node (what the depth-first search
+//             re-explores once per way of getting there);
+//   backward  cost(node) = min over its candidates, first slot on ties, of mismatches + cost(child): the value and the
+//             choice the reference's recursion arrives at (its strict `<` keeps the first minimum; a candidate it
+//             does not explore because miss >= best-so-far could not have been strictly better);
+//   then the walk is read off from the root.
+// The result is that of exh_search.  Levels are ~13 for a 250 bp read where exh_search takes ~500 iterations.
+// A level with more than 4 distinct nodes, or more than `max_levels` levels, returns EXH_OVERFLOW (the read then
+// goes to the depth-first kernel's second pass).
+// Tables (u32 words, LDS): T[0..32) two node arrays {rec, pos, strand, cheapest way here} x 4; per level 52 words:
+// 16 candidates x {sid, aux, miss | fits<<16 | alive<<17 | child<<18}, 4 node words {cost | argmin<<16 | end<<18 | used<<19};
+// then max_levels words of scratch for reading the walk off.
+#define DP_LEVEL_WORDS 52
+#define DP_FITS (1u << 16)
+#define DP_ALIVE (1u << 17)
+#define DP_END (1u << 18)
+#define DP_USED (1u << 19)
+
+template <int DIR>
+__device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
+                                           uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t budget, bool partial,
+                                           uint32_t* T, uint32_t max_levels, int32_t* BEST, uint32_t* best_n, int lane) {
+    const int i = lane >> 4, c = (lane >> 2) & 3, sub = lane & 3, k = lane >> 2;
+    const bool leader = sub == 0;
+    *best_n = 0;
+    if (lane == 0) { T[0] = a_rec; T[1] = a_pos; T[2] = a_canon ? 1u : 0u; T[3] = 0; }
+    wave_sync();
+    uint32_t n_cur = 1, lvl = 0;
+    for (; n_cur; ++lvl) {
+        if (lvl >= max_levels) { wave_sync(); return EXH_OVERFLOW; }
+        const uint4 nd = reinterpret_cast<const uint4*>(T)[(lvl & 1) * 4 + i];
+        const bool nvalid = (uint32_t)i < n_cur;
+        const uint32_t rec = nd.x, pos = nd.y, prefix = nd.w;
+        const bool canon = (nd.z & 1u) != 0;
+        const bool end_here = nvalid && ((DIR == 0) ? (pos == 0) : (L - pos - K1 == 0));
+        const bool has_rec = nvalid && !end_here && rec != BGR_NONE;
+        const bool useR = (DIR == 0) ? canon : !canon;
+        const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
+        uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
+        if (has_rec) {
+            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + (useR ? 4u : 0u) + (uint32_t)c) * 2;
+            sl = sp[0];
+            m0 = sp[1];
+        }
+        const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+        const u64 zmask = __ballot(leader && (!has_rec || id == 0));
+        const uint32_t nb = (uint32_t)(zmask >> (16 * i)) & 0x1111u;
+        const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+        if (DIR == 1 && partial && lvl == 0) {  // alignerExhaustive.cpp:217-221 (-i): nothing starts here, nothing to pay
+            const bool none = rl32(first_zero, 0) == 0 && !(rl32(end_here ? 1u : 0u, 0));
+            if (none) { wave_sync(); return 0; }
+        }
+        const bool valid = has_rec && (uint32_t)c < first_zero;
+        const bool fwd = (sl.x & fbit) != 0;
+        const uint32_t len = valid ? sl.y : 0;
+        const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+        const int32_t sid = fwd ? (int32_t)id : -(int32_t)id;
+        const uint32_t ext = len - K1;
+        bool fits;
+        uint32_t n, ustart, rstart, nrec;
+        bool ncanon;
+        if (DIR == 0) {
+            fits = ext >= pos;
+            n = fits ? pos : ext;
+            ustart = fits ? ext - pos : 0;
+            rstart = fits ? 0 : pos - ext;
+            nrec = fwd ? m0.y : m0.z;
+            ncanon = (m0.x & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
+        } else {
+            const uint32_t rl = L - pos - K1;
+            fits = ext >= rl;
+            n = fits ? rl : ext;
+            ustart = K1;
+            rstart = pos + K1;
+            nrec = fwd ? m0.z : m0.y;
+            ncanon = (m0.x & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
+        }
+        if (!valid) n = 0;
+        uint32_t cnt = 0;
+        for (uint32_t b = (uint32_t)sub * 32; b < n; b += 128) cnt += ham_chunk(g, CMP, NM, useN, fw, fo + ustart + b, rstart + b, n - b);
+        cnt += quad_xor1(cnt);
+        cnt += quad_xor2(cnt);
+        const uint32_t miss = cnt > 0xFFFFu ? 0xFFFFu : cnt;
+        const uint32_t ptotal = prefix + miss;
+        const bool alive = valid && ptotal <= budget;  // a walk through here costs at least this much
+        const uint32_t aux = fits ? ((DIR == 0) ? ext - pos : L - pos) : 0u;
+        const bool need = alive && !fits;
+        const uint32_t npos = (DIR == 0) ? pos - ext : pos + ext;
+        const u64 key = (u64)nrec << 32 | (u64)(npos << 1) | (ncanon ? 1u : 0u);
+        // candidates that reach the same node share it: the first of them (slot order over the level) creates it
+        const u64 needmask = __ballot(need && leader);
+        uint32_t first_k = (uint32_t)k;
+        for (u64 mm = needmask; mm; mm &= mm - 1) {
+            const int src = __ffsll((long long)mm) - 1;
+            const u64 kk = rl64(key, src);
+            if (need && kk == key && (uint32_t)(src >> 2) < first_k) first_k = (uint32_t)(src >> 2);
+        }
+        const bool is_first = need && leader && first_k == (uint32_t)k;
+        const u64 fmask = __ballot(is_first);
+        const uint32_t n_next = (uint32_t)__popcll(fmask);
+        if (n_next > 4) { wave_sync(); return EXH_OVERFLOW; }
+        const uint32_t child = (uint32_t)__popcll(fmask & ((1ULL << (4 * first_k)) - 1));
+        uint32_t* NX = T + ((lvl + 1) & 1) * 16;
+        if (is_first) { NX[child * 4] = nrec; NX[child * 4 + 1] = npos; NX[child * 4 + 2] = ncanon ? 1u : 0u; NX[child * 4 + 3] = 0xFFFFFFFFu; }
+        uint32_t* LV_ = T + 32 + lvl * DP_LEVEL_WORDS;
+        if (leader && nvalid) {
+            LV_[3 * k] = (uint32_t)sid;
+            LV_[3 * k + 1] = aux;
+            LV_[3 * k + 2] = miss | (fits ? DP_FITS : 0u) | (alive ? DP_ALIVE : 0u) | (child << 18);
+        }
+        if (leader && c == 0) LV_[48 + i] = (nvalid ? DP_USED : 0u) | (end_here ? DP_END : 0u);
+        wave_sync();
+        if (need && leader) atomicMin(&NX[child * 4 + 3], ptotal);
+        wave_sync();
+        n_cur = n_next;
+    }
+    const uint32_t levels = lvl;
+    // ---- backward: cheapest continuation of every node, first slot on ties --------------------------------
+    for (int l = (int)levels - 1; l >= 0; --l) {
+        uint32_t* LV_ = T + 32 + (uint32_t)l * DP_LEVEL_WORDS;
+        uint32_t sel = 0xFFFFFFFFu;
+        if (lane < 16) {
+            const uint32_t used = LV_[48 + (lane >> 2)] & DP_USED;
+            uint32_t total = 0xFFFFu;
+            if (used) {
+                const uint32_t pk = LV_[3 * lane + 2];
+                if (pk & DP_ALIVE) {
+                    uint32_t cc = 0;
+                    if (!(pk & DP_FITS)) cc = ((uint32_t)l + 1 < levels) ? (T[32 + ((uint32_t)l + 1) * DP_LEVEL_WORDS + 48 + ((pk >> 18) & 3u)] & 0xFFFFu) : 0xFFFFu;
+                    total = (pk & 0xFFFFu) + cc;
+                    if (total > 0xFFFFu) total = 0xFFFFu;
+                }
+            }
+            sel = total << 2 | (uint32_t)(lane & 3);
+        }
+        uint32_t o = quad_xor1(sel);
+        sel = o < sel ? o : sel;
+        o = quad_xor2(sel);
+        sel = o < sel ? o : sel;
+        wave_sync();
+        if (lane < 16 && (lane & 3) == 0) {
+            const uint32_t fl = LV_[48 + (lane >> 2)];
+            const uint32_t cost = (fl & DP_END) ? 0u : (sel >> 2);
+            LV_[48 + (lane >> 2)] = (fl & (DP_END | DP_USED)) | cost | ((sel & 3u) << 16);
+        }
+        wave_sync();
+    }
+    const uint32_t root = T[32 + 48];
+    const uint32_t s = (root & DP_END) ? 0u : (root & 0xFFFFu);
+    if (s > budget) return budget + 1;
+    // ---- read the walk off (lane 0; at most `levels` steps) -------------------------------------------------
+    if (lane == 0) {
+        int32_t* W_ = reinterpret_cast<int32_t*>(T + 32 + max_levels * DP_LEVEL_WORDS);
+        uint32_t d = 0, node = 0, n_out = 0;
+        for (;;) {
+            const uint32_t* LV_ = T + 32 + d * DP_LEVEL_WORDS;
+            const uint32_t w = LV_[48 + node];
+            if (w & DP_END) {
+                // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); right: every depth pushes 0 (:64,:210)
+                if (DIR == 0) {
+                    if (d == 0) { BEST[0] = 0; n_out = 1; }
+                    else { for (uint32_t j = 0; j < d; ++j) BEST[j] = W_[d - 1 - j]; n_out = d; }
+                } else {
+                    for (uint32_t j = 0; j < d; ++j) BEST[j] = W_[j];
+                    BEST[d] = 0;
+                    n_out = d + 1;
+                }
+                break;
+            }
+            const uint32_t cc = (w >> 16) & 3u;
+            const uint32_t* C = LV_ + 3 * (node * 4 + cc);
+            const int32_t sid = (int32_t)C[0];
+            const uint32_t aux = C[1], pk = C[2];
+            if (pk & DP_FITS) {
+                if (DIR == 0) {  // [offset, this (farthest) unitig, ..., nearest unitig]
+                    BEST[0] = (int32_t)aux; BEST[1] = sid;
+                    for (uint32_t j = 0; j < d; ++j) BEST[2 + j] = W_[d - 1 - j];
+                } else {         // [nearest ... this (farthest) unitig, end offset]
+                    for (uint32_t j = 0; j < d; ++j) BEST[j] = W_[j];
+                    BEST[d] = sid; BEST[d + 1] = (int32_t)aux;
+                }
+                n_out = d + 2;
+                break;
+            }
+            W_[d] = sid;
+            node = (pk >> 18) & 3u;
+            if (++d >= levels) break;  // (cannot happen: a finite cost ends in a fitting candidate or an end node)
+        }
+        T[0] = n_out;
+    }
+    wave_sync();
+    *best_n = rl32(T[0], 0);
+    wave_sync();
+    return s;
+}
+
+// alignReadExhaustive (alignerExhaustive.cpp:35-58): every read position is an anchor candidate
+// (getListOverlap, aligner.cpp:318-342, keeps them all); per anchor the best left walk with budget m, then
+// the best right walk with what is left; no reverse-complement retry.  Only position 0 and positions whose
+// (k-1)-mer is an overlap of the graph can succeed (anywhere else getEnd() is empty), so the position scan
+// is the same lane-parallel membership test as in the greedy kernel.
+// DEEP (pass 2): the search state (OUT | CUR | BEST | frames) of every wave lives in HBM (io.deep_scratch) instead
+// of LDS, sized for the worst case, so neither the depth of the search nor the read length is bounded by LDS.
+template <bool STAGE, bool DEEP>
+__global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    // per wave: FW3 | FWQ | RCW | NM | OUT | CUR | BEST | frames   (the last four in HBM when DEEP)
+    const uint32_t per_wave_words = DEEP ? 4 * W : 4 * W + 3 * (io.path_cap / 2) + (io.frames_per_wave * FR_WORDS) / 2;
+    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FWQ = FW3 + W;
+    u64* RCW = FWQ + W;
+    u64* NM = RCW + W;
+    int32_t* OUT = DEEP ? reinterpret_cast<int32_t*>(io.deep_scratch + (u64)(blockIdx.x * waves + wave) * io.deep_stride)
+                        : reinterpret_cast<int32_t*>(NM + W);
+    int32_t* CUR = OUT + io.path_cap;
+    int32_t* BEST = CUR + io.path_cap;
+    uint32_t* FR = reinterpret_cast<uint32_t*>(BEST + io.path_cap);
+
+    uint32_t c_reads = 0, c_al = 0, c_na = 0;
+    unsigned long long c_ov = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+    const uint32_t m = prm.max_mismatch;
+
+    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[subset_ctr] by the pass before)
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
+    for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        const uint32_t r = io.subset ? io.subset[it] : it;
+        const u64 off = io.read_offs[r];
+        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
+        if (hasN) derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane);
+        const u64* ROLL = hasN ? FWQ : FW3;  // the rolling `num` stream
+        uint32_t p_n = 0;
+        const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
+        bool done = false, overflow = false;
+        for (uint32_t base = 0; base < npos && !done && !overflow; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < npos;
+            u64 num = 0;
+            if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
+            const uint32_t idx = find_key<!STAGE>(g, LV, units, num < rc ? num : rc, valid);
+            u64 mask = __ballot(idx != BGR_NONE);
+            if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const uint32_t a_rec = rl32(idx, src), a_pos = base + (uint32_t)src;
+                const u64 a_num = rl64(lds_win32(ROLL, a_pos) >> (64 - 2 * K1), 0);  // re-read (uniform) instead of keeping `num` live across the search
+                const bool a_canon = a_num <= rcb_fast(a_num, K1);
+                uint32_t nl = 0, nr = 0, eb = 0;
+                if (a_pos == 0) {  // checkBeginExhaustive at position 0 is [0] at no cost (alignerExhaustive.cpp:159): no search
+                    if (lane == 0) OUT[0] = 0;
+                    nl = 1;
+                } else {
+                    eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane);
+                    if (eb == EXH_OVERFLOW) { overflow = true; break; }
+                    if (eb > m) continue;
+                    for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                }
+                wave_sync();
+                // position 0 is tried whatever its (k-1)-mer: when that is no overlap of the graph getBegin() is empty, and only an
+                // empty right side or -i can make the anchor succeed (alignerExhaustive.cpp:206-221): no search either
+                if (a_rec == BGR_NONE && !prm.partial && L - a_pos - K1 != 0) continue;
+                const uint32_t ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane);
+                if (ee == EXH_OVERFLOW) { overflow = true; break; }
+                if (ee > m - eb) continue;
+                for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];
+                p_n = nl + nr;
+                done = true;
+                break;
+            }
+        }
+        wave_sync();
+        if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
+            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+            continue;
+        }
+        c_ov += npos;
+        uint32_t abase = 0;
+        if (done) abase = publish_path(io, OUT, 0, p_n, &chunk_pos, &chunk_end, lane);
+        if (lane == 0) io.results[r] = make_uint2(abase, p_n | ((uint32_t)(done ? BGR_ST_ALIGNED : BGR_ST_FAILED) << 24));
+        ++c_reads;
+        c_al += done ? 1 : 0;
+        c_na += done ? 0 : 1;
+        wave_sync();
+    }
+    if (lane == 0 && c_reads) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)c_reads);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        atomicAdd(&counters[4], c_ov);
+    }
+}
+
+// ============================== exhaustive, four reads per wavefront ===================================
+// The level search (exh_dp) gives a wave ONE read, and after de-duplication a level of the walk rarely holds more than one
+// node: 4 candidate slots x 4 chunk lanes = 16 of the 64 lanes work.  Here a wave takes four reads, 16 lanes each, and runs
+// their searches side by side, for the shape nearly every read has: every level has exactly ONE node (all candidates that go
+// on lead to the same (record, position, strand): bubbles that close again), at most X4_LEVELS levels per side, no N, and
+// the first anchor that can succeed does.  Per side: a forward sweep scores the node's <= 4 candidates per level (kept:
+// id, offset, mismatches, fits, alive), a backward sweep settles cost(level) = first minimum over the slots of mismatches
+// [+ cost(level + 1) when the walk goes on] -- the value and the choice of the reference's recursion
+// (alignerExhaustive.cpp:61-259; see exh_dp) -- and the walk is read off.  Anything else (a level with two nodes, a failing
+// first anchor, N, -i) is listed for bgr_align_exhaustive_dp_kernel / the depth-first passes, which map it from scratch.
+#ifndef BGR_X4_OCC
+#define BGR_X4_OCC 6
+#endif
+#define X4_LEVELS 16
+#define X4_LV_WORDS 16  // per level: [0..3] sid, [4..7] aux (the path int a walk ending there emits), [8..11] miss | fits<<16 | alive<<17, [12] node flags, [13] chosen slot
+#define X4_END 1u
+#define X4_INF 0xFFFFu
+
+// One side of the search for up to four reads (act = the group takes part).  DIR 0: left of the anchor (exL), DIR 1: right
+// (exR).  On return, for the groups that took part: *cost = best total (X4_INF: none within the budget; the caller compares
+// with its budget), *n_out ints written to OUTG[o_off ...] in output order, *fb = the search left the shape this kernel
+// handles (the read goes on the list).
+template <int DIR>
+__device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t act, uint32_t a_rec, uint32_t a_canon,
+                                          uint32_t a_pos, uint32_t budget, uint32_t* LVT, int32_t* OUTG, uint32_t o_off, int lane, uint32_t* cost_o,
+                                          uint32_t* n_out, uint32_t* fb_o) {
+    const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u, sub = (uint32_t)lane & 15u;
+    uint32_t fwd = act, fb = 0, lvl = 0, nlev = 0, prefix = 0;
+    uint32_t pos = a_pos, rec = a_rec, canon = a_canon;
+    // ---- forward: one node per level ----
+    for (;;) {
+        if (fwd && lvl >= X4_LEVELS) { fb = 1; fwd = 0; }
+        const uint32_t end_here = (fwd && ((DIR == 0) ? (pos == 0) : (L - pos - K1 == 0))) ? 1u : 0u;
+        if (end_here) {  // left: the read's first base is reached; right: nothing is left of the read
+            if (sub == 0) LVT[lvl * X4_LV_WORDS + 12] = X4_END;
+            nlev = lvl + 1;
+            fwd = 0;
+        }
+        if (!__any(fwd != 0)) break;
+        const uint32_t useR = ((DIR == 0) ? canon : (canon ^ 1u));
+        uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
+        if (fwd && rec != G4_REC_MASK) {
+            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + useR * 4u + c) * 2;
+            sl = sp[0];
+            m0 = sp[1];
+        }
+        const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+        const u64 zmask = __ballot(id == 0);
+        const uint32_t zb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
+        const uint32_t first_zero = zb ? (uint32_t)(__ffs((int)zb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+        const uint32_t valid = c < first_zero ? 1u : 0u;
+        const uint32_t fwdu = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
+        const uint32_t len = sl.y;
+        const uint32_t fw = sl.z, fo = sl.w + (fwdu ? 0u : len);
+        const uint32_t ext = len - K1;
+        uint32_t fits, n, ustart, rstart, nrec, cbit, aux, npos;
+        if (DIR == 0) {
+            fits = ext >= pos ? 1u : 0u;
+            n = fits ? pos : ext;
+            ustart = fits ? ext - pos : 0;
+            rstart = fits ? 0 : pos - ext;
+            nrec = fwdu ? m0.y : m0.z;
+            cbit = fwdu ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND;
+            aux = ext - pos;   // offset in the last unitig (:126,:175)
+            npos = pos - ext;
+        } else {
+            const uint32_t rl = L - pos - K1;
+            fits = ext >= rl ? 1u : 0u;
+            n = fits ? rl : ext;
+            ustart = K1;
+            rstart = pos + K1;
+            nrec = fwdu ? m0.z : m0.y;
+            cbit = fwdu ? BGR_META_CANON_END : BGR_META_CANON_RCBEG;
+            aux = L - pos;     // |readLeft| + k-1 (:99,:231)
+            npos = pos + ext;
+        }
+        if (!valid) n = 0;
+        uint32_t cnt = 0;
+        for (uint32_t b = q * 32; __any(b < n); b += 128)
+            if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
+        cnt += quad_xor1(cnt);
+        cnt += quad_xor2(cnt);
+        const uint32_t miss = cnt > 0xFFFFu ? 0xFFFFu : cnt;
+        const uint32_t ptotal = prefix + miss;
+        const uint32_t alive = (valid && ptotal <= budget) ? 1u : 0u;  // a walk through here costs at least this much
+        const uint32_t need = (alive && !fits) ? 1u : 0u;
+        if (fwd && q == 0) {
+            uint32_t* R = LVT + lvl * X4_LV_WORDS;
+            R[c] = fwdu ? id : 0u - id;
+            R[4 + c] = aux;
+            R[8 + c] = miss | (fits << 16) | (alive << 17);
+            if (c == 0) R[12] = 0;
+        }
+        // the candidates that go on must all reach the same node
+        const u64 nmask = __ballot(need && q == 0 && fwd);
+        const uint32_t nb = (uint32_t)(nmask >> ((uint32_t)lane & 48u)) & 0x1111u;
+        const uint32_t src = ((uint32_t)lane & 48u) | (nb ? (uint32_t)(__ffs((int)nb) - 1) : 0u);
+        const uint32_t kpk = nrec | ((m0.x & cbit) ? G4_CANON : 0u);
+        const uint32_t k_rec = lane_get(kpk, src), k_pos = lane_get(npos, src);
+        const u64 dmask = __ballot(need && fwd && (kpk != k_rec || npos != k_pos));
+        uint32_t pmin = need ? ptotal : 0xFFFFFFFFu;
+        uint32_t o = row_ror4(pmin);
+        pmin = o < pmin ? o : pmin;
+        o = row_ror8(pmin);
+        pmin = o < pmin ? o : pmin;
+        if (fwd) {
+            nlev = lvl + 1;
+            if ((uint32_t)(dmask >> ((uint32_t)lane & 48u)) & 0xFFFFu) { fb = 1; fwd = 0; }  // a level with two nodes
+            else if (!nb) fwd = 0;                                                      // every candidate ends here or is too dear
+            else { prefix = pmin; pos = k_pos; rec = k_rec & G4_REC_MASK; canon = (k_rec >> 28) & 1u; ++lvl; }
+        }
+    }
+    wave_sync();
+    // ---- backward: cost of every level, first slot on ties ----
+    const uint32_t ok = (act && !fb) ? 1u : 0u;
+    const uint32_t n0 = rl32(ok ? nlev : 0u, 0), n1 = rl32(ok ? nlev : 0u, 16), n2 = rl32(ok ? nlev : 0u, 32), n3 = rl32(ok ? nlev : 0u, 48);
+    const uint32_t maxl = max(max(n0, n1), max(n2, n3));
+    uint32_t cnext = X4_INF;
+    for (int l = (int)maxl - 1; l >= 0; --l) {
+        const uint32_t in = (ok && (uint32_t)l < nlev) ? 1u : 0u;
+        uint32_t key = 0xFFFFFFFFu, flags = 0;
+        if (in) {
+            const uint32_t* R = LVT + (uint32_t)l * X4_LV_WORDS;
+            flags = R[12];
+            if (sub < 4) {
+                const uint32_t pk = R[8 + sub];
+                uint32_t total = X4_INF;
+                if (pk & (1u << 17)) {
+                    total = (pk & 0xFFFFu) + ((pk & (1u << 16)) ? 0u : cnext);
+                    if (total > X4_INF) total = X4_INF;
+                }
+                key = total << 2 | sub;
+            }
+        }
+        uint32_t o = quad_xor1(key);
+        key = o < key ? o : key;
+        o = quad_xor2(key);
+        key = o < key ? o : key;
+        key = lane_get(key, (uint32_t)lane & 48u);
+        if (in) {
+            cnext = (flags & X4_END) ? 0u : (key >> 2);
+            if (sub == 0) LVT[(uint32_t)l * X4_LV_WORDS + 13] = key & 3u;
+        }
+    }
+    wave_sync();
+    // ---- read the walk off: level j's chosen slot, down to the first level that ends the walk ----
+    uint32_t endj = 0, sid = 0, auxv = 0, isend = 0;
+    if (ok && sub < nlev) {
+        const uint32_t* R = LVT + sub * X4_LV_WORDS;
+        const uint32_t a = R[13];
+        isend = R[12] & X4_END;
+        const uint32_t pk = R[8 + a];
+        endj = (isend || (pk & (1u << 16))) ? 1u : 0u;
+        sid = R[a];
+        auxv = R[4 + a];
+    }
+    const u64 emask = __ballot(endj != 0);
+    const uint32_t eb16 = (uint32_t)(emask >> ((uint32_t)lane & 48u)) & 0xFFFFu;
+    const uint32_t d = eb16 ? (uint32_t)(__ffs((int)eb16) - 1) : 0u;           // depth of the level that ends the walk
+    const uint32_t d_end = lane_get(isend, ((uint32_t)lane & 48u) | d);       // ... by reaching the read's end (no unitig taken there)
+    uint32_t n = 0;
+    const uint32_t good = (ok && cnext <= budget && eb16) ? 1u : 0u;
+    if (good) {
+        int32_t* O = OUTG + o_off;
+        if (DIR == 0) {
+            // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); else [offset, farthest unitig, ..., nearest]
+            if (d_end) { n = d == 0 ? 1u : d; if (d == 0) { if (sub == 0) O[0] = 0; } else if (sub < d) O[d - 1 - sub] = (int32_t)sid; }
+            else { n = d + 2; if (sub == d) { O[0] = (int32_t)auxv; O[1] = (int32_t)sid; } else if (sub < d) O[1 + (d - sub)] = (int32_t)sid; }
+        } else {
+            // right: every depth pushes 0 at the read's end (:64,:210); else [nearest ... farthest unitig, end offset]
+            if (d_end) { n = d + 1; if (sub < d) O[sub] = (int32_t)sid; if (sub == d) O[d] = 0; }
+            else { n = d + 2; if (sub <= d) O[sub] = (int32_t)sid; if (sub == d) O[d + 1] = (int32_t)auxv; }
+        }
+    }
+    wave_sync();
+    *cost_o = good ? cnext : X4_INF;
+    *n_out = n;
+    *fb_o = fb;
+}
+
+template <bool STAGE>
+__global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    // per wave: 4 x { read words W | level table X4_LEVELS x X4_LV_WORDS u32 | out ints 2 x (X4_LEVELS + 2) }
+    const uint32_t out_ints = 2 * (X4_LEVELS + 2);
+    const uint32_t grp_words = W + (X4_LEVELS * X4_LV_WORDS + out_ints + 1) / 2;
+    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
+    u64* WV = lds + 64 + mphf_words + (u64)wave * (4 * grp_words);
+    u64* F = WV + grp * grp_words;
+    uint32_t* LVT = reinterpret_cast<uint32_t*>(F + W);
+    int32_t* OUTG = reinterpret_cast<int32_t*>(LVT + X4_LEVELS * X4_LV_WORDS);
+    const uint32_t m = prm.max_mismatch;
+
+    uint32_t c_al = 0, c_na = 0;
+    unsigned long long c_ov = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+
+    for (uint32_t rbase = (blockIdx.x * waves + wave) * 4; rbase < io.n_reads; rbase += gridDim.x * waves * 4) {
+        const uint32_t r = rbase + grp;
+        const uint32_t have = r < io.n_reads ? 1u : 0u;
+        u64 off = 0;
+        uint32_t L = 0, fast = 0;
+        if (have) {
+            off = io.read_offs[r];
+            L = (uint32_t)(io.read_offs[r + 1] - off);
+            fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;
+            if (L <= K1) fast = 0;  // (a read of k-1 bases or fewer: the general kernel)
+        }
+        {
+            u64 f = 0;
+            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
+            if (sub < W) F[sub] = f;
+        }
+        wave_sync();
+        // ---- the first position that can anchor the read (getListOverlap keeps every position, aligner.cpp:318-342; only
+        // position 0 and overlap (k-1)-mers of the graph can succeed): position 0 when its k-mer is an overlap, else the first hit
+        uint32_t a_pos = 0, a_rec = BGR_NONE;
+        for (uint32_t qq = 0; qq < 4; ++qq) {
+            if (!rl32(fast, (int)(16 * qq))) continue;
+            const uint32_t Lq = rl32(L, (int)(16 * qq));
+            const u64* A = WV + qq * grp_words;
+            const uint32_t npos = Lq - K1 + 1;
+            for (uint32_t base = 0; base < npos; base += 64) {
+                const uint32_t i = base + (uint32_t)lane;
+                const bool valid = i < npos;
+                u64 num = 0;
+                if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                const u64 rcn = rcb_fast(num, K1);
+                uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
+                const u64 mask = __ballot(idx != BGR_NONE);
+                if (mask) {
+                    if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
+                    const int s1 = __ffsll((long long)mask) - 1;
+                    const uint32_t h1 = rl32(idx, s1);
+                    if (grp == qq) { a_pos = base + (uint32_t)s1; a_rec = h1; }
+                    break;
+                }
+            }
+        }
+        const uint32_t npos_g = L >= K1 ? L - K1 + 1 : 0;
+        const uint32_t anchored = (fast && a_rec != BGR_NONE) ? 1u : 0u;
+        // left side: [0] at position 0 (no search), else the search with the whole budget
+        uint32_t eb = 0, nl = 0, fbl = 0;
+        {
+            const uint32_t actl = (anchored && a_pos != 0) ? 1u : 0u;
+            uint32_t cl = 0, nll = 0;
+            x4_search<0>(g, F, L, K1, actl, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, m, LVT, OUTG, 0, lane, &cl, &nll, &fbl);
+            if (actl) { eb = cl; nl = nll; }
+            else if (anchored) { if (sub == 0) OUTG[0] = 0; nl = 1; }
+        }
+        wave_sync();
+        uint32_t ee = 0, nr = 0, fbr = 0;
+        {
+            const uint32_t actr = (anchored && !fbl && eb <= m) ? 1u : 0u;
+            uint32_t cr = 0, nrr = 0;
+            x4_search<1>(g, F, L, K1, actr, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, actr ? m - eb : 0u, LVT, OUTG, nl, lane, &cr, &nrr, &fbr);
+            if (actr) { ee = cr; nr = nrr; } else ee = X4_INF;
+        }
+        // 0 = aligned; 2 = not aligned for sure (no overlap (k-1)-mer anywhere in the read: every position fails); 4 = the list
+        uint32_t outcome = 4;
+        if (fast && !anchored) outcome = 2;
+        else if (anchored && !fbl && !fbr && eb <= m && ee != X4_INF && eb + ee <= m) outcome = 0;
+        const uint32_t aligned = outcome == 0 ? 1u : 0u;
+        const uint32_t p_n = aligned ? nl + nr : 0;
+        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        if (tot > chunk_end - chunk_pos) {
+            const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(io.cursor, want);
+            chunk_pos = rl32(got, 0);
+            chunk_end = chunk_pos + want;
+        }
+        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const bool room = chunk_pos + tot <= io.arena_cap;
+        chunk_pos += tot;
+        for (uint32_t j = sub; j < p_n; j += 16)
+            if (room) io.arena[gbase + j] = OUTG[j];
+        if (!room && lane == 0 && tot) io.cursor[1] = 1;
+        if (sub == 0 && have) {
+            if (outcome == 0) io.results[r] = make_uint2(gbase, p_n | ((uint32_t)BGR_ST_ALIGNED << 24));
+            else if (outcome == 2) io.results[r] = make_uint2(0u, (uint32_t)BGR_ST_FAILED << 24);
+            else io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+        }
+        const u64 fin = __ballot(sub == 0 && have && outcome != 4);
+        c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
+        c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
+        for (int gq = 0; gq < 4; ++gq)
+            if ((fin >> (16 * gq)) & 1) c_ov += rl32(npos_g, 16 * gq);  // overlaps += listOverlap.size() (alignerExhaustive.cpp:38)
+        wave_sync();
+    }
+    if (lane == 0 && (c_al | c_na)) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)(c_al + c_na));
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        atomicAdd(&counters[4], c_ov);
+    }
+}
+
+// Pass 1 of exhaustive mode with the level-by-level search (exh_dp); what it cannot hold goes to the overflow list and
+// through bgr_align_exhaustive_kernel<false, true>.
+template <bool STAGE>
+__global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;
+    const uint32_t K1 = g.k - 1;
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    // per wave: FW3 | FWQ | RCW | NM | OUT | BEST | tables (32 + levels * 52 + levels words, see exh_dp)
+    const uint32_t table_words = 32 + io.frames_per_wave * (DP_LEVEL_WORDS + 1);
+    const uint32_t per_wave_words = 4 * W + 2 * (io.path_cap / 2) + ((table_words + 3) / 4) * 2;  // whole 16-byte units
+    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FWQ = FW3 + W;
+    u64* RCW = FWQ + W;
+    u64* NM = RCW + W;
+    int32_t* OUT = reinterpret_cast<int32_t*>(NM + W);
+    int32_t* BEST = OUT + io.path_cap;
+    uint32_t* T = reinterpret_cast<uint32_t*>(BEST + io.path_cap);
+
+    uint32_t c_reads = 0, c_al = 0, c_na = 0;
+    unsigned long long c_ov = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+    const uint32_t m = prm.max_mismatch;
+
+    // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[subset_ctr] by the pass before)
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
+    for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        const uint32_t r = io.subset ? io.subset[it] : it;
+        const u64 off = io.read_offs[r];
+        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
+        if (hasN) derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane);
+        const u64* ROLL = hasN ? FWQ : FW3;  // the rolling `num` stream
+        uint32_t p_n = 0;
+        const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
+        bool done = false, overflow = false;
+        for (uint32_t base = 0; base < npos && !done && !overflow; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < npos;
+            u64 num = 0;
+            if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
+            const uint32_t idx = find_key<!STAGE>(g, LV, units, num < rc ? num : rc, valid);
+            u64 mask = __ballot(idx != BGR_NONE);
+            if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const uint32_t a_rec = rl32(idx, src), a_pos = base + (uint32_t)src;
+                const u64 a_num = rl64(lds_win32(ROLL, a_pos) >> (64 - 2 * K1), 0);  // re-read (uniform) instead of keeping `num` live across the search
+                const bool a_canon = a_num <= rcb_fast(a_num, K1);
+                uint32_t nl = 0, nr = 0, eb = 0;
+                if (a_pos == 0) {  // checkBeginExhaustive at position 0 is [0] at no cost (alignerExhaustive.cpp:159): no search
+                    if (lane == 0) OUT[0] = 0;
+                    nl = 1;
+                } else {
+                    eb = exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, T, io.frames_per_wave, BEST, &nl, lane);
+                    if (eb == EXH_OVERFLOW) { overflow = true; break; }
+                    if (eb > m) continue;
+                    for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
+                }
+                wave_sync();
+                // position 0 is tried whatever its (k-1)-mer: when that is no overlap of the graph getBegin() is empty, and only an
+                // empty right side or -i can make the anchor succeed (alignerExhaustive.cpp:206-221): no search either
+                if (a_rec == BGR_NONE && !prm.partial && L - a_pos - K1 != 0) continue;
+                const uint32_t ee = exh_dp<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, T, io.frames_per_wave, BEST, &nr, lane);
+                if (ee == EXH_OVERFLOW) { overflow = true; break; }
+                if (ee > m - eb) continue;
+                for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];
+                p_n = nl + nr;
+                done = true;
+                break;
+            }
+        }
+        wave_sync();
+        if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
+            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+            continue;
+        }
+        c_ov += npos;
+        uint32_t abase = 0;
+        if (done) abase = publish_path(io, OUT, 0, p_n, &chunk_pos, &chunk_end, lane);
+        if (lane == 0) io.results[r] = make_uint2(abase, p_n | ((uint32_t)(done ? BGR_ST_ALIGNED : BGR_ST_FAILED) << 24));
+        ++c_reads;
+        c_al += done ? 1 : 0;
+        c_na += done ? 0 : 1;
+        wave_sync();
+    }
+    if (lane == 0 && c_reads) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)c_reads);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        atomicAdd(&counters[4], c_ov);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_exhaustive(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
+    if (io.exh4) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive4_kernel<true>, g, io, p, cfg, stream)
+                                       : launch_one(bgr_align_exhaustive4_kernel<false>, g, io, p, cfg, stream);
+    if (io.deep_scratch) return launch_one(bgr_align_exhaustive_kernel<false, true>, g, io, p, cfg, stream);
+    if (io.level_search) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_dp_kernel<true>, g, io, p, cfg, stream)
+                                               : launch_one(bgr_align_exhaustive_dp_kernel<false>, g, io, p, cfg, stream);
+    return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_kernel<true, false>, g, io, p, cfg, stream)
+                          : launch_one(bgr_align_exhaustive_kernel<false, false>, g, io, p, cfg, stream);
+}
+const void* exhaustive_kernel_fn(uint32_t which) {  // 0 depth-first, 1 level search, 2 four reads per wave
+    return which == 1 ? reinterpret_cast<const void*>(&bgr_align_exhaustive_dp_kernel<false>)
+         : which == 2 ? reinterpret_cast<const void*>(&bgr_align_exhaustive4_kernel<false>)
+                      : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
+}
+
+}  // namespace bgr

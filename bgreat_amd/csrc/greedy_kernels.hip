@@ -1,0 +1,455 @@
+// greedy_kernels.hip -- greedy mode (alignReadGreedy, alignerGreedy.cpp:35-57,167-364) on gfx950.
+//   bgr_align_greedy4_kernel  four reads per wavefront: the position scans one after the other on all 64 lanes, the four
+//                             extensions side by side, 16 lanes each; settles the common shapes, lists the rest
+//   bgr_align_greedy_kernel   the general kernel: one read per wavefront, every anchor, both strands, N planes, any path length
+#include "device_common.h"
+
+namespace bgr {
+namespace {
+
+template <bool STAGE>
+__global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;
+    const uint32_t K1 = g.k - 1;
+    // as the second pass behind bgr_align_greedy4_kernel it maps only the reads that kernel listed (count in cursor[subset_ctr])
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
+    if ((uint32_t)(blockIdx.x * waves) >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    const uint32_t per_wave_words = 4 * W + io.path_cap / 2;
+    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FWQ = FW3 + W;
+    u64* RCW = FWQ + W;
+    u64* NM = RCW + W;
+    int32_t* PATH = reinterpret_cast<int32_t*>(NM + W);
+
+    uint32_t c_lane = 0;                    // per-lane status counter (a VGPR: the kernel is short of SGPRs, not of VGPRs)
+    uint32_t chunk_pos = 0, chunk_end = 0;  // this wave's slice of the path arena
+    // getNOverlap(read, 0) still looks at position 0 before testing the count (aligner.cpp:349-368)
+    const uint32_t effort = prm.effort ? prm.effort : 1;
+
+    for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        const uint32_t r = io.subset ? io.subset[it] : it;
+        const u64 off = io.read_offs[r];
+        const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
+        // (prefetching the next read one iteration ahead was measured: no gain at 24 waves/CU, it only added spills)
+        const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
+        bool derived = false;
+
+        // ---- passes: forward read, then its reverse complement (alignerGreedy.cpp:54) -----------
+        uint32_t status = BGR_ST_NOANCHOR, p_lo = 0, p_n = 0;
+        uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
+        if (!prm.effort && npos > 1) npos = 1;
+#ifdef BGR_PHASE_TIMING  /* diagnostic builds: env BGR_DEBUG_STOP = 1 stops after packing, 2 after the position scan */
+        if (prm.debug_stop == 1) npos = 0;
+#endif
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((pass == 1 || hasN) && !derived) { derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane); derived = true; }
+            // A read without N: FWQ == FW3 and the rolling reverse k-mer == rcb(forward k-mer), so pass 0 needs FW3 only.
+            const bool plain = (pass == 0) && !hasN;
+            const u64* A = pass ? RCW : (plain ? FW3 : FWQ);   // forward-strand k-mers of this pass
+            const u64* B = pass ? FW3 : RCW;                   // reverse-strand k-mers (rolling nuc2intrc: N -> 0)
+            const u64* CMP = pass ? RCW : FW3;                 // characters compared by missmatchNumber
+            const bool useN = (pass == 0) && hasN;
+            uint32_t tried = 0;
+            bool done = false;
+            for (uint32_t base = 0; base < npos && !done && tried < effort; base += 64) {
+                const uint32_t i = base + lane;
+                const bool valid = i < npos;
+                u64 num = 0, rcn = 0;
+                if (valid) {
+                    num = lds_win32(A, i) >> (64 - 2 * K1);
+                    rcn = plain ? rcb_fast(num, K1) : lds_win32(B, L - K1 - i) >> (64 - 2 * K1);
+                }
+                const u64 rep = num < rcn ? num : rcn;
+                const uint32_t idx = find_key<!STAGE>(g, LV, units, rep, valid);
+                u64 mask = __ballot(idx != BGR_NONE);
+#ifdef BGR_PHASE_TIMING
+                if (prm.debug_stop == 2) { if (mask) { ++tried; done = true; p_n = 0; } mask = 0; }
+#endif
+                while (mask && tried < effort) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    ++tried;
+                    // the anchor's k-mers are re-read from LDS (uniform) rather than kept in two 64-bit VGPRs across the walk
+                    const uint32_t a_pos = base + (uint32_t)src;
+                    const u64 a_num = rl64(lds_win32(A, a_pos) >> (64 - 2 * K1), 0);
+                    const u64 a_rcn = plain ? rcb_fast(a_num, K1) : rl64(lds_win32(B, L - K1 - a_pos) >> (64 - 2 * K1), 0);
+                    uint32_t a_rec = rl32(idx, src);
+                    // getBegin/getEnd recompute rc = rcb(num) (aligner.cpp:149,211); it differs from the
+                    // rolling rcnum only when an N was rolled into the window.
+                    const u64 rc2 = rcb_fast(a_num, K1);
+                    if (rc2 != a_rcn) a_rec = find_key<false>(g, LV, units, a_num < rc2 ? a_num : rc2, true);
+                    if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, a_pos, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
+                        done = true;
+                        break;
+                    }
+                }
+            }
+            if (done) { status = BGR_ST_ALIGNED | (pass ? BGR_ST_RC : 0); break; }
+            if (tried == 0) { status = BGR_ST_NOANCHOR | (pass ? BGR_ST_RC : 0); break; }  // ++noOverlapRead, no retry
+            status = BGR_ST_FAILED | BGR_ST_RC;  // all anchors failed: retry on the reverse complement once
+        }
+        // ---- stage D: publish ---------------------------------------------------------------------
+        wave_sync();
+        uint32_t abase = 0;
+        if ((status & BGR_ST_MASK) == BGR_ST_ALIGNED) abase = publish_path(io, PATH, p_lo, p_n, &chunk_pos, &chunk_end, lane);
+        else p_n = 0;
+        if (lane == 0) io.results[r] = make_uint2(abase, p_n | (status << 24));
+        c_lane += (uint32_t)lane == (status & BGR_ST_MASK);  // lane s counts the reads that ended with status s
+        wave_sync();
+    }
+    {   // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        const uint32_t total = rl32(c_lane, BGR_ST_NOANCHOR) + rl32(c_lane, BGR_ST_FAILED) + rl32(c_lane, BGR_ST_ALIGNED);
+        if (lane == 0 && total) atomicAdd(&counters[0], (unsigned long long)total);
+        if (lane == BGR_ST_NOANCHOR && c_lane) atomicAdd(&counters[1], (unsigned long long)c_lane);
+        if (lane == BGR_ST_ALIGNED && c_lane) atomicAdd(&counters[2], (unsigned long long)c_lane);
+        if (lane == BGR_ST_FAILED && c_lane) atomicAdd(&counters[3], (unsigned long long)c_lane);
+    }
+}
+
+// ================================= greedy, four reads per wavefront ====================================
+// bgr_align_greedy_kernel above walks one read per wave: a walk step is two dependent loads (slot, bases) scored by at
+// most 4 candidates x a few 32-base chunks, i.e. a handful of the 64 lanes, and per read there are ~4 such steps in a row.
+// Here a wave takes FOUR reads: their position scans still run one after the other on all 64 lanes (a scan is lane-
+// efficient: one (k-1)-mer per lane), then the four extensions run side by side, 16 lanes each (4 candidates x 4 chunk
+// lanes = 128 bases per step), so four slot/base load chains are in flight per wave and every wave instruction of a walk
+// step serves four reads.  Path ints stay in registers (lane j of a group holds int j of each direction).
+// The kernel settles the common case only -- no N in the read, first anchor extends within the budget (or there is
+// no anchor at all), at most G4_PATH ints per direction.  Every other read (N, failed first anchor: the reference then
+// tries further anchors and the reverse complement, alignerGreedy.cpp:41-56; long paths) is put on a list and mapped by
+// bgr_align_greedy_kernel right behind, so results are the reference's for every read.
+#ifndef BGR_G4_OCC
+#define BGR_G4_OCC 8
+#endif
+#define G4_PATH 16
+
+
+// One extension step for up to four walks, one per 16-lane group.  `phase` (uniform within a group): 0 = the group sits
+// out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
+// behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
+// Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
+__device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t phase, uint32_t rec, uint32_t canon,
+                                            uint32_t pos, uint32_t budget, int lane, uint32_t* miss, uint32_t* ext_o, int32_t* sid_o) {
+    const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u;
+    const uint32_t left = phase == 1 ? 1u : 0u;
+    // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
+    const uint32_t useR = canon == left ? 1u : 0u;
+    uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
+    if (phase != 0 && rec != G4_REC_MASK) {
+        const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + useR * 4u + c) * 2;
+        sl = sp[0];
+        m0 = sp[1];
+    }
+    const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
+    const u64 zmask = __ballot(id == 0);  // (all lanes of a candidate agree; a group that sits out reads as "no candidate")
+    const uint32_t nb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
+    const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+    const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
+    const uint32_t len = sl.y;
+    const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+    const uint32_t ext = len - K1;
+    // left: `rl` bases of the read lie left of the overlap; right: behind it (first step) / from its start (later steps)
+    const uint32_t kk = phase == 2 ? K1 : 0u;
+    const uint32_t rl = left ? pos : L - pos - kk;
+    const uint32_t fits = ext >= rl ? 1u : 0u;
+    const uint32_t span = left ? ext : ext + K1 - kk;  // what is compared when the walk goes on: the unitig beyond the overlap, or all of it
+    uint32_t n = fits ? rl : (span < rl ? span : rl);  // (later right steps: read.substr(pos, |u|) is clipped at |read|)
+    const uint32_t ustart = left ? ext - n : kk;
+    const uint32_t rstart = left ? rl - n : pos + kk;
+    const uint32_t nrec = fwd == left ? m0.y : m0.z;
+    const uint32_t cbit = left ? (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND) : (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
+    if (c >= first_zero) n = 0;
+    uint32_t cnt = 0;
+    for (uint32_t b = q * 32; __any(b < n); b += 128)
+        if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
+    cnt += quad_xor1(cnt);
+    cnt += quad_xor2(cnt);
+    // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
+    uint32_t key = c < first_zero ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
+    uint32_t o = row_ror4(key);
+    key = o < key ? o : key;
+    o = row_ror8(key);
+    key = o < key ? o : key;
+    const uint32_t src = ((uint32_t)lane & 48u) | ((key & 3u) << 2);
+    const uint32_t pk = nrec | ((m0.x & cbit) ? G4_CANON : 0u) | (fits ? G4_FITS : 0u);
+    const uint32_t w1 = lane_get(pk, src);
+    *ext_o = lane_get(ext, src);
+    *sid_o = (int32_t)lane_get(fwd ? id : 0u - id, src);
+    *miss = key >> 2;
+    return (key >> 2) <= budget ? w1 | G4_FOUND : 0u;  // an empty record gives key 0xFFFFFFFF: not found
+}
+
+// A read the kernel cannot finish in this launch is listed with where to go on: which strand (the reference maps the
+// reverse complement once every forward anchor has failed, alignerGreedy.cpp:54), how many anchors of that strand have
+// been tried (getNOverlap hands out the first `effort` of them) and the position the scan resumes from.
+#define G4_ST_RC (1u << 31)
+#define G4_ST_TRIED_SHIFT 20
+#define G4_ST_POS_MASK 0xFFFFFu
+
+// LIST: the launch maps the reads an earlier launch listed (io.subset) instead of all reads of the batch.
+template <bool STAGE, bool LIST>
+__global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;  // <= 16 (checked by the host): one lane per word of a read
+    const uint32_t K1 = g.k - 1;
+    // later passes map the reads an earlier pass listed (count in cursor[subset_ctr]), from the state it left in g4_state
+    const uint32_t total = LIST ? io.cursor[io.subset_ctr] : io.n_reads;
+    if ((uint32_t)(blockIdx.x * waves) * 4u >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
+    uint2* LV;
+    uint32_t mphf_words;
+    const uint32_t* units = block_prologue<STAGE>(g, lds, &LV, &mphf_words);
+    u64* RD = lds + 64 + mphf_words + (u64)wave * (8 * W);  // the four reads of this wave: forward words | reverse-complement words
+    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
+    const uint32_t m = prm.max_mismatch;
+    const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
+
+    uint32_t c_noov = 0, c_al = 0, c_na = 0;  // wave-uniform counts of the reads settled here
+    uint32_t chunk_pos = 0, chunk_end = 0;    // this wave's slice of the path arena
+    uint32_t lst_pos = 0, lst_end = 0;        // this wave's slice of the list for the next pass (reserved io.list_chunk entries at a
+                                              // time: one single-address atomic per listed read caps a launch near 300 M/s)
+
+    // (per-lane flags are kept as 0/1 words in VGPRs on purpose: as `bool`s they become 64-bit lane masks in SGPRs, and this
+    // kernel is short of SGPRs, not of VGPRs)
+    for (uint32_t ibase = (blockIdx.x * waves + wave) * 4; ibase < total; ibase += gridDim.x * waves * 4) {
+        const uint32_t it = ibase + grp;
+        uint32_t have = it < total ? 1u : 0u;
+        uint32_t r = 0, st = 0;
+        u64 off = 0;
+        uint32_t L = 0, fast = 0;
+        if (have && LIST) {
+            r = io.subset[it];
+            if (r == BGR_NONE) have = 0;  // a hole: the unused tail of some wave's chunk of the list
+            else st = io.g4_state[r];
+        } else {
+            r = it;
+        }
+        if (have) {
+            off = io.read_offs[r];
+            L = (uint32_t)(io.read_offs[r + 1] - off);
+            fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
+        }
+        uint32_t rc = st >> 31;
+        uint32_t tried = (st >> G4_ST_TRIED_SHIFT) & 0x7FFu;
+        uint32_t s_from = st & G4_ST_POS_MASK;
+        u64* F = RD + grp * (2 * W);
+        {   // stage the 2-bit words: lane `sub` of a group brings word `sub` of its read
+            u64 f = 0;
+            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
+            if (sub < W) F[sub] = f;
+        }
+        wave_sync();
+        uint32_t act = fast;                 // the group takes part in the current round
+        uint32_t outcome = 4, nst = 0, rc_out = rc;  // what became of the read (below); 4 = general kernel
+        uint32_t nl = 0, nr = 0;
+        int32_t pl = 0, pr = 0;  // lane `sub` keeps path int number `sub` of the left walk (near -> far, offset last) / right walk
+        for (uint32_t round = 0;; ++round) {
+            if (__any(act && rc)) {  // reverseComplements(read) (utils.cpp:66-73) of the groups that are on their second strand
+                if (act && rc && sub < W) {
+                    const long long p = (long long)L - 32 * ((long long)sub + 1);
+                    u64 w = 0;
+                    if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
+                    else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                    F[W + sub] = w;
+                }
+                wave_sync();
+            }
+            const u64* FW = F + (rc ? W : 0);  // the strand this pass maps
+
+            // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each read from where its scan stands and,
+            // when it lies in the same 64 positions, the one after it; record | canonical << 28
+            uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
+            for (uint32_t q = 0; q < 4; ++q) {
+                if (!rl32(act, (int)(16 * q))) continue;
+                const uint32_t Lq = rl32(L, (int)(16 * q));
+                const u64* A = RD + q * (2 * W) + (rl32(rc, (int)(16 * q)) ? W : 0);
+                const uint32_t left_q = eff - rl32(tried, (int)(16 * q));  // anchors this strand may still try (>= 1)
+                uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
+                if (!prm.effort && npos > 1) npos = 1;
+                for (uint32_t base = rl32(s_from, (int)(16 * q)); base < npos; base += 64) {
+                    const uint32_t i = base + (uint32_t)lane;
+                    const bool valid = i < npos;
+                    u64 num = 0;
+                    if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                    const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
+                    uint32_t idx = find_key<!STAGE>(g, LV, units, num < rcn ? num : rcn, valid);
+                    const u64 mask = __ballot(idx != BGR_NONE);
+                    if (mask) {
+                        if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
+                        const int s1 = __ffsll((long long)mask) - 1;
+                        const u64 mask2 = mask & (mask - 1);
+                        const uint32_t h1 = rl32(idx, s1);
+                        uint32_t h2 = BGR_NONE, p2 = 0;
+                        if (mask2 && left_q >= 2) {  // a second anchor is tried when the first fails
+                            const int s2 = __ffsll((long long)mask2) - 1;
+                            h2 = rl32(idx, s2);
+                            p2 = base + (uint32_t)s2;
+                        }
+                        if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
+                        break;
+                    }
+                }
+            }
+
+            // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast; a group whose anchor fails
+            // starts over from the next one, if the scan has seen it, while the others go on ----
+            uint32_t phase = (act && a_rec != BGR_NONE) ? 1u : 0u;
+            uint32_t pos = a_pos, rec = a_rec & G4_REC_MASK, canon = (a_rec >> 28) & 1u, budget = m;
+            uint32_t bad = 0, failed = 0;
+            if (act) { nl = 0; nr = 0; }
+            for (;;) {
+                if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
+                    if (sub == nl) pl = 0;
+                    ++nl;
+                    phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                }
+                if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
+                if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
+                if ((phase == 1 && nl > G4_PATH - 2) || (phase >= 2 && nr > G4_PATH - 1)) { bad = 1; phase = 0; }  // path too long for the registers
+                if (!__any(phase != 0)) break;
+                uint32_t miss, ext;
+                int32_t sid;
+                const uint32_t w1 = g4_step(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+                if (phase != 0) {
+                    if (!(w1 & G4_FOUND)) {
+                        ++tried;
+                        if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
+                            a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
+                            nl = 0; nr = 0; budget = m;
+                            phase = 1; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                        } else { failed = 1; phase = 0; }
+                    } else if (phase == 1) {
+                        if (sub == nl) pl = sid;
+                        ++nl;
+                        budget -= miss;
+                        if (w1 & G4_FITS) {
+                            if (sub == nl) pl = (int32_t)(ext - pos);
+                            ++nl;
+                            phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
+                        } else { pos -= ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; }
+                    } else {
+                        if (sub == nr) pr = sid;
+                        ++nr;
+                        budget -= miss;
+                        if (w1 & G4_FITS) phase = 0;
+                        else { pos += ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; phase = 3; }
+                    }
+                }
+            }
+
+            // ---- what became of each read (alignerGreedy.cpp:35-57) ---------------------------------------------------------------
+            // 0 = aligned, 1 = no anchor on this strand and none tried before (++noOverlapRead), 2 = not aligned (both strands done),
+            // 3 = goes on in a later pass with `nst`, 4 = general kernel (N in the read, path too long for the registers)
+            uint32_t o_now = 4, n_now = 0;
+            {
+                const uint32_t npos_g = (L >= K1 ? L - K1 + 1 : 0);
+                const uint32_t npos_e = (!prm.effort && npos_g > 1) ? 1u : npos_g;
+                if (bad) o_now = 4;
+                else if (a_rec != BGR_NONE && !failed) o_now = 0;
+                else if (a_rec == BGR_NONE && tried == 0) o_now = 1;
+                else {
+                    // the strand's anchors are used up when `effort` of them have been tried or the scan has passed the last position
+                    const uint32_t resume = a_pos + 1;  // (a_pos = the anchor tried last; unused when the scan found none)
+                    const uint32_t used_up = (a_rec == BGR_NONE || tried >= eff || resume >= npos_e) ? 1u : 0u;
+                    if (!used_up) { o_now = 3; n_now = (rc << 31) | (tried << G4_ST_TRIED_SHIFT) | resume; }
+                    else if (!rc) { o_now = 3; n_now = G4_ST_RC; }  // the reverse complement, from its first position
+                    else o_now = 2;
+                    if (tried > 0x7FFu) o_now = 4;
+                }
+            }
+            if (act) { outcome = o_now; nst = n_now; rc_out = rc; }
+            // A launch over a LIST goes straight on to the reverse complement of the reads whose forward anchors are used up now
+            // (most of such a launch's reads: a second round is as densely packed as the first); the launch over all reads leaves
+            // them to the next one (7 % of its reads: three of four groups would sit idle).
+            const uint32_t again = (LIST && round == 0 && act && o_now == 3 && n_now == G4_ST_RC) ? 1u : 0u;
+            if (!LIST) break;
+            if (!__any(again != 0)) break;
+            act = again; rc = 1; tried = 0; s_from = 0;
+        }
+        if (outcome == 3 && io.g4_last) outcome = 4;  // no further pass of this kernel: the general kernel maps the read from scratch
+
+        // ---- publish: reverse(left) ++ right into the arena ----------------------------------------------------------------------
+        const uint32_t aligned = outcome == 0 ? 1u : 0u;
+        const uint32_t p_n = aligned ? nl + nr : 0;
+        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        if (tot > chunk_end - chunk_pos) {  // one global atomic per ~50 reads (see publish_path)
+            const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(io.cursor, want);
+            chunk_pos = rl32(got, 0);
+            chunk_end = chunk_pos + want;
+        }
+        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const bool room = chunk_pos + tot <= io.arena_cap;
+        chunk_pos += tot;
+#pragma unroll
+        for (uint32_t jj = 0; jj < 2; ++jj) {
+            const uint32_t j = sub + 16 * jj;
+            const uint32_t vl = lane_get((uint32_t)pl, ((uint32_t)lane & 48u) | ((nl - 1 - j) & 15u));
+            const uint32_t vr = lane_get((uint32_t)pr, ((uint32_t)lane & 48u) | ((j - nl) & 15u));
+            if (j < p_n && room) io.arena[gbase + j] = (int32_t)(j < nl ? vl : vr);
+        }
+        if (!room && lane == 0 && tot) io.cursor[1] = 1;  // overflow: reported by the host as an error
+        if (sub == 0 && have) {
+            if (outcome <= 2) {
+                const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc_out ? BGR_ST_RC : 0u);
+                io.results[r] = make_uint2(aligned ? gbase : 0u, p_n | (code << 24));
+            } else if (outcome == 3) {
+                io.g4_state[r] = nst;
+            } else {
+                io.gen_list[atomicAdd(io.cursor + io.gen_ctr, 1u)] = r;
+            }
+        }
+        {   // the reads that go on in the next pass: appended to this wave's slice of the list
+            const u64 lm = __ballot(sub == 0 && have && outcome == 3);
+            if (lm) {
+                const uint32_t cnt = (uint32_t)__popcll(lm);
+                if (cnt > lst_end - lst_pos) {  // what is left of the old slice becomes holes
+                    for (uint32_t j = lst_pos + (uint32_t)lane; j < lst_end; j += 64) io.ovf_list[j] = BGR_NONE;
+                    uint32_t got = 0;
+                    if (lane == 0) got = atomicAdd(io.cursor + io.ovf_ctr, io.list_chunk);
+                    lst_pos = rl32(got, 0);
+                    lst_end = lst_pos + io.list_chunk;
+                }
+                if (sub == 0 && have && outcome == 3) io.ovf_list[lst_pos + (uint32_t)__popcll(lm & ((1ULL << lane) - 1))] = r;
+                lst_pos += cnt;
+            }
+        }
+        c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
+        c_noov += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 1));
+        c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
+        wave_sync();
+    }
+    for (uint32_t j = lst_pos + (uint32_t)lane; j < lst_end; j += 64) io.ovf_list[j] = BGR_NONE;
+    if (lane == 0 && (c_al | c_noov | c_na)) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov + c_na));
+        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_greedy(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
+    if (io.greedy4 && io.subset) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, true>, g, io, p, cfg, stream)
+                                                       : launch_one(bgr_align_greedy4_kernel<false, true>, g, io, p, cfg, stream);
+    if (io.greedy4) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, false>, g, io, p, cfg, stream)
+                                          : launch_one(bgr_align_greedy4_kernel<false, false>, g, io, p, cfg, stream);
+    return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
+                          : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
+}
+const void* greedy_kernel_fn(bool four_reads) {
+    return four_reads ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, true>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
+}
+
+}  // namespace bgr

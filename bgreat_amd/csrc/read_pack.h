@@ -1,4 +1,4 @@
-// read_pack.h -- host twin of the device pre-pass (bgr_pack_reads_kernel, align_kernels.hip): reads as the 2-bit planes the
+// read_pack.h -- host twin of the device pre-pass (bgr_pack_reads_kernel, batch_kernels.hip): reads as the 2-bit planes the
 // mapping kernels read, so that a batch crosses PCIe at ~0.3 byte per base instead of 1.  Host only, header only.
 //
 // Layout (same as on the device): str2num codes (utils.cpp:117-129: A0 C1 G2, anything else 3 -- the parser admits only
