@@ -19,6 +19,9 @@ for f in ("greedy_kernels.hip", "exhaustive_kernels.hip", "anchors_kernel.hip", 
     print("## " + f)
     for m in re.finditer(r"- \.agpr_count:.*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?"
                          r"\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", s, re.S):
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", m.group(1)], capture_output=True, text=True).stdout.strip() or m.group(1)
+        try:
+            name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip() or m.group(1)
+        except OSError:
+            name = m.group(1)
         name = re.sub(r"\(BgrDeviceGraph.*$|\(unsigned.*$|\(HIP_vector.*$", "", name).replace("void bgr::(anonymous namespace)::", "").replace("bgr::", "")
         print("%-52s vgpr %3s sgpr %3s vgpr_spill %2s sgpr_spill %2s scratch %3s" % (name, m.group(5), m.group(3), m.group(6), m.group(4), m.group(2)))
