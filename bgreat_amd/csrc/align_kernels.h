@@ -34,6 +34,7 @@ struct BatchIO {
     uint32_t* g4_state;          // n words: where a listed read's mapping stands (strand, anchors tried, scan position)
     uint32_t* gen_list;          // reads for the general kernel (count at cursor[gen_ctr])
     uint32_t gen_ctr;
+    uint32_t anc4;               // anchors mode: launch the four-reads-per-wave kernel (what it does not settle goes on ovf_list)
     uint32_t exh4;               // exhaustive mode: launch the four-reads-per-wave kernel (what it does not settle goes on ovf_list)
     uint32_t list_chunk;         // entries of ovf_list a wave reserves per global atomic (4..16; the unused ones become holes = BGR_NONE)
     uint32_t g4_last;            // last pass of the four-reads-per-wave kernel: everything unfinished goes on gen_list
@@ -84,7 +85,7 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
 }
 
 // Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive depth-first,
-// 2 anchors, 3 exhaustive level search, 4 greedy four-reads-per-wave, 5 exhaustive four-reads-per-wave).
+// 2 anchors, 3 exhaustive level search, 4 greedy four-reads-per-wave, 5 exhaustive four-reads-per-wave, 6 anchors four-reads-per-wave).
 uint32_t resident_waves_per_cu(uint32_t mode);
 
 // (results, arena) of the last mapping launch -> input-ordered CSR on the device.  phase 0: block_sums[ceil(n/4096)] and

@@ -104,7 +104,10 @@ __global__ void __launch_bounds__(1024, BGR_ANC_OCC) bgr_align_anchors_kernel(Bg
     uint32_t chunk_pos = 0, chunk_end = 0;
     const uint32_t effort = prm.effort ? prm.effort : 1;  // getNAnchors(read, 0) still takes a hit at position 0
 
-    for (uint32_t r = blockIdx.x * waves + wave; r < io.n_reads; r += gridDim.x * waves) {
+    // as the second pass behind bgr_align_anchors4_kernel it maps only the reads that kernel listed (count in cursor[subset_ctr])
+    const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
+    for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
         const bool hasN = load_packed(io, r, off, L, W, FW3, NM, lane);
@@ -230,11 +233,290 @@ __global__ void __launch_bounds__(1024, BGR_ANC_OCC) bgr_align_anchors_kernel(Bg
     }
 }
 
+// ============================ anchors mode, four reads per wavefront ===================================
+// The kernel above gives a wave one read; per read it does a few BooPHF lookups (lane = level: a handful of the 64 lanes),
+// one placement compare and the greedy walks (a handful of lanes again).  Here a wave takes four reads, 16 lanes each:
+// lane `sub` of a group probes level `sub` of the lookup, compares bases [32 sub, 32 sub + 32) of the placement, and the
+// walks run through g4_step like the greedy kernel's.  All four groups step through the reference's loop in lockstep --
+// lookup at the current position, placement of the anchoring unitig if the lookup answered, walks, next position / next
+// strand -- which is efficient because every read does about the same work (the first `effort` answers are tried, then
+// the reverse complement).  Reads with an N, paths longer than G4_PATH ints per side and graphs with more than 16 active
+// BooPHF levels go to bgr_align_anchors_kernel (listed / not launched).
+#ifndef BGR_ANC4_OCC
+#define BGR_ANC4_OCC 4
+#endif
+
+__device__ __forceinline__ u64 lane_get64(u64 v, uint32_t src) {
+    return ((u64)lane_get((uint32_t)(v >> 32), src) << 32) | lane_get((uint32_t)v, src);
+}
+
+// boomphf::mphf::lookup (BooPHF.h:783-818) for one key per 16-lane group (need = the group looks up): index or ~0
+__device__ __forceinline__ u64 anc_lookup4(const AncView& a, u64 key, uint32_t need, int lane) {
+    const uint32_t sub = (uint32_t)lane & 15u, gb = (uint32_t)lane & 48u;
+    u64 s0 = bgr_boo_hash64(key, BGR_BOO_SEED0), s1 = bgr_boo_hash64(key, BGR_BOO_SEED1);
+    u64 hv = sub == 0 ? s0 : s1;
+    for (uint32_t i = 2; i < a.n_active; ++i) {  // BooPHF.h:336-356: the level hashes are a sequence, walked in step
+        const u64 v = bgr_boo_next(&s0, &s1);
+        if (sub == i) hv = v;
+    }
+    bool hit = false;
+    u64 pos = 0;
+    if (need && sub < a.n_active) {
+        pos = bgr_mod_magic(hv, a.lv_domain, a.lv_magic);
+        hit = (a.bits[a.lv_word_base + (pos >> 6)] >> (pos & 63)) & 1;
+    }
+    const u64 mask = __ballot(hit);
+    const uint32_t m16 = (uint32_t)(mask >> gb) & 0xFFFFu;
+    const uint32_t src = gb | (m16 ? (uint32_t)(__ffs((int)m16) - 1) : 0u);  // the first level whose bit is set answers
+    const u64 fpos = lane_get64(pos, src), wb = lane_get64(a.lv_word_base, src), rb = lane_get64(a.lv_rank_base, src);
+    const u64 widx = fpos >> 6, blk = fpos >> 9;
+    uint32_t cnt = 0;
+    if (m16 && sub < 8) {  // BooPHF.h:609-622 rank: sample of the 512-bit block + popcount of the words before the bit
+        const u64 wi = blk * 8 + (u64)sub;
+        if (wi < widx) cnt = (uint32_t)__popcll(a.bits[wb + wi]);
+        else if (wi == widx) cnt = (uint32_t)__popcll(a.bits[wb + wi] & ((1ULL << (fpos & 63)) - 1));
+    }
+    cnt = row16_sum(cnt);
+    u64 res = ~0ULL;
+    if (m16) res = a.ranks[rb + blk] + cnt;
+    const uint32_t slow = (need && !m16) ? 1u : 0u;  // what 24 levels could not place (repeated k-mers): exact, sorted {key, index}
+    if (a.n_final && __any(slow != 0)) {
+        u64 lo = 0, hi = slow ? a.n_final : 0;
+        while (__any(lo < hi)) {
+            if (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (a.fin[2 * mid] < key) lo = mid + 1; else hi = mid;
+            }
+        }
+        if (slow && lo < a.n_final && a.fin[2 * lo] == key) res = a.last_rank + a.fin[2 * lo + 1];
+    }
+    return res;
+}
+
+__global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
+    const uint32_t K = g.k, K1 = g.k - 1;
+    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u, gb = (uint32_t)lane & 48u;
+    u64* RD = lds + 64 + (u64)wave * (8 * W);  // the four reads of this wave: forward words | reverse-complement words
+    u64* F = RD + grp * (2 * W);
+    const AncView av = anc_view(g, (int)sub);
+    const u64 km1_mask = (1ULL << (2 * K1)) - 1;  // offsetUpdate - 1 (aligner.h:101-102): update() keeps k-1 digits
+    const uint32_t m = prm.max_mismatch;
+    const uint32_t effort = prm.effort ? prm.effort : 1;  // getNAnchors(read, 0) still takes a hit at position 0
+
+    uint32_t c_noov = 0, c_al = 0, c_na = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+
+    for (uint32_t rbase = (blockIdx.x * waves + wave) * 4; rbase < io.n_reads; rbase += gridDim.x * waves * 4) {
+        const uint32_t r = rbase + grp;
+        const uint32_t have = r < io.n_reads ? 1u : 0u;
+        u64 off = 0;
+        uint32_t L = 0, fast = 0;
+        if (have) {
+            off = io.read_offs[r];
+            L = (uint32_t)(io.read_offs[r + 1] - off);
+            fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
+        }
+        {
+            u64 f = 0;
+            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
+            if (sub < W) F[sub] = f;
+        }
+        wave_sync();
+        const uint32_t dk = L < K ? L : K;                                  // read.substr(0, k) of a shorter read is the whole read
+        const uint32_t last_i = !prm.effort ? 0u : (L > K ? L - K : 0u);    // the loop leaves after position i when i + k >= |read|
+        // what became of the read: 0 aligned, 1 no anchor (++noOverlapRead), 2 not aligned, 4 general kernel
+        uint32_t outcome = fast ? 1u : 4u, rc = 0;
+        uint32_t active = (fast && L > 0) ? 1u : 0u;   // (an empty read: no anchor, no strand switch, alignerGreedy.cpp:60-67)
+        // getNAnchors (aligner.cpp:381-405): the first k-mer by str2num, then the (k-1)-mer rolling updates applied to it
+        u64 num = active ? lds_win32(F, 0) >> (64 - 2 * dk) : 0;
+        u64 rcnum = rcb_fast(num, K);
+        uint32_t i = 0, tried = 0;
+        uint32_t nl = 0, nr = 0, nmid = 0;
+        int32_t pl = 0, pr = 0, mid0 = 0, mid1 = 0;
+        while (__any(active != 0)) {
+            const u64* S = F + (rc ? W : 0);  // the characters of this pass's read (reverseComplements: N -> 'A')
+            // ---- one lookup per group at its current position ----
+            const u64 idx = anc_lookup4(av, num < rcnum ? num : rcnum, active, lane);
+            const uint32_t found = (active && idx != ~0ULL) ? 1u : 0u;
+            uint32_t success = 0, bad = 0;
+            if (__any(found != 0)) {
+                tried += found;
+                // ---- alignReadGreedyAnchors loop body for this anchor (alignerGreedy.cpp:68-161): place the unitig on the read ----
+                u64 pv = 0;
+                BgrUnitigMeta mt;
+                mt.len = 0; mt.flags = 0; mt.rec_beg = 0; mt.rec_end = 0; mt.F = 0; mt.pad = 0;
+                if (found) { pv = av.pos[idx]; mt = g.meta[(uint32_t)(pv >> 32)]; }
+                const uint32_t un = (uint32_t)(pv >> 32);
+                uint32_t pU = (uint32_t)pv;
+                const uint32_t pR = i, len = mt.len;
+                const uint32_t okp = (found && len >= K) ? 1u : 0u;  // :72-75 (an index nobody wrote holds unitig 0, the empty string)
+                const uint32_t fw = (uint32_t)(mt.F >> 5);
+                uint32_t fo = (uint32_t)(mt.F & 31);
+                u64 ukm = 0, rkm = 0;
+                if (okp) {
+                    ukm = seq_win32(g.seq, fw, fo + pU) >> (64 - 2 * K);
+                    const uint32_t rdk = L - pR < K ? L - pR : K;
+                    rkm = lds_win32(S, pR) >> (64 - 2 * rdk);
+                }
+                const uint32_t returned = ukm != rkm ? 1u : 0u;  // :76-83: any difference means "take the reverse complement"
+                if (returned) { fo += len; pU = len - K - pU; }
+                const int32_t uid = returned ? -(int32_t)un : (int32_t)un;
+                // the oriented unitig's end (k-1)-mers as neighbour records (what str2num + getEnd/getBegin find)
+                const uint32_t rec_b = returned ? mt.rec_end : mt.rec_beg, rec_e = returned ? mt.rec_beg : mt.rec_end;
+                const uint32_t can_b = (mt.flags & (returned ? BGR_META_CANON_RCEND : BGR_META_CANON_BEG)) ? 1u : 0u;
+                const uint32_t can_e = (mt.flags & (returned ? BGR_META_CANON_RCBEG : BGR_META_CANON_END)) ? 1u : 0u;
+                const uint32_t c12 = pR >= pU ? 1u : 0u;                       // the unitig starts inside the read (cases 1, 2)
+                const uint32_t longr = (L - pR >= len - pU) ? 1u : 0u;         // the read reaches the unitig's end (cases 1, 3)
+                const uint32_t start = pR - pU, uoff = pU - pR;               // (whichever the case uses)
+                uint32_t ub, rb, n;
+                if (c12) { ub = fo; rb = start; n = longr ? len : L - start; }  // CASE 1 (:87-110) / CASE 2 (:111-130)
+                else { ub = fo + uoff; rb = 0; n = longr ? len - uoff : L; }   // CASE 3 (:133-148) / CASE 4 (:149-160)
+                if (!okp) n = 0;
+                uint32_t errors = 0;
+                for (uint32_t b = sub * 32; __any(b < n); b += 512)
+                    if (b < n) errors += ham_chunk(g, S, nullptr, false, fw, ub + b, rb + b, n - b);
+                errors = row16_sum(errors);
+                const uint32_t good = (okp && errors <= m) ? 1u : 0u;
+                // ---- the walks from the unitig's ends: left (cases 1, 2), right (cases 1, 3) ----
+                const uint32_t want_left = (good && c12) ? 1u : 0u, want_right = (good && longr) ? 1u : 0u;
+                const uint32_t r_pos = c12 ? start + len - K1 : len - uoff - K1;
+                uint32_t phase = want_left ? 1u : (want_right ? 2u : 0u);
+                uint32_t pos = want_left ? start : r_pos, rec = want_left ? rec_b : rec_e, canon = want_left ? can_b : can_e, budget = m - errors;
+                uint32_t wfail = 0;
+                if (found) {
+                    nl = 0; nr = 0;
+                    if (c12) { mid0 = uid; nmid = 1; } else { mid0 = (int32_t)uoff; mid1 = uid; nmid = 2; }
+                }
+                for (;;) {
+                    if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0
+                        if (sub == nl) pl = 0;
+                        ++nl;
+                        phase = want_right ? 2u : 0u; pos = r_pos; rec = rec_e; canon = can_e;
+                    }
+                    if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the unitig
+                    if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k
+                    if ((phase == 1 && nl > G4_PATH - 2) || (phase >= 2 && nr > G4_PATH - 1)) { bad = 1; phase = 0; }  // path too long for the registers
+                    if (!__any(phase != 0)) break;
+                    uint32_t miss, ext;
+                    int32_t sid;
+                    const uint32_t w1 = g4_step(g, S, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+                    if (phase != 0) {
+                        if (!(w1 & G4_FOUND)) { wfail = 1; phase = 0; }
+                        else if (phase == 1) {
+                            if (sub == nl) pl = sid;
+                            ++nl;
+                            budget -= miss;
+                            if (w1 & G4_FITS) {
+                                if (sub == nl) pl = (int32_t)(ext - pos);
+                                ++nl;
+                                phase = want_right ? 2u : 0u; pos = r_pos; rec = rec_e; canon = can_e;
+                            } else { pos -= ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; }
+                        } else {
+                            if (sub == nr) pr = sid;
+                            ++nr;
+                            budget -= miss;
+                            if (w1 & G4_FITS) phase = 0;
+                            else { pos += ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; phase = 3; }
+                        }
+                    }
+                }
+                success = (good && !wfail && !bad) ? 1u : 0u;
+            }
+            // ---- where each group goes from here (alignerGreedy.cpp:60-164, aligner.cpp:381-405) ----
+            uint32_t pass_end = 0;
+            if (active) {
+                if (bad) { outcome = 4; active = 0; }
+                else if (success) { outcome = 0; active = 0; }
+                else if ((found && tried >= effort) || i >= last_i) pass_end = 1;
+                else {  // update() / updateRC() (aligner.cpp:305-315) with read[i + k]
+                    const u64 d = lds_win32(S, i + K) >> 62;
+                    num = ((num << 2) + d) & km1_mask;
+                    rcnum = (rcnum >> 2) + ((3 - d) << (2 * K - 4));
+                    ++i;
+                }
+            }
+            uint32_t sw = 0;
+            if (pass_end) {
+                if (tried == 0) { outcome = 1; active = 0; }          // ++noOverlapRead, no retry
+                else if (rc) { outcome = 2; active = 0; }             // every anchor failed on both strands
+                else sw = 1;                                          // once more on the reverse complement (:162)
+            }
+            if (__any(sw != 0)) {
+                if (sw && sub < W) {
+                    const long long p = (long long)L - 32 * ((long long)sub + 1);
+                    u64 w = 0;
+                    if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
+                    else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                    F[W + sub] = w;
+                }
+                wave_sync();
+                if (sw) {
+                    rc = 1; i = 0; tried = 0;
+                    num = lds_win32(F + W, 0) >> (64 - 2 * dk);
+                    rcnum = rcb_fast(num, K);
+                }
+            }
+        }
+        // ---- publish: reverse(left) ++ [offset,] unitig ++ right ----
+        const uint32_t aligned = (have && outcome == 0) ? 1u : 0u;
+        const uint32_t p_n = aligned ? nl + nmid + nr : 0;
+        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        if (tot > chunk_end - chunk_pos) {
+            const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(io.cursor, want);
+            chunk_pos = rl32(got, 0);
+            chunk_end = chunk_pos + want;
+        }
+        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const bool room = chunk_pos + tot <= io.arena_cap;
+        chunk_pos += tot;
+#pragma unroll
+        for (uint32_t jj = 0; jj < 3; ++jj) {
+            const uint32_t j = sub + 16 * jj;
+            const uint32_t vl = lane_get((uint32_t)pl, gb | ((nl - 1 - j) & 15u));
+            const uint32_t vr = lane_get((uint32_t)pr, gb | ((j - nl - nmid) & 15u));
+            int32_t v = (int32_t)vr;
+            if (j < nl) v = (int32_t)vl;
+            else if (j < nl + nmid) v = (j == nl) ? mid0 : mid1;
+            if (j < p_n && room) io.arena[gbase + j] = v;
+        }
+        if (!room && lane == 0 && tot) io.cursor[1] = 1;
+        if (sub == 0 && have) {
+            if (outcome <= 2) {
+                const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc ? BGR_ST_RC : 0u);
+                io.results[r] = make_uint2(aligned ? gbase : 0u, p_n | (code << 24));
+            } else {
+                io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+            }
+        }
+        c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
+        c_noov += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 1));
+        c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
+        wave_sync();
+    }
+    if (lane == 0 && (c_al | c_noov | c_na)) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
+        atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov + c_na));
+        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
+        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
+        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+    }
+}
+
 }  // namespace
 
 hipError_t launch_anchors(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
+    if (io.anc4) return launch_one(bgr_align_anchors4_kernel, g, io, p, cfg, stream);
     return launch_one(bgr_align_anchors_kernel, g, io, p, cfg, stream);
 }
-const void* anchors_kernel_fn() { return reinterpret_cast<const void*>(&bgr_align_anchors_kernel); }
+const void* anchors_kernel_fn(bool four_reads) {
+    return four_reads ? reinterpret_cast<const void*>(&bgr_align_anchors4_kernel) : reinterpret_cast<const void*>(&bgr_align_anchors_kernel);
+}
 
 }  // namespace bgr

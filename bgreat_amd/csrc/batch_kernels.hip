@@ -163,12 +163,13 @@ hipError_t launch_exhaustive(const BgrDeviceGraph& g, const BatchIO& io, const K
 hipError_t launch_anchors(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream);
 const void* greedy_kernel_fn(bool four_reads);
 const void* exhaustive_kernel_fn(uint32_t which);
-const void* anchors_kernel_fn();
+const void* anchors_kernel_fn(bool four_reads);
 
 uint32_t resident_waves_per_cu(uint32_t mode) {
     hipFuncAttributes fa;
     const void* fn = mode == 0 ? greedy_kernel_fn(false)
-                   : mode == 2 ? anchors_kernel_fn()
+                   : mode == 2 ? anchors_kernel_fn(false)
+                   : mode == 6 ? anchors_kernel_fn(true)
                    : mode == 3 ? exhaustive_kernel_fn(1)
                    : mode == 4 ? greedy_kernel_fn(true)
                    : mode == 5 ? exhaustive_kernel_fn(2)

@@ -73,7 +73,7 @@ struct bgr_aligner {
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
-    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0;
+    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0;
     uint64_t knob_split_limit = 0;
     int num_cus = 0;
     size_t lds_per_cu = 0;
@@ -442,6 +442,7 @@ int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
         case BGR_KNOB_DEBUG_STOP: a->knob_debug_stop = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_GREEDY_FAST: if (value > 1) break; a->knob_greedy_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_EXH_FAST: if (value > 1) break; a->knob_exh_fast = (uint32_t)value; return BGR_OK;
+        case BGR_KNOB_ANCHORS_FAST: if (value > 1) break; a->knob_anc_fast = (uint32_t)value; return BGR_OK;
         default: break;
     }
     return fail(BGR_E_ARG, "bgr_aligner_set_knob: unknown knob or value out of range");
@@ -589,6 +590,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     bgr::LaunchCfg cfg_x4;
     const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && words <= 16 && !a->graph->header.has_exc && p->max_mismatch < 0x7FFF &&
                          geometry(4 * 8 * (words + 146), (n_reads + 3) / 4, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)));
+    // Anchors mode, first pass: four reads per wave (bgr_align_anchors4_kernel); reads with an N and very long paths are listed
+    // for the one-read-per-wave kernel.
+    bgr::LaunchCfg cfg_a4;
+    const bool a4_pass = p->mode == BGR_MODE_ANCHORS && !a->knob_anc_fast && words <= 16 && !a->graph->header.has_exc && a->graph->header.anc_active_levels <= 16 &&
+                         geometry(8 * 8 * words, (n_reads + 3) / 4, true, false, cfg_a4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(6)));
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
@@ -598,10 +604,12 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
                                (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0) +
                                (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0) +
                                (fast_pass ? (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk : 0) +
-                               (x4_pass ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk : 0);
+                               (x4_pass ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk : 0) +
+                               (a4_pass ? (uint64_t)cfg_a4.blocks * cfg_a4.waves_per_block * arena_chunk : 0);
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf | (level_search && !deep_only ? 2u : 0u) | (fast_pass ? 4u : 0u);
+    if (a4_pass) { a->last_launch[0] = cfg_a4.blocks; a->last_launch[1] = cfg_a4.waves_per_block * 64; a->last_launch[2] = cfg_a4.lds_bytes; a->last_launch[3] = 4u; }
     if (x4_pass) { a->last_launch[0] = cfg_x4.blocks; a->last_launch[1] = cfg_x4.waves_per_block * 64; a->last_launch[2] = cfg_x4.lds_bytes; a->last_launch[3] = cfg_x4.stage_mphf | (level_search ? 2u : 0u) | 4u; }
     if (fast_pass) { a->last_launch[0] = cfg_fast.blocks; a->last_launch[1] = cfg_fast.waves_per_block * 64; a->last_launch[2] = cfg_fast.lds_bytes; a->last_launch[3] = cfg_fast.stage_mphf | 4u; }
 
@@ -633,6 +641,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.gen_ctr = 8;
     io.g4_last = 0;
     io.exh4 = 0;
+    io.anc4 = 0;
     io.list_chunk = 16;
     io.subset_ctr = 2;
     io.ovf_ctr = 2;
@@ -704,6 +713,19 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         io.subset = static_cast<uint32_t*>(a->ovf2.p);
         io.subset_ctr = 8;
     }
+    if (a4_pass) {
+        HIP_TRY(a->g4st.ensure(n_reads * 4));
+        bgr::BatchIO ioa = io;
+        ioa.anc4 = 1;
+        ioa.subset = nullptr;
+        ioa.ovf_list = static_cast<uint32_t*>(a->g4st.p);
+        ioa.ovf_ctr = 5;
+        e = bgr::launch_align(a->dg, ioa, kp, cfg_a4, a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (anchors, four reads per wave): ") + hipGetErrorString(e));
+        HIP_TRY(mark("bgr_align_anchors4_kernel (all reads)"));
+        io.subset = static_cast<uint32_t*>(a->g4st.p);
+        io.subset_ctr = 5;
+    }
     if (x4_pass) {
         HIP_TRY(a->g4st.ensure(n_reads * 4));
         bgr::BatchIO iox = io;
@@ -721,7 +743,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(mark(p->mode == BGR_MODE_GREEDY ? (fast_pass ? "bgr_align_greedy_kernel (listed reads)" : "bgr_align_greedy_kernel")
-                 : p->mode == BGR_MODE_ANCHORS ? "bgr_align_anchors_kernel"
+                 : p->mode == BGR_MODE_ANCHORS ? (a4_pass ? "bgr_align_anchors_kernel (listed reads)" : "bgr_align_anchors_kernel")
                  : deep_only ? "bgr_align_exhaustive_kernel (HBM stack)" : level_search ? "bgr_align_exhaustive_dp_kernel" : "bgr_align_exhaustive_kernel"));
     if (two_pass && !deep_only) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
         const uint32_t* pending = io.ovf_list;

@@ -127,63 +127,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #ifndef BGR_G4_OCC
 #define BGR_G4_OCC 8
 #endif
-#define G4_PATH 16
 
-
-// One extension step for up to four walks, one per 16-lane group.  `phase` (uniform within a group): 0 = the group sits
-// out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
-// behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
-// Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
-__device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t phase, uint32_t rec, uint32_t canon,
-                                            uint32_t pos, uint32_t budget, int lane, uint32_t* miss, uint32_t* ext_o, int32_t* sid_o) {
-    const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u;
-    const uint32_t left = phase == 1 ? 1u : 0u;
-    // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
-    const uint32_t useR = canon == left ? 1u : 0u;
-    uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
-    if (phase != 0 && rec != G4_REC_MASK) {
-        const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + useR * 4u + c) * 2;
-        sl = sp[0];
-        m0 = sp[1];
-    }
-    const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
-    const u64 zmask = __ballot(id == 0);  // (all lanes of a candidate agree; a group that sits out reads as "no candidate")
-    const uint32_t nb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
-    const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
-    const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
-    const uint32_t len = sl.y;
-    const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
-    const uint32_t ext = len - K1;
-    // left: `rl` bases of the read lie left of the overlap; right: behind it (first step) / from its start (later steps)
-    const uint32_t kk = phase == 2 ? K1 : 0u;
-    const uint32_t rl = left ? pos : L - pos - kk;
-    const uint32_t fits = ext >= rl ? 1u : 0u;
-    const uint32_t span = left ? ext : ext + K1 - kk;  // what is compared when the walk goes on: the unitig beyond the overlap, or all of it
-    uint32_t n = fits ? rl : (span < rl ? span : rl);  // (later right steps: read.substr(pos, |u|) is clipped at |read|)
-    const uint32_t ustart = left ? ext - n : kk;
-    const uint32_t rstart = left ? rl - n : pos + kk;
-    const uint32_t nrec = fwd == left ? m0.y : m0.z;
-    const uint32_t cbit = left ? (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND) : (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
-    if (c >= first_zero) n = 0;
-    uint32_t cnt = 0;
-    for (uint32_t b = q * 32; __any(b < n); b += 128)
-        if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
-    cnt += quad_xor1(cnt);
-    cnt += quad_xor2(cnt);
-    // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
-    uint32_t key = c < first_zero ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
-    uint32_t o = row_ror4(key);
-    key = o < key ? o : key;
-    o = row_ror8(key);
-    key = o < key ? o : key;
-    const uint32_t src = ((uint32_t)lane & 48u) | ((key & 3u) << 2);
-    const uint32_t pk = nrec | ((m0.x & cbit) ? G4_CANON : 0u) | (fits ? G4_FITS : 0u);
-    const uint32_t w1 = lane_get(pk, src);
-    *ext_o = lane_get(ext, src);
-    *sid_o = (int32_t)lane_get(fwd ? id : 0u - id, src);
-    *miss = key >> 2;
-    return (key >> 2) <= budget ? w1 | G4_FOUND : 0u;  // an empty record gives key 0xFFFFFFFF: not found
-}
 
 // A read the kernel cannot finish in this launch is listed with where to go on: which strand (the reference maps the
 // reverse complement once every forward anchor has failed, alignerGreedy.cpp:54), how many anchors of that strand have

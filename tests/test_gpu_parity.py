@@ -122,6 +122,34 @@ def test_anchors_mode_random_vs_oracle(k, L, m, e, seed):
     assert al.counters() == o.counters()
 
 
+@pytest.mark.parametrize("seed,k,L,m,e,nfrac", [(1, 31, 150, 2, 2, 0.0), (2, 21, 100, 3, 1, 0.002), (3, 32, 250, 5, 4, 0.0), (4, 12, 60, 1, 3, 0.0), (5, 31, 40, 0, 0, 0.0),
+                                                  (6, 9, 90, 2, 8, 0.0)])
+def test_anchors_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m, e, nfrac):
+    """-G maps with bgr_align_anchors4_kernel (four reads per wave) and leaves N reads and very long paths to the one-read-per-wave
+    kernel.  With and without the first pass, and the oracle, must agree row for row, counters included."""
+    s = Synth(120000, max(k + 5, 60), 2, k, 6100 + seed)
+    seqs, offs = s.unitigs()
+    n = 9003 - seed
+    reads, roffs = s.reads(0, n, L, m + 1, 6200 + seed)
+    if nfrac:
+        reads = _inject_n(reads, np.random.default_rng(seed), nfrac)
+    g = B.Graph.build(k, seqs, offs, anchors=True)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs, anchors=True)
+    p2, po2, st2 = o.align(reads, roffs, m=m, effort=e, mode=2)
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=e, mode=B.MODE_ANCHORS)
+    assert al.launch_info()["four_reads_per_wave"]
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    c1, c2 = al.counters(), o.counters()
+    c1["overlaps"] = c2["overlaps"] = 0
+    assert c1 == c2
+    al.set_knob(B.KNOB_ANCHORS_FAST, 1)
+    p3, po3, st3 = al.align(reads, roffs, m=m, effort=e, mode=B.MODE_ANCHORS)
+    assert not al.launch_info()["four_reads_per_wave"]
+    assert np.array_equal(st3, st2) and np.array_equal(po3, po2) and np.array_equal(p3, p2)
+
+
 def test_anchors_mode_needs_the_anchors_index():
     s = Synth(30000, 90, 2, 31, 3)
     seqs, offs = s.unitigs()
