@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC_OCC) bgr_align_anchors_kernel(Bg
 // the reverse complement).  Reads with an N, paths longer than G4_PATH ints per side and graphs with more than 16 active
 // BooPHF levels go to bgr_align_anchors_kernel (listed / not launched).
 #ifndef BGR_ANC4_OCC
-#define BGR_ANC4_OCC 4
+#define BGR_ANC4_OCC 5 /* 96 VGPRs: 632 Mreads/s; 4 (110 VGPRs): 574; 6 (80 VGPRs): 621 */
 #endif
 
 __device__ __forceinline__ u64 lane_get64(u64 v, uint32_t src) {
