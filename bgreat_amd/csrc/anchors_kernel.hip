@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
             off = io.read_offs[r];
             L = (uint32_t)(io.read_offs[r + 1] - off);
             fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
+            if (((L + 31) >> 5) >= W) fast = 0;                // so does a read too long for one lane per word
         }
         {
             u64 f = 0;

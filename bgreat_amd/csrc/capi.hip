@@ -583,18 +583,19 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // Greedy mode, first pass: four reads per wave (bgr_align_greedy4_kernel) when a read fits one lane per word and the graph
     // has no exception planes; what it does not settle is listed and mapped by the general kernel (cfg) right behind.
     bgr::LaunchCfg cfg_fast;
-    const bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && words <= 16 && !a->graph->header.has_exc &&
-                           geometry(8 * 8 * words, (n_reads + 3) / 4, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
+    const uint32_t wfast = std::min<uint32_t>(words, 16);  // the four-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
+    const bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
+                           geometry(8 * 8 * wfast, (n_reads + 3) / 4, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
     // Exhaustive mode, first pass: four reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
-    const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && words <= 16 && !a->graph->header.has_exc && p->max_mismatch < 0x7FFF &&
-                         geometry(4 * 8 * (words + 146), (n_reads + 3) / 4, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)));
+    const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && !a->graph->header.has_exc && p->max_mismatch < 0x7FFF &&
+                         geometry(4 * 8 * (wfast + 146), (n_reads + 3) / 4, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)));
     // Anchors mode, first pass: four reads per wave (bgr_align_anchors4_kernel); reads with an N and very long paths are listed
     // for the one-read-per-wave kernel.
     bgr::LaunchCfg cfg_a4;
-    const bool a4_pass = p->mode == BGR_MODE_ANCHORS && !a->knob_anc_fast && words <= 16 && !a->graph->header.has_exc && a->graph->header.anc_active_levels <= 16 &&
-                         geometry(8 * 8 * words, (n_reads + 3) / 4, true, false, cfg_a4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(6)));
+    const bool a4_pass = p->mode == BGR_MODE_ANCHORS && !a->knob_anc_fast && !a->graph->header.has_exc && a->graph->header.anc_active_levels <= 16 &&
+                         geometry(8 * 8 * wfast, (n_reads + 3) / 4, true, false, cfg_a4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(6)));
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
@@ -695,6 +696,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         for (int ps = 0; ps < kFastPasses; ++ps) {
             bgr::BatchIO iof = io;
             iof.greedy4 = 1;
+            iof.words_per_read = wfast;
             iof.g4_state = static_cast<uint32_t*>(a->g4st.p);
             iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
             iof.gen_ctr = 8;
@@ -717,6 +719,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         HIP_TRY(a->g4st.ensure(n_reads * 4));
         bgr::BatchIO ioa = io;
         ioa.anc4 = 1;
+        ioa.words_per_read = wfast;
         ioa.subset = nullptr;
         ioa.ovf_list = static_cast<uint32_t*>(a->g4st.p);
         ioa.ovf_ctr = 5;
@@ -730,6 +733,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         HIP_TRY(a->g4st.ensure(n_reads * 4));
         bgr::BatchIO iox = io;
         iox.exh4 = 1;
+        iox.words_per_read = wfast;
         iox.level_search = 0;
         iox.subset = nullptr;
         iox.ovf_list = static_cast<uint32_t*>(a->g4st.p);

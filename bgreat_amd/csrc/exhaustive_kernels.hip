@@ -643,6 +643,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
             L = (uint32_t)(io.read_offs[r + 1] - off);
             fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;
             if (L <= K1) fast = 0;  // (a read of k-1 bases or fewer: the general kernel)
+            if (((L + 31) >> 5) >= W) fast = 0;  // (or too long for one lane per word)
         }
         {
             u64 f = 0;

@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
-    const uint32_t W = io.words_per_read;  // <= 16 (checked by the host): one lane per word of a read
+    const uint32_t W = io.words_per_read;  // <= 16 (set by the host): one lane per word of a read
     const uint32_t K1 = g.k - 1;
     // later passes map the reads an earlier pass listed (count in cursor[subset_ctr]), from the state it left in g4_state
     const uint32_t total = LIST ? io.cursor[io.subset_ctr] : io.n_reads;
@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
             off = io.read_offs[r];
             L = (uint32_t)(io.read_offs[r + 1] - off);
             fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
+            if (((L + 31) >> 5) >= W) fast = 0;                // so does a read too long for one lane per word (a batch of mixed lengths)
         }
         uint32_t rc = st >> 31;
         uint32_t tried = (st >> G4_ST_TRIED_SHIFT) & 0x7FFu;

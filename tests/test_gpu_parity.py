@@ -520,6 +520,37 @@ def test_devices_init_on_one_gpu():
     assert np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2)   # the blob survived the in-place broadcast
 
 
+@pytest.mark.parametrize("mode,m", [(0, 2), (1, 3), (2, 2)])
+def test_batch_of_mixed_lengths_keeps_the_fast_pass(mode, m):
+    """A few long reads in a batch of short ones: the four-reads-per-wave kernels still take the short reads (one lane per
+    word: < 480 bases) and list the long ones for the one-read-per-wave kernels.  Rows equal the oracle's."""
+    k = 31
+    s = Synth(300000, 80, 2, k, 5100 + mode)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(k, seqs, offs, anchors=(mode == 2))
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs, anchors=(mode == 2))
+    short, soffs = s.reads(0, 6000, 150, m, 5200 + mode)
+    long_, loffs = s.reads(6000, 40, 2500, m, 5300 + mode)
+    # interleave: a long read after every 150 short ones
+    parts, lens = [], []
+    li = 0
+    for i in range(6000):
+        parts.append(short[i * 150:(i + 1) * 150]); lens.append(150)
+        if i % 150 == 149 and li < 40:
+            parts.append(long_[li * 2500:(li + 1) * 2500]); lens.append(2500); li += 1
+    reads = np.concatenate(parts)
+    roffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=2, mode=mode)
+    assert al.launch_info()["four_reads_per_wave"]
+    listed = al.pass_counts()
+    p2, po2, st2 = o.align(reads, roffs, m=m, effort=2, mode=mode)
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    if mode:
+        assert listed[2] >= li   # the long reads went on the list of the first pass
+
+
 def test_ragged_and_empty_batches():
     s = Synth(60000, 75, 2, 31, 77)
     seqs, offs = s.unitigs()
