@@ -78,6 +78,8 @@ def parse_args():
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end leg per GPU (0 disables)")
     ap.add_argument("--pcie-steps", type=int, default=3, help="timed bgr_align_batch calls of the PCIe-inclusive leg (0 disables)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--debug-stop", type=int, default=0, help="diagnostic builds of the library only (-DBGR_PHASE_TIMING, loaded through BGR_LIB_PATH): "
+                                                              "1 = the mapping kernel stops behind the staging of the reads, 2 = behind the anchor scan")
     args = ap.parse_args()
     presets = {  # SURVEY.md 8d synthetic inputs; explicit flags given on the command line win over the preset
         "small": dict(genome=250_000, site_spacing=75, alleles=2, read_len=100, reads_per_step=1_000_000),
@@ -106,7 +108,8 @@ def run_pmc_passes(args):
     fwd = ["--pmc-child", "--steps", str(args.pmc_steps), "--warmup", "0", "--workload", args.workload, "--reads-per-step", str(args.reads_per_step),
            "--read-len", str(args.read_len), "--k", str(args.k), "--mismatch", str(args.mismatch), "--effort", str(args.effort),
            "--genome", str(args.genome), "--site-spacing", str(args.site_spacing), "--alleles", str(args.alleles), "--lds-mphf", str(args.lds_mphf),
-           "--waves", str(args.waves), "--blocks-per-cu", str(args.blocks_per_cu), "--gamma", str(args.gamma), "--cpu-threads", str(args.cpu_threads)]
+           "--waves", str(args.waves), "--blocks-per-cu", str(args.blocks_per_cu), "--gamma", str(args.gamma), "--cpu-threads", str(args.cpu_threads),
+           "--debug-stop", str(args.debug_stop)]
     for flag in ("exhaustive", "anchors", "general_kernel_only"):
         if getattr(args, flag):
             fwd.append("--" + flag.replace("_", "-"))
@@ -203,6 +206,8 @@ def main():
     al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
     if args.general_kernel_only:
         al.set_knob(B.KNOB_GREEDY_FAST, 1)
+    if args.debug_stop:
+        al.set_knob(B.KNOB_DEBUG_STOP, args.debug_stop)
     if rank == 0:
         log("graph: %s  (%.1fs)" % (graph_info, time.time() - t0))
 

@@ -213,6 +213,9 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
             uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
             for (uint32_t q = 0; q < 4; ++q) {
                 if (!rl32(act, (int)(16 * q))) continue;
+#ifdef BGR_PHASE_TIMING
+                if (prm.debug_stop == 1) continue;  // 1 = stops behind the staging of the reads
+#endif
                 const uint32_t Lq = rl32(L, (int)(16 * q));
                 const u64* A = RD + q * (2 * W) + (rl32(rc, (int)(16 * q)) ? W : 0);
                 const uint32_t left_q = eff - rl32(tried, (int)(16 * q));  // anchors this strand may still try (>= 1)
@@ -246,6 +249,9 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
             // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast; a group whose anchor fails
             // starts over from the next one, if the scan has seen it, while the others go on ----
             uint32_t phase = (act && a_rec != BGR_NONE) ? 1u : 0u;
+#ifdef BGR_PHASE_TIMING  /* diagnostic builds (tools/phase_cost.sh): knob DEBUG_STOP = 2 stops behind the anchor scan */
+            if (prm.debug_stop == 2) phase = 0;
+#endif
             uint32_t pos = a_pos, rec = a_rec & G4_REC_MASK, canon = (a_rec >> 28) & 1u, budget = m;
             uint32_t bad = 0, failed = 0;
             if (act) { nl = 0; nr = 0; }

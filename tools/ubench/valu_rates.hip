@@ -65,6 +65,26 @@ __global__ void __launch_bounds__(256) k(uint64_t* out, uint32_t seed) {
         if (OP == 17) BODYSALU;
         if (OP == 18) BODY32_3("v_bfe_u32");
         if (OP == 19) BODY32_3("v_add3_u32");
+        if (OP == 20) BODY32("v_and_b32");
+        if (OP == 21) BODY32("v_or_b32");
+        if (OP == 22) BODY32("v_sub_u32");
+        if (OP == 23) BODY32_1("v_mov_b32");
+        if (OP == 24) BODY32_1("v_not_b32");
+        if (OP == 25) BODY32("v_lshrrev_b32");
+        if (OP == 26) BODY32("v_cndmask_b32");   // (e32: vcc implicit)
+        if (OP == 30) asm volatile(R4("v_cndmask_b32_e64 %0, %8, %0, s[20:21]\n v_cndmask_b32_e64 %1, %8, %1, s[20:21]\n v_cndmask_b32_e64 %2, %8, %2, s[20:21]\n v_cndmask_b32_e64 %3, %8, %3, s[20:21]\n"
+                                     "v_cndmask_b32_e64 %4, %8, %4, s[20:21]\n v_cndmask_b32_e64 %5, %8, %5, s[20:21]\n v_cndmask_b32_e64 %6, %8, %6, s[20:21]\n v_cndmask_b32_e64 %7, %8, %7, s[20:21]\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(s) : "s20", "s21");
+        if (OP == 31) asm volatile(R4("v_cmp_lt_u32 vcc, %8, %0\n v_cmp_lt_u32 vcc, %8, %1\n v_cmp_lt_u32 vcc, %8, %2\n v_cmp_lt_u32 vcc, %8, %3\n"
+                                     "v_cmp_lt_u32 vcc, %8, %4\n v_cmp_lt_u32 vcc, %8, %5\n v_cmp_lt_u32 vcc, %8, %6\n v_cmp_lt_u32 vcc, %8, %7\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(s) : "vcc");
+        if (OP == 32) asm volatile(R4("v_cmp_lt_u32 vcc, %8, %0\n v_cndmask_b32 %0, %8, %0, vcc\n v_cmp_lt_u32 vcc, %8, %1\n v_cndmask_b32 %1, %8, %1, vcc\n"
+                                     "v_cmp_lt_u32 vcc, %8, %2\n v_cndmask_b32 %2, %8, %2, vcc\n v_cmp_lt_u32 vcc, %8, %3\n v_cndmask_b32 %3, %8, %3, vcc\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "v"(s), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+        if (OP == 33) BODY32("v_lshlrev_b32");
+        if (OP == 27) BODY32("v_max_u32");
+        if (OP == 28) BODY32("v_subrev_u32");
+        if (OP == 29) BODY32("v_ashrrev_i32");
     }
     uint64_t x = 0;
     for (int i = 0; i < 8; ++i) x ^= a[i] ^ b[i];
@@ -97,7 +117,20 @@ int main() {
     printf("columns: waves resident per SIMD (w1 = one wave alone)\n");
     run<0>("v_add_u32", d);
     run<1>("v_xor_b32", d);
+    run<20>("v_and_b32", d);
+    run<21>("v_or_b32", d);
+    run<22>("v_sub_u32", d);
+    run<28>("v_subrev_u32", d);
+    run<23>("v_mov_b32", d);
+    run<24>("v_not_b32", d);
+    run<26>("v_cndmask e32 vcc", d);
+    run<30>("v_cndmask e64 sgpr", d);
+    run<31>("v_cmp_lt_u32", d);
+    run<32>("cmp+cndmask pairs", d);
     run<2>("v_lshlrev_b32", d);
+    run<25>("v_lshrrev_b32", d);
+    run<29>("v_ashrrev_i32", d);
+    run<27>("v_max_u32", d);
     run<14>("v_min_u32", d);
     run<3>("v_lshl_or_b32", d);
     run<15>("v_and_or_b32", d);
