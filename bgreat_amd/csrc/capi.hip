@@ -195,9 +195,9 @@ int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* o) {
     if (!g || !o) return fail(BGR_E_ARG, "bgr_graph_info: null argument");
     const BgrBlobHeader& h = g->header;
     memset(o, 0, sizeof(*o));
-    o->k = h.k; o->n_levels = h.n_levels; o->n_unitigs = h.n_unitigs; o->n_keys = h.n_keys;
+    o->k = h.k; o->n_levels = 2; o->n_unitigs = h.n_unitigs; o->n_keys = h.n_placed + h.n_fallback;
     o->n_left_keys = h.n_left_keys; o->n_right_keys = h.n_right_keys; o->n_fallback = h.n_fallback;
-    o->total_bases = h.total_bases; o->blob_bytes = h.blob_bytes; o->mphf_bytes = h.n_units * 16;
+    o->total_bases = h.total_bases; o->blob_bytes = h.blob_bytes; o->mphf_bytes = h.n_buckets * 4;
     o->max_unitig_len = h.max_unitig_len; o->has_exceptions = h.has_exc; o->has_anchors = h.anc_n ? 1 : 0; o->gamma = h.gamma;
     return BGR_OK;
 }
@@ -494,7 +494,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
                                                       level_search ? level_cap : kExhFrameCap);
     bool two_pass = exhaustive && (frames < frames_deep || level_search);  // the level search can also overflow on a wide level
     const size_t lds_cu = a->lds_per_cu;
-    const uint32_t mphf_bytes = a->dg.units_bytes;
+    const uint32_t mphf_bytes = a->dg.table_bytes;
     // Resident waves per CU are bounded by registers (bgr::resident_waves_per_cu); LDS decides how they are grouped:
     // `b` workgroups per CU of `w` waves each, every staged workgroup holding its own copy of the MPHF cascade.
     // More resident waves hide more of the walk's dependent-load latency (measured 16 -> 24 waves/CU: +18 %), and a
@@ -506,7 +506,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         uint32_t waves = 0, bpc = 0;
         bool stage = false;
         auto fits = [&](uint32_t b, uint32_t w, bool st) {
-            return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 7) / 8) * 8 : 0) + (uint64_t)w * pw) <= lds_fit;
+            return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 15) / 16) * 16 : 0) + (uint64_t)w * pw) <= lds_fit;
         };
         if (allow_tuning && (a->cfg_waves || a->cfg_blocks_per_cu)) {  // explicit tuning through bgr_aligner_configure
             stage = allow_stage && p->mode != BGR_MODE_ANCHORS && (a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true)));
@@ -517,7 +517,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
         } else {
             uint32_t best_res = 0;
-            if (allow_stage && a->cfg_lds_mphf != 1 && p->mode != BGR_MODE_ANCHORS && a->graph->header.n_units * 16 < 0xFFFFFFFFull) {
+            if (allow_stage && a->cfg_lds_mphf != 1 && p->mode != BGR_MODE_ANCHORS && a->graph->header.n_buckets * 4 < 0xFFFFFFFFull) {
                 const uint32_t bs[] = {1, 2, 3, 4, 6};
                 for (uint32_t b : bs) {
                     uint32_t w = std::min<uint32_t>(16, cap / b);
@@ -547,7 +547,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             if (best_res == 0) waves = 0;
         }
         if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return false;
-        cfg.lds_bytes = kLdsFixed + (stage ? ((mphf_bytes + 7) / 8) * 8 : 0) + waves * pw;
+        cfg.lds_bytes = kLdsFixed + (stage ? ((mphf_bytes + 15) / 16) * 16 : 0) + waves * pw;
         cfg.blocks = (uint32_t)std::min<uint64_t>((n_items + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
         cfg.waves_per_block = waves;
         cfg.stage_mphf = stage ? 1 : 0;

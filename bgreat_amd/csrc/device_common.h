@@ -78,69 +78,34 @@ __device__ __forceinline__ u64 rev2_fast(u64 x) {
 }
 __device__ __forceinline__ u64 rcb_fast(u64 x, uint32_t n) { return (~rev2_fast(x)) >> (64 - 2 * n); }
 
-// MPHF cascade walk for one key per lane (graph_layout.h: 2-bit position states).  Returns the minimal index
-// or BGR_NONE; the caller compares keys[idx].  Straight-line body, wave-uniform trip count: the loop runs
-// until no lane is still on a "several keys here" position -- about 2-3 levels at gamma 2, because a lane
-// that lands on an empty position (most read positions are not overlaps) is rejected at once.
-// LV = level descriptors {units, base} staged in LDS.
-// SPEC (cascade in L2/HBM, not staged in LDS): the state word of level l+1 is requested together with level l's -- its
-// address needs only the hash (double hashing), not level l's answer -- so two dependent-looking loads are in flight
-// at once; lanes that stop on level l simply drop it.
-template <bool SPEC, typename UP>
-__device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
-    u64 m = bgr_mix64(key);
-    uint32_t hl = (uint32_t)m;
-    const uint32_t hb = (uint32_t)(m >> 32) | 1u;
-    const uint32_t nl = g.n_levels;
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
+// Key table lookup for one key per lane (graph_layout.h): the slot of `key` -- its index into keys[] and recs[] -- or
+// BGR_NONE when the key is no overlap of the graph (the membership test of aligner.cpp:158,219,353,361).  Both buckets are
+// read at once (two independent dword loads, from LDS when the table is staged there, else from L2/HBM); a byte that
+// equals the fingerprint is confirmed against keys[].  Most read positions are no overlaps and match no byte, so the loop
+// below usually runs once per call for the wave's few candidates (members and ~3 % false matches).
+template <typename TP>
+__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u64 key, bool active) {
+    const u64 m = bgr_mix64(key);
+    const uint32_t b1 = __umulhi((uint32_t)m, g.n_buckets), b2 = __umulhi((uint32_t)(m >> 32), g.n_buckets);
+    uint32_t w1 = 0, w2 = 0;
+    if (active) { w1 = tab[b1]; w2 = tab[b2]; }
+    const uint32_t f4 = bgr_tab_fp(m) * 0x01010101u;  // (an empty slot is 0 and the fingerprint is not: lanes that sit out match nothing)
+    uint32_t c1 = bgr_zero_bytes(w1 ^ f4), c2 = b2 != b1 ? bgr_zero_bytes(w2 ^ f4) : 0u;
     uint32_t res = BGR_NONE;
-    if (SPEC) {
-        // cascade in L2/HBM: one 16-byte unit per level answers membership candidate AND minimal index, the next level's unit
-        // requested ahead (a second dependent access for the rank would cost a full L2 round trip: measured 7.98 -> 9.63 ms)
-        uint4 qn = make_uint4(0, 0, 0, 0);
-        if (active && nl) { const uint2 lv = LV[0]; qn = reinterpret_cast<const uint4*>(units)[lv.y + __umulhi(hl, lv.x)]; }
-        for (uint32_t l = 0; l < nl; ++l) {
-            if (!__any(active)) break;
-            const uint4 q = qn;
-            if (active && l + 1 < nl) { const uint2 lv1 = LV[l + 1]; qn = reinterpret_cast<const uint4*>(units)[lv1.y + __umulhi(hl + hb, lv1.x)]; }
-            const uint32_t p = bgr_level_pos(hl);
-            const uint32_t wi = p >> 4, sh = (p & 15) * 2;
-            const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
-            const uint32_t st = (w >> sh) & 3u;
-            uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
-            r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
-            r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
-            if (active && st == 1u) res = r;
-            active = active && st == 3u;
-            hl += hb;
-        }
-    } else {
-        // cascade in LDS: per level only the state word that holds the position is read (a dword: a quarter of the unit); the
-        // position where the walk ends on state 1 is remembered (unit << 6 | position) and its rank worked out once, behind
-        // the loop (4.49 -> 4.09 ms per 5 M reads: the loop body halves)
-        uint32_t hit = BGR_NONE;
-        for (uint32_t l = 0; l < nl; ++l) {
-            if (!__any(active)) break;
-            const uint2 lv = LV[l];
-            const uint32_t u = lv.y + __umulhi(hl, lv.x);
-            const uint32_t p = bgr_level_pos(hl);
-            const uint32_t w = units[(size_t)u * 4 + (p >> 4)];
-            const uint32_t st = (w >> ((p & 15) * 2)) & 3u;
-            if (active && st == 1u) hit = u << 6 | p;
-            active = active && st == 3u;
-            hl += hb;
-        }
-        if (hit != BGR_NONE) {  // minimal index = rank of the position among the placed ones: the unit's running rank + the placed states before it
-            const uint4 q = reinterpret_cast<const uint4*>(units)[hit >> 6];
-            const uint32_t p = hit & 63u, wi = p >> 4, sh = (p & 15) * 2;
-            const uint32_t w = wi == 0 ? q.x : (wi == 1 ? q.y : q.z);
-            uint32_t r = q.w + __popc(bgr_unique_mask(w) & ((1u << sh) - 1u));
-            r += wi >= 1 ? __popc(bgr_unique_mask(q.x)) : 0;
-            r += wi >= 2 ? __popc(bgr_unique_mask(q.y)) : 0;
-            res = r;
+    while (wave_any((c1 | c2) != 0)) {
+        if (c1 | c2) {
+            const bool first = c1 != 0;
+            const uint32_t c = first ? c1 : c2;
+            const uint32_t idx = (first ? b1 : b2) * 4 + ((uint32_t)(__ffs((int)c) - 1) >> 3);
+            if (g.keys[idx] == key) { res = idx; c1 = 0; c2 = 0; }
+            else if (first) c1 &= c1 - 1;
+            else c2 &= c2 - 1;
         }
     }
-    if ((g.flags & BGR_GF_HAS_FALLBACK) && __any(active)) {
-        if (active) {  // bisection in the (tiny) sorted fallback list; its location comes from the blob header
+    if ((g.flags & BGR_GF_HAS_FALLBACK) && wave_any(active && res == BGR_NONE)) {
+        if (active && res == BGR_NONE) {  // bisection in the (tiny) sorted fallback list; its location comes from the blob header
             const uint32_t nfb = (uint32_t)g.hdr->n_fallback;
             const u64* fb = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(g.hdr) + g.hdr->off_fallback);
             uint32_t lo = 0, hi = nfb;
@@ -148,17 +113,10 @@ __device__ __forceinline__ uint32_t mphf_lookup(const BgrDeviceGraph& g, const u
                 uint32_t mid = (lo + hi) >> 1;
                 if (fb[mid] < key) lo = mid + 1; else hi = mid;
             }
-            if (lo < nfb && fb[lo] == key) res = (uint32_t)g.hdr->n_placed + lo;
+            if (lo < nfb && fb[lo] == key) res = 4u * g.n_buckets + lo;
         }
     }
     return res;
-}
-// membership: MPHF index of key if key is an overlap of the graph, else BGR_NONE (aligner.cpp:158,219,353,361)
-template <bool SPEC, typename UP>
-__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, const uint2* LV, UP units, u64 key, bool active) {
-    uint32_t idx = mphf_lookup<SPEC>(g, LV, units, key, active);
-    if (idx != BGR_NONE && g.keys[idx] != key) idx = BGR_NONE;
-    return idx;
 }
 
 // ---- stage A: the read's 2-bit words, from the planes the pre-pass (bgr_pack_reads_kernel) or the host packer wrote ----
@@ -584,21 +542,18 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
 
 // ================================================ kernels ===============================================
 template <bool STAGE>
-__device__ __forceinline__ const uint32_t* block_prologue(const BgrDeviceGraph& g, u64* lds, uint2** LVout, uint32_t* mphf_words) {
-    // LDS: [level descriptors 512 B][optional MPHF copy][per-wave regions]
-    uint2* LV = reinterpret_cast<uint2*>(lds);
-    if (threadIdx.x < BGR_MAX_LEVELS) LV[threadIdx.x] = make_uint2(g.hdr->levels[threadIdx.x].units, g.hdr->levels[threadIdx.x].base);
-    *mphf_words = STAGE ? (g.units_bytes + 7) / 8 : 0;
-    const uint32_t* units = g.units;
+__device__ __forceinline__ const uint32_t* block_prologue(const BgrDeviceGraph& g, u64* lds, uint32_t* tab_words) {
+    // LDS: [512 B reserved][optional copy of the key table, rounded up to 16 B][per-wave regions]
+    *tab_words = STAGE ? ((g.table_bytes + 15) / 16) * 2 : 0;
+    const uint32_t* table = g.table;
     if (STAGE) {
-        const uint4* src = reinterpret_cast<const uint4*>(g.units);
+        const uint4* src = reinterpret_cast<const uint4*>(g.table);  // (the blob keeps 16 spare bytes behind the table)
         uint4* dst = reinterpret_cast<uint4*>(lds + 64);
-        for (uint32_t i = threadIdx.x; i < g.units_bytes / 16; i += blockDim.x) dst[i] = src[i];
-        units = reinterpret_cast<const uint32_t*>(lds + 64);
+        for (uint32_t i = threadIdx.x; i < (g.table_bytes + 15) / 16; i += blockDim.x) dst[i] = src[i];
+        table = reinterpret_cast<const uint32_t*>(lds + 64);
     }
     __syncthreads();
-    *LVout = LV;
-    return units;
+    return table;
 }
 
 // Arena space comes in per-wave chunks: ONE global atomic per ~50 reads instead of one per read (a

@@ -55,76 +55,59 @@ inline uint64_t window(const uint64_t* seq, uint64_t pos, uint32_t n) {  // n in
 }
 inline uint64_t align256(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
 
-struct Cascade {
-    std::vector<BgrLevel> levels;
-    std::vector<uint32_t> units;  // 4 u32 per unit
-    std::vector<uint64_t> fallback;
+struct KeyTable {
+    std::vector<uint32_t> buckets;   // 4 one-byte fingerprints per dword, 0 = empty
+    std::vector<uint32_t> who;       // per slot: which key (index into the sorted key list) lives there, BGR_NONE = empty
+    std::vector<uint64_t> fallback;  // keys that found no slot, sorted
     uint64_t n_placed = 0;
 };
 
-// BBHash-style cascade over `keys` (sorted, unique) with 2-bit position states (graph_layout.h).  Level l
-// places every remaining key that is alone on its position (state 1); positions hit by several keys get
-// state 3 and those keys move on.  What is left after the last level (or once only a handful remain) goes
-// to a sorted fallback list searched by bisection.
-void build_cascade(const std::vector<uint64_t>& keys, double gamma, unsigned T, Cascade& c) {
-    struct Rem { uint64_t key; uint32_t h, hb; };
-    std::vector<Rem> rem(keys.size()), next;
-    parallel_ranges(T, keys.size(), [&](uint64_t b, uint64_t e, unsigned) {
-        for (uint64_t i = b; i < e; ++i) {
-            uint64_t m = bgr_mix64(keys[i]);
-            rem[i] = {keys[i], (uint32_t)m, (uint32_t)(m >> 32) | 1u};
-        }
+// Two-choice bucketed table over `keys` (sorted, unique), graph_layout.h: a key lives in one of the four slots of
+// bucket 1 or bucket 2 of its hash; when both are full a resident is evicted to its other bucket (random walk, at most
+// kMaxKicks moves).  Keys are inserted in sorted order by one thread with a fixed pseudo-random sequence, so the table
+// -- and with it every index in the blob -- does not depend on the thread count.
+void build_key_table(const std::vector<uint64_t>& keys, double slots_per_key, unsigned T, KeyTable& t) {
+    const uint64_t n = keys.size();
+    const uint32_t nb = (uint32_t)std::max<uint64_t>(1, (uint64_t)std::ceil(slots_per_key * (double)n / 4.0));
+    t.buckets.assign(nb, 0);
+    std::vector<uint64_t> mix(n);
+    parallel_ranges(T, n, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; ++i) mix[i] = bgr_mix64(keys[i]);
     });
-    uint32_t base = 0;
-    std::vector<std::vector<Rem>> part(T);
-    for (int l = 0; l < BGR_MAX_LEVELS && !rem.empty(); ++l) {
-        if (l > 0 && rem.size() <= 4) break;  // a handful left: cheaper in the fallback list than more levels
-        uint64_t want = (uint64_t)std::ceil(gamma * (double)rem.size() / BGR_UNIT_POS);
-        uint32_t nu = (uint32_t)std::max<uint64_t>(1, want);
-        size_t ubase = c.units.size();
-        c.units.resize(ubase + (size_t)nu * 4, 0);
-        uint32_t* U = c.units.data() + ubase;
-        unsigned Tl = rem.size() < 4096 ? 1 : T;
-        parallel_ranges(Tl, rem.size(), [&](uint64_t b, uint64_t e, unsigned) {  // 0 -> 1 -> 3, any order
-            for (uint64_t i = b; i < e; ++i) {
-                const Rem& r = rem[i];
-                uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
-                uint32_t* w = &U[(size_t)u * 4 + (p >> 4)];
-                uint32_t sh = 2 * (p & 15);
-                uint32_t old = __atomic_fetch_or(w, 1u << sh, __ATOMIC_RELAXED);
-                if ((old >> sh) & 1u) __atomic_fetch_or(w, 2u << sh, __ATOMIC_RELAXED);
-            }
-        });
-        std::vector<uint64_t> placed(Tl, 0);
-        parallel_ranges(Tl, rem.size(), [&](uint64_t b, uint64_t e, unsigned t) {
-            std::vector<Rem>& out = part[t];
-            out.clear();
-            uint64_t np = 0;
-            for (uint64_t i = b; i < e; ++i) {
-                const Rem& r = rem[i];
-                uint32_t u = bgr_level_unit(r.h, nu), p = bgr_level_pos(r.h);
-                uint32_t st = (U[(size_t)u * 4 + (p >> 4)] >> (2 * (p & 15))) & 3u;
-                if (st == 3u) out.push_back({r.key, r.h + r.hb, r.hb}); else ++np;
-            }
-            placed[t] = np;
-        });
-        next.clear();
-        for (unsigned t = 0; t < Tl; ++t) {
-            next.insert(next.end(), part[t].begin(), part[t].end());
-            c.n_placed += placed[t];
+    std::vector<uint32_t>& who = t.who;
+    who.assign((size_t)nb * 4, BGR_NONE);
+    uint8_t* fp = reinterpret_cast<uint8_t*>(t.buckets.data());
+    auto try_place = [&](uint32_t bucket, uint32_t i) {
+        for (uint32_t s = 0; s < 4; ++s) {
+            const size_t slot = (size_t)bucket * 4 + s;
+            if (!fp[slot]) { fp[slot] = (uint8_t)bgr_tab_fp(mix[i]); who[slot] = i; return true; }
         }
-        c.levels.push_back({nu, base});
-        base += nu;
-        rem.swap(next);
+        return false;
+    };
+    const int kMaxKicks = 4000;
+    uint64_t rng = 0x9E3779B97F4A7C15ULL;
+    for (uint64_t i0 = 0; i0 < n; ++i0) {
+        uint32_t cur = (uint32_t)i0;
+        uint32_t from = BGR_NONE;  // the bucket `cur` was just evicted from
+        bool done = false;
+        for (int kick = 0; kick <= kMaxKicks; ++kick) {
+            const uint32_t b1 = bgr_tab_bucket((uint32_t)mix[cur], nb), b2 = bgr_tab_bucket((uint32_t)(mix[cur] >> 32), nb);
+            if (try_place(b1, cur) || (b2 != b1 && try_place(b2, cur))) { done = true; break; }
+            if (kick == kMaxKicks) break;
+            rng = rng * 6364136223846793005ULL + 1442695040888963407ULL;
+            uint32_t vb = (rng >> 33) & 1u ? b1 : b2;
+            if (vb == from && b1 != b2) vb = vb == b1 ? b2 : b1;  // do not walk straight back
+            const size_t slot = (size_t)vb * 4 + ((rng >> 40) & 3u);
+            const uint32_t victim = who[slot];
+            fp[slot] = (uint8_t)bgr_tab_fp(mix[cur]);
+            who[slot] = cur;
+            cur = victim;
+            from = vb;
+        }
+        if (!done) t.fallback.push_back(keys[cur]);
     }
-    for (const Rem& r : rem) c.fallback.push_back(r.key);
-    std::sort(c.fallback.begin(), c.fallback.end());
-    // rank of every unit = placed keys in all units before it (over all levels)
-    uint32_t run = 0;
-    for (size_t u = 0; u < c.units.size() / 4; ++u) {
-        c.units[u * 4 + 3] = run;
-        for (int w = 0; w < 3; ++w) run += __builtin_popcount(bgr_unique_mask(c.units[u * 4 + w]));
-    }
+    std::sort(t.fallback.begin(), t.fallback.end());
+    t.n_placed = n - t.fallback.size();
 }
 
 inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m) {  // aligner.cpp:481-489: first free of 1..3, else overwrite 4
@@ -144,26 +127,24 @@ inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m) {  // al
 }  // namespace
 
 uint32_t host_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key) {
-    const uint32_t* units = reinterpret_cast<const uint32_t*>(base + h->off_units);
-    uint64_t m = bgr_mix64(key);
-    uint32_t hl = (uint32_t)m, hb = (uint32_t)(m >> 32) | 1u;
-    for (uint32_t l = 0; l < h->n_levels; ++l, hl += hb) {
-        uint32_t u = h->levels[l].base + bgr_level_unit(hl, h->levels[l].units), p = bgr_level_pos(hl);
-        const uint32_t* q = units + (size_t)u * 4;
-        uint32_t sh = 2 * (p & 15), st = (q[p >> 4] >> sh) & 3u;
-        if (st == 0) return BGR_NONE;  // no key hashes here
-        if (st == 1) {
-            uint32_t r = q[3];
-            for (uint32_t w = 0; w < (p >> 4); ++w) r += __builtin_popcount(bgr_unique_mask(q[w]));
-            r += __builtin_popcount(bgr_unique_mask(q[p >> 4]) & ((1u << sh) - 1u));
-            return r;
+    const uint32_t* table = reinterpret_cast<const uint32_t*>(base + h->off_table);
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(base + h->off_keys);
+    const uint32_t nb = (uint32_t)h->n_buckets;
+    const uint64_t m = bgr_mix64(key);
+    const uint32_t bk[2] = {bgr_tab_bucket((uint32_t)m, nb), bgr_tab_bucket((uint32_t)(m >> 32), nb)};
+    const uint32_t f4 = bgr_tab_fp(m) * 0x01010101u;
+    for (int c = 0; c < 2; ++c) {
+        if (c == 1 && bk[1] == bk[0]) break;
+        for (uint32_t z = bgr_zero_bytes(table[bk[c]] ^ f4); z; z &= z - 1) {
+            const uint32_t idx = bk[c] * 4 + ((uint32_t)__builtin_ctz(z) >> 3);
+            if (keys[idx] == key) return idx;
         }
     }
     if (h->n_fallback) {
         const uint64_t* fb = reinterpret_cast<const uint64_t*>(base + h->off_fallback);
         const uint64_t* e = fb + h->n_fallback;
         const uint64_t* it = std::lower_bound(fb, e, key);
-        if (it != e && *it == key) return (uint32_t)(h->n_placed + (it - fb));
+        if (it != e && *it == key) return (uint32_t)(4 * h->n_buckets + (it - fb));
     }
     return BGR_NONE;
 }
@@ -171,16 +152,16 @@ uint32_t host_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key) 
 void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGraph& dg) {
     const uint8_t* base = static_cast<const uint8_t*>(basev);
     memset(&dg, 0, sizeof(dg));
-    dg.units = reinterpret_cast<const uint32_t*>(base + h->off_units);
+    dg.table = reinterpret_cast<const uint32_t*>(base + h->off_table);
     dg.keys = reinterpret_cast<const uint64_t*>(base + h->off_keys);
     dg.recs = reinterpret_cast<const BgrSlot*>(base + h->off_recs);
     dg.meta = reinterpret_cast<const BgrUnitigMeta*>(base + h->off_meta);
     dg.seq = reinterpret_cast<const uint64_t*>(base + h->off_seq);
     dg.hdr = reinterpret_cast<const BgrBlobHeader*>(base);
     dg.k = h->k;
-    dg.n_levels = h->n_levels;
+    dg.n_buckets = (uint32_t)h->n_buckets;
     dg.flags = (h->has_exc ? BGR_GF_HAS_EXC : 0u) | (h->n_fallback ? BGR_GF_HAS_FALLBACK : 0u);
-    dg.units_bytes = (uint32_t)(h->n_units * 16);
+    dg.table_bytes = (uint32_t)(h->n_buckets * 4);
 }
 
 // Everything the kernels later trust about a blob can be checked on its header alone (section extents, level table):
@@ -190,29 +171,22 @@ bool validate_blob_header(const BgrBlobHeader* h, uint64_t bytes, std::string& e
     if (bytes < sizeof(BgrBlobHeader)) { err = "blob smaller than its header"; return false; }
     if (h->magic != BGR_MAGIC || h->version != BGR_BLOB_VERSION) { err = "not a bgreat graph blob (magic/version)"; return false; }
     if (h->blob_bytes != bytes) { err = "blob size does not match its header"; return false; }
-    if (h->n_levels > BGR_MAX_LEVELS || h->k < 2 || h->k > 32) { err = "corrupt blob header"; return false; }
+    if (h->k < 2 || h->k > 32) { err = "corrupt blob header"; return false; }
     // off + count * size <= bytes without overflow; sections start behind the header, 256-byte aligned
     auto inside = [&](uint64_t off, uint64_t count, uint64_t size) {
         if (off < sizeof(BgrBlobHeader) || off > bytes || (off & 255u)) return false;
         return count <= (bytes - off) / size;
     };
-    if (h->n_keys >= 0x0FFFFFFFull || h->n_unitigs > 0x40000000ull || h->n_units >= (1ull << 26)) { err = "corrupt blob header (counts)"; return false; }
-    if (!inside(h->off_units, h->n_units, 16) || !inside(h->off_keys, h->n_keys, 8) || !inside(h->off_recs, h->n_keys, sizeof(BgrSlot) * 8) ||
+    if (h->n_keys >= 0x0FFFFFFFull || h->n_unitigs > 0x40000000ull || h->n_buckets == 0 || h->n_buckets >= (1ull << 26)) { err = "corrupt blob header (counts)"; return false; }
+    if (!inside(h->off_table, h->n_buckets, 4) || !inside(h->off_keys, h->n_keys, 8) || !inside(h->off_recs, h->n_keys, sizeof(BgrSlot) * 8) ||
         !inside(h->off_meta, h->n_unitigs + 1, sizeof(BgrUnitigMeta)) || !inside(h->off_seq, h->seq_words, 8)) { err = "blob section outside the blob"; return false; }
     if (h->n_fallback && !inside(h->off_fallback, h->n_fallback, 8)) { err = "blob section outside the blob"; return false; }
-    if (h->n_placed > h->n_keys || h->n_fallback > h->n_keys || h->n_placed + h->n_fallback != h->n_keys) { err = "corrupt blob header (key counts)"; return false; }
+    if (h->n_keys != 4 * h->n_buckets + h->n_fallback || h->n_placed > 4 * h->n_buckets) { err = "corrupt blob header (key counts)"; return false; }
     if (h->seq_words < 2 || h->total_bases > (h->seq_words - 2) * 32 || h->seq_words * 8 >= (1ull << 32)) { err = "corrupt blob header (sequence store)"; return false; }
     if (h->has_exc) {  // one bit per base, read 64 bits at a time one word past the addressed one
         const uint64_t plane_words = (h->total_bases + 63) / 64 + 2;
         if (!inside(h->off_exc, plane_words, 8) || !inside(h->off_excn, plane_words, 8)) { err = "blob exception planes outside the blob"; return false; }
     }
-    uint64_t units = 0;
-    for (uint32_t i = 0; i < h->n_levels; ++i) {  // levels tile the unit array in order
-        const BgrLevel& lv = h->levels[i];
-        if (lv.units == 0 || lv.base != units || lv.units > h->n_units - units) { err = "corrupt MPHF level table"; return false; }
-        units += lv.units;
-    }
-    if (units != h->n_units) { err = "corrupt MPHF level table"; return false; }
     if (h->anc_n) {
         if (!inside(h->off_anc_bits, h->anc_words, 8) || !inside(h->off_anc_ranks, h->anc_rank_words, 8) ||
             (h->anc_n_final && !inside(h->off_anc_final, h->anc_n_final, 16)) || !inside(h->off_anc_pos, h->anc_n, 8)) { err = "blob section outside the blob"; return false; }
@@ -291,7 +265,7 @@ bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& s
 
 bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* offs, double gamma, uint32_t flags, HostGraph& out, std::string& err) {
     if (k < 2 || k > 32) { err = "k must be in [2,32] (kmer is uint64_t, utils.h:27)"; return false; }
-    if (gamma != 0.0 && !(gamma >= 0.5 && gamma <= 64.0)) { err = "gamma must be in [0.5,64] (0 = choose)"; return false; }
+    if (gamma != 0.0 && !(gamma >= 1.03 && gamma <= 64.0)) { err = "gamma (key table slots per key) must be in [1.03,64] (0 = choose)"; return false; }
     const uint32_t K1 = k - 1;
     // aligner.cpp:418-420: stop at the first sequence shorter than k
     uint64_t n = 0;
@@ -366,13 +340,12 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     if (keys.size() >= 0x0FFFFFFFull) { err = "too many overlap keys (limit 2^28-1)"; return false; }
     tm.lap("keys");
 
-    // gamma 0 = choose: a cascade that can be staged in LDS twice per CU (<= ~66 KB, about one byte per key at 1.5)
-    // is built tight; one that stays in L2/HBM anyway gets more empty positions, so non-member probes stop sooner
-    // (chr1-scale graph: 283 -> 300 Mreads/s from 1.5 to 2.0).
-    if (gamma == 0.0) gamma = keys.size() <= 67000 ? 1.5 : 2.0;
-    Cascade cas;
-    build_cascade(keys, gamma, T, cas);
-    tm.lap("cascade");
+    // gamma 0 = choose: 1.07 slots per key (fill 0.935, well below the two-choice/four-slot threshold of 0.977, so the
+    // eviction walks stay short); at one byte per slot the table of ~70 k keys can still be staged in LDS twice per CU
+    if (gamma == 0.0) gamma = 1.07;
+    KeyTable tab;
+    build_key_table(keys, gamma, T, tab);
+    tm.lap("keytable");
 
     // ---- anchors index of -G (aligner.cpp:434-442,457-462): canonical k-mers j = 0 .. len-k-1 of every unitig ----
     AnchorMphf anc;
@@ -409,23 +382,21 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     h.version = BGR_BLOB_VERSION;
     h.k = k;
     h.n_unitigs = n;
-    h.n_keys = keys.size();
-    h.n_placed = cas.n_placed;
-    h.n_fallback = cas.fallback.size();
+    h.n_buckets = tab.buckets.size();
+    h.n_placed = tab.n_placed;
+    h.n_fallback = tab.fallback.size();
+    h.n_keys = 4 * h.n_buckets + h.n_fallback;
+    if (h.n_keys >= 0x0FFFFFFFull) { err = "too many overlap keys (limit 2^28-1 table slots)"; return false; }
     h.seq_words = seq_words;
     h.total_bases = total;
-    h.n_units = cas.units.size() / 4;
-    if (h.n_units >= (1ull << 26)) { err = "graph too large: the MPHF cascade must stay below 2^26 units (the kernels keep unit << 6 | position in 32 bits)"; return false; }
-    h.n_levels = (uint32_t)cas.levels.size();
     h.has_exc = has_exc ? 1 : 0;
     h.max_unitig_len = maxlen;
     h.n_left_keys = left.size();
     h.n_right_keys = right.size();
     h.gamma = gamma;
-    for (size_t l = 0; l < cas.levels.size(); ++l) h.levels[l] = cas.levels[l];
     uint64_t off = align256(4096);
     static_assert(sizeof(BgrBlobHeader) <= 4096, "header must fit its 4 KiB slot");
-    h.off_units = off;    off = align256(off + h.n_units * 16 + 16);
+    h.off_table = off;    off = align256(off + h.n_buckets * 4 + 16);
     h.off_keys = off;     off = align256(off + h.n_keys * 8 + 8);
     h.off_recs = off;     off = align256(off + h.n_keys * sizeof(BgrSlot) * 8 + 256);
     h.off_meta = off;     off = align256(off + (n + 1) * sizeof(BgrUnitigMeta));
@@ -453,8 +424,8 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     if (!out.blob.reset(off / 8)) { err = "out of memory for the graph blob"; return false; }  // zero pages, touched below in parallel
     uint8_t* base = reinterpret_cast<uint8_t*>(out.blob.data());
     memcpy(base, &h, sizeof(h));
-    memcpy(base + h.off_units, cas.units.data(), cas.units.size() * 4);
-    if (h.n_fallback) memcpy(base + h.off_fallback, cas.fallback.data(), h.n_fallback * 8);
+    memcpy(base + h.off_table, tab.buckets.data(), tab.buckets.size() * 4);
+    if (h.n_fallback) memcpy(base + h.off_fallback, tab.fallback.data(), h.n_fallback * 8);
 
     // ---- pack both strands into the blob; non-ACGT exceptions of the forward strand -----------------
     uint64_t* seq = reinterpret_cast<uint64_t*>(base + h.off_seq);
@@ -481,21 +452,22 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     }
     tm.lap("pack");
 
-    // keys by MPHF index (also proves the hash is a bijection onto [0, n_keys))
+    // keys by table slot (~0 = empty slot), then the fallback list's; every key must now be found where it was put
     uint64_t* kout = reinterpret_cast<uint64_t*>(base + h.off_keys);
-    std::vector<uint8_t> taken(keys.size(), 0);
+    parallel_ranges(T, 4 * h.n_buckets, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t j = b; j < e; ++j) kout[j] = tab.who[j] == BGR_NONE ? BGR_EMPTY_KEY : keys[tab.who[j]];
+    });
+    for (uint64_t j = 0; j < h.n_fallback; ++j) kout[4 * h.n_buckets + j] = tab.fallback[j];
     const BgrBlobHeader* hp = reinterpret_cast<const BgrBlobHeader*>(base);
     std::atomic<bool> bad{false};
     parallel_ranges(T, keys.size(), [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t j = b; j < e; ++j) {
-            uint64_t key = keys[j];
-            uint32_t idx = host_lookup(hp, base, key);
-            if (idx == BGR_NONE || idx >= keys.size() || __atomic_exchange_n(&taken[idx], (uint8_t)1, __ATOMIC_RELAXED)) { bad.store(true); return; }
-            kout[idx] = key;
+            const uint32_t idx = host_lookup(hp, base, keys[j]);
+            if (idx == BGR_NONE || idx >= h.n_keys || kout[idx] != keys[j]) { bad.store(true); return; }
         }
     });
-    if (bad.load()) { err = "internal: MPHF is not a bijection"; return false; }
-    tm.lap("keytable");
+    if (bad.load()) { err = "internal: a key is not found in the key table"; return false; }
+    tm.lap("keycheck");
 
     // ---- slot fill in unitig order (aligner.cpp:466-533) + orientation bits ---------------------
     // Pass 1 (parallel over unitigs): record indices and flags.  Pass 2: the fill order within a record is the
@@ -514,7 +486,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         }
     });
     tm.lap("lookup");
-    const uint64_t nk = keys.size();
+    const uint64_t nk = h.n_keys;
     parallel_ranges(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
         const uint64_t lo = nk * tb / T, hi = nk * te / T;
         for (uint64_t i = 1; i <= n; ++i) {

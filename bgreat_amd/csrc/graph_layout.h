@@ -15,15 +15,17 @@
 //          (offset 0) for ordinary graphs.
 //   meta   32 B per unitig id: len, and the record index + canonical flag of BOTH end (k-1)-mers, so
 //          a walk step never hashes: the next neighbour record is a direct index.
-//   MPHF   ONE minimal perfect hash over the union of the reference's left and right overlap key sets
-//          (index values are unobservable).  BBHash-style cascade, but every position
-//          keeps a 2-bit STATE instead of one bit: 0 = no key hashes here, 1 = exactly one key (placed),
-//          3 = several keys (they all move to the next level).  A query that lands on state 0 is rejected
-//          at once -- most read positions are not overlaps, so most lanes stop on level 0 or 1 -- state 1
-//          gives the minimal index, state 3 continues.  A level is an array of 16-byte units
-//          {48 states, u32 rank = placed keys in all earlier units}: ONE dwordx4 load per level.
-//   keys   u64 key per MPHF index (membership check, aligner.cpp:158,219,353,361).
-//   recs   256 B per MPHF index: the 4 "left table" slots (one 128-byte line) and the 4 "right table" slots (the
+//   table  ONE key table over the union of the reference's left and right overlap key sets (index values are
+//          unobservable): two-choice bucketed hashing with one-byte fingerprints.  A bucket is one
+//          dword = 4 slots; a slot holds 0 (empty) or the fingerprint 1..255 of the key that lives there, and the slot
+//          number (4 * bucket + slot) IS the key's index into `keys` and `recs`.  A query reads its two buckets (two
+//          independent dword loads, no dependent second access), compares the four bytes of each with its fingerprint
+//          and confirms a match against `keys`; a non-member is rejected by the fingerprints alone 97 times in 100 --
+//          most read positions are not overlaps -- so the 8-byte key load is left to the members and a few false matches.
+//          About 8.6 bits per key at the default fill (0.935): the table of an E. coli-scale graph fits LDS twice per CU.
+//          Keys that found no slot after the eviction budget (in practice none) go to a sorted fallback list.
+//   keys   u64 key per table slot, ~0 for an empty slot (membership check, aligner.cpp:158,219,353,361).
+//   recs   256 B per table slot: the 4 "left table" slots (one 128-byte line) and the 4 "right table" slots (the
 //          next line) of that key (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite,
 //          aligner.cpp:466-533).  A slot is 32 B: {id | orientation bits, len, F as seq word + base-in-word} --
 //          everything a walk step needs to start streaming the candidate's bases -- plus the unitig's own end
@@ -42,9 +44,8 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 8u  /* 8: slot_fill_x100; 7: anchors levels with division magic; 6: 32-byte slots carrying the unitig's end records */
-#define BGR_MAX_LEVELS 48
-#define BGR_UNIT_POS 48u /* 2-bit states per 16-byte unit */
+#define BGR_BLOB_VERSION 9u  /* 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
+#define BGR_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL /* keys[] of an empty table slot: no (k-1)-mer, k <= 32, has bit 62 or 63 set */
 #define BGR_NONE 0xFFFFFFFFu
 #define BGR_SLOT_ID_MASK 0x3FFFFFFFu
 // slot flag bits (see graph_build.cpp fill_records):
@@ -64,8 +65,8 @@
 typedef struct {
     uint32_t len;     // bases
     uint32_t flags;   // BGR_META_*
-    uint32_t rec_beg; // MPHF index of canonical(first k-1 bases)
-    uint32_t rec_end; // MPHF index of canonical(last k-1 bases)
+    uint32_t rec_beg; // table slot of canonical(first k-1 bases)
+    uint32_t rec_end; // table slot of canonical(last k-1 bases)
     uint64_t F;       // base offset of the forward strand in `seq` (reverse complement at F + len)
     uint64_t pad;
 } BgrUnitigMeta;      // 32 B; the first 16 B are what a walk step needs about the unitig it has chosen
@@ -80,11 +81,6 @@ typedef struct {
     uint32_t rec_end;
     uint32_t pad;
 } BgrSlot;            // 32 B; a neighbour record is BgrSlot[8]: left-table slots 0..3, right-table slots 4..7
-
-typedef struct {
-    uint32_t units;  // number of 48-position units on this level
-    uint32_t base;   // index of the level's first unit in the unit array
-} BgrLevel;
 
 // ---- anchors index (-G, optional) --------------------------------------------------------------------
 // The reference's anchors mode looks read k-mers up in a boomphf::mphf over the canonical k-mers of all unitigs
@@ -110,19 +106,18 @@ typedef struct {
     uint32_t version, k;
     uint64_t blob_bytes;
     uint64_t n_unitigs;     // ids 1..n_unitigs (meta has n_unitigs+1 entries, entry 0 unused)
-    uint64_t n_keys;        // MPHF domain: keys, recs
-    uint64_t n_placed;      // keys placed on cascade levels; the rest sit in the sorted fallback list
+    uint64_t n_keys;        // index space of keys[] and recs[]: 4 * n_buckets table slots, then the fallback list's entries
+    uint64_t n_placed;      // keys that live in the table; the rest (normally none) sit in the sorted fallback list
     uint64_t n_fallback;
     uint64_t seq_words;     // u64 words in seq (incl. 2 trailing pad words)
     uint64_t total_bases;   // 2 * sum(len)
-    uint64_t n_units;       // total 16-byte MPHF units
-    uint64_t off_units, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback;
-    uint32_t n_levels, has_exc;
+    uint64_t n_buckets;     // 4-slot buckets (one dword each) of the key table
+    uint64_t off_table, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback;
+    uint32_t reserved0, has_exc;
     uint64_t max_unitig_len;
     uint64_t n_left_keys, n_right_keys;  // sizes of the reference's two key sets (informational)
     uint32_t slot_fill_x100, pad0;       // 100 x mean number of filled slots per non-empty half record (how branchy the graph is)
-    double gamma;
-    BgrLevel levels[BGR_MAX_LEVELS];
+    double gamma;           // table slots per key
     // anchors index (all zero when the graph was built without it)
     uint64_t anc_n;          // anchors = k-mers of all unitigs but each unitig's last, repeats included (aligner.cpp:434-442)
     uint64_t anc_last_rank;  // set bits over all levels; indices of anc_final entries start here
@@ -139,18 +134,19 @@ typedef struct {
 #define BGR_GF_HAS_EXC 1u
 #define BGR_GF_HAS_FALLBACK 2u
 typedef struct {
-    const uint32_t* units;   // n_units * 4 u32  (x,y,z = 48 two-bit states, w = rank)
+    const uint32_t* table;   // n_buckets dwords: 4 one-byte fingerprints each (slot s = byte s), 0 = empty
     const uint64_t* keys;
     const BgrSlot* recs;     // n_keys * 8 slots (L0..L3, R0..R3)
     const BgrUnitigMeta* meta;
     const uint64_t* seq;
     const BgrBlobHeader* hdr;
-    uint32_t k, n_levels, flags, units_bytes;  // units_bytes: size of the unit array (LDS staging)
+    uint32_t k, n_buckets, flags, table_bytes;  // table_bytes = 4 * n_buckets (LDS staging)
 } BgrDeviceGraph;
 
 // ---- hashing shared by the host builder and the device lookup ---------------------------------------
-// 64 -> 64 finaliser (SplitMix64's); the cascade uses double hashing on its two halves:
-//   level l: h_l = ha + l*hb (mod 2^32), unit = mulhi32(h_l, units_l), position = ((h_l & 0xFFFF) * 48) >> 16.
+// 64 -> 64 finaliser (SplitMix64's).  Of m = bgr_mix64(key) the table uses: bucket 1 = mulhi32(low word, n_buckets),
+// bucket 2 = mulhi32(high word, n_buckets) -- both decided by the words' HIGH bits -- and the fingerprint = the low
+// byte of the low word, 0 mapped to 1.
 BGR_HD uint64_t bgr_mix64(uint64_t x) {
     x ^= x >> 30;
     x *= 0xBF58476D1CE4E5B9ULL;
@@ -159,10 +155,10 @@ BGR_HD uint64_t bgr_mix64(uint64_t x) {
     x ^= x >> 31;
     return x;
 }
-BGR_HD uint32_t bgr_level_unit(uint32_t h, uint32_t units) { return (uint32_t)(((uint64_t)h * (uint64_t)units) >> 32); }
-BGR_HD uint32_t bgr_level_pos(uint32_t h) { return ((h & 0xFFFFu) * BGR_UNIT_POS) >> 16; }
-// placed ("unique", state 1) positions of one state word, as a mask on the even bits
-BGR_HD uint32_t bgr_unique_mask(uint32_t w) { return w & ~(w >> 1) & 0x55555555u; }
+BGR_HD uint32_t bgr_tab_bucket(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((uint64_t)h * (uint64_t)n_buckets) >> 32); }
+BGR_HD uint32_t bgr_tab_fp(uint64_t m) { const uint32_t f = (uint32_t)m & 0xFFu; return f ? f : 1u; }
+// bit 7 of every byte of x that is zero (exact: no borrow between bytes)
+BGR_HD uint32_t bgr_zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }
 
 // ---- BooPHF's hashing, needed bit-exact by the anchors index (BooPHF.h:251-264 hash64, :336-356 the level hashes)
 BGR_HD uint64_t bgr_boo_hash64(uint64_t key, uint64_t seed) {

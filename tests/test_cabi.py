@@ -52,7 +52,7 @@ def test_graph_build_info_and_blob_roundtrip():
 
 
 def test_blob_validation_refuses_corrupt_headers():
-    """A blob from a file or from another rank is only trusted after every section and the MPHF level table have been
+    """A blob from a file or from another rank is only trusted after every section and the key table's size have been
     checked against its size (the kernels index HBM with those numbers): corrupt single header fields one at a time."""
     s = Synth(30000, 75, 2, 31, 6)
     seqs, offs = s.unitigs()
@@ -60,31 +60,21 @@ def test_blob_validation_refuses_corrupt_headers():
     B.Graph.from_blob(blob)   # intact: accepted
     hdr = blob[:4096].view(np.uint64)
     # BgrBlobHeader (graph_layout.h): u64 words 0 magic, 1 version|k, 2 blob_bytes, 3 n_unitigs, 4 n_keys, 5 n_placed, 6 n_fallback,
-    # 7 seq_words, 8 total_bases, 9 n_units, 10.. off_units, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback
+    # 7 seq_words, 8 total_bases, 9 n_buckets, 10.. off_table, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback
     def corrupt(word, value):
         bad = blob.copy()
         bad[:4096].view(np.uint64)[word] = value
         with pytest.raises(B.BgrError):
             B.Graph.from_blob(bad)
     corrupt(3, int(hdr[3]) + (1 << 40))          # n_unitigs: meta section would leave the blob
-    corrupt(4, int(hdr[4]) + 1)                  # n_keys no longer n_placed + n_fallback
+    corrupt(4, int(hdr[4]) + 1)                  # n_keys no longer 4 * n_buckets + n_fallback
     corrupt(4, (1 << 61))                        # count * size overflows 64 bits
     corrupt(7, int(hdr[7]) + (1 << 30))          # seq_words beyond the blob
-    corrupt(9, int(hdr[9]) + 1)                  # n_units: the level table no longer tiles the unit array
-    corrupt(10, int(hdr[10]) + 8)                # off_units not 256-byte aligned
+    corrupt(9, 0)                                # no buckets at all
+    corrupt(9, int(hdr[9]) + 1)                  # n_buckets: the index space no longer matches the table
+    corrupt(10, int(hdr[10]) + 8)                # off_table not 256-byte aligned
     corrupt(12, len(blob))                       # off_recs at the end of the blob
     corrupt(14, 0xFFFFFFFFFFFFFF00)              # off_seq + size wraps around
-    # the level table follows the scalar fields: find levels[0] = {units, base = 0}, levels[1] = {units, base = units0}
-    words = blob[:4096].view(np.uint32)
-    for i in range(20, 200):                     # first {units>0, base==0} pair followed by {units, base == units0}
-        if words[i] > 0 and words[i + 1] == 0 and words[i + 3] == words[i]:
-            bad = blob.copy()
-            bad[:4096].view(np.uint32)[i + 3] += 1   # level 1 no longer starts where level 0 ends
-            with pytest.raises(B.BgrError):
-                B.Graph.from_blob(bad)
-            break
-    else:
-        pytest.fail("level table not found in the header")
     with pytest.raises(B.BgrError):
         B.Graph.from_blob(blob[:-256])           # truncated
 
