@@ -73,7 +73,7 @@ def parse_args():
     ap.add_argument("--gamma", type=float, default=0.0, help="MPHF positions per key and level (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the four-reads-per-wave passes (diagnostic)")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and valu_issue_frac become null)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and the issue fractions become null)")
     ap.add_argument("--pmc-steps", type=int, default=3)
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end leg per GPU (0 disables)")
     ap.add_argument("--pcie-steps", type=int, default=3, help="timed bgr_align_batch calls of the PCIe-inclusive leg (0 disables)")
@@ -317,14 +317,19 @@ def main():
             roofline["limiter"] = "valu_issue"
             roofline["valu_insts_per_read"] = round(pmc["SQ_INSTS_VALU"] / R, 1)
             roofline["salu_insts_per_read"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / R, 1)
-            # profiles/r02_valu_rates.txt: ~4.1 cycles per wave64 instruction for shifts/min/popcount/mul/DPP/readlane, ~2.2 for plain
-            # add/logic; SQ_ACTIVE_INST_VALU counts the busy time of the vector ALUs in units of 4 cycles
-            if pmc.get("SQ_ACTIVE_INST_VALU") is not None:
-                roofline["valu_issue_frac"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, 4)
-            roofline["valu_issue_frac_at_4_cycles"] = round(pmc["SQ_INSTS_VALU"] * 4.0 / simd_cycles, 4)
+            # profiles/r02_valu_rates.txt (tools/ubench/valu_rates.hip): a wave64 vector instruction occupies its SIMD for ~2.2 cycles
+            # (plain VOP1/VOP2 add/sub/and/or/xor/mov/not/right shifts, >= 2 waves on the SIMD) or ~4.1 cycles (everything else:
+            # left shifts, min/max, compares, cndmask, bfe, mul, 3-operand and 64-bit forms, DPP, readlane).  SQ_ACTIVE_INST_VALU
+            # counts 1 per instruction like SQ_INSTS_VALU (profiles/r02_valu_pmc_calibration.txt), so the counters give the
+            # instruction count only and the busy fraction is bracketed by the two prices; the static mix of the dominant kernel
+            # (tools/isa_mix.py, profiles/r02_isa_mix.txt) prices an instruction at ~3.3 cycles
+            roofline["valu_issue_frac_bounds"] = {"at_2.2_cycles": round(pmc["SQ_INSTS_VALU"] * 2.2 / simd_cycles, 4),
+                                                  "at_3.3_cycles_static_mix": round(pmc["SQ_INSTS_VALU"] * 3.3 / simd_cycles, 4),
+                                                  "at_4.1_cycles": round(pmc["SQ_INSTS_VALU"] * 4.1 / simd_cycles, 4)}
             roofline["salu_issue_frac"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / (N_SIMD / 4 * (avg_launch_ms / 1e3) * CLOCK_GHZ * 1e9), 4)  # one scalar unit per CU
-            roofline["issue_note"] = ("instructions per launch from rocprofv3 SQ counters (same child runs); VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x launch time "
-                                      "x %.1f GHz); SALU = SQ_INSTS_SALU / (256 CUs x cycles): one scalar instruction per cycle and CU" % CLOCK_GHZ)
+            roofline["issue_note"] = ("instructions per launch from rocprofv3 SQ counters (same child runs); VALU busy fraction = SQ_INSTS_VALU x cycles per "
+                                      "instruction / (1024 SIMDs x launch time x %.1f GHz), bracketed by the two measured issue prices; SALU = SQ_INSTS_SALU / "
+                                      "(256 CUs x cycles): one scalar instruction per cycle and CU" % CLOCK_GHZ)
         roofline["pmc_seconds"] = pmc.get("_seconds")
         roofline["pmc_per_kernel"] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in pmc.get("_per_kernel", {}).items()}
     elif pmc:

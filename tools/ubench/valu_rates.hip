@@ -123,7 +123,6 @@ int main() {
     run<28>("v_subrev_u32", d);
     run<23>("v_mov_b32", d);
     run<24>("v_not_b32", d);
-    run<26>("v_cndmask e32 vcc", d);
     run<30>("v_cndmask e64 sgpr", d);
     run<31>("v_cmp_lt_u32", d);
     run<32>("cmp+cndmask pairs", d);
