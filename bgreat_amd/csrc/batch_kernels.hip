@@ -1,5 +1,7 @@
 // batch_kernels.hip -- the kernels around the mapping passes of a launch: the pre-pass that packs ASCII reads into 2-bit
 // planes, the scatter of a host-packed batch's N-mask words, results -> CSR on the device, and the launch dispatch.
+#include <algorithm>
+
 #include "device_common.h"
 
 namespace bgr {
@@ -7,45 +9,102 @@ namespace bgr {
 // ======================================= pre-pass: ASCII reads -> 2-bit planes ================================
 // Streaming kernel in front of every mapping launch that is handed ASCII reads (what getReads yields, aligner.cpp:46-117):
 // str2num codes (utils.cpp:117-129: A0 C1 G2, anything else 3) 32 bases per u64, first base most significant, plus
-// the N mask for the few reads that hold an N (their bit is set in `hasn`, which the caller zeroes).  8 lanes per read,
-// 32 bases per lane and step.  ~150 B in + 48 B out per 150 bp read: HBM-streaming bound.
-__global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* reads, const u64* read_offs, uint32_t n, u64 total_bytes, u64* fw3,
-                                                             u64* nmw, uint32_t* hasn) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t r = t >> 3, j0 = t & 7;
-    const int lane = threadIdx.x & 63;
-    bool sawN = false;
-    u64 off = 0;
-    uint32_t L = 0, Wr = 0, woff = 0;
-    if (r < n) {
-        off = read_offs[r];
-        L = (uint32_t)(read_offs[r + 1] - off);
-        Wr = (L + 31) >> 5;
-        woff = packed_word_offset(off, r);
-        for (uint32_t j = j0; j < Wr; j += 8) {
-            u64 w, nm;
-            pack32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, &w, &nm);
-            fw3[woff + j] = w;
-            sawN |= nm != 0;
+// the N mask for the few reads that hold an N (their bit is set in `hasn`, which the caller zeroes).  `lpr` lanes per
+// read (the batch's mean words per read, rounded up), 32 bases per lane and step.  ~150 B in + 40 B out per 150 bp read.
+
+// 4 ASCII bases (one dword, first base in the low byte; a zero byte = past the end) -> their 2-bit codes, one per byte.
+// On the alphabet the parser admits (ACGTN, aligner.cpp:56-61; either case): high bit = bit 2 of the character (G T N),
+// low bit = bit 4 (T) | bit 3 (N) | bit 1 & ~bit 2 (C): A0 C1 G2 T3 N3, and 0 for a zero byte.
+__device__ __forceinline__ uint32_t codes4(uint32_t x) {
+    const uint32_t lo = ((x >> 4) | (x >> 3) | ((x >> 1) & ~(x >> 2))) & 0x01010101u;
+    return ((x >> 1) & 0x02020202u) | lo;
+}
+// the four 2-bit fields of c (bytes 0..3, values 0..3) as one byte in bits 24..31, first base in the top two bits: the
+// partial products c << 30, c << 20, c << 10, c put b0 b1 b2 b3 at bits 30 28 26 24 and nothing else at or above bit 24
+__device__ __forceinline__ uint32_t gather4(uint32_t c) { return c * 0x40100401u; }
+// top bytes of four such products -> one dword, p0's first
+__device__ __forceinline__ uint32_t top_bytes(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+    const uint32_t a = __builtin_amdgcn_perm(p0, p1, 0x07030000u);  // [p0.b3, p1.b3, -, -]
+    const uint32_t b = __builtin_amdgcn_perm(p2, p3, 0x07030000u);
+    return __builtin_amdgcn_perm(a, b, 0x07060302u);                // [a.b3, a.b2, b.b3, b.b2]
+}
+
+// 32 bases [32j, 32j+32) of a read as 8 dwords of ASCII (first base in the low byte of xs[0]), zero beyond the read's end
+__device__ __forceinline__ void load32(const uint8_t* rd, uint32_t L, uint32_t j, bool whole_in_buffer, uint32_t xs[8]) {
+    const uint32_t valid = L - 32 * j;  // >= 1
+    if (whole_in_buffer) {  // all 32 bytes lie inside the batch buffer: two (unaligned) 16-byte loads, bytes past the read masked off
+        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
+        const u32x4_unaligned v0 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j);
+        const u32x4_unaligned v1 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j + 16);
+        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+        if (valid < 32) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t lo = 4u * d;
+                if (valid <= lo) xs[d] = 0;
+                else if (valid < lo + 4) xs[d] &= 0xFFFFFFFFu >> (8 * (lo + 4 - valid));
+            }
+        }
+    } else {  // the batch's last bytes: never touch a byte past the buffer
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4u * d + e < valid) x |= (uint32_t)rd[32 * j + 4 * d + e] << (8 * e);
+            xs[d] = x;
         }
     }
-    // a read with an N: all its N-plane words are written (the mapping kernels read the plane only for such reads)
-    const u64 any = __ballot(sawN);
-    if ((any >> (lane & ~7)) & 0xFFu) {
-        for (uint32_t j = j0; j < Wr; j += 8) {
-            u64 w, nm;
-            pack32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, &w, &nm);
-            nmw[woff + j] = nm;
+}
+__device__ __forceinline__ u64 pack_codes(const uint32_t c[8]) {
+    const uint32_t hi = top_bytes(gather4(c[0]), gather4(c[1]), gather4(c[2]), gather4(c[3]));
+    const uint32_t lo = top_bytes(gather4(c[4]), gather4(c[5]), gather4(c[6]), gather4(c[7]));
+    return (u64)hi << 32 | lo;
+}
+
+__global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* reads, const u64* read_offs, uint32_t n, u64 total_bytes, u64* fw3,
+                                                             u64* nmw, uint32_t* hasn, uint32_t lpr, uint32_t inv_lpr, uint32_t reads_per_block) {
+    const uint32_t slot = (threadIdx.x * inv_lpr) >> 16;  // threadIdx.x / lpr (inv_lpr checked exact for 0..255 by the launcher)
+    const uint32_t j0 = threadIdx.x - slot * lpr;
+    const uint32_t r = blockIdx.x * reads_per_block + slot;
+    if (slot >= reads_per_block || r >= n) return;
+    const u64 off = read_offs[r];
+    const uint32_t L = (uint32_t)(read_offs[r + 1] - off);
+    const uint32_t Wr = (L + 31) >> 5;
+    const uint32_t woff = packed_word_offset(off, r);
+    uint32_t sawN = 0;
+    for (uint32_t j = j0; j < Wr; j += lpr) {
+        uint32_t xs[8], c[8];
+        load32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, xs);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { c[d] = codes4(xs[d]); sawN |= xs[d]; }  // (bit 3 of a character: set for N only)
+        fw3[woff + j] = pack_codes(c);
+    }
+    // a read with an N: all its N-plane words are written (the mapping kernels read the plane only for such reads).  Rare:
+    // whichever lane saw an N writes the read's whole N plane (two lanes of one read write the same words).
+    if (sawN & 0x08080808u) {
+        for (uint32_t j = 0; j < Wr; ++j) {
+            uint32_t xs[8], c[8];
+            load32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, xs);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) c[d] = ((xs[d] >> 3) & 0x01010101u) * 3u;
+            nmw[woff + j] = pack_codes(c);
         }
-        if (j0 == 0) atomicOr(&hasn[r >> 5], 1u << (r & 31));
+        atomicOr(&hasn[r >> 5], 1u << (r & 31));
     }
 }
 
 hipError_t launch_pack_reads(const uint8_t* reads, const uint64_t* read_offs, uint32_t n, uint64_t total_bytes, uint64_t* fw3, uint64_t* nmw,
                              uint32_t* hasn, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)(((uint64_t)n * 8 + 255) / 256);
-    hipLaunchKernelGGL(bgr_pack_reads_kernel, dim3(blocks), dim3(256), 0, stream, reads, read_offs, n, total_bytes, fw3, nmw, hasn);
+    // lanes per read: the mean number of 32-base words per read, rounded up (150 bp: 5), at most 16; longer reads loop
+    uint32_t lpr = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (total_bytes / n + 31) / 32));
+    uint32_t inv = (65536 + lpr - 1) / lpr;
+    for (uint32_t t = 0; t < 256; ++t)
+        if (((t * inv) >> 16) != t / lpr) { lpr = 8; inv = 65536 / 8; break; }  // (never taken for lpr <= 16; kept as a guard)
+    const uint32_t rpb = 256 / lpr;
+    const uint32_t blocks = (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL(bgr_pack_reads_kernel, dim3(blocks), dim3(256), 0, stream, reads, read_offs, n, total_bytes, fw3, nmw, hasn, lpr, inv, rpb);
     return hipGetLastError();
 }
 

@@ -141,69 +141,6 @@ __device__ __forceinline__ bool load_packed(const BatchIO& io, uint32_t r, u64 o
     return hasN;
 }
 
-// 4 ASCII bases starting at byte 4*bi of the read as one dword (first base in the low byte), 0 past the end
-__device__ __forceinline__ uint32_t load4(const uint8_t* rd, uint32_t L, uint32_t bi) {
-    const uint32_t b0 = bi * 4;
-    uint32_t x = 0;
-    if (b0 < L) {
-        const uint32_t nb = L - b0;
-        if (nb >= 4) {
-            x = *reinterpret_cast<const u32_unaligned*>(rd + b0);  // possibly unaligned dword
-        } else {  // the last 1..3 bases: never touch bytes past the read (they may be past the buffer)
-            x = rd[b0];
-            if (nb > 1) x |= (uint32_t)rd[b0 + 1] << 8;
-            if (nb > 2) x |= (uint32_t)rd[b0 + 2] << 16;
-        }
-    }
-    return x;
-}
-
-// 4 ASCII bases (one dword, first base in the low byte; a zero byte = past the end) -> one byte of 2-bit codes, first base
-// in the top two bits, and the same for the N mask (3 on 'N').  A0 C1 G2 T3 = ((c>>1)^(c>>2))&3; exact for the
-// alphabet ACGTN the parser admits (aligner.cpp:56-61).
-__device__ __forceinline__ void pack4(uint32_t x, uint32_t* code, uint32_t* nmask) {
-    uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
-    const uint32_t t = x ^ 0x4E4E4E4Eu;                                 // zero byte <=> 'N'
-    const uint32_t isn = ((t - 0x01010101u) & ~t & 0x80808080u) >> 7;  // 0x01 per 'N' byte
-    const uint32_t n3 = isn * 3u;
-    c |= n3;
-    *code = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
-    *nmask = ((n3 << 6) | (n3 >> 4) | (n3 >> 14) | (n3 >> 24)) & 0xFFu;
-}
-
-// 32 bases [32j, 32j+32) of a read -> its FW3 word (first base most significant) and N-mask word
-__device__ __forceinline__ void pack32(const uint8_t* rd, uint32_t L, uint32_t j, u64 abs_end_ok, u64* fw, u64* nm) {
-    uint32_t xs[8];
-    if (abs_end_ok) {  // all 32 bytes lie inside the batch buffer: two (unaligned) 16-byte loads, bytes past the read masked off
-        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
-        const u32x4_unaligned v0 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j);
-        const u32x4_unaligned v1 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j + 16);
-        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
-        const uint32_t valid = L - 32 * j;  // >= 1
-        if (valid < 32) {
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const uint32_t lo = 4u * d;
-                if (valid <= lo) xs[d] = 0;
-                else if (valid < lo + 4) xs[d] &= 0xFFFFFFFFu >> (8 * (lo + 4 - valid));
-            }
-        }
-    } else {
-#pragma unroll
-        for (int d = 0; d < 8; ++d) xs[d] = load4(rd, L, 8 * j + d);
-    }
-    u64 w = 0, n = 0;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        uint32_t c, m;
-        pack4(xs[d], &c, &m);
-        w = (w << 8) | c;
-        n = (n << 8) | m;
-    }
-    *fw = w;
-    *nm = n;
-}
-
 // RCW (reverse-complement stream) and FWQ (rolling-update quirk stream) from FW3/NM.  Only needed when the read
 // contains N (the rolling k-mers then differ from plain windows) or for the reverse-complement retry; a read
 // without N maps from FW3 alone (FWQ == FW3, and the reverse k-mer of a window is rcb of its forward k-mer).
