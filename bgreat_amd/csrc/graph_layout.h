@@ -144,19 +144,16 @@ typedef struct {
 } BgrDeviceGraph;
 
 // ---- hashing shared by the host builder and the device lookup ---------------------------------------
-// 64 -> 64 finaliser (SplitMix64's).  Of m = bgr_mix64(key) the table uses: bucket 1 = mulhi32(low word, n_buckets),
-// bucket 2 = mulhi32(high word, n_buckets) -- both decided by the words' HIGH bits -- and the fingerprint = the low
-// byte of the low word, 0 mapped to 1.
+// Key -> 64 hash bits: fold the high word into the low one, one 64-bit multiply.  Of m = bgr_mix64(key) the table uses
+// bucket 1 = mulhi32(low word, n_buckets) and bucket 2 = mulhi32(high word, n_buckets) -- decided by the words' HIGH bits,
+// which a multiplication mixes best -- and the fingerprint = the low byte of the HIGH word, 0 mapped to 1.  (Membership is
+// decided by the key compare, never by the hash: a weak hash could only cost table fill or false fingerprint matches.)
 BGR_HD uint64_t bgr_mix64(uint64_t x) {
-    x ^= x >> 30;
-    x *= 0xBF58476D1CE4E5B9ULL;
-    x ^= x >> 27;
-    x *= 0x94D049BB133111EBULL;
-    x ^= x >> 31;
-    return x;
+    x ^= x >> 32;
+    return x * 0x9E3779B97F4A7C15ULL;
 }
 BGR_HD uint32_t bgr_tab_bucket(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((uint64_t)h * (uint64_t)n_buckets) >> 32); }
-BGR_HD uint32_t bgr_tab_fp(uint64_t m) { const uint32_t f = (uint32_t)m & 0xFFu; return f ? f : 1u; }
+BGR_HD uint32_t bgr_tab_fp(uint64_t m) { const uint32_t f = (uint32_t)(m >> 32) & 0xFFu; return f ? f : 1u; }
 // bit 7 of every byte of x that is zero (exact: no borrow between bytes)
 BGR_HD uint32_t bgr_zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }
 
