@@ -81,16 +81,23 @@ __device__ __forceinline__ u64 rcb_fast(u64 x, uint32_t n) { return (~rev2_fast(
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
 // Key table lookup for one key per lane (graph_layout.h): the slot of `key` -- its index into keys[] and recs[] -- or
-// BGR_NONE when the key is no overlap of the graph (the membership test of aligner.cpp:158,219,353,361).  Both buckets are
-// read at once (two independent dword loads, from LDS when the table is staged there, else from L2/HBM); a byte that
+// BGR_NONE when the key is no overlap of the graph (the membership test of aligner.cpp:158,219,353,361).  A byte that
 // equals the fingerprint is confirmed against keys[].  Most read positions are no overlaps and match no byte, so the loop
 // below usually runs once per call for the wave's few candidates (members and ~3 % false matches).
-template <typename TP>
+// Table staged in LDS (LAZY2 = false): both buckets are read at once, two independent ds_read_b32.
+// Table in L2/HBM (LAZY2 = true): such a launch is bound by the L2's request rate (one request per lane and probe), so
+// bucket 2 is only read by the lanes whose bucket 1 is full -- the builder fills bucket 1 first and never empties a slot, so
+// a key can sit in bucket 2 only then.  At the sparse fill such graphs are built with (0.55) that is one lane in five:
+// 1.2 instead of 2 requests per position (chr1-scale graph: 749 -> 930 Mreads/s).
+template <bool LAZY2 = false, typename TP>
 __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u64 key, bool active) {
     const u64 m = bgr_mix64(key);
     const uint32_t b1 = __umulhi((uint32_t)m, g.n_buckets), b2 = __umulhi((uint32_t)(m >> 32), g.n_buckets);
     uint32_t w1 = 0, w2 = 0;
-    if (active) { w1 = tab[b1]; w2 = tab[b2]; }
+    if (LAZY2) {
+        if (active) w1 = tab[b1];
+        if (active && bgr_zero_bytes(w1) == 0) w2 = tab[b2];
+    } else if (active) { w1 = tab[b1]; w2 = tab[b2]; }
     const uint32_t f4 = bgr_tab_fp(m) * 0x01010101u;  // (an empty slot is 0 and the fingerprint is not: lanes that sit out match nothing)
     uint32_t c1 = bgr_zero_bytes(w1 ^ f4), c2 = b2 != b1 ? bgr_zero_bytes(w2 ^ f4) : 0u;
     uint32_t res = BGR_NONE;

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
             u64 num = 0;
             if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
-            const uint32_t idx = find_key(g, units, num < rc ? num : rc, valid);
+            const uint32_t idx = find_key<!STAGE>(g, units, num < rc ? num : rc, valid);
             u64 mask = __ballot(idx != BGR_NONE);
             if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
             while (mask) {
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
                 u64 num = 0;
                 if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);
-                uint32_t idx = find_key(g, units, num < rcn ? num : rcn, valid);
+                uint32_t idx = find_key<!STAGE>(g, units, num < rcn ? num : rcn, valid);
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {
                     if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
             u64 num = 0;
             if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
-            const uint32_t idx = find_key(g, units, num < rc ? num : rc, valid);
+            const uint32_t idx = find_key<!STAGE>(g, units, num < rc ? num : rc, valid);
             u64 mask = __ballot(idx != BGR_NONE);
             if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
             while (mask) {

@@ -340,9 +340,12 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     if (keys.size() >= 0x0FFFFFFFull) { err = "too many overlap keys (limit 2^28-1)"; return false; }
     tm.lap("keys");
 
-    // gamma 0 = choose: 1.07 slots per key (fill 0.935, well below the two-choice/four-slot threshold of 0.977, so the
-    // eviction walks stay short); at one byte per slot the table of ~70 k keys can still be staged in LDS twice per CU
-    if (gamma == 0.0) gamma = 1.07;
+    // gamma 0 = choose.  A table that can be staged in LDS twice per CU (<= ~72 KB: one byte per slot) is built tight, 1.07
+    // slots per key (fill 0.935, below the two-choice/four-slot threshold of 0.977, so the eviction walks stay short).  A
+    // larger one is probed in L2, where the request rate is the limit: built sparse (1.8 slots per key) few first buckets
+    // are full and few lanes need the second probe (find_key, device_common.h; chr1-scale graph, slots per key 1.07 / 1.4 /
+    // 1.8 / 2.5: 800 / 900 / 930 / 870 Mreads/s -- beyond 2 the table outgrows the L2).
+    if (gamma == 0.0) gamma = (double)keys.size() * 1.07 <= 73000.0 ? 1.07 : 1.8;
     KeyTable tab;
     build_key_table(keys, gamma, T, tab);
     tm.lap("keytable");
@@ -464,9 +467,13 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         for (uint64_t j = b; j < e; ++j) {
             const uint32_t idx = host_lookup(hp, base, keys[j]);
             if (idx == BGR_NONE || idx >= h.n_keys || kout[idx] != keys[j]) { bad.store(true); return; }
+            if (idx < 4 * h.n_buckets) {  // what find_key<LAZY2> relies on: a key sits in its bucket 2 only when its bucket 1 is full
+                const uint32_t b1 = bgr_tab_bucket((uint32_t)bgr_mix64(keys[j]), (uint32_t)h.n_buckets);
+                if (idx / 4 != b1 && bgr_zero_bytes(tab.buckets[b1]) != 0) { bad.store(true); return; }
+            }
         }
     });
-    if (bad.load()) { err = "internal: a key is not found in the key table"; return false; }
+    if (bad.load()) { err = "internal: key table inconsistent"; return false; }
     tm.lap("keycheck");
 
     // ---- slot fill in unitig order (aligner.cpp:466-533) + orientation bits ---------------------

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                     rcn = plain ? rcb_fast(num, K1) : lds_win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
-                const uint32_t idx = find_key(g, units, rep, valid);
+                const uint32_t idx = find_key<!STAGE>(g, units, rep, valid);
                 u64 mask = __ballot(idx != BGR_NONE);
 #ifdef BGR_PHASE_TIMING
                 if (prm.debug_stop == 2) { if (mask) { ++tried; done = true; p_n = 0; } mask = 0; }
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                     // getBegin/getEnd recompute rc = rcb(num) (aligner.cpp:149,211); it differs from the
                     // rolling rcnum only when an N was rolled into the window.
                     const u64 rc2 = rcb_fast(a_num, K1);
-                    if (rc2 != a_rcn) a_rec = find_key(g, units, a_num < rc2 ? a_num : rc2, true);
+                    if (rc2 != a_rcn) a_rec = find_key<!STAGE>(g, units, a_num < rc2 ? a_num : rc2, true);
                     if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, a_pos, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
                         done = true;
                         break;
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(Bgr
                     u64 num = 0;
                     if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
                     const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
-                    uint32_t idx = find_key(g, units, num < rcn ? num : rcn, valid);
+                    uint32_t idx = find_key<!STAGE>(g, units, num < rcn ? num : rcn, valid);
                     const u64 mask = __ballot(idx != BGR_NONE);
                     if (mask) {
                         if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
