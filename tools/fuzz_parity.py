@@ -30,7 +30,9 @@ for it in range(60):
     if it % 7 == 3:   # unitigs with N as well
         seqs = seqs.copy(); seqs[rng.choice(len(seqs), size=20, replace=False)] = ord("N")
     anc = MODE == "anchors"
-    g = B.Graph.build(k, seqs, offs, anchors=anc); al = B.Aligner(g, 0); o = oracle_py.Oracle(k, seqs, offs, anchors=anc)
+    gamma = float(rng.choice([0.0, 0.0, 1.07, 1.8, 3.0]))   # key table fill: dense (LDS staging) ... sparse (L2 probing)
+    g = B.Graph.build(k, seqs, offs, gamma, anchors=anc); al = B.Aligner(g, 0); o = oracle_py.Oracle(k, seqs, offs, anchors=anc)
+    if it % 3 == 1: al.configure(0, 0, 1)   # key table probed in L2 instead of LDS (second bucket read only when the first is full)
     effort = int(rng.choice([0, 1, 2, 2, 3, 8]))
     cap = int(rng.choice([3, 6, 16, 24]))
     al.set_knob(B.KNOB_EXH_FRAME_CAP, cap)
