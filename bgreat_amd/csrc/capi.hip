@@ -586,6 +586,8 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     const uint32_t wfast = std::min<uint32_t>(words, 16);  // the four-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
     const bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
                            geometry(8 * 8 * wfast, (n_reads + 3) / 4, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
+    bgr::LaunchCfg cfg_fast_list = cfg_fast;  // the launches over a list are compiled for 6 waves per SIMD (80 VGPRs)
+    if (fast_pass && !geometry(8 * 8 * wfast, (n_reads + 3) / 4, false, true, cfg_fast_list, 24)) cfg_fast_list = cfg_fast;
     // Exhaustive mode, first pass: four reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
@@ -708,7 +710,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             iof.subset_ctr = 2 + (uint32_t)ps - 1;
             iof.ovf_list = lists[ps & 1];
             iof.ovf_ctr = 2 + (uint32_t)ps;
-            e = bgr::launch_align(a->dg, iof, kp, cfg_fast, a->stream);
+            e = bgr::launch_align(a->dg, iof, kp, ps ? cfg_fast_list : cfg_fast, a->stream);
             if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (four-reads-per-wave pass): ") + hipGetErrorString(e));
             HIP_TRY(mark(ps == 0 ? "bgr_align_greedy4_kernel pass 1 (all reads)" : ps == 1 ? "bgr_align_greedy4_kernel pass 2 (listed reads)" : "bgr_align_greedy4_kernel pass 3 (listed reads)"));
         }

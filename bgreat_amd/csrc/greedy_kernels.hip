@@ -126,6 +126,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #ifndef BGR_G4_OCC
 #define BGR_G4_OCC 8
 #endif
+#ifndef BGR_G4L_OCC
+#define BGR_G4L_OCC 6 /* the launches over a list */
+#endif
 
 
 // A read the kernel cannot finish in this launch is listed with where to go on: which strand (the reference maps the
@@ -137,7 +140,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 
 // LIST: the launch maps the reads an earlier launch listed (io.subset) instead of all reads of the batch.
 template <bool STAGE, bool LIST>
-__global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -398,7 +401,7 @@ hipError_t launch_greedy(const BgrDeviceGraph& g, const BatchIO& io, const Kerne
                           : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
 }
 const void* greedy_kernel_fn(bool four_reads) {
-    return four_reads ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, true>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
+    return four_reads ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, false>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
 }
 
 }  // namespace bgr
