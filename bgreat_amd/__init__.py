@@ -19,6 +19,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "bgreat")
 MODE_GREEDY, MODE_EXHAUSTIVE, MODE_ANCHORS = 0, 1, 2
 ST_NOANCHOR, ST_FAILED, ST_ALIGNED, ST_MASK, ST_RC = 0, 1, 2, 3, 4
 BUILD_ANCHORS = 1
+BUILD_NO_EVICTIONS = 2  # test hook: keys whose two buckets are full go to the fallback list
 
 # every symbol include/bgreat_gpu.h declares (checked by tests/test_cabi.py)
 SYMBOLS = [
@@ -29,7 +30,7 @@ SYMBOLS = [
     "bgr_aligner_reset_counters", "bgr_aligner_kernel_time", "bgr_aligner_reset_kernel_time", "bgr_aligner_launch_info",
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
-    "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup",
+    "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup", "bgr_graph_key_lookup",
     "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST = 1, 2, 3, 4, 5, 6, 7
@@ -112,6 +113,7 @@ def lib():
     L.bgr_graph_build_ex.argtypes = [u32, u64, vp, vp, C.c_double, u32, C.POINTER(vp)]
     L.bgr_graph_build_from_fasta_ex.argtypes = [C.c_char_p, u32, C.c_double, u32, C.POINTER(vp)]
     L.bgr_graph_anchor_lookup.argtypes = [vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.bgr_graph_key_lookup.argtypes = [vp, u64, C.POINTER(C.c_uint32)]
     L.bgr_graph_blob.restype = vp
     L.bgr_graph_blob.argtypes = [vp, C.POINTER(u64)]
     L.bgr_graph_from_blob.argtypes = [vp, u64, C.POINTER(vp)]
@@ -204,12 +206,13 @@ class Graph:
         self.h = handle
 
     @classmethod
-    def build(cls, k, seqs, offsets, gamma=0.0, anchors=False):
-        """anchors=True also builds the k-mer anchors index of -G mode (MODE_ANCHORS)."""
+    def build(cls, k, seqs, offsets, gamma=0.0, anchors=False, no_evictions=False):
+        """anchors=True also builds the k-mer anchors index of -G mode (MODE_ANCHORS); gamma = key table slots per key (0 = default)."""
         seqs = _as_u8(seqs)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         h = C.c_void_p()
-        _check(lib().bgr_graph_build_ex(k, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, gamma, BUILD_ANCHORS if anchors else 0, C.byref(h)))
+        _check(lib().bgr_graph_build_ex(k, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, gamma,
+                                        (BUILD_ANCHORS if anchors else 0) | (BUILD_NO_EVICTIONS if no_evictions else 0), C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -217,6 +220,12 @@ class Graph:
         h = C.c_void_p()
         _check(lib().bgr_graph_build_from_fasta_ex(path.encode(), k, gamma, BUILD_ANCHORS if anchors else 0, C.byref(h)))
         return cls(h)
+
+    def key_lookup(self, key):
+        """slot of a canonical (k-1)-mer in the overlap key table, None for a non-member"""
+        slot = C.c_uint32()
+        _check(lib().bgr_graph_key_lookup(self.h, int(key), C.byref(slot)))
+        return None if slot.value == 0xFFFFFFFF else int(slot.value)
 
     def anchor_lookup(self, kmer):
         """(index, unitig, offset) of boomphf::mphf::lookup(kmer) on the anchors index; index None for ULLONG_MAX."""

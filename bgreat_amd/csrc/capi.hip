@@ -124,7 +124,7 @@ int bgr_graph_build(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint
 
 int bgr_graph_build_ex(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, uint32_t flags, bgr_graph** out) {
     if (!out || (n_unitigs && (!seqs || !offsets))) return fail(BGR_E_ARG, "bgr_graph_build: null argument");
-    if (flags & ~(uint32_t)BGR_BUILD_ANCHORS) return fail(BGR_E_ARG, "bgr_graph_build: unknown flag");
+    if (flags & ~(uint32_t)(BGR_BUILD_ANCHORS | BGR_BUILD_NO_EVICTIONS)) return fail(BGR_E_ARG, "bgr_graph_build: unknown flag");
     bgr_graph* g = new bgr_graph();
     std::string err;
     uint64_t zero[1] = {0};
@@ -170,6 +170,13 @@ int bgr_graph_anchor_lookup(const bgr_graph* g, uint64_t kmer, uint64_t* index_o
     const uint64_t idx = bgr::anchor_lookup(g->host.header(), g->host.base(), kmer);
     *index_out = idx;
     if (position_out) *position_out = idx == ~0ULL ? 0 : reinterpret_cast<const uint64_t*>(g->host.base() + g->header.off_anc_pos)[idx];
+    return BGR_OK;
+}
+
+int bgr_graph_key_lookup(const bgr_graph* g, uint64_t key, uint32_t* slot_out) {
+    if (!g || !slot_out) return fail(BGR_E_ARG, "bgr_graph_key_lookup: null argument");
+    if (g->host.blob.empty()) return fail(BGR_E_ARG, "bgr_graph_key_lookup: graph has no host blob");
+    *slot_out = bgr::host_lookup(g->host.header(), g->host.base(), key);
     return BGR_OK;
 }
 

@@ -66,7 +66,7 @@ struct KeyTable {
 // bucket 1 or bucket 2 of its hash; when both are full a resident is evicted to its other bucket (random walk, at most
 // kMaxKicks moves).  Keys are inserted in sorted order by one thread with a fixed pseudo-random sequence, so the table
 // -- and with it every index in the blob -- does not depend on the thread count.
-void build_key_table(const std::vector<uint64_t>& keys, double slots_per_key, unsigned T, KeyTable& t) {
+void build_key_table(const std::vector<uint64_t>& keys, double slots_per_key, unsigned T, bool evictions, KeyTable& t) {
     const uint64_t n = keys.size();
     const uint32_t nb = (uint32_t)std::max<uint64_t>(1, (uint64_t)std::ceil(slots_per_key * (double)n / 4.0));
     t.buckets.assign(nb, 0);
@@ -84,7 +84,7 @@ void build_key_table(const std::vector<uint64_t>& keys, double slots_per_key, un
         }
         return false;
     };
-    const int kMaxKicks = 4000;
+    const int kMaxKicks = evictions ? 4000 : 0;
     uint64_t rng = 0x9E3779B97F4A7C15ULL;
     for (uint64_t i0 = 0; i0 < n; ++i0) {
         uint32_t cur = (uint32_t)i0;
@@ -347,7 +347,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     // 1.8 / 2.5: 800 / 900 / 930 / 870 Mreads/s -- beyond 2 the table outgrows the L2).
     if (gamma == 0.0) gamma = (double)keys.size() * 1.07 <= 73000.0 ? 1.07 : 1.8;
     KeyTable tab;
-    build_key_table(keys, gamma, T, tab);
+    build_key_table(keys, gamma, T, !(flags & BGR_BUILD_NO_EVICTIONS), tab);
     tm.lap("keytable");
 
     // ---- anchors index of -G (aligner.cpp:434-442,457-462): canonical k-mers j = 0 .. len-k-1 of every unitig ----

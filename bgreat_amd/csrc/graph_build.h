@@ -37,10 +37,11 @@ struct HostGraph {
 };
 
 // seqs/offs: n unitig sequences in file order (offs[n+1]).  Loading stops at the first sequence shorter
-// than k, as aligner.cpp:418-420 does.  gamma: MPHF positions per remaining key on each cascade level (0 = choose: 1.5 when the cascade fits LDS staging, else 2).
+// than k, as aligner.cpp:418-420 does.  gamma: key table slots per key (0 = choose: 1.07 when the table fits LDS staging, else 1.8).
 // Returns false (and sets err) on invalid arguments / limits.
 // flags: BGR_BUILD_ANCHORS adds the anchors index of -G mode (graph_layout.h).
 #define BGR_BUILD_ANCHORS 1u
+#define BGR_BUILD_NO_EVICTIONS 2u  // test hook (include/bgreat_gpu.h)
 bool build_graph(uint32_t k, uint64_t n, const char* seqs, const uint64_t* offs, double gamma, uint32_t flags, HostGraph& out, std::string& err);
 
 // Host threads used by build_graph / read_unitig_fasta (0 = default: the machine's cores, at most 16).  The blob

@@ -89,12 +89,18 @@ int bgr_graph_build_from_fasta(const char* unitig_fasta_path, uint32_t k, double
  * boomphf::mphf bit for bit because the reference consumes its answers for non-keys too (aligner.cpp:387-389).
  * Costs ~9.5 bytes per unitig base on the host and in HBM. */
 #define BGR_BUILD_ANCHORS 1u
+#define BGR_BUILD_NO_EVICTIONS 2u /* test hook: the key table is built without eviction walks, so a key that finds both of
+                                      its buckets full goes to the sorted fallback list (normally empty); same results, slower */
 int bgr_graph_build_ex(uint32_t k, uint64_t n_unitigs, const char* seqs, const uint64_t* offsets, double gamma, uint32_t flags, bgr_graph** out);
 int bgr_graph_build_from_fasta_ex(const char* unitig_fasta_path, uint32_t k, double gamma, uint32_t flags, bgr_graph** out);
 /* boomphf::mphf::lookup on the anchors index, host side (BooPHF.h:783-818): the index of a canonical k-mer, a false
  * index for many non-keys, UINT64_MAX otherwise; *position_out (may be NULL) = unitig id << 32 | offset stored
  * there.  Used by the CPU tests to pin the index against the oracle's. */
 int bgr_graph_anchor_lookup(const bgr_graph* g, uint64_t kmer, uint64_t* index_out, uint64_t* position_out);
+/* The overlap key table, host side: the membership test of aligner.cpp:158,219,353,361 ("is this canonical (k-1)-mer an
+ * overlap of the graph") as the kernels make it.  *slot_out = the key's slot (its index into the blob's keys / records)
+ * or UINT32_MAX for a non-member.  Used by the CPU tests. */
+int bgr_graph_key_lookup(const bgr_graph* g, uint64_t canonical_k1mer, uint32_t* slot_out);
 /* The graph as one position-independent byte blob (what is copied to HBM / broadcast between GPUs). */
 const void* bgr_graph_blob(const bgr_graph* g, uint64_t* bytes);
 int bgr_graph_from_blob(const void* blob, uint64_t bytes, bgr_graph** out); /* copies the blob */

@@ -79,6 +79,69 @@ def test_blob_validation_refuses_corrupt_headers():
         B.Graph.from_blob(blob[:-256])           # truncated
 
 
+def _canonical_end_kmers(seqs, offs, k):
+    """The reference's overlap key set (aligner.cpp:466-533): canonical first and last (k-1)-mers of every unitig."""
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    K1 = k - 1
+    keys = set()
+    for i in range(len(offs) - 1):
+        u = bytes(seqs[int(offs[i]):int(offs[i + 1])])
+        if len(u) < k:
+            break
+        for w in (u[:K1], u[-K1:]):
+            x = 0
+            for ch in w:
+                x = x << 2 | code.get(ch, 3)
+            rc = 0
+            for ch in reversed(w):
+                rc = rc << 2 | (3 - code.get(ch, 3))
+            keys.add(min(x, rc))
+    return keys
+
+
+@pytest.mark.parametrize("gamma,no_evictions", [(0.0, False), (1.03, False), (1.8, False), (4.0, False), (1.07, True)])
+def test_overlap_key_table(gamma, no_evictions):
+    """Two-choice fingerprint table (graph_layout.h): every overlap key is found in a slot of its own, non-members are
+    rejected, and a key sits in its second bucket only when the first is full (what the L2 probing of find_key relies on).
+    no_evictions is the test hook that sends keys to the fallback list."""
+    k = 21
+    s = Synth(60000, 45, 3, k, 17)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(k, seqs, offs, gamma, no_evictions=no_evictions)
+    info = g.info()
+    keys = _canonical_end_kmers(seqs, offs, k)
+    assert info["n_keys"] == len(keys)
+    assert (info["n_fallback"] > 0) == no_evictions
+    slots = [g.key_lookup(x) for x in keys]
+    assert None not in slots and len(set(slots)) == len(slots)
+    rng = np.random.default_rng(5)
+    for x in rng.integers(0, 1 << (2 * (k - 1)), size=20000, dtype=np.uint64):
+        assert (g.key_lookup(int(x)) is not None) == (int(x) in keys)
+    # blob side: the fingerprint bytes, the key per slot, the placement invariant
+    blob = np.array(g.blob())
+    hdr = blob[:4096].view(np.uint64)
+    n_buckets, off_table, off_keys = int(hdr[9]), int(hdr[10]), int(hdr[11])
+    table = blob[off_table:off_table + 4 * n_buckets]
+    kslot = blob[off_keys:off_keys + 8 * (4 * n_buckets + info["n_fallback"])].view(np.uint64)
+    assert int((table != 0).sum()) == len(keys) - info["n_fallback"]
+    assert np.array_equal(table == 0, kslot[:4 * n_buckets] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    full = (table.reshape(-1, 4) != 0).all(axis=1)
+    M = (1 << 64) - 1
+    for x, slot in zip(keys, slots):
+        if slot >= 4 * n_buckets:
+            continue                                   # fallback list entry
+        y = x ^ (x >> 32)
+        m = (y * 0x9E3779B97F4A7C15) & M               # bgr_mix64
+        b1 = ((m & 0xFFFFFFFF) * n_buckets) >> 32
+        b2 = ((m >> 32) * n_buckets) >> 32
+        assert slot // 4 in (b1, b2) and int(kslot[slot]) == x
+        assert int(table[slot]) == max(1, (m >> 32) & 0xFF)
+        if slot // 4 != b1:
+            assert full[b1]
+    if not no_evictions and gamma in (0.0, 1.03):
+        assert 4 * n_buckets <= 1.08 * len(keys) + 4  # the tight fill small graphs are staged in LDS with
+
+
 def test_graph_build_rejects_bad_k():
     seqs = np.frombuffer(b"ACGTACGTAC", dtype=np.uint8)
     offs = np.array([0, 10], dtype=np.uint64)

@@ -575,18 +575,39 @@ def test_ragged_and_empty_batches():
     assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
 
 
-@pytest.mark.parametrize("stage", [1, 2])
-def test_mphf_in_lds_and_in_hbm_agree(stage):
+@pytest.mark.parametrize("stage,gamma", [(1, 0.0), (2, 0.0), (1, 1.8), (2, 1.8)])
+def test_mphf_in_lds_and_in_hbm_agree(stage, gamma):
+    """Key table staged in LDS (both buckets read at once) or probed in L2 (second bucket only when the first is full),
+    at the tight fill of small graphs and the sparse one of large graphs."""
     s = Synth(200000, 75, 2, 31, 55)
     seqs, offs = s.unitigs()
     reads, roffs = s.reads(0, 30000, 150, 3, 56)
-    g = B.Graph.build(31, seqs, offs)
+    g = B.Graph.build(31, seqs, offs, gamma)
     al = B.Aligner(g, 0)
     al.configure(lds_mphf=stage)
     o = oracle_py.Oracle(31, seqs, offs)
     p1, po1, st1 = al.align(reads, roffs)
     assert al.launch_info()["mphf_in_lds"] == (stage == 2)
     p2, po2, st2 = o.align(reads, roffs)
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+
+
+@pytest.mark.parametrize("mode", [B.MODE_GREEDY, B.MODE_EXHAUSTIVE])
+@pytest.mark.parametrize("stage", [1, 2])
+def test_keys_in_the_fallback_list_are_found(mode, stage):
+    """BUILD_NO_EVICTIONS (test hook) leaves the keys whose two buckets were full in the sorted fallback list: the kernels'
+    bisection path, which ordinary graphs never take."""
+    s = Synth(120000, 60, 3, 31, 91)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 12000, 120, 3, 92)
+    g = B.Graph.build(31, seqs, offs, 1.07, no_evictions=True)
+    assert g.info()["n_fallback"] > 100
+    al = B.Aligner(g, 0)
+    al.configure(lds_mphf=stage)
+    o = oracle_py.Oracle(31, seqs, offs)
+    m = 2 if mode == B.MODE_GREEDY else 4
+    p1, po1, st1 = al.align(reads, roffs, m=m, mode=mode)
+    p2, po2, st2 = o.align(reads, roffs, m=m, mode=1 if mode == B.MODE_EXHAUSTIVE else 0)
     assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
 
 
