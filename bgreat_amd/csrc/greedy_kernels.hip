@@ -360,10 +360,14 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
                 io.gen_list[atomicAdd(io.cursor + io.gen_ctr, 1u)] = r;
             }
         }
-        {   // the reads that go on in the next pass: appended to this wave's slice of the list
-            const u64 lm = __ballot(sub == 0 && have && outcome == 3);
+        {   // the reads that go on in the next pass: appended to this wave's slice of the list -- those that start their reverse
+            // complement from the slice's front, those that resume a forward scan from its back (the next pass takes four
+            // consecutive entries per wave, and only the second kind needs its second round: kept apart, few quads pay for it)
+            const bool listed = sub == 0 && have && outcome == 3;
+            const u64 lm = __ballot(listed);
             if (lm) {
-                const uint32_t cnt = (uint32_t)__popcll(lm);
+                const u64 lb = __ballot(listed && nst != G4_ST_RC);
+                const uint32_t cnt = (uint32_t)__popcll(lm), cnt_b = (uint32_t)__popcll(lb);
                 if (cnt > lst_end - lst_pos) {  // what is left of the old slice becomes holes
                     for (uint32_t j = lst_pos + (uint32_t)lane; j < lst_end; j += 64) io.ovf_list[j] = BGR_NONE;
                     uint32_t got = 0;
@@ -371,8 +375,13 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
                     lst_pos = rl32(got, 0);
                     lst_end = lst_pos + io.list_chunk;
                 }
-                if (sub == 0 && have && outcome == 3) io.ovf_list[lst_pos + (uint32_t)__popcll(lm & ((1ULL << lane) - 1))] = r;
-                lst_pos += cnt;
+                const u64 below = (1ULL << lane) - 1;
+                if (listed) {
+                    if (nst != G4_ST_RC) io.ovf_list[lst_end - 1 - (uint32_t)__popcll(lb & below)] = r;
+                    else io.ovf_list[lst_pos + (uint32_t)__popcll(lm & ~lb & below)] = r;
+                }
+                lst_pos += cnt - cnt_b;
+                lst_end -= cnt_b;
             }
         }
         c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
