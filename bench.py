@@ -70,7 +70,7 @@ def parse_args():
                          "branchy = configs[4] (exhaustive, m=5, 250 bp)")
     ap.add_argument("--exhaustive", action="store_true")
     ap.add_argument("--anchors", action="store_true", help="-G: greedy mapping from k-mer anchors (diagnostic; not the headline metric)")
-    ap.add_argument("--gamma", type=float, default=0.0, help="MPHF positions per key and level (0 = library default)")
+    ap.add_argument("--gamma", type=float, default=0.0, help="overlap key table slots per key (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the four-reads-per-wave passes (diagnostic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and the issue fractions become null)")
@@ -295,7 +295,7 @@ def main():
                 "traffic": None,
                 "definition": "achieved = ALGORITHMIC bytes of the REFERENCE's control flow (SURVEY 8d: gamma-10 BooPHF probes, rank words, 24-B records, "
                               "compared bases, path ints; oracle counter mode) x reads per launch / launch time.  This implementation moves far fewer "
-                              "bytes (own cascade probed in LDS): `traffic` is what HBM saw, `limiter` what bounds the launch",
+                              "bytes (its own key table is probed in LDS, or in L2 for large graphs): `traffic` is what HBM saw, `limiter` what bounds the launch",
                 "launch": "pre-pass + mapping passes of one batch, enqueued back to back on one stream (HIP events around the sequence)",
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "kernels_ms": kernels_ms, "dominant_kernel": dominant,
                 "alg_bytes_per_read": round(alg_bytes_per_read, 1), "reads_per_launch": R}
@@ -314,7 +314,6 @@ def main():
             roofline["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
         if pmc.get("SQ_INSTS_VALU") is not None:
             simd_cycles = N_SIMD * (avg_launch_ms / 1e3) * CLOCK_GHZ * 1e9
-            roofline["limiter"] = "valu_issue"
             roofline["valu_insts_per_read"] = round(pmc["SQ_INSTS_VALU"] / R, 1)
             roofline["salu_insts_per_read"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / R, 1)
             # profiles/r02_valu_rates.txt (tools/ubench/valu_rates.hip): a wave64 vector instruction occupies its SIMD for ~2.2 cycles
@@ -326,6 +325,10 @@ def main():
             roofline["valu_issue_frac_bounds"] = {"at_2.2_cycles": round(pmc["SQ_INSTS_VALU"] * 2.2 / simd_cycles, 4),
                                                   "at_3.3_cycles_static_mix": round(pmc["SQ_INSTS_VALU"] * 3.3 / simd_cycles, 4),
                                                   "at_4.1_cycles": round(pmc["SQ_INSTS_VALU"] * 4.1 / simd_cycles, 4)}
+            # what bounds the launch: the larger of the vector-issue fraction (at the static mix's price) and the HBM-side fraction
+            tf = roofline.get("traffic_frac")
+            vf = roofline["valu_issue_frac_bounds"]["at_3.3_cycles_static_mix"]
+            roofline["limiter"] = "valu_issue" if tf is None or vf >= tf else "memory (L2 fill / HBM traffic)"
             roofline["salu_issue_frac"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / (N_SIMD / 4 * (avg_launch_ms / 1e3) * CLOCK_GHZ * 1e9), 4)  # one scalar unit per CU
             roofline["issue_note"] = ("instructions per launch from rocprofv3 SQ counters (same child runs); VALU busy fraction = SQ_INSTS_VALU x cycles per "
                                       "instruction / (1024 SIMDs x launch time x %.1f GHz), bracketed by the two measured issue prices; SALU = SQ_INSTS_SALU / "

@@ -63,11 +63,11 @@ typedef struct {
 } bgr_params;
 
 typedef struct {
-    uint32_t k, n_levels;
-    uint64_t n_unitigs, n_keys, n_left_keys, n_right_keys, n_fallback;
-    uint64_t total_bases, blob_bytes, mphf_bytes, max_unitig_len;
+    uint32_t k, n_levels;  /* n_levels: buckets a key table lookup reads at most (2) */
+    uint64_t n_unitigs, n_keys, n_left_keys, n_right_keys, n_fallback; /* n_keys: distinct overlap (k-1)-mers */
+    uint64_t total_bases, blob_bytes, mphf_bytes, max_unitig_len;      /* mphf_bytes: size of the overlap key table */
     uint32_t has_exceptions, has_anchors; /* has_anchors: built with BGR_BUILD_ANCHORS (needed by BGR_MODE_ANCHORS) */
-    double gamma;
+    double gamma;  /* key table slots per key */
 } bgr_graph_info_t;
 
 const char* bgr_last_error(void);
@@ -76,7 +76,9 @@ int bgr_device_count(void); /* number of HIP devices visible, 0 if none / no dri
 /* ---- index ----------------------------------------------------------------------------------------
  * Replaces Aligner::Aligner + Aligner::indexUnitigs/indexUnitigsAux (aligner.h:80-105, aligner.cpp:407-547).
  * `seqs`/`offsets[n+1]`: the unitig sequences in file order (ids are 1-based ordinals, as in the reference).
- * Loading stops at the first sequence shorter than k (aligner.cpp:418-420).  gamma <= 0 selects the default.
+ * Loading stops at the first sequence shorter than k (aligner.cpp:418-420).  gamma = slots per key of the overlap key
+ * table that stands in for leftMPHF/rightMPHF + the key compare (1.03 .. 64; <= 0 selects the default: 1.07 when the table can be
+ * staged in LDS, else 1.8).
  * The graph is built on the host; inputs are only read during the call. */
 /* Host threads of the index build (the reference: BooPHF's `coreNumber` threads, aligner.cpp:450,458); 0 = default
  * (all cores, at most 16).  The built graph does not depend on it.  Process-wide. */
@@ -194,7 +196,7 @@ int bgr_aligner_reset_kernel_time(bgr_aligner* a);
  * NULL behind the last).  Launches of different modes since the last reset share positions. */
 int bgr_aligner_kernel_times(bgr_aligner* a, uint64_t* launches, double slot_ms[8], const char* slot_names[8]);
 /* Launch geometry of the last mapping kernel (for logs): blocks, threads per block, dynamic LDS bytes, and flags:
- * bit 0 = the MPHF cascade was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first),
+ * bit 0 = the overlap key table was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first),
  * bit 2 = the mode ran its four-reads-per-wave first pass (the numbers then describe that launch). */
 int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
 /* How the last mapping launch went through its passes.  Greedy mode: out[0..2] = reads the first / second / third launch of
@@ -203,8 +205,8 @@ int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
  * out[3] = reads mapped by the general kernel.  Exhaustive mode: out[2] = reads the four-reads-per-wave pass left to the level
  * / depth-first search, out[0] = reads that search listed for its second pass, out[1] = for its third.  Synchronises the stream. */
 int bgr_aligner_pass_counts(bgr_aligner* a, uint32_t out[4]);
-/* Tuning knobs (0 keeps the default): waves per workgroup, workgroups per CU, force MPHF LDS staging
- * (0 auto, 1 off, 2 on). */
+/* Tuning knobs (0 keeps the default): waves per workgroup, workgroups per CU, LDS staging of the overlap
+ * key table (0 auto, 1 off: probed in L2, 2 on). */
 int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blocks_per_cu, uint32_t lds_mphf);
 
 /* Test / diagnostic hooks, set once per aligner (they used to be environment variables read on every launch):
