@@ -220,6 +220,16 @@ __device__ __forceinline__ uint32_t ham_chunk(const BgrDeviceGraph& g, const u64
     return __popcll(mm);
 }
 
+// mismatches between n (1..32) read bases from base rb on and the unitig bases next to the overlap, taken from the slot
+// (`near`: read away from the overlap; a walk to the left sees their reverse complement).  Reads without N only.
+__device__ __forceinline__ uint32_t ham_near(const u64* CMP, u64 near, bool left, uint32_t n, uint32_t rb) {
+    const u64 u = left ? ~rev2_fast(near >> (64 - 2 * n)) : near;
+    const u64 x = u ^ lds_win32(CMP, rb);
+    u64 mm = (x | (x >> 1)) & EVEN_BITS;
+    if (n < 32) mm &= ~(~0ULL >> (2 * n));
+    return __popcll(mm);
+}
+
 template <int DIR>
 __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
                                                    uint32_t K1, uint32_t rec, bool canon, uint32_t pos, int lane) {
@@ -240,7 +250,7 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
     const bool fwd = (sl.x & fbit) != 0;
     const uint32_t len = valid ? sl.y : 0;
     // oriented strand start: forward at (Fw, Fo), reverse complement `len` bases further
-    const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+    const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwd ? 0u : len);
     sc.sid = fwd ? (int32_t)id : -(int32_t)id;
     sc.ext = len - K1;
     bool fits;
@@ -418,6 +428,7 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 // out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
 // behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
 // Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
+template <bool NEAR = false>
 __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t phase, uint32_t rec, uint32_t canon,
                                             uint32_t pos, uint32_t budget, int lane, uint32_t* miss, uint32_t* ext_o, int32_t* sid_o) {
     const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u;
@@ -436,7 +447,7 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
     const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
     const uint32_t len = sl.y;
-    const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+    const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwd ? 0u : len);
     const uint32_t ext = len - K1;
     // left: `rl` bases of the read lie left of the overlap; right: behind it (first step) / from its start (later steps)
     const uint32_t kk = phase == 2 ? K1 : 0u;
@@ -449,9 +460,16 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     const uint32_t nrec = fwd == left ? m0.y : m0.z;
     const uint32_t cbit = left ? (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND) : (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
     if (c >= first_zero) n = 0;
+    // at most 32 bases next to the overlap: they sit in the slot itself (graph_layout.h `near`), no load from seq.  Not for the
+    // later right steps (they compare the overlap as well, alignerGreedy.cpp:222,243) nor for a unitig that hangs on the overlap both ways
+    const uint32_t both = BGR_SLOT_F0 | BGR_SLOT_F1;
+    // (NEAR: the launches whose graph lives in L2/HBM; with everything in L2 and the key table in LDS the launch is bound by
+    // instruction issue and the second compare path costs more than the loads it saves: 1 206 vs 1 286 Mreads/s)
+    const bool near_ok = NEAR && n <= 32 && phase != 3 && (sl.x & both) != both && !(g.flags & BGR_GF_HAS_EXC);
     uint32_t cnt = 0;
-    for (uint32_t b = q * 32; __any(b < n); b += 128)
-        if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
+    if (NEAR && near_ok && n && q == 0) cnt = ham_near(FW, bgr_slot_near(sl.w, m0.x, m0.w), left != 0, n, rstart);
+    for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 128)
+        if (b < n && !near_ok) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
     cnt += quad_xor1(cnt);
     cnt += quad_xor2(cnt);
     // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")

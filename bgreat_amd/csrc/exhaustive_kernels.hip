@@ -181,7 +181,7 @@ __device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* C
         const bool valid = has_rec && (uint32_t)c < first_zero;
         const bool fwd = (sl.x & fbit) != 0;
         const uint32_t len = valid ? sl.y : 0;
-        const uint32_t fw = sl.z, fo = sl.w + (fwd ? 0u : len);
+        const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwd ? 0u : len);
         const int32_t sid = fwd ? (int32_t)id : -(int32_t)id;
         const uint32_t ext = len - K1;
         bool fits;
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
 // (exR).  On return, for the groups that took part: *cost = best total (X4_INF: none within the budget; the caller compares
 // with its budget), *n_out ints written to OUTG[o_off ...] in output order, *fb = the search left the shape this kernel
 // handles (the read goes on the list).
-template <int DIR>
+template <int DIR, bool NEAR>
 __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t act, uint32_t a_rec, uint32_t a_canon,
                                           uint32_t a_pos, uint32_t budget, uint32_t* LVT, int32_t* OUTG, uint32_t o_off, int lane, uint32_t* cost_o,
                                           uint32_t* n_out, uint32_t* fb_o) {
@@ -481,7 +481,7 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         const uint32_t valid = c < first_zero ? 1u : 0u;
         const uint32_t fwdu = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
         const uint32_t len = sl.y;
-        const uint32_t fw = sl.z, fo = sl.w + (fwdu ? 0u : len);
+        const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwdu ? 0u : len);
         const uint32_t ext = len - K1;
         uint32_t fits, n, ustart, rstart, nrec, cbit, aux, npos;
         if (DIR == 0) {
@@ -505,9 +505,15 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
             npos = pos + ext;
         }
         if (!valid) n = 0;
+        // at most 32 bases next to the overlap sit in the slot itself (graph_layout.h `near`): no load from seq (the exhaustive walks
+        // never compare the overlap again, alignerExhaustive.cpp:99,231)
+        const uint32_t both = BGR_SLOT_F0 | BGR_SLOT_F1;
+        // (NEAR: graphs that live in L2/HBM; issue-bound launches over a small graph are better off without the second compare path)
+        const bool near_ok = NEAR && n <= 32 && (sl.x & both) != both && !(g.flags & BGR_GF_HAS_EXC);
         uint32_t cnt = 0;
-        for (uint32_t b = q * 32; __any(b < n); b += 128)
-            if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
+        if (NEAR && near_ok && n && q == 0) cnt = ham_near(FW, bgr_slot_near(sl.w, m0.x, m0.w), DIR == 0, n, rstart);
+        for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 128)
+            if (b < n && !near_ok) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
         cnt += quad_xor1(cnt);
         cnt += quad_xor2(cnt);
         const uint32_t miss = cnt > 0xFFFFu ? 0xFFFFu : cnt;
@@ -681,7 +687,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         {
             const uint32_t actl = (anchored && a_pos != 0) ? 1u : 0u;
             uint32_t cl = 0, nll = 0;
-            x4_search<0>(g, F, L, K1, actl, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, m, LVT, OUTG, 0, lane, &cl, &nll, &fbl);
+            x4_search<0, !STAGE>(g, F, L, K1, actl, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, m, LVT, OUTG, 0, lane, &cl, &nll, &fbl);
             if (actl) { eb = cl; nl = nll; }
             else if (anchored) { if (sub == 0) OUTG[0] = 0; nl = 1; }
         }
@@ -690,7 +696,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         {
             const uint32_t actr = (anchored && !fbl && eb <= m) ? 1u : 0u;
             uint32_t cr = 0, nrr = 0;
-            x4_search<1>(g, F, L, K1, actr, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, actr ? m - eb : 0u, LVT, OUTG, nl, lane, &cr, &nrr, &fbr);
+            x4_search<1, !STAGE>(g, F, L, K1, actr, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, actr ? m - eb : 0u, LVT, OUTG, nl, lane, &cr, &nrr, &fbr);
             if (actr) { ee = cr; nr = nrr; } else ee = X4_INF;
         }
         // 0 = aligned; 2 = not aligned for sure (no overlap (k-1)-mer anywhere in the read: every position fails); 4 = the list

@@ -110,18 +110,22 @@ void build_key_table(const std::vector<uint64_t>& keys, double slots_per_key, un
     t.n_placed = n - t.fallback.size();
 }
 
-inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m) {  // aligner.cpp:481-489: first free of 1..3, else overwrite 4
+// `near_from` = base offset in seq of the strand on which the unitig begins with the slot's key (or its reverse complement)
+inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m, const uint64_t* seq, uint64_t near_from, uint32_t K1) {  // aligner.cpp:481-489: first free of 1..3, else overwrite 4
     int j = 3;
     if (s[0].idf == 0) j = 0;
     else if (s[1].idf == 0) j = 1;
     else if (s[2].idf == 0) j = 2;
+    const uint32_t ext = m.len - K1, nb = ext < 32 ? ext : 32;
+    uint64_t near = nb ? window(seq, near_from + K1, nb) << (64 - 2 * nb) : 0;  // the bases behind the overlap, first one on top
     s[j].idf = idf;
     s[j].len = m.len;
     s[j].Fw = (uint32_t)(m.F >> 5);
-    s[j].Fo = (uint32_t)(m.F & 31);
-    s[j].mflags = m.flags;
+    s[j].Fo_x = (uint32_t)(m.F & 31) | ((uint32_t)((near >> 32) & 15u) << 8);
+    s[j].mflags_x = (m.flags & 15u) | (uint32_t)((near >> 32) & 0xFFFFFFF0u);
     s[j].rec_beg = m.rec_beg;
     s[j].rec_end = m.rec_end;
+    s[j].near_lo = (uint32_t)near;
 }
 
 }  // namespace
@@ -505,12 +509,12 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
             uint32_t ib = m.rec_beg, ie = m.rec_end;
             // left-table slot of key x : F0 = (beg == x), F1 = (end == rc(x)); right-table slot of key y: F0 = (end == y), F1 = (beg == rc(y))
             if (mb) {
-                if (beg <= rcBeg) fill_slot(recs + (size_t)ib * 8, id | BGR_SLOT_F0 /* beg == key */ | (end == rcBeg ? BGR_SLOT_F1 : 0), m);
-                else fill_slot(recs + (size_t)ib * 8 + 4, id | (end == rcBeg ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* beg == rc(key) */, m);
+                if (beg <= rcBeg) fill_slot(recs + (size_t)ib * 8, id | BGR_SLOT_F0 /* beg == key */ | (end == rcBeg ? BGR_SLOT_F1 : 0), m, seq, m.F, K1);  // forward begins with the key
+                else fill_slot(recs + (size_t)ib * 8 + 4, id | (end == rcBeg ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* beg == rc(key) */, m, seq, m.F, K1);  // forward begins with rc(key)
             }
             if (me) {
-                if (end <= rcEnd) fill_slot(recs + (size_t)ie * 8 + 4, id | BGR_SLOT_F0 /* end == key */ | (beg == rcEnd ? BGR_SLOT_F1 : 0), m);
-                else fill_slot(recs + (size_t)ie * 8, id | (beg == rcEnd ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* end == rc(key) */, m);
+                if (end <= rcEnd) fill_slot(recs + (size_t)ie * 8 + 4, id | BGR_SLOT_F0 /* end == key */ | (beg == rcEnd ? BGR_SLOT_F1 : 0), m, seq, m.F + m.len, K1);  // the reverse strand begins with rc(key)
+                else fill_slot(recs + (size_t)ie * 8, id | (beg == rcEnd ? BGR_SLOT_F0 : 0) | BGR_SLOT_F1 /* end == rc(key) */, m, seq, m.F + m.len, K1);  // the reverse strand begins with the key
             }
         }
     });

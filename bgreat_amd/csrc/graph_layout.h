@@ -44,7 +44,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 9u  /* 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
+#define BGR_BLOB_VERSION 10u /* 10: slots carry the 32 bases next to the overlap; 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
 #define BGR_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL /* keys[] of an empty table slot: no (k-1)-mer, k <= 32, has bit 62 or 63 set */
 #define BGR_NONE 0xFFFFFFFFu
 #define BGR_SLOT_ID_MASK 0x3FFFFFFFu
@@ -75,12 +75,22 @@ typedef struct {
     uint32_t idf;     // unitig id | BGR_SLOT_F0 | BGR_SLOT_F1 ; 0 = empty slot
     uint32_t len;
     uint32_t Fw;      // forward strand starts at base Fo of seq word Fw  (F = 32*Fw + Fo): 32-bit address arithmetic
-    uint32_t Fo;      //   in the kernels (seq must stay below 4 GiB = 2^34 bases, checked at build time)
-    uint32_t mflags;  // BGR_META_* of this unitig
+    uint32_t Fo_x;    //   in the kernels (seq must stay below 4 GiB = 2^34 bases, checked at build time).  Bits 0..4 = Fo,
+                      //   bits 8..11 = bits 0..3 of `near` (below)
+    uint32_t mflags_x;// bits 0..3 = BGR_META_* of this unitig; bits 4..31 = bits 4..31 of `near`'s high word
     uint32_t rec_beg; // == meta[id].rec_beg / rec_end: the neighbour records at the unitig's two ends
     uint32_t rec_end;
-    uint32_t pad;
+    uint32_t near_lo; // `near` (64 bits, bgr_slot_near): the <= 32 unitig bases NEXT TO the overlap this slot hangs on, outside it,
+                      //   read away from the overlap in the orientation in which the unitig BEGINS with the key (or with the
+                      //   key's reverse complement), first base most significant, zero beyond the unitig's end.  A walk to the
+                      //   right compares exactly these bases, a walk to the left their reverse complement, so a step over
+                      //   a short unitig (or a short rest of the read) never touches `seq`.  Valid when exactly one of F0/F1
+                      //   is set (a hairpin unitig hangs on its overlap both ways) and the graph has no exception planes.
 } BgrSlot;            // 32 B; a neighbour record is BgrSlot[8]: left-table slots 0..3, right-table slots 4..7
+#define BGR_SLOT_FO_MASK 31u
+BGR_HD uint64_t bgr_slot_near(uint32_t Fo_x, uint32_t mflags_x, uint32_t near_lo) {
+    return ((uint64_t)((mflags_x & 0xFFFFFFF0u) | ((Fo_x >> 8) & 15u)) << 32) | near_lo;
+}
 
 // ---- anchors index (-G, optional) --------------------------------------------------------------------
 // The reference's anchors mode looks read k-mers up in a boomphf::mphf over the canonical k-mers of all unitigs

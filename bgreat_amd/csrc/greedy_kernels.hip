@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
                 if (!__any(phase != 0)) break;
                 uint32_t miss, ext;
                 int32_t sid;
-                const uint32_t w1 = g4_step(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+                const uint32_t w1 = g4_step<!STAGE>(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
                 if (phase != 0) {
                     if (!(w1 & G4_FOUND)) {
                         ++tried;
