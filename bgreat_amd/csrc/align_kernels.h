@@ -10,6 +10,12 @@
 
 namespace bgr {
 
+// lanes per read of the many-reads-per-wave greedy kernel (bgr_align_greedy4_kernel): 16 = four reads per wave, 8 = eight
+#ifndef BGR_G4_GROUP_LANES
+#define BGR_G4_GROUP_LANES 8
+#endif
+constexpr uint32_t kG4GroupLanes = BGR_G4_GROUP_LANES, kG4ReadsPerWave = 64 / BGR_G4_GROUP_LANES;
+
 struct BatchIO {
     const uint64_t* fw3;         // 2-bit plane of the batch (bgr_pack_reads_kernel / host packer): read r at word (read_offs[r] >> 5) + r
     const uint64_t* nmw;         // N-mask plane, same addressing; valid only for reads whose bit is set in hasn

@@ -591,10 +591,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // has no exception planes; what it does not settle is listed and mapped by the general kernel (cfg) right behind.
     bgr::LaunchCfg cfg_fast;
     const uint32_t wfast = std::min<uint32_t>(words, 16);  // the four-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
-    const bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
-                           geometry(8 * 8 * wfast, (n_reads + 3) / 4, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
+    bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
+                           geometry(bgr::kG4ReadsPerWave * 8 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
     bgr::LaunchCfg cfg_fast_list = cfg_fast;  // the launches over a list are compiled for 6 waves per SIMD (80 VGPRs)
-    if (fast_pass && !geometry(8 * 8 * wfast, (n_reads + 3) / 4, false, true, cfg_fast_list, 24)) cfg_fast_list = cfg_fast;
+    // (a launch over a list also keeps the reads' reverse complements: twice the words per read)
+    if (fast_pass && !geometry(bgr::kG4ReadsPerWave * 16 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, false, true, cfg_fast_list, 24)) fast_pass = false;
     // Exhaustive mode, first pass: four reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
@@ -657,7 +658,9 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.ovf_ctr = 2;
     if (fast_pass) {
         // the lists between the passes are written in per-wave slices of 16 entries (bgr::kG4ListChunk): room for the holes
-        const uint64_t list_cap = n_reads + n_reads / 4 + (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 2 * 16 + 64;  // <= 3 holes per 16 at a slice change, <= 15 at a wave's end
+        // a wave lists up to kG4ReadsPerWave reads at a time: a slice change leaves at most that many - 1 holes, and the slice behind it
+        // is then filled at once, so at least 9 of 16 allocated entries are reads; plus the unused tail of every wave's last slice
+        const uint64_t list_cap = 2 * n_reads + (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 2 * 16 + 64;
         HIP_TRY(a->ovf.ensure(list_cap * 4));
         HIP_TRY(a->ovf2.ensure(n_reads * 4));
         HIP_TRY(a->ovf3.ensure(list_cap * 4));
@@ -712,7 +715,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             iof.g4_last = ps == kFastPasses - 1 ? 1u : 0u;
             // slices of 16 list entries per atomic for big batches (a single-address atomic per read caps a launch near 300 M/s),
             // of 4 for small ones (every wave leaves the unused tail of its last slice as holes)
-            iof.list_chunk = n_reads >= (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 256 ? 16u : 4u;
+            iof.list_chunk = n_reads >= (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 256 ? 16u : std::max<uint32_t>(4u, bgr::kG4ReadsPerWave);
             iof.subset = ps ? lists[(ps - 1) & 1] : nullptr;
             iof.subset_ctr = 2 + (uint32_t)ps - 1;
             iof.ovf_list = lists[ps & 1];

@@ -295,6 +295,7 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
 __device__ __forceinline__ uint32_t quad_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t quad_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t row_ror4(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x124, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t half_row_mirror(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t row_ror8(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 
@@ -428,10 +429,11 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 // out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
 // behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
 // Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
-template <bool NEAR = false>
+template <bool NEAR = false, int GL = 16>
 __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t phase, uint32_t rec, uint32_t canon,
                                             uint32_t pos, uint32_t budget, int lane, uint32_t* miss, uint32_t* ext_o, int32_t* sid_o) {
-    const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u;
+    constexpr uint32_t QL = GL / 4;  // lanes per candidate slot: each takes 32 bases per round of the compare
+    const uint32_t c = ((uint32_t)lane / QL) & 3u, q = (uint32_t)lane % QL;
     const uint32_t left = phase == 1 ? 1u : 0u;
     // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
     const uint32_t useR = canon == left ? 1u : 0u;
@@ -443,8 +445,8 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     }
     const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
     const u64 zmask = __ballot(id == 0);  // (all lanes of a candidate agree; a group that sits out reads as "no candidate")
-    const uint32_t nb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
-    const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+    const uint32_t nb = (uint32_t)(zmask >> ((uint32_t)lane & (64u - GL))) & (GL == 16 ? 0x1111u : 0x55u);
+    const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) / QL : 4u;  // the reference stops at the first empty slot
     const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
     const uint32_t len = sl.y;
     const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwd ? 0u : len);
@@ -468,17 +470,17 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     const bool near_ok = NEAR && n <= 32 && phase != 3 && (sl.x & both) != both && !(g.flags & BGR_GF_HAS_EXC);
     uint32_t cnt = 0;
     if (NEAR && near_ok && n && q == 0) cnt = ham_near(FW, bgr_slot_near(sl.w, m0.x, m0.w), left != 0, n, rstart);
-    for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 128)
+    for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 32 * QL)
         if (b < n && !near_ok) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
     cnt += quad_xor1(cnt);
-    cnt += quad_xor2(cnt);
+    if (QL == 4) cnt += quad_xor2(cnt);
     // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
     uint32_t key = c < first_zero ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
-    uint32_t o = row_ror4(key);
+    uint32_t o = GL == 16 ? row_ror4(key) : quad_xor2(key);   // 16 lanes: slots sit 4 lanes apart; 8 lanes: 2 apart
     key = o < key ? o : key;
-    o = row_ror8(key);
+    o = GL == 16 ? row_ror8(key) : half_row_mirror(key);      // (lane 7 - l of the half row: the other two slots)
     key = o < key ? o : key;
-    const uint32_t src = ((uint32_t)lane & 48u) | ((key & 3u) << 2);
+    const uint32_t src = ((uint32_t)lane & (64u - GL)) | ((key & 3u) * QL);
     const uint32_t pk = nrec | ((m0.x & cbit) ? G4_CANON : 0u) | (fits ? G4_FITS : 0u);
     const uint32_t w1 = lane_get(pk, src);
     *ext_o = lane_get(ext, src);

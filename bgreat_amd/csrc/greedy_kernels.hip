@@ -139,8 +139,10 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #define G4_ST_POS_MASK 0xFFFFFu
 
 // LIST: the launch maps the reads an earlier launch listed (io.subset) instead of all reads of the batch.
-template <bool STAGE, bool LIST>
+// GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight.
+template <bool STAGE, bool LIST, int GL>
 __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    constexpr uint32_t RPW = 64 / GL;  // reads per wave
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -148,11 +150,13 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
     const uint32_t K1 = g.k - 1;
     // later passes map the reads an earlier pass listed (count in cursor[subset_ctr]), from the state it left in g4_state
     const uint32_t total = LIST ? io.cursor[io.subset_ctr] : io.n_reads;
-    if ((uint32_t)(blockIdx.x * waves) * 4u >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
+    if ((uint32_t)(blockIdx.x * waves) * RPW >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
     uint32_t mphf_words;
     const uint32_t* units = block_prologue<STAGE>(g, lds, &mphf_words);
-    u64* RD = lds + 64 + mphf_words + (u64)wave * (8 * W);  // the four reads of this wave: forward words | reverse-complement words
-    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
+    const uint32_t RS = LIST ? 2 * W : W;  // words per read: forward words [| reverse-complement words: only a launch over a list maps that strand]
+    u64* RD = lds + 64 + mphf_words + (u64)wave * (RPW * RS);
+    const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
+    const uint32_t gbase_lane = (uint32_t)lane & ~(uint32_t)(GL - 1);
     const uint32_t m = prm.max_mismatch;
     const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
 
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
 
     // (per-lane flags are kept as 0/1 words in VGPRs on purpose: as `bool`s they become 64-bit lane masks in SGPRs, and this
     // kernel is short of SGPRs, not of VGPRs)
-    for (uint32_t ibase = (blockIdx.x * waves + wave) * 4; ibase < total; ibase += gridDim.x * waves * 4) {
+    for (uint32_t ibase = (blockIdx.x * waves + wave) * RPW; ibase < total; ibase += gridDim.x * waves * RPW) {
         const uint32_t it = ibase + grp;
         uint32_t have = it < total ? 1u : 0u;
         uint32_t r = 0, st = 0;
@@ -185,11 +189,11 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
         uint32_t rc = st >> 31;
         uint32_t tried = (st >> G4_ST_TRIED_SHIFT) & 0x7FFu;
         uint32_t s_from = st & G4_ST_POS_MASK;
-        u64* F = RD + grp * (2 * W);
-        {   // stage the 2-bit words: lane `sub` of a group brings word `sub` of its read
+        u64* F = RD + grp * RS;
+        for (uint32_t j = sub; j < W; j += GL) {  // stage the 2-bit words: the lanes of a group bring the words of its read
             u64 f = 0;
-            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
-            if (sub < W) F[sub] = f;
+            if (fast && j < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + j];
+            F[j] = f;
         }
         wave_sync();
         uint32_t act = fast;                 // the group takes part in the current round
@@ -198,31 +202,33 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
         int32_t pl = 0, pr = 0;  // lane `sub` keeps path int number `sub` of the left walk (near -> far, offset last) / right walk
         for (uint32_t round = 0;; ++round) {
             if (__any(act && rc)) {  // reverseComplements(read) (utils.cpp:66-73) of the groups that are on their second strand
-                if (act && rc && sub < W) {
-                    const long long p = (long long)L - 32 * ((long long)sub + 1);
-                    u64 w = 0;
-                    if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
-                    else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
-                    F[W + sub] = w;
+                if (LIST && act && rc) {
+                    for (uint32_t j = sub; j < W; j += GL) {
+                        const long long p = (long long)L - 32 * ((long long)j + 1);
+                        u64 w = 0;
+                        if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
+                        else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                        F[W + j] = w;
+                    }
                 }
                 wave_sync();
             }
-            const u64* FW = F + (rc ? W : 0);  // the strand this pass maps
+            const u64* FW = F + ((LIST && rc) ? W : 0);  // the strand this pass maps
 
             // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each read from where its scan stands and,
             // when it lies in the same 64 positions, the one after it; record | canonical << 28
             uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
-            for (uint32_t q = 0; q < 4; ++q) {
-                if (!rl32(act, (int)(16 * q))) continue;
+            for (uint32_t q = 0; q < RPW; ++q) {
+                if (!rl32(act, (int)(GL * q))) continue;
 #ifdef BGR_PHASE_TIMING
                 if (prm.debug_stop == 1) continue;  // 1 = stops behind the staging of the reads
 #endif
-                const uint32_t Lq = rl32(L, (int)(16 * q));
-                const u64* A = RD + q * (2 * W) + (rl32(rc, (int)(16 * q)) ? W : 0);
-                const uint32_t left_q = eff - rl32(tried, (int)(16 * q));  // anchors this strand may still try (>= 1)
+                const uint32_t Lq = rl32(L, (int)(GL * q));
+                const u64* A = RD + q * RS + ((LIST && rl32(rc, (int)(GL * q))) ? W : 0);
+                const uint32_t left_q = eff - rl32(tried, (int)(GL * q));  // anchors this strand may still try (>= 1)
                 uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
                 if (!prm.effort && npos > 1) npos = 1;
-                for (uint32_t base = rl32(s_from, (int)(16 * q)); base < npos; base += 64) {
+                for (uint32_t base = rl32(s_from, (int)(GL * q)); base < npos; base += 64) {
                     const uint32_t i = base + (uint32_t)lane;
                     const bool valid = i < npos;
                     u64 num = 0;
@@ -264,11 +270,11 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
                 }
                 if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
                 if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
-                if ((phase == 1 && nl > G4_PATH - 2) || (phase >= 2 && nr > G4_PATH - 1)) { bad = 1; phase = 0; }  // path too long for the registers
+                if ((phase == 1 && nl > GL - 2) || (phase >= 2 && nr > GL - 1)) { bad = 1; phase = 0; }  // path too long for the registers
                 if (!__any(phase != 0)) break;
                 uint32_t miss, ext;
                 int32_t sid;
-                const uint32_t w1 = g4_step<!STAGE>(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+                const uint32_t w1 = g4_step<!STAGE, GL>(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
                 if (phase != 0) {
                     if (!(w1 & G4_FOUND)) {
                         ++tried;
@@ -330,8 +336,13 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
         // ---- publish: reverse(left) ++ right into the arena ----------------------------------------------------------------------
         const uint32_t aligned = outcome == 0 ? 1u : 0u;
         const uint32_t p_n = aligned ? nl + nr : 0;
-        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
-        const uint32_t tot = n0 + n1 + n2 + n3;
+        uint32_t tot = 0, before = 0;  // ints of the whole wave / of the groups in front of this one
+#pragma unroll
+        for (uint32_t i = 0; i < RPW; ++i) {
+            const uint32_t ni = rl32(p_n, (int)(GL * i));
+            if (grp > i) before += ni;
+            tot += ni;
+        }
         if (tot > chunk_end - chunk_pos) {  // one global atomic per ~50 reads (see publish_path)
             const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
             uint32_t got = 0;
@@ -339,14 +350,14 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
             chunk_pos = rl32(got, 0);
             chunk_end = chunk_pos + want;
         }
-        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const uint32_t gbase = chunk_pos + before;
         const bool room = chunk_pos + tot <= io.arena_cap;
         chunk_pos += tot;
 #pragma unroll
         for (uint32_t jj = 0; jj < 2; ++jj) {
-            const uint32_t j = sub + 16 * jj;
-            const uint32_t vl = lane_get((uint32_t)pl, ((uint32_t)lane & 48u) | ((nl - 1 - j) & 15u));
-            const uint32_t vr = lane_get((uint32_t)pr, ((uint32_t)lane & 48u) | ((j - nl) & 15u));
+            const uint32_t j = sub + GL * jj;
+            const uint32_t vl = lane_get((uint32_t)pl, gbase_lane | ((nl - 1 - j) & (GL - 1)));
+            const uint32_t vr = lane_get((uint32_t)pr, gbase_lane | ((j - nl) & (GL - 1)));
             if (j < p_n && room) io.arena[gbase + j] = (int32_t)(j < nl ? vl : vr);
         }
         if (!room && lane == 0 && tot) io.cursor[1] = 1;  // overflow: reported by the host as an error
@@ -402,15 +413,16 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
 }  // namespace
 
 hipError_t launch_greedy(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
-    if (io.greedy4 && io.subset) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, true>, g, io, p, cfg, stream)
-                                                       : launch_one(bgr_align_greedy4_kernel<false, true>, g, io, p, cfg, stream);
-    if (io.greedy4) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, false>, g, io, p, cfg, stream)
-                                          : launch_one(bgr_align_greedy4_kernel<false, false>, g, io, p, cfg, stream);
+    constexpr int GL = (int)kG4GroupLanes;
+    if (io.greedy4 && io.subset) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, true, GL>, g, io, p, cfg, stream)
+                                                       : launch_one(bgr_align_greedy4_kernel<false, true, GL>, g, io, p, cfg, stream);
+    if (io.greedy4) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, false, GL>, g, io, p, cfg, stream)
+                                          : launch_one(bgr_align_greedy4_kernel<false, false, GL>, g, io, p, cfg, stream);
     return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
                           : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
 }
 const void* greedy_kernel_fn(bool four_reads) {
-    return four_reads ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, false>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
+    return four_reads ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, false, (int)kG4GroupLanes>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
 }
 
 }  // namespace bgr
