@@ -72,7 +72,7 @@ def parse_args():
     ap.add_argument("--anchors", action="store_true", help="-G: greedy mapping from k-mer anchors (diagnostic; not the headline metric)")
     ap.add_argument("--gamma", type=float, default=0.0, help="overlap key table slots per key (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the four-reads-per-wave passes (diagnostic)")
+    ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the eight-reads-per-wave passes (diagnostic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and the issue fractions become null)")
     ap.add_argument("--pmc-steps", type=int, default=3)
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end leg per GPU (0 disables)")

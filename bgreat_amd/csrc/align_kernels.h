@@ -10,7 +10,7 @@
 
 namespace bgr {
 
-// lanes per read of the many-reads-per-wave greedy kernel (bgr_align_greedy4_kernel): 16 = four reads per wave, 8 = eight
+// lanes per read of the many-reads-per-wave greedy kernel (bgr_align_greedy_multi_kernel): 16 = four reads per wave, 8 = eight
 #ifndef BGR_G4_GROUP_LANES
 #define BGR_G4_GROUP_LANES 8
 #endif
@@ -35,7 +35,7 @@ struct BatchIO {
     uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
-    uint32_t greedy4;            // greedy mode: launch the four-reads-per-wave kernel; reads it cannot finish in this launch go on ovf_list
+    uint32_t greedy_multi;            // greedy mode: launch the eight-reads-per-wave kernel; reads it cannot finish in this launch go on ovf_list
                                  // (with their state in g4_state, for its next pass) or on gen_list (for the general kernel)
     uint32_t* g4_state;          // n words: where a listed read's mapping stands (strand, anchors tried, scan position)
     uint32_t* gen_list;          // reads for the general kernel (count at cursor[gen_ctr])
@@ -43,7 +43,7 @@ struct BatchIO {
     uint32_t anc4;               // anchors mode: launch the four-reads-per-wave kernel (what it does not settle goes on ovf_list)
     uint32_t exh4;               // exhaustive mode: launch the four-reads-per-wave kernel (what it does not settle goes on ovf_list)
     uint32_t list_chunk;         // entries of ovf_list a wave reserves per global atomic (4..16; the unused ones become holes = BGR_NONE)
-    uint32_t g4_last;            // last pass of the four-reads-per-wave kernel: everything unfinished goes on gen_list
+    uint32_t g4_last;            // last pass of the eight-reads-per-wave greedy kernel: everything unfinished goes on gen_list
     uint32_t subset_ctr, ovf_ctr; // which words of `cursor` count the reads of `subset` / collect the reads put on `ovf_list`
 };
 
@@ -91,7 +91,7 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
 }
 
 // Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive depth-first,
-// 2 anchors, 3 exhaustive level search, 4 greedy four-reads-per-wave, 5 exhaustive four-reads-per-wave, 6 anchors four-reads-per-wave).
+// 2 anchors, 3 exhaustive level search, 4 greedy eight-reads-per-wave, 5 exhaustive four-reads-per-wave, 6 anchors four-reads-per-wave).
 uint32_t resident_waves_per_cu(uint32_t mode);
 
 // (results, arena) of the last mapping launch -> input-ordered CSR on the device.  phase 0: block_sums[ceil(n/4096)] and

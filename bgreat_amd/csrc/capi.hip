@@ -587,10 +587,10 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         if (deep_only) cfg = cfg_deep;
         mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, true, cfg_mid);
     }
-    // Greedy mode, first pass: four reads per wave (bgr_align_greedy4_kernel) when a read fits one lane per word and the graph
+    // Greedy mode, first pass: eight reads per wave (bgr_align_greedy_multi_kernel) when a read fits one lane per word and the graph
     // has no exception planes; what it does not settle is listed and mapped by the general kernel (cfg) right behind.
     bgr::LaunchCfg cfg_fast;
-    const uint32_t wfast = std::min<uint32_t>(words, 16);  // the four-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
+    const uint32_t wfast = std::min<uint32_t>(words, 16);  // the many-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
     bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
                            geometry(bgr::kG4ReadsPerWave * 8 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
     bgr::LaunchCfg cfg_fast_list = cfg_fast;  // the launches over a list are compiled for 6 waves per SIMD (80 VGPRs)
@@ -646,7 +646,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.deep_scratch = nullptr;
     io.deep_stride = (uint32_t)deep_stride;
     io.level_search = level_search ? 1u : 0u;
-    io.greedy4 = 0;
+    io.greedy_multi = 0;
     io.g4_state = nullptr;
     io.gen_list = nullptr;
     io.gen_ctr = 8;
@@ -699,7 +699,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         HIP_TRY(mark("bgr_pack_reads_kernel"));
     }
     if (fast_pass) {
-        // Three launches of the four-reads-per-wave kernel: all reads; then twice what the launch before could not finish (the
+        // Three launches of the eight-reads-per-wave kernel: all reads; then twice what the launch before could not finish (the
         // next anchors of a read whose first ones failed, then its reverse complement), densely packed four to a wave again.
         // What is left after that -- and reads the kernel does not take at all (N, very long paths) -- is mapped from scratch
         // by the general kernel.  All enqueued back to back: with an empty list a launch's workgroups exit at once.
@@ -707,7 +707,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         const int kFastPasses = 3;
         for (int ps = 0; ps < kFastPasses; ++ps) {
             bgr::BatchIO iof = io;
-            iof.greedy4 = 1;
+            iof.greedy_multi = 1;
             iof.words_per_read = wfast;
             iof.g4_state = static_cast<uint32_t*>(a->g4st.p);
             iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
@@ -721,8 +721,8 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             iof.ovf_list = lists[ps & 1];
             iof.ovf_ctr = 2 + (uint32_t)ps;
             e = bgr::launch_align(a->dg, iof, kp, ps ? cfg_fast_list : cfg_fast, a->stream);
-            if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (four-reads-per-wave pass): ") + hipGetErrorString(e));
-            HIP_TRY(mark(ps == 0 ? "bgr_align_greedy4_kernel pass 1 (all reads)" : ps == 1 ? "bgr_align_greedy4_kernel pass 2 (listed reads)" : "bgr_align_greedy4_kernel pass 3 (listed reads)"));
+            if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (eight-reads-per-wave pass): ") + hipGetErrorString(e));
+            HIP_TRY(mark(ps == 0 ? "bgr_align_greedy_multi_kernel pass 1 (all reads)" : ps == 1 ? "bgr_align_greedy_multi_kernel pass 2 (listed reads)" : "bgr_align_greedy_multi_kernel pass 3 (listed reads)"));
         }
         io.subset = static_cast<uint32_t*>(a->ovf2.p);
         io.subset_ctr = 8;

@@ -1,6 +1,6 @@
 // greedy_kernels.hip -- greedy mode (alignReadGreedy, alignerGreedy.cpp:35-57,167-364) on gfx950.
-//   bgr_align_greedy4_kernel  four reads per wavefront: the position scans one after the other on all 64 lanes, the four
-//                             extensions side by side, 16 lanes each; settles the common shapes, lists the rest
+//   bgr_align_greedy_multi_kernel  eight reads per wavefront (lanes per read: a template parameter): the position scans one after the
+//                             other on all 64 lanes, the extensions side by side, 8 lanes each; settles the common shapes, lists the rest
 //   bgr_align_greedy_kernel   the general kernel: one read per wavefront, every anchor, both strands, N planes, any path length
 #include "device_common.h"
 
@@ -14,7 +14,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;
     const uint32_t K1 = g.k - 1;
-    // as the second pass behind bgr_align_greedy4_kernel it maps only the reads that kernel listed (count in cursor[subset_ctr])
+    // as the second pass behind bgr_align_greedy_multi_kernel it maps only the reads that kernel listed (count in cursor[subset_ctr])
     const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
     if ((uint32_t)(blockIdx.x * waves) >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
     uint32_t mphf_words;
@@ -112,15 +112,17 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
     }
 }
 
-// ================================= greedy, four reads per wavefront ====================================
+// ================================= greedy, several reads per wavefront ====================================
 // bgr_align_greedy_kernel above walks one read per wave: a walk step is two dependent loads (slot, bases) scored by at
-// most 4 candidates x a few 32-base chunks, i.e. a handful of the 64 lanes, and per read there are ~4 such steps in a row.
-// Here a wave takes FOUR reads: their position scans still run one after the other on all 64 lanes (a scan is lane-
-// efficient: one (k-1)-mer per lane), then the four extensions run side by side, 16 lanes each (4 candidates x 4 chunk
-// lanes = 128 bases per step), so four slot/base load chains are in flight per wave and every wave instruction of a walk
-// step serves four reads.  Path ints stay in registers (lane j of a group holds int j of each direction).
+// most 4 candidates x a few 32-base chunks, i.e. a handful of the 64 lanes, and per read there are ~3 such steps in a row.
+// Here a wave takes 64 / GL reads, GL lanes each (GL = 8: EIGHT reads; round 2 started with GL = 16, four reads): their
+// position scans still run one after the other on all 64 lanes (a scan is lane-efficient: one (k-1)-mer per lane), then
+// the extensions run side by side, GL lanes each (4 candidate slots x GL/4 chunk lanes of 32 bases: 64 bases per round of
+// the compare at GL = 8), so eight slot/base load chains are in flight per wave and every wave instruction of a walk step
+// serves eight reads (a quad of reads needs max-over-4 = 3.4 steps, an octet 3.7: the instructions per read nearly halve).
+// Path ints stay in registers (lane j of a group holds int j of each direction: GL ints per direction).
 // The kernel settles the common case only -- no N in the read, first anchor extends within the budget (or there is
-// no anchor at all), at most G4_PATH ints per direction.  Every other read (N, failed first anchor: the reference then
+// no anchor at all), at most GL path ints per direction.  Every other read (N, failed first anchor: the reference then
 // tries further anchors and the reverse complement, alignerGreedy.cpp:41-56; long paths) is put on a list and mapped by
 // bgr_align_greedy_kernel right behind, so results are the reference's for every read.
 #ifndef BGR_G4_OCC
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 // LIST: the launch maps the reads an earlier launch listed (io.subset) instead of all reads of the batch.
 // GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight.
 template <bool STAGE, bool LIST, int GL>
-__global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_align_greedy4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_align_greedy_multi_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     constexpr uint32_t RPW = 64 / GL;  // reads per wave
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
                 }
             }
 
-            // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), four reads abreast; a group whose anchor fails
+            // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), the wave's reads abreast; a group whose anchor fails
             // starts over from the next one, if the scan has seen it, while the others go on ----
             uint32_t phase = (act && a_rec != BGR_NONE) ? 1u : 0u;
 #ifdef BGR_PHASE_TIMING  /* diagnostic builds (tools/phase_cost.sh): knob DEBUG_STOP = 2 stops behind the anchor scan */
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
             }
         }
         {   // the reads that go on in the next pass: appended to this wave's slice of the list -- those that start their reverse
-            // complement from the slice's front, those that resume a forward scan from its back (the next pass takes four
+            // complement from the slice's front, those that resume a forward scan from its back (the next pass takes
             // consecutive entries per wave, and only the second kind needs its second round: kept apart, few quads pay for it)
             const bool listed = sub == 0 && have && outcome == 3;
             const u64 lm = __ballot(listed);
@@ -414,15 +416,15 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
 
 hipError_t launch_greedy(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     constexpr int GL = (int)kG4GroupLanes;
-    if (io.greedy4 && io.subset) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, true, GL>, g, io, p, cfg, stream)
-                                                       : launch_one(bgr_align_greedy4_kernel<false, true, GL>, g, io, p, cfg, stream);
-    if (io.greedy4) return cfg.stage_mphf ? launch_one(bgr_align_greedy4_kernel<true, false, GL>, g, io, p, cfg, stream)
-                                          : launch_one(bgr_align_greedy4_kernel<false, false, GL>, g, io, p, cfg, stream);
+    if (io.greedy_multi && io.subset) return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, true, GL>, g, io, p, cfg, stream)
+                                                       : launch_one(bgr_align_greedy_multi_kernel<false, true, GL>, g, io, p, cfg, stream);
+    if (io.greedy_multi) return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, false, GL>, g, io, p, cfg, stream)
+                                          : launch_one(bgr_align_greedy_multi_kernel<false, false, GL>, g, io, p, cfg, stream);
     return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
                           : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
 }
-const void* greedy_kernel_fn(bool four_reads) {
-    return four_reads ? reinterpret_cast<const void*>(&bgr_align_greedy4_kernel<true, false, (int)kG4GroupLanes>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
+const void* greedy_kernel_fn(bool many_reads) {
+    return many_reads ? reinterpret_cast<const void*>(&bgr_align_greedy_multi_kernel<true, false, (int)kG4GroupLanes>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
 }
 
 }  // namespace bgr

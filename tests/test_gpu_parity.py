@@ -447,7 +447,7 @@ def test_gpu_matches_oracle_random(seed, k, L, m, e, nfrac, d, alleles):
     (1, 31, 150, 2, 2, 0.0, 140, 2), (2, 31, 100, 2, 2, 0.003, 75, 2), (3, 21, 250, 5, 1, 0.0, 40, 4), (4, 8, 90, 3, 3, 0.0, 12, 3),
     (5, 31, 150, 0, 0, 0.0, 100, 2), (6, 32, 440, 4, 2, 0.001, 60, 4), (7, 12, 64, 1, 8, 0.0, 20, 2), (8, 31, 33, 2, 2, 0.0, 90, 2)])
 def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m, e, nfrac, d, alleles):
-    """Greedy mode maps with bgr_align_greedy4_kernel (four reads per wave, first anchor only) and hands what that does not
+    """Greedy mode maps with bgr_align_greedy_multi_kernel (four reads per wave, first anchor only) and hands what that does not
     settle -- N reads, failed first anchors, long paths (small k: many short unitigs) -- to the general kernel.  Both
     routes and the oracle must agree row for row, counters included; batch sizes that leave 1..3 reads in the last wave."""
     s = Synth(150000, d, alleles, k, 7100 + seed)
