@@ -447,9 +447,10 @@ def test_gpu_matches_oracle_random(seed, k, L, m, e, nfrac, d, alleles):
     (1, 31, 150, 2, 2, 0.0, 140, 2), (2, 31, 100, 2, 2, 0.003, 75, 2), (3, 21, 250, 5, 1, 0.0, 40, 4), (4, 8, 90, 3, 3, 0.0, 12, 3),
     (5, 31, 150, 0, 0, 0.0, 100, 2), (6, 32, 440, 4, 2, 0.001, 60, 4), (7, 12, 64, 1, 8, 0.0, 20, 2), (8, 31, 33, 2, 2, 0.0, 90, 2)])
 def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m, e, nfrac, d, alleles):
-    """Greedy mode maps with bgr_align_greedy_multi_kernel (four reads per wave, first anchor only) and hands what that does not
-    settle -- N reads, failed first anchors, long paths (small k: many short unitigs) -- to the general kernel.  Both
-    routes and the oracle must agree row for row, counters included; batch sizes that leave 1..3 reads in the last wave."""
+    """Greedy mode maps with bgr_align_greedy_multi_kernel (eight reads per wave, 8 lanes each; three launches up the reference's
+    retry ladder) and hands what that does not settle -- N reads, long paths (small k: many short unitigs) -- to the general
+    kernel.  Both routes and the oracle must agree row for row, counters included; the batch sizes leave 0..7 reads in the
+    last wave."""
     s = Synth(150000, d, alleles, k, 7100 + seed)
     seqs, offs = s.unitigs()
     n = 20003 - seed
@@ -471,6 +472,22 @@ def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m
     assert not al.launch_info()["four_reads_per_wave"]
     assert np.array_equal(st3, st2) and np.array_equal(po3, po2) and np.array_equal(p3, p2)
     assert al.counters() == o.counters()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 15, 17, 63, 65])
+def test_tiny_batches_through_the_many_reads_per_wave_kernels(n):
+    """A single, partly filled wave (fewer reads than a wave takes, a last group alone) in all three modes."""
+    k = 31
+    s = Synth(60000, 70, 2, k, 4242)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, n, 150, 3, 4300 + n)
+    g = B.Graph.build(k, seqs, offs, anchors=True)
+    al = B.Aligner(g, 0)
+    o = oracle_py.Oracle(k, seqs, offs, anchors=True)
+    for mode in (B.MODE_GREEDY, B.MODE_EXHAUSTIVE, B.MODE_ANCHORS):
+        p1, po1, st1 = al.align(reads, roffs, m=2, mode=mode)
+        p2, po2, st2 = o.align(reads, roffs, m=2, mode={B.MODE_GREEDY: 0, B.MODE_EXHAUSTIVE: 1, B.MODE_ANCHORS: 2}[mode])
+        assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2), mode
 
 
 @pytest.mark.parametrize("mode,m", [(0, 2), (1, 3), (2, 2)])
