@@ -15,6 +15,13 @@ namespace bgr {
 #define BGR_G4_GROUP_LANES 8
 #endif
 constexpr uint32_t kG4GroupLanes = BGR_G4_GROUP_LANES, kG4ReadsPerWave = 64 / BGR_G4_GROUP_LANES;
+// the same for the exhaustive first pass (bgr_align_exhaustive4_kernel); its level table holds one level per lane of a read's group
+#ifndef BGR_X4_GROUP_LANES
+#define BGR_X4_GROUP_LANES 8
+#endif
+constexpr uint32_t kX4GroupLanes = BGR_X4_GROUP_LANES, kX4ReadsPerWave = 64 / BGR_X4_GROUP_LANES;
+// u64 words per read besides the read's own: level table (8 or 16 levels of a walk per side, 16 words each) + out ints
+constexpr uint32_t x4_group_words(uint32_t levels) { return (levels * 16 + 2 * (levels + 2) + 1) / 2; }
 
 struct BatchIO {
     const uint64_t* fw3;         // 2-bit plane of the batch (bgr_pack_reads_kernel / host packer): read r at word (read_offs[r] >> 5) + r
@@ -41,7 +48,8 @@ struct BatchIO {
     uint32_t* gen_list;          // reads for the general kernel (count at cursor[gen_ctr])
     uint32_t gen_ctr;
     uint32_t anc4;               // anchors mode: launch the four-reads-per-wave kernel (what it does not settle goes on ovf_list)
-    uint32_t exh4;               // exhaustive mode: launch the four-reads-per-wave kernel (what it does not settle goes on ovf_list)
+    uint32_t exh4;               // exhaustive mode: launch the several-reads-per-wave kernel (what it does not settle goes on ovf_list);
+                                 //   the value = levels per side of its level table (8 or 16)
     uint32_t list_chunk;         // entries of ovf_list a wave reserves per global atomic (4..16; the unused ones become holes = BGR_NONE)
     uint32_t g4_last;            // last pass of the eight-reads-per-wave greedy kernel: everything unfinished goes on gen_list
     uint32_t subset_ctr, ovf_ctr; // which words of `cursor` count the reads of `subset` / collect the reads put on `ovf_list`

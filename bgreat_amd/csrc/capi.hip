@@ -489,11 +489,14 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // on a graph with an occasional 2-way bubble (about 1.2x), the level search where a read crosses many multi-way
     // sites (3.6x at 4 alleles every ~36 bp, m=5).  Estimate: (extra candidates per record) x (m+1) x (unitigs per read).
     bool level_search = false;
+    uint32_t x4_levels = 16;  // levels (unitigs) per side of a walk the several-reads-per-wave pass keeps in LDS
     if (exhaustive) {
         const BgrBlobHeader& gh = a->graph->header;
         const double mean_ext = std::max(1.0, (double)gh.total_bases / (2.0 * (double)std::max<uint64_t>(1, gh.n_unitigs)) - (double)(gh.k - 1));
         const double branching = (gh.slot_fill_x100 / 100.0 - 1.0) * (double)(p->max_mismatch + 1) * ((double)max_read_len / mean_ext);
         level_search = a->knob_search ? a->knob_search == 2 : branching >= 15.0;
+        // short walks (E. coli-scale graph, 150 bp: 2-3 unitigs per side): half the table, twice the waves per CU (1 200 vs 1 440 Mreads/s)
+        if (2.0 * (double)max_read_len / mean_ext <= 8.0) x4_levels = 8;
     }
     // level search: a level is one unitig of the walk; 16 levels cover 250 bp reads on a graph that branches every ~36 bp
     const uint32_t level_cap = fc_set ? kExhFrameCap : std::max<uint32_t>(16, (max_read_len / 64) * 4);
@@ -596,11 +599,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     bgr::LaunchCfg cfg_fast_list = cfg_fast;  // the launches over a list are compiled for 6 waves per SIMD (80 VGPRs)
     // (a launch over a list also keeps the reads' reverse complements: twice the words per read)
     if (fast_pass && !geometry(bgr::kG4ReadsPerWave * 16 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, false, true, cfg_fast_list, 24)) fast_pass = false;
-    // Exhaustive mode, first pass: four reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
+    // Exhaustive mode, first pass: eight reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
     const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && !a->graph->header.has_exc && p->max_mismatch < 0x7FFF &&
-                         geometry(4 * 8 * (wfast + 146), (n_reads + 3) / 4, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)));
+                         geometry(bgr::kX4ReadsPerWave * 8 * (wfast + bgr::x4_group_words(x4_levels)), (n_reads + bgr::kX4ReadsPerWave - 1) / bgr::kX4ReadsPerWave, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)));
     // Anchors mode, first pass: four reads per wave (bgr_align_anchors4_kernel); reads with an N and very long paths are listed
     // for the one-read-per-wave kernel.
     bgr::LaunchCfg cfg_a4;
@@ -744,7 +747,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (x4_pass) {
         HIP_TRY(a->g4st.ensure(n_reads * 4));
         bgr::BatchIO iox = io;
-        iox.exh4 = 1;
+        iox.exh4 = x4_levels;
         iox.words_per_read = wfast;
         iox.level_search = 0;
         iox.subset = nullptr;

@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
 // The level search (exh_dp) gives a wave ONE read, and after de-duplication a level of the walk rarely holds more than one
 // node: 4 candidate slots x 4 chunk lanes = 16 of the 64 lanes work.  Here a wave takes four reads, 16 lanes each, and runs
 // their searches side by side, for the shape nearly every read has: every level has exactly ONE node (all candidates that go
-// on lead to the same (record, position, strand): bubbles that close again), at most X4_LEVELS levels per side, no N, and
+// on lead to the same (record, position, strand): bubbles that close again), at most 8 or 16 levels per side (chosen per launch), no N, and
 // the first anchor that can succeed does.  Per side: a forward sweep scores the node's <= 4 candidates per level (kept:
 // id, offset, mismatches, fits, alive), a backward sweep settles cost(level) = first minimum over the slots of mismatches
 // [+ cost(level + 1) when the walk goes on] -- the value and the choice of the reference's recursion
@@ -441,7 +441,6 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
 #ifndef BGR_X4_OCC
 #define BGR_X4_OCC 6
 #endif
-#define X4_LEVELS 16
 #define X4_LV_WORDS 16  // per level: [0..3] sid, [4..7] aux (the path int a walk ending there emits), [8..11] miss | fits<<16 | alive<<17, [12] node flags, [13] chosen slot
 #define X4_END 1u
 #define X4_INF 0xFFFFu
@@ -450,16 +449,20 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
 // (exR).  On return, for the groups that took part: *cost = best total (X4_INF: none within the budget; the caller compares
 // with its budget), *n_out ints written to OUTG[o_off ...] in output order, *fb = the search left the shape this kernel
 // handles (the read goes on the list).
-template <int DIR, bool NEAR>
+template <int DIR, bool NEAR, int GL, int XLV>
 __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t act, uint32_t a_rec, uint32_t a_canon,
                                           uint32_t a_pos, uint32_t budget, uint32_t* LVT, int32_t* OUTG, uint32_t o_off, int lane, uint32_t* cost_o,
                                           uint32_t* n_out, uint32_t* fb_o) {
-    const uint32_t c = ((uint32_t)lane >> 2) & 3u, q = (uint32_t)lane & 3u, sub = (uint32_t)lane & 15u;
+    constexpr uint32_t QL = GL / 4, XL = XLV, RPW = 64 / GL;  // lanes per candidate slot; levels per side; reads per wave
+    constexpr uint32_t NH = XL / GL;  // the walk is read off GL levels at a time
+    constexpr uint32_t Q0 = GL == 16 ? 0x1111u : 0x55u, GM = GL == 16 ? 0xFFFFu : 0xFFu;  // the slots' first lanes / all lanes of a group
+    const uint32_t c = ((uint32_t)lane / QL) & 3u, q = (uint32_t)lane % QL, sub = (uint32_t)lane % GL;
+    const uint32_t gl0 = (uint32_t)lane & (64u - GL);  // first lane of the group
     uint32_t fwd = act, fb = 0, lvl = 0, nlev = 0, prefix = 0;
     uint32_t pos = a_pos, rec = a_rec, canon = a_canon;
     // ---- forward: one node per level ----
     for (;;) {
-        if (fwd && lvl >= X4_LEVELS) { fb = 1; fwd = 0; }
+        if (fwd && lvl >= XL) { fb = 1; fwd = 0; }
         const uint32_t end_here = (fwd && ((DIR == 0) ? (pos == 0) : (L - pos - K1 == 0))) ? 1u : 0u;
         if (end_here) {  // left: the read's first base is reached; right: nothing is left of the read
             if (sub == 0) LVT[lvl * X4_LV_WORDS + 12] = X4_END;
@@ -476,8 +479,8 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         }
         const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
         const u64 zmask = __ballot(id == 0);
-        const uint32_t zb = (uint32_t)(zmask >> ((uint32_t)lane & 48u)) & 0x1111u;
-        const uint32_t first_zero = zb ? (uint32_t)(__ffs((int)zb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+        const uint32_t zb = (uint32_t)(zmask >> gl0) & Q0;
+        const uint32_t first_zero = zb ? (uint32_t)(__ffs((int)zb) - 1) / QL : 4u;  // the reference stops at the first empty slot
         const uint32_t valid = c < first_zero ? 1u : 0u;
         const uint32_t fwdu = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
         const uint32_t len = sl.y;
@@ -512,10 +515,10 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         const bool near_ok = NEAR && n <= 32 && (sl.x & both) != both && !(g.flags & BGR_GF_HAS_EXC);
         uint32_t cnt = 0;
         if (NEAR && near_ok && n && q == 0) cnt = ham_near(FW, bgr_slot_near(sl.w, m0.x, m0.w), DIR == 0, n, rstart);
-        for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 128)
+        for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 32 * QL)
             if (b < n && !near_ok) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
         cnt += quad_xor1(cnt);
-        cnt += quad_xor2(cnt);
+        if (QL == 4) cnt += quad_xor2(cnt);
         const uint32_t miss = cnt > 0xFFFFu ? 0xFFFFu : cnt;
         const uint32_t ptotal = prefix + miss;
         const uint32_t alive = (valid && ptotal <= budget) ? 1u : 0u;  // a walk through here costs at least this much
@@ -529,19 +532,19 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         }
         // the candidates that go on must all reach the same node
         const u64 nmask = __ballot(need && q == 0 && fwd);
-        const uint32_t nb = (uint32_t)(nmask >> ((uint32_t)lane & 48u)) & 0x1111u;
-        const uint32_t src = ((uint32_t)lane & 48u) | (nb ? (uint32_t)(__ffs((int)nb) - 1) : 0u);
+        const uint32_t nb = (uint32_t)(nmask >> gl0) & Q0;
+        const uint32_t src = gl0 | (nb ? (uint32_t)(__ffs((int)nb) - 1) : 0u);
         const uint32_t kpk = nrec | ((m0.x & cbit) ? G4_CANON : 0u);
         const uint32_t k_rec = lane_get(kpk, src), k_pos = lane_get(npos, src);
         const u64 dmask = __ballot(need && fwd && (kpk != k_rec || npos != k_pos));
         uint32_t pmin = need ? ptotal : 0xFFFFFFFFu;
-        uint32_t o = row_ror4(pmin);
+        uint32_t o = GL == 16 ? row_ror4(pmin) : quad_xor2(pmin);
         pmin = o < pmin ? o : pmin;
-        o = row_ror8(pmin);
+        o = GL == 16 ? row_ror8(pmin) : half_row_mirror(pmin);
         pmin = o < pmin ? o : pmin;
         if (fwd) {
             nlev = lvl + 1;
-            if ((uint32_t)(dmask >> ((uint32_t)lane & 48u)) & 0xFFFFu) { fb = 1; fwd = 0; }  // a level with two nodes
+            if ((uint32_t)(dmask >> gl0) & GM) { fb = 1; fwd = 0; }  // a level with two nodes
             else if (!nb) fwd = 0;                                                      // every candidate ends here or is too dear
             else { prefix = pmin; pos = k_pos; rec = k_rec & G4_REC_MASK; canon = (k_rec >> 28) & 1u; ++lvl; }
         }
@@ -549,8 +552,9 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
     wave_sync();
     // ---- backward: cost of every level, first slot on ties ----
     const uint32_t ok = (act && !fb) ? 1u : 0u;
-    const uint32_t n0 = rl32(ok ? nlev : 0u, 0), n1 = rl32(ok ? nlev : 0u, 16), n2 = rl32(ok ? nlev : 0u, 32), n3 = rl32(ok ? nlev : 0u, 48);
-    const uint32_t maxl = max(max(n0, n1), max(n2, n3));
+    uint32_t maxl = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < RPW; ++i) maxl = max(maxl, rl32(ok ? nlev : 0u, (int)(GL * i)));
     uint32_t cnext = X4_INF;
     for (int l = (int)maxl - 1; l >= 0; --l) {
         const uint32_t in = (ok && (uint32_t)l < nlev) ? 1u : 0u;
@@ -572,40 +576,58 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         key = o < key ? o : key;
         o = quad_xor2(key);
         key = o < key ? o : key;
-        key = lane_get(key, (uint32_t)lane & 48u);
+        key = lane_get(key, gl0);
         if (in) {
             cnext = (flags & X4_END) ? 0u : (key >> 2);
             if (sub == 0) LVT[(uint32_t)l * X4_LV_WORDS + 13] = key & 3u;
         }
     }
     wave_sync();
-    // ---- read the walk off: level j's chosen slot, down to the first level that ends the walk ----
-    uint32_t endj = 0, sid = 0, auxv = 0, isend = 0;
-    if (ok && sub < nlev) {
-        const uint32_t* R = LVT + sub * X4_LV_WORDS;
-        const uint32_t a = R[13];
-        isend = R[12] & X4_END;
-        const uint32_t pk = R[8 + a];
-        endj = (isend || (pk & (1u << 16))) ? 1u : 0u;
-        sid = R[a];
-        auxv = R[4 + a];
+    // ---- read the walk off: level j's chosen slot, down to the first level that ends the walk (lane `sub` takes the levels
+    // sub, sub + GL, ...) ----
+    uint32_t sidv[NH], auxvv[NH], isendv[NH];
+    uint32_t ebits = 0;  // bit j = level j ends the walk
+#pragma unroll
+    for (uint32_t h = 0; h < NH; ++h) {
+        const uint32_t j = sub + h * GL;
+        uint32_t endj = 0;
+        sidv[h] = 0; auxvv[h] = 0; isendv[h] = 0;
+        if (ok && j < nlev) {
+            const uint32_t* R = LVT + j * X4_LV_WORDS;
+            const uint32_t a = R[13];
+            isendv[h] = R[12] & X4_END;
+            const uint32_t pk = R[8 + a];
+            endj = (isendv[h] || (pk & (1u << 16))) ? 1u : 0u;
+            sidv[h] = R[a];
+            auxvv[h] = R[4 + a];
+        }
+        const u64 emask = __ballot(endj != 0);
+        ebits |= ((uint32_t)(emask >> gl0) & GM) << (h * GL);
     }
-    const u64 emask = __ballot(endj != 0);
-    const uint32_t eb16 = (uint32_t)(emask >> ((uint32_t)lane & 48u)) & 0xFFFFu;
-    const uint32_t d = eb16 ? (uint32_t)(__ffs((int)eb16) - 1) : 0u;           // depth of the level that ends the walk
-    const uint32_t d_end = lane_get(isend, ((uint32_t)lane & 48u) | d);       // ... by reaching the read's end (no unitig taken there)
+    const uint32_t d = ebits ? (uint32_t)(__ffs((int)ebits) - 1) : 0u;  // depth of the level that ends the walk
+    uint32_t d_end = 0;                                                 // ... by reaching the read's end (no unitig taken there)
+#pragma unroll
+    for (uint32_t h = 0; h < NH; ++h) {
+        const uint32_t v = lane_get(isendv[h], gl0 | (d % GL));
+        if (d / GL == h) d_end = v;
+    }
     uint32_t n = 0;
-    const uint32_t good = (ok && cnext <= budget && eb16) ? 1u : 0u;
+    const uint32_t good = (ok && cnext <= budget && ebits) ? 1u : 0u;
     if (good) {
         int32_t* O = OUTG + o_off;
-        if (DIR == 0) {
-            // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); else [offset, farthest unitig, ..., nearest]
-            if (d_end) { n = d == 0 ? 1u : d; if (d == 0) { if (sub == 0) O[0] = 0; } else if (sub < d) O[d - 1 - sub] = (int32_t)sid; }
-            else { n = d + 2; if (sub == d) { O[0] = (int32_t)auxv; O[1] = (int32_t)sid; } else if (sub < d) O[1 + (d - sub)] = (int32_t)sid; }
-        } else {
-            // right: every depth pushes 0 at the read's end (:64,:210); else [nearest ... farthest unitig, end offset]
-            if (d_end) { n = d + 1; if (sub < d) O[sub] = (int32_t)sid; if (sub == d) O[d] = 0; }
-            else { n = d + 2; if (sub <= d) O[sub] = (int32_t)sid; if (sub == d) O[d + 1] = (int32_t)auxv; }
+#pragma unroll
+        for (uint32_t h = 0; h < NH; ++h) {
+            const uint32_t j = sub + h * GL;
+            const int32_t sid = (int32_t)sidv[h];
+            if (DIR == 0) {
+                // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); else [offset, farthest unitig, ..., nearest]
+                if (d_end) { n = d == 0 ? 1u : d; if (d == 0) { if (j == 0) O[0] = 0; } else if (j < d) O[d - 1 - j] = sid; }
+                else { n = d + 2; if (j == d) { O[0] = (int32_t)auxvv[h]; O[1] = sid; } else if (j < d) O[1 + (d - j)] = sid; }
+            } else {
+                // right: every depth pushes 0 at the read's end (:64,:210); else [nearest ... farthest unitig, end offset]
+                if (d_end) { n = d + 1; if (j < d) O[j] = sid; if (j == d) O[d] = 0; }
+                else { n = d + 2; if (j <= d) O[j] = sid; if (j == d) O[d + 1] = (int32_t)auxvv[h]; }
+            }
         }
     }
     wave_sync();
@@ -614,8 +636,10 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
     *fb_o = fb;
 }
 
-template <bool STAGE>
+// XLV = levels (unitigs) of a walk per side the level table holds: 8 for short walks (less LDS per read: more waves), else 16
+template <bool STAGE, int GL, int XLV>
 __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    constexpr uint32_t RPW = 64 / GL, XL = XLV;  // reads per wave; levels per side
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -623,21 +647,21 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const uint32_t K1 = g.k - 1;
     uint32_t mphf_words;
     const uint32_t* units = block_prologue<STAGE>(g, lds, &mphf_words);
-    // per wave: 4 x { read words W | level table X4_LEVELS x X4_LV_WORDS u32 | out ints 2 x (X4_LEVELS + 2) }
-    const uint32_t out_ints = 2 * (X4_LEVELS + 2);
-    const uint32_t grp_words = W + (X4_LEVELS * X4_LV_WORDS + out_ints + 1) / 2;
-    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
-    u64* WV = lds + 64 + mphf_words + (u64)wave * (4 * grp_words);
+    // per wave: RPW x { read words W | level table XL x X4_LV_WORDS u32 | out ints 2 x (XL + 2) }  (x4_group_words, align_kernels.h)
+    const uint32_t out_ints = 2 * (XL + 2);
+    const uint32_t grp_words = W + (XL * X4_LV_WORDS + out_ints + 1) / 2;
+    const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
+    u64* WV = lds + 64 + mphf_words + (u64)wave * (RPW * grp_words);
     u64* F = WV + grp * grp_words;
     uint32_t* LVT = reinterpret_cast<uint32_t*>(F + W);
-    int32_t* OUTG = reinterpret_cast<int32_t*>(LVT + X4_LEVELS * X4_LV_WORDS);
+    int32_t* OUTG = reinterpret_cast<int32_t*>(LVT + XL * X4_LV_WORDS);
     const uint32_t m = prm.max_mismatch;
 
     uint32_t c_al = 0, c_na = 0;
     unsigned long long c_ov = 0;
     uint32_t chunk_pos = 0, chunk_end = 0;
 
-    for (uint32_t rbase = (blockIdx.x * waves + wave) * 4; rbase < io.n_reads; rbase += gridDim.x * waves * 4) {
+    for (uint32_t rbase = (blockIdx.x * waves + wave) * RPW; rbase < io.n_reads; rbase += gridDim.x * waves * RPW) {
         const uint32_t r = rbase + grp;
         const uint32_t have = r < io.n_reads ? 1u : 0u;
         u64 off = 0;
@@ -649,18 +673,18 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
             if (L <= K1) fast = 0;  // (a read of k-1 bases or fewer: the general kernel)
             if (((L + 31) >> 5) >= W) fast = 0;  // (or too long for one lane per word)
         }
-        {
+        for (uint32_t j = sub; j < W; j += GL) {
             u64 f = 0;
-            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
-            if (sub < W) F[sub] = f;
+            if (fast && j < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + j];
+            F[j] = f;
         }
         wave_sync();
         // ---- the first position that can anchor the read (getListOverlap keeps every position, aligner.cpp:318-342; only
         // position 0 and overlap (k-1)-mers of the graph can succeed): position 0 when its k-mer is an overlap, else the first hit
         uint32_t a_pos = 0, a_rec = BGR_NONE;
-        for (uint32_t qq = 0; qq < 4; ++qq) {
-            if (!rl32(fast, (int)(16 * qq))) continue;
-            const uint32_t Lq = rl32(L, (int)(16 * qq));
+        for (uint32_t qq = 0; qq < RPW; ++qq) {
+            if (!rl32(fast, (int)(GL * qq))) continue;
+            const uint32_t Lq = rl32(L, (int)(GL * qq));
             const u64* A = WV + qq * grp_words;
             const uint32_t npos = Lq - K1 + 1;
             for (uint32_t base = 0; base < npos; base += 64) {
@@ -687,7 +711,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         {
             const uint32_t actl = (anchored && a_pos != 0) ? 1u : 0u;
             uint32_t cl = 0, nll = 0;
-            x4_search<0, !STAGE>(g, F, L, K1, actl, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, m, LVT, OUTG, 0, lane, &cl, &nll, &fbl);
+            x4_search<0, !STAGE, GL, XLV>(g, F, L, K1, actl, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, m, LVT, OUTG, 0, lane, &cl, &nll, &fbl);
             if (actl) { eb = cl; nl = nll; }
             else if (anchored) { if (sub == 0) OUTG[0] = 0; nl = 1; }
         }
@@ -696,7 +720,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         {
             const uint32_t actr = (anchored && !fbl && eb <= m) ? 1u : 0u;
             uint32_t cr = 0, nrr = 0;
-            x4_search<1, !STAGE>(g, F, L, K1, actr, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, actr ? m - eb : 0u, LVT, OUTG, nl, lane, &cr, &nrr, &fbr);
+            x4_search<1, !STAGE, GL, XLV>(g, F, L, K1, actr, a_rec & G4_REC_MASK, (a_rec >> 28) & 1u, a_pos, actr ? m - eb : 0u, LVT, OUTG, nl, lane, &cr, &nrr, &fbr);
             if (actr) { ee = cr; nr = nrr; } else ee = X4_INF;
         }
         // 0 = aligned; 2 = not aligned for sure (no overlap (k-1)-mer anywhere in the read: every position fails); 4 = the list
@@ -705,8 +729,13 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         else if (anchored && !fbl && !fbr && eb <= m && ee != X4_INF && eb + ee <= m) outcome = 0;
         const uint32_t aligned = outcome == 0 ? 1u : 0u;
         const uint32_t p_n = aligned ? nl + nr : 0;
-        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
-        const uint32_t tot = n0 + n1 + n2 + n3;
+        uint32_t tot = 0, before = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < RPW; ++i) {
+            const uint32_t ni = rl32(p_n, (int)(GL * i));
+            if (grp > i) before += ni;
+            tot += ni;
+        }
         if (tot > chunk_end - chunk_pos) {
             const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
             uint32_t got = 0;
@@ -714,10 +743,10 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
             chunk_pos = rl32(got, 0);
             chunk_end = chunk_pos + want;
         }
-        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const uint32_t gbase = chunk_pos + before;
         const bool room = chunk_pos + tot <= io.arena_cap;
         chunk_pos += tot;
-        for (uint32_t j = sub; j < p_n; j += 16)
+        for (uint32_t j = sub; j < p_n; j += GL)
             if (room) io.arena[gbase + j] = OUTG[j];
         if (!room && lane == 0 && tot) io.cursor[1] = 1;
         if (sub == 0 && have) {
@@ -728,8 +757,8 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         const u64 fin = __ballot(sub == 0 && have && outcome != 4);
         c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
         c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
-        for (int gq = 0; gq < 4; ++gq)
-            if ((fin >> (16 * gq)) & 1) c_ov += rl32(npos_g, 16 * gq);  // overlaps += listOverlap.size() (alignerExhaustive.cpp:38)
+        for (int gq = 0; gq < (int)RPW; ++gq)
+            if ((fin >> (GL * gq)) & 1) c_ov += rl32(npos_g, (int)(GL * gq));  // overlaps += listOverlap.size() (alignerExhaustive.cpp:38)
         wave_sync();
     }
     if (lane == 0 && (c_al | c_na)) {
@@ -844,8 +873,13 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
 }  // namespace
 
 hipError_t launch_exhaustive(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
-    if (io.exh4) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive4_kernel<true>, g, io, p, cfg, stream)
-                                       : launch_one(bgr_align_exhaustive4_kernel<false>, g, io, p, cfg, stream);
+    if (io.exh4) {
+        constexpr int GL = (int)kX4GroupLanes;
+        if (io.exh4 == 8) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive4_kernel<true, GL, 8>, g, io, p, cfg, stream)
+                                                : launch_one(bgr_align_exhaustive4_kernel<false, GL, 8>, g, io, p, cfg, stream);
+        return cfg.stage_mphf ? launch_one(bgr_align_exhaustive4_kernel<true, GL, 16>, g, io, p, cfg, stream)
+                              : launch_one(bgr_align_exhaustive4_kernel<false, GL, 16>, g, io, p, cfg, stream);
+    }
     if (io.deep_scratch) return launch_one(bgr_align_exhaustive_kernel<false, true>, g, io, p, cfg, stream);
     if (io.level_search) return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_dp_kernel<true>, g, io, p, cfg, stream)
                                                : launch_one(bgr_align_exhaustive_dp_kernel<false>, g, io, p, cfg, stream);
@@ -854,7 +888,7 @@ hipError_t launch_exhaustive(const BgrDeviceGraph& g, const BatchIO& io, const K
 }
 const void* exhaustive_kernel_fn(uint32_t which) {  // 0 depth-first, 1 level search, 2 four reads per wave
     return which == 1 ? reinterpret_cast<const void*>(&bgr_align_exhaustive_dp_kernel<false>)
-         : which == 2 ? reinterpret_cast<const void*>(&bgr_align_exhaustive4_kernel<false>)
+         : which == 2 ? reinterpret_cast<const void*>(&bgr_align_exhaustive4_kernel<false, (int)kX4GroupLanes, 16>)
                       : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
 }
 
