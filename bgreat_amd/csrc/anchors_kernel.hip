@@ -250,9 +250,21 @@ __device__ __forceinline__ u64 lane_get64(u64 v, uint32_t src) {
     return ((u64)lane_get((uint32_t)(v >> 32), src) << 32) | lane_get((uint32_t)v, src);
 }
 
-// boomphf::mphf::lookup (BooPHF.h:783-818) for one key per 16-lane group (need = the group looks up): index or ~0
+// sum over the GL (16 or 8) lanes of a group, in every lane
+template <int GL>
+__device__ __forceinline__ uint32_t group_sum(uint32_t x) {
+    if (GL == 16) return row16_sum(x);
+    x += quad_xor1(x);
+    x += quad_xor2(x);
+    x += half_row_mirror(x);
+    return x;
+}
+
+// boomphf::mphf::lookup (BooPHF.h:783-818) for one key per GL-lane group (need = the group looks up): index or ~0.
+// Lane j of a group probes level j: the index must have at most GL active levels.
+template <int GL>
 __device__ __forceinline__ u64 anc_lookup4(const AncView& a, u64 key, uint32_t need, int lane) {
-    const uint32_t sub = (uint32_t)lane & 15u, gb = (uint32_t)lane & 48u;
+    const uint32_t sub = (uint32_t)lane % GL, gb = (uint32_t)lane & (64u - GL);
     u64 s0 = bgr_boo_hash64(key, BGR_BOO_SEED0), s1 = bgr_boo_hash64(key, BGR_BOO_SEED1);
     u64 hv = sub == 0 ? s0 : s1;
     for (uint32_t i = 2; i < a.n_active; ++i) {  // BooPHF.h:336-356: the level hashes are a sequence, walked in step
@@ -266,7 +278,7 @@ __device__ __forceinline__ u64 anc_lookup4(const AncView& a, u64 key, uint32_t n
         hit = (a.bits[a.lv_word_base + (pos >> 6)] >> (pos & 63)) & 1;
     }
     const u64 mask = __ballot(hit);
-    const uint32_t m16 = (uint32_t)(mask >> gb) & 0xFFFFu;
+    const uint32_t m16 = (uint32_t)(mask >> gb) & (GL == 16 ? 0xFFFFu : 0xFFu);
     const uint32_t src = gb | (m16 ? (uint32_t)(__ffs((int)m16) - 1) : 0u);  // the first level whose bit is set answers
     const u64 fpos = lane_get64(pos, src), wb = lane_get64(a.lv_word_base, src), rb = lane_get64(a.lv_rank_base, src);
     const u64 widx = fpos >> 6, blk = fpos >> 9;
@@ -276,7 +288,7 @@ __device__ __forceinline__ u64 anc_lookup4(const AncView& a, u64 key, uint32_t n
         if (wi < widx) cnt = (uint32_t)__popcll(a.bits[wb + wi]);
         else if (wi == widx) cnt = (uint32_t)__popcll(a.bits[wb + wi] & ((1ULL << (fpos & 63)) - 1));
     }
-    cnt = row16_sum(cnt);
+    cnt = group_sum<GL>(cnt);
     u64 res = ~0ULL;
     if (m16) res = a.ranks[rb + blk] + cnt;
     const uint32_t slow = (need && !m16) ? 1u : 0u;  // what 24 levels could not place (repeated k-mers): exact, sorted {key, index}
@@ -293,14 +305,16 @@ __device__ __forceinline__ u64 anc_lookup4(const AncView& a, u64 key, uint32_t n
     return res;
 }
 
+template <int GL>
 __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+    constexpr uint32_t RPW = 64 / GL;  // reads per wave
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
     const uint32_t K = g.k, K1 = g.k - 1;
-    const uint32_t grp = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u, gb = (uint32_t)lane & 48u;
-    u64* RD = lds + 64 + (u64)wave * (8 * W);  // the four reads of this wave: forward words | reverse-complement words
+    const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL, gb = (uint32_t)lane & (64u - GL);
+    u64* RD = lds + 64 + (u64)wave * (RPW * 2 * W);  // the reads of this wave: forward words | reverse-complement words
     u64* F = RD + grp * (2 * W);
     const AncView av = anc_view(g, (int)sub);
     const u64 km1_mask = (1ULL << (2 * K1)) - 1;  // offsetUpdate - 1 (aligner.h:101-102): update() keeps k-1 digits
@@ -310,7 +324,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
     uint32_t c_noov = 0, c_al = 0, c_na = 0;
     uint32_t chunk_pos = 0, chunk_end = 0;
 
-    for (uint32_t rbase = (blockIdx.x * waves + wave) * 4; rbase < io.n_reads; rbase += gridDim.x * waves * 4) {
+    for (uint32_t rbase = (blockIdx.x * waves + wave) * RPW; rbase < io.n_reads; rbase += gridDim.x * waves * RPW) {
         const uint32_t r = rbase + grp;
         const uint32_t have = r < io.n_reads ? 1u : 0u;
         u64 off = 0;
@@ -321,10 +335,10 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
             fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
             if (((L + 31) >> 5) >= W) fast = 0;                // so does a read too long for one lane per word
         }
-        {
+        for (uint32_t j = sub; j < W; j += GL) {
             u64 f = 0;
-            if (fast && sub < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + sub];
-            if (sub < W) F[sub] = f;
+            if (fast && j < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + j];
+            F[j] = f;
         }
         wave_sync();
         const uint32_t dk = L < K ? L : K;                                  // read.substr(0, k) of a shorter read is the whole read
@@ -341,7 +355,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
         while (__any(active != 0)) {
             const u64* S = F + (rc ? W : 0);  // the characters of this pass's read (reverseComplements: N -> 'A')
             // ---- one lookup per group at its current position ----
-            const u64 idx = anc_lookup4(av, num < rcnum ? num : rcnum, active, lane);
+            const u64 idx = anc_lookup4<GL>(av, num < rcnum ? num : rcnum, active, lane);
             const uint32_t found = (active && idx != ~0ULL) ? 1u : 0u;
             uint32_t success = 0, bad = 0;
             if (__any(found != 0)) {
@@ -378,9 +392,9 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                 else { ub = fo + uoff; rb = 0; n = longr ? len - uoff : L; }   // CASE 3 (:133-148) / CASE 4 (:149-160)
                 if (!okp) n = 0;
                 uint32_t errors = 0;
-                for (uint32_t b = sub * 32; __any(b < n); b += 512)
+                for (uint32_t b = sub * 32; __any(b < n); b += 32 * GL)
                     if (b < n) errors += ham_chunk(g, S, nullptr, false, fw, ub + b, rb + b, n - b);
-                errors = row16_sum(errors);
+                errors = group_sum<GL>(errors);
                 const uint32_t good = (okp && errors <= m) ? 1u : 0u;
                 // ---- the walks from the unitig's ends: left (cases 1, 2), right (cases 1, 3) ----
                 const uint32_t want_left = (good && c12) ? 1u : 0u, want_right = (good && longr) ? 1u : 0u;
@@ -400,11 +414,11 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                     }
                     if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the unitig
                     if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k
-                    if ((phase == 1 && nl > G4_PATH - 2) || (phase >= 2 && nr > G4_PATH - 1)) { bad = 1; phase = 0; }  // path too long for the registers
+                    if ((phase == 1 && nl > GL - 2) || (phase >= 2 && nr > GL - 1)) { bad = 1; phase = 0; }  // path too long for the registers
                     if (!__any(phase != 0)) break;
                     uint32_t miss, ext;
                     int32_t sid;
-                    const uint32_t w1 = g4_step(g, S, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+                    const uint32_t w1 = g4_step<false, GL>(g, S, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
                     if (phase != 0) {
                         if (!(w1 & G4_FOUND)) { wfail = 1; phase = 0; }
                         else if (phase == 1) {
@@ -447,12 +461,14 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                 else sw = 1;                                          // once more on the reverse complement (:162)
             }
             if (__any(sw != 0)) {
-                if (sw && sub < W) {
-                    const long long p = (long long)L - 32 * ((long long)sub + 1);
-                    u64 w = 0;
-                    if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
-                    else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
-                    F[W + sub] = w;
+                if (sw) {
+                    for (uint32_t j = sub; j < W; j += GL) {
+                        const long long p = (long long)L - 32 * ((long long)j + 1);
+                        u64 w = 0;
+                        if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
+                        else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                        F[W + j] = w;
+                    }
                 }
                 wave_sync();
                 if (sw) {
@@ -465,8 +481,13 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
         // ---- publish: reverse(left) ++ [offset,] unitig ++ right ----
         const uint32_t aligned = (have && outcome == 0) ? 1u : 0u;
         const uint32_t p_n = aligned ? nl + nmid + nr : 0;
-        const uint32_t n0 = rl32(p_n, 0), n1 = rl32(p_n, 16), n2 = rl32(p_n, 32), n3 = rl32(p_n, 48);
-        const uint32_t tot = n0 + n1 + n2 + n3;
+        uint32_t tot = 0, before = 0;
+#pragma unroll
+        for (uint32_t i2 = 0; i2 < RPW; ++i2) {
+            const uint32_t ni = rl32(p_n, (int)(GL * i2));
+            if (grp > i2) before += ni;
+            tot += ni;
+        }
         if (tot > chunk_end - chunk_pos) {
             const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
             uint32_t got = 0;
@@ -474,14 +495,14 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
             chunk_pos = rl32(got, 0);
             chunk_end = chunk_pos + want;
         }
-        const uint32_t gbase = chunk_pos + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        const uint32_t gbase = chunk_pos + before;
         const bool room = chunk_pos + tot <= io.arena_cap;
         chunk_pos += tot;
 #pragma unroll
-        for (uint32_t jj = 0; jj < 3; ++jj) {
-            const uint32_t j = sub + 16 * jj;
-            const uint32_t vl = lane_get((uint32_t)pl, gb | ((nl - 1 - j) & 15u));
-            const uint32_t vr = lane_get((uint32_t)pr, gb | ((j - nl - nmid) & 15u));
+        for (uint32_t jj = 0; jj < 3; ++jj) {  // up to GL + 2 + GL ints
+            const uint32_t j = sub + GL * jj;
+            const uint32_t vl = lane_get((uint32_t)pl, gb | ((nl - 1 - j) & (GL - 1)));
+            const uint32_t vr = lane_get((uint32_t)pr, gb | ((j - nl - nmid) & (GL - 1)));
             int32_t v = (int32_t)vr;
             if (j < nl) v = (int32_t)vl;
             else if (j < nl + nmid) v = (j == nl) ? mid0 : mid1;
@@ -513,11 +534,12 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
 }  // namespace
 
 hipError_t launch_anchors(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
-    if (io.anc4) return launch_one(bgr_align_anchors4_kernel, g, io, p, cfg, stream);
+    if (io.anc4 == 8) return launch_one(bgr_align_anchors4_kernel<8>, g, io, p, cfg, stream);  // (the value = lanes per read)
+    if (io.anc4) return launch_one(bgr_align_anchors4_kernel<16>, g, io, p, cfg, stream);
     return launch_one(bgr_align_anchors_kernel, g, io, p, cfg, stream);
 }
 const void* anchors_kernel_fn(bool four_reads) {
-    return four_reads ? reinterpret_cast<const void*>(&bgr_align_anchors4_kernel) : reinterpret_cast<const void*>(&bgr_align_anchors_kernel);
+    return four_reads ? reinterpret_cast<const void*>(&bgr_align_anchors4_kernel<8>) : reinterpret_cast<const void*>(&bgr_align_anchors_kernel);
 }
 
 }  // namespace bgr

@@ -607,8 +607,10 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // Anchors mode, first pass: four reads per wave (bgr_align_anchors4_kernel); reads with an N and very long paths are listed
     // for the one-read-per-wave kernel.
     bgr::LaunchCfg cfg_a4;
+    // lanes per read: a lookup spreads BooPHF's active levels over the lanes of the read's group (8 when they fit, else 16)
+    const uint32_t a4_lanes = a->graph->header.anc_active_levels <= 8 ? 8u : 16u, a4_rpw = 64 / a4_lanes;
     const bool a4_pass = p->mode == BGR_MODE_ANCHORS && !a->knob_anc_fast && !a->graph->header.has_exc && a->graph->header.anc_active_levels <= 16 &&
-                         geometry(8 * 8 * wfast, (n_reads + 3) / 4, true, false, cfg_a4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(6)));
+                         geometry(a4_rpw * 16 * wfast, (n_reads + a4_rpw - 1) / a4_rpw, true, false, cfg_a4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(6)));
     const uint32_t waves = cfg.waves_per_block;
     // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
@@ -733,7 +735,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (a4_pass) {
         HIP_TRY(a->g4st.ensure(n_reads * 4));
         bgr::BatchIO ioa = io;
-        ioa.anc4 = 1;
+        ioa.anc4 = a4_lanes;
         ioa.words_per_read = wfast;
         ioa.subset = nullptr;
         ioa.ovf_list = static_cast<uint32_t*>(a->g4st.p);
