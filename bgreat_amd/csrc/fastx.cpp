@@ -10,7 +10,7 @@
 #include <cstring>
 #include <thread>
 #if defined(__SSE2__)
-#include <emmintrin.h>
+#include <immintrin.h>
 #endif
 
 namespace bgr {
@@ -59,8 +59,47 @@ inline bool valid_chars(const char* p, uint64_t n) {  // aligner.cpp:56-61
 
 // One pass over a line: returns the position of its '\n' (or `end`), and whether every byte before it is one of
 // ACGTN (aligner.cpp:56-61).  Replaces memchr + valid_chars on the sequence line of a record (the bulk of a file).
+#if defined(__x86_64__)
+// The same with 32 bytes per step, when the CPU has AVX2 (checked once at run time: the binary is built without -march).
+// Validity by two nibble look-ups instead of five compares: the admitted characters are 0x41 0x43 0x47 0x4E (high nibble 4,
+// low nibble 1 3 7 E) and 0x54 (high nibble 5, low nibble 4); a byte passes when its two table entries share a bit.
+__attribute__((target("avx2"))) const char* scan_line_avx2(const char* p, const char* end, unsigned& bad_io, bool& found) {
+    const __m256i lut_lo = _mm256_setr_epi8(0, 1, 0, 1, 2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 1, 2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0);
+    const __m256i lut_hi = _mm256_setr_epi8(0, 0, 0, 0, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i nib = _mm256_set1_epi8(0x0F), vNL = _mm256_set1_epi8('\n'), zero = _mm256_setzero_si256();
+    unsigned bad = bad_io;
+    found = false;
+    while (p + 32 <= end) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+        const __m256i lo = _mm256_shuffle_epi8(lut_lo, _mm256_and_si256(v, nib));
+        const __m256i hi = _mm256_shuffle_epi8(lut_hi, _mm256_and_si256(_mm256_srli_epi16(v, 4), nib));
+        const unsigned m_bad = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_and_si256(lo, hi), zero));
+        const unsigned m_nl = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vNL));
+        if (m_nl) {
+            const unsigned idx = (unsigned)__builtin_ctz(m_nl);
+            bad |= m_bad & (idx ? (0xFFFFFFFFu >> (32 - idx)) : 0u);
+            bad_io = bad;
+            found = true;
+            return p + idx;
+        }
+        bad |= m_bad;
+        p += 32;
+    }
+    bad_io = bad;
+    return p;
+}
+static const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+#endif
+
 inline const char* scan_line(const char* p, const char* end, bool& valid) {
     unsigned bad = 0;
+#if defined(__x86_64__)
+    if (kHaveAvx2) {
+        bool found;
+        p = scan_line_avx2(p, end, bad, found);
+        if (found) { valid = bad == 0; return p; }
+    }
+#endif
 #if defined(__SSE2__)
     const __m128i vA = _mm_set1_epi8('A'), vC = _mm_set1_epi8('C'), vG = _mm_set1_epi8('G'), vT = _mm_set1_epi8('T'),
                   vN = _mm_set1_epi8('N'), vNL = _mm_set1_epi8('\n');

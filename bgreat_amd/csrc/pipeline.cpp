@@ -60,12 +60,14 @@ public:
         cv_.notify_all();
         for (auto& t : ts_) t.join();
     }
+    // tag: which stage the work belongs to (BGREAT_TIMING: thread CPU seconds per stage, cpu_us)
     template <typename F>
-    void run(size_t n, F fn) {
+    void run(size_t n, F fn, int tag = 0) {
         if (n == 0) return;
-        if (n == 1 || ts_.empty()) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+        if (n == 1 || ts_.empty()) { const uint64_t c0 = cpu_now(); for (size_t i = 0; i < n; ++i) fn(i); cpu_us[tag] += cpu_now() - c0; return; }
         Job job;
         job.n = n;
+        job.tag = tag;
         job.fn = [&fn](size_t i) { fn(i); };
         const size_t helpers = std::min<size_t>(ts_.size(), n - 1);
         job.pending = helpers;
@@ -86,8 +88,13 @@ private:
         std::mutex m;
         std::condition_variable cv;
         size_t pending = 0;
+        int tag = 0;
     };
-    static void work(Job& j) { for (size_t i; (i = j.next.fetch_add(1)) < j.n;) j.fn(i); }
+    void work(Job& j) {
+        const uint64_t c0 = cpu_now();
+        for (size_t i; (i = j.next.fetch_add(1)) < j.n;) j.fn(i);
+        cpu_us[j.tag] += cpu_now() - c0;
+    }
     void loop() {
         for (;;) {
             Job* j = nullptr;
@@ -108,6 +115,15 @@ private:
     std::condition_variable cv_;
     std::deque<Job*> q_;
     bool stop_ = false;
+public:
+    bool timing = false;
+    std::atomic<uint64_t> cpu_us[8] = {};
+    uint64_t cpu_now() const {  // CPU time of the calling thread, microseconds (0 unless timing)
+        if (!timing) return 0;
+        timespec ts;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return (uint64_t)ts.tv_sec * 1000000ull + (uint64_t)ts.tv_nsec / 1000;
+    }
 };
 
 struct HostBuf {  // grow-only host buffer; `pinned` = page-locked (20 GB/s to allocate on an idle process, several times slower
@@ -235,15 +251,28 @@ struct ProgressMarker {
     }
 };
 
-inline char* put_int(char* o, int32_t v) {  // to_string(v) + '.'  (aligner.cpp:600-609)
-    char num[12];
-    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
-    int len = 0;
-    do { num[len++] = (char)('0' + u % 10); u /= 10; } while (u);
-    if (v < 0) *o++ = '-';
-    while (len) *o++ = num[--len];
-    *o++ = '.';
-    return o;
+// to_string(v) + '.'  (aligner.cpp:600-609).  Two digits per step from a table, written back to front into their final place
+// (the per-digit divide loop this replaces was the largest single cost of the host pipeline: ~50 ns per read).
+static const char kDigitPairs[] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263"
+    "646566676869707172737475767778798081828384858687888990919293949596979899";
+inline char* put_int(char* o, int32_t v) {
+    uint32_t u = (uint32_t)v;
+    if (v < 0) { *o++ = '-'; u = 0u - u; }
+    const unsigned len = u < 10 ? 1 : u < 100 ? 2 : u < 1000 ? 3 : u < 10000 ? 4 : u < 100000 ? 5 : u < 1000000 ? 6 : u < 10000000 ? 7 :
+                         u < 100000000 ? 8 : u < 1000000000 ? 9 : 10;
+    char* e = o + len;
+    char* w = e;
+    while (u >= 100) {
+        const uint32_t q = u / 100, r = u - q * 100;
+        w -= 2;
+        memcpy(w, kDigitPairs + 2 * r, 2);
+        u = q;
+    }
+    if (u >= 10) memcpy(w - 2, kDigitPairs + 2 * u, 2);
+    else w[-1] = (char)('0' + u);
+    *e++ = '.';
+    return e;
 }
 
 // ---- correction mode (-c): recoverPath / getUnitig / compactionEnd (aligner.cpp:270-302, utils.cpp:171-179) ------
@@ -434,6 +463,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         return free_batches.pop(b);
     };
     const bool timing = getenv("BGREAT_TIMING") != nullptr;
+    pool.timing = timing;
     std::atomic<uint64_t> us_parse{0}, us_gather{0}, us_gpu{0}, us_format{0}, us_write{0}, us_alloc{0};
     auto now_us = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<bool> failed{false};
@@ -519,7 +549,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 bgr::FastqPlan plan(mf->data, mf->size, chunk_bytes);
                 const size_t nc = plan.chunks();
                 uint64_t tp0 = now_us();
-                pool.run(nc, [&](size_t c) { plan.count_chunk(c); });
+                pool.run(nc, [&](size_t c) { plan.count_chunk(c); }, 1);
                 plan.finish_counts();
                 us_parse += now_us() - tp0;
                 std::unique_ptr<Batch> b;
@@ -554,7 +584,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     for (auto& ch : fq) ch.track_iters = marker.on;
                     std::vector<char> done(c_end - c, 1);
                     tp0 = now_us();
-                    pool.run(c_end - c, [&](size_t j) { done[j] = plan.parse_chunk(c + j, fq[j]) ? 1 : 0; });
+                    pool.run(c_end - c, [&](size_t j) { done[j] = plan.parse_chunk(c + j, fq[j]) ? 1 : 0; }, 1);
                     us_parse += now_us() - tp0;
                     for (size_t j = 0; j < fq.size() && ok; ++j) {
                         feed(fq[j]);
@@ -593,7 +623,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 pool.run(c_end - c, [&](size_t j) {
                     uint64_t e = (c + j + 1 < starts.size()) ? starts[c + j + 1] : mf->size;
                     bgr::parse_fasta_chunk(mf->data, starts[c + j], e, gi.k, *bp->chunks[j]);
-                });
+                }, 1);
                 size_t total = 0;
                 for (auto& ch : b->chunks) total += ch->recs.size();
                 b->recs.reserve(total);
@@ -661,7 +691,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                         for (uint32_t j = 0; j < words; ++j) { pt.idx.push_back((uint32_t)(w0 + j)); pt.val.push_back(nm[j]); }
                     }
                 }
-            });
+            }, 2);
             uint64_t nmc = 0;
             b.pin->max_len = 0;
             for (const Part& pt : parts) { nmc += pt.idx.size(); b.pin->max_len = std::max(b.pin->max_len, pt.max_len); }
@@ -743,7 +773,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                         if (ovlF && !o->ob[t].empty() && fwrite(o->ob[t].data(), 1, o->ob[t].size(), ovlF) != o->ob[t].size()) fail(BGR_E_IO, "write to the no-overlap file failed");
                     }
                 }
-            });
+            }, 4);
             us_write += now_us() - tw0;
             free_bufs.push(std::move(o));
         }
@@ -811,7 +841,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     if (lo >= hi) return;
                     if (!extended) format_range(*cp, lo, hi, pb[t], nb[t]);
                     else okv[t] = format_range_ext(*cp, lo, hi, correction ? &unitigs : nullptr, ovlF != nullptr, pb[t], nb[t], ob[t], bugv[t]) ? 1 : 0;
-                });
+                }, 3);
                 // "bug compaction": like the reference, everything before the offending read is written, nothing after it
                 unsigned t_stop = threads;
                 for (unsigned t = 0; t < threads; ++t)
@@ -853,6 +883,9 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     if (timing)
         fprintf(stderr, "bgreat: stage busy time (s): parse %.3f  alloc %.3f  gather %.3f  gpu(sum over %zu workers) %.3f  format %.3f  write %.3f\n",
                 us_parse / 1e6, us_alloc / 1e6, us_gather / 1e6, aligners.size(), us_gpu / 1e6, us_format / 1e6, us_write / 1e6);
+    if (timing)  // thread CPU seconds spent inside the pool's tasks, by stage
+        fprintf(stderr, "bgreat: pool CPU time (s): parse %.3f  gather/pack %.3f  format %.3f  write %.3f  other %.3f\n", pool.cpu_us[1] / 1e6,
+                pool.cpu_us[2] / 1e6, pool.cpu_us[3] / 1e6, pool.cpu_us[4] / 1e6, pool.cpu_us[0] / 1e6);
     if (failed) return bgr::set_error(first_rc, first_err);
     return BGR_OK;
 }

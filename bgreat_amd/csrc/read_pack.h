@@ -52,6 +52,26 @@ inline bool have_ssse3() {
     static const bool ok = __builtin_cpu_supports("ssse3");
     return ok;
 }
+// 32 characters -> one plane word (first base in the top two bits); *nmask32: bit i set = character i is 'N'
+__attribute__((target("avx2"))) inline uint64_t pack32_avx2(const unsigned char* s, uint32_t* nmask32) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s));
+    const __m256i three = _mm256_set1_epi8(3);
+    const __m256i isn = _mm256_cmpeq_epi8(v, _mm256_set1_epi8('N'));
+    __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
+    c = _mm256_or_si256(c, _mm256_and_si256(isn, three));
+    const __m256i nib = _mm256_maddubs_epi16(c, _mm256_set1_epi16(0x0104));     // byte pairs -> c0*4 + c1
+    const __m256i byt = _mm256_madd_epi16(nib, _mm256_set1_epi32(0x00010010));  // nibble pairs -> n0*16 + n1 (4 bases per 32-bit lane)
+    const __m256i sel = _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i out = _mm256_shuffle_epi8(byt, sel);  // per 128-bit half: its four bytes, first base's byte on top of the low dword
+    *nmask32 = (uint32_t)_mm256_movemask_epi8(isn);
+    const uint32_t hi = (uint32_t)_mm_cvtsi128_si32(_mm256_castsi256_si128(out));
+    const uint32_t lo = (uint32_t)_mm_cvtsi128_si32(_mm256_extracti128_si256(out, 1));
+    return (uint64_t)hi << 32 | lo;
+}
+inline bool have_avx2() {
+    static const bool ok = __builtin_cpu_supports("avx2");
+    return ok;
+}
 #endif
 
 inline uint32_t pack16(const unsigned char* s, uint32_t* nmask16) {
@@ -70,6 +90,16 @@ inline bool pack_read(const char* seq, uint32_t len, uint64_t* fw, uint64_t* nm)
     uint32_t done = 0;
     for (uint32_t w = 0; w < words; ++w) {
         uint32_t half[2] = {0, 0}, nmh[2] = {0, 0};
+#if defined(__x86_64__)
+        if (len - done >= 32 && have_avx2()) {  // a whole word at once
+            uint32_t nm32;
+            fw[w] = pack32_avx2(s + done, &nm32);
+            done += 32;
+            nmh[0] = nm32 & 0xFFFFu;
+            nmh[1] = nm32 >> 16;
+            goto mask;
+        }
+#endif
         for (int h = 0; h < 2; ++h) {
             if (done >= len) break;
             if (len - done >= 16) {
@@ -84,6 +114,9 @@ inline bool pack_read(const char* seq, uint32_t len, uint64_t* fw, uint64_t* nm)
             }
         }
         fw[w] = (uint64_t)half[0] << 32 | half[1];
+#if defined(__x86_64__)
+    mask:
+#endif
         if (nmh[0] | nmh[1]) {
             if (!any && nm) for (uint32_t j = 0; j < w; ++j) nm[j] = 0;
             any = true;

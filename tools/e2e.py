@@ -64,9 +64,9 @@ def main():
             ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
             line = [l for l in p.stderr.splitlines() if l.startswith("bgreat: mapping")][-1]
             secs = float(line.split()[2])
-            stages = [l for l in p.stderr.splitlines() if "stage busy" in l]
-            if stages:
-                print(stages[-1], file=sys.stderr)
+            for l in p.stderr.splitlines():
+                if "stage busy" in l or "pool CPU" in l:
+                    print(l, file=sys.stderr)
             out["run%d" % rep] = {"wall_s": round(wall, 3), "mapping_s": secs, "mreads_per_s": round(args.reads / secs / 1e6, 3),
                                   "input_GB_per_s": round(fsize / secs / 1e9, 3),
                                   "cpu_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "cpu_sys_s": round(ru1.ru_stime - ru0.ru_stime, 2)}
