@@ -336,11 +336,11 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;
     const uint32_t K1 = g.k - 1;
-    uint32_t mphf_words;
-    const uint32_t* units = block_prologue<STAGE>(g, lds, &mphf_words);
+    uint32_t ktab_words;
+    const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     // per wave: FW3 | FWQ | RCW | NM | OUT | CUR | BEST | frames   (the last four in HBM when DEEP)
     const uint32_t per_wave_words = DEEP ? 4 * W : 4 * W + 3 * (io.path_cap / 2) + (io.frames_per_wave * FR_WORDS) / 2;
-    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FW3 = lds + 64 + ktab_words + (u64)wave * per_wave_words;
     u64* FWQ = FW3 + W;
     u64* RCW = FWQ + W;
     u64* NM = RCW + W;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
             u64 num = 0;
             if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
-            const uint32_t idx = find_key<!STAGE>(g, units, num < rc ? num : rc, valid);
+            const uint32_t idx = find_key<!STAGE>(g, ktab, num < rc ? num : rc, valid);
             u64 mask = __ballot(idx != BGR_NONE);
             if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
             while (mask) {
@@ -645,13 +645,13 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
     const uint32_t K1 = g.k - 1;
-    uint32_t mphf_words;
-    const uint32_t* units = block_prologue<STAGE>(g, lds, &mphf_words);
+    uint32_t ktab_words;
+    const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     // per wave: RPW x { read words W | level table XL x X4_LV_WORDS u32 | out ints 2 x (XL + 2) }  (x4_group_words, align_kernels.h)
     const uint32_t out_ints = 2 * (XL + 2);
     const uint32_t grp_words = W + (XL * X4_LV_WORDS + out_ints + 1) / 2;
     const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
-    u64* WV = lds + 64 + mphf_words + (u64)wave * (RPW * grp_words);
+    u64* WV = lds + 64 + ktab_words + (u64)wave * (RPW * grp_words);
     u64* F = WV + grp * grp_words;
     uint32_t* LVT = reinterpret_cast<uint32_t*>(F + W);
     int32_t* OUTG = reinterpret_cast<int32_t*>(LVT + XL * X4_LV_WORDS);
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
                 u64 num = 0;
                 if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);
-                uint32_t idx = find_key<!STAGE>(g, units, num < rcn ? num : rcn, valid);
+                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid);
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {
                     if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
@@ -779,12 +779,12 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;
     const uint32_t K1 = g.k - 1;
-    uint32_t mphf_words;
-    const uint32_t* units = block_prologue<STAGE>(g, lds, &mphf_words);
+    uint32_t ktab_words;
+    const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     // per wave: FW3 | FWQ | RCW | NM | OUT | BEST | tables (32 + levels * 52 + levels words, see exh_dp)
     const uint32_t table_words = 32 + io.frames_per_wave * (DP_LEVEL_WORDS + 1);
     const uint32_t per_wave_words = 4 * W + 2 * (io.path_cap / 2) + ((table_words + 3) / 4) * 2;  // whole 16-byte units
-    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FW3 = lds + 64 + ktab_words + (u64)wave * per_wave_words;
     u64* FWQ = FW3 + W;
     u64* RCW = FWQ + W;
     u64* NM = RCW + W;
@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
             u64 num = 0;
             if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
-            const uint32_t idx = find_key<!STAGE>(g, units, num < rc ? num : rc, valid);
+            const uint32_t idx = find_key<!STAGE>(g, ktab, num < rc ? num : rc, valid);
             u64 mask = __ballot(idx != BGR_NONE);
             if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
             while (mask) {

@@ -17,10 +17,10 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
     // as the second pass behind bgr_align_greedy_multi_kernel it maps only the reads that kernel listed (count in cursor[subset_ctr])
     const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
     if ((uint32_t)(blockIdx.x * waves) >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
-    uint32_t mphf_words;
-    const uint32_t* units = block_prologue<STAGE>(g, lds, &mphf_words);
+    uint32_t ktab_words;
+    const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     const uint32_t per_wave_words = 4 * W + io.path_cap / 2;
-    u64* FW3 = lds + 64 + mphf_words + (u64)wave * per_wave_words;
+    u64* FW3 = lds + 64 + ktab_words + (u64)wave * per_wave_words;
     u64* FWQ = FW3 + W;
     u64* RCW = FWQ + W;
     u64* NM = RCW + W;
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                     rcn = plain ? rcb_fast(num, K1) : lds_win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
-                const uint32_t idx = find_key<!STAGE>(g, units, rep, valid);
+                const uint32_t idx = find_key<!STAGE>(g, ktab, rep, valid);
                 u64 mask = __ballot(idx != BGR_NONE);
 #ifdef BGR_PHASE_TIMING
                 if (prm.debug_stop == 2) { if (mask) { ++tried; done = true; p_n = 0; } mask = 0; }
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                     // getBegin/getEnd recompute rc = rcb(num) (aligner.cpp:149,211); it differs from the
                     // rolling rcnum only when an N was rolled into the window.
                     const u64 rc2 = rcb_fast(a_num, K1);
-                    if (rc2 != a_rcn) a_rec = find_key<!STAGE>(g, units, a_num < rc2 ? a_num : rc2, true);
+                    if (rc2 != a_rcn) a_rec = find_key<!STAGE>(g, ktab, a_num < rc2 ? a_num : rc2, true);
                     if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, a_pos, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
                         done = true;
                         break;
@@ -153,10 +153,10 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
     // later passes map the reads an earlier pass listed (count in cursor[subset_ctr]), from the state it left in g4_state
     const uint32_t total = LIST ? io.cursor[io.subset_ctr] : io.n_reads;
     if ((uint32_t)(blockIdx.x * waves) * RPW >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
-    uint32_t mphf_words;
-    const uint32_t* units = block_prologue<STAGE>(g, lds, &mphf_words);
+    uint32_t ktab_words;
+    const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     const uint32_t RS = LIST ? 2 * W : W;  // words per read: forward words [| reverse-complement words: only a launch over a list maps that strand]
-    u64* RD = lds + 64 + mphf_words + (u64)wave * (RPW * RS);
+    u64* RD = lds + 64 + ktab_words + (u64)wave * (RPW * RS);
     const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
     const uint32_t gbase_lane = (uint32_t)lane & ~(uint32_t)(GL - 1);
     const uint32_t m = prm.max_mismatch;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
                     u64 num = 0;
                     if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
                     const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
-                    uint32_t idx = find_key<!STAGE>(g, units, num < rcn ? num : rcn, valid);
+                    uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid);
                     const u64 mask = __ballot(idx != BGR_NONE);
                     if (mask) {
                         if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
