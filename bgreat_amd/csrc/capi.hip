@@ -5,11 +5,14 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bgreat_gpu.h"
@@ -75,6 +78,9 @@ struct bgr_aligner {
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
     uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0;
     uint64_t knob_split_limit = 0;
+    uint32_t knob_overlap = 0;      // BGR_KNOB_BATCH_OVERLAP
+    bgr_aligner* twin = nullptr;    // second stream + buffers for the overlapped form of bgr_align_batch (created on first use)
+    bool is_twin = false;
     int num_cus = 0;
     size_t lds_per_cu = 0;
     hipEvent_t ev[kTimerRing][kTimerSlots + 1];  // ev[i][0] = start of launch i, ev[i][j] = behind its j-th kernel
@@ -422,6 +428,7 @@ int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out) {
 
 void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
+    if (a->twin) { bgr_aligner_destroy(a->twin); a->twin = nullptr; }
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
         a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->ovf3.release(); a->g4st.release(); a->deep.release(); a->small.release();
@@ -447,6 +454,7 @@ int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
         case BGR_KNOB_EXH_SEARCH: if (value > 2) break; a->knob_search = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_BATCH_SPLIT_LIMIT: a->knob_split_limit = value; return BGR_OK;
         case BGR_KNOB_DEBUG_STOP: a->knob_debug_stop = (uint32_t)value; return BGR_OK;
+        case BGR_KNOB_BATCH_OVERLAP: a->knob_overlap = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_GREEDY_FAST: if (value > 1) break; a->knob_greedy_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_EXH_FAST: if (value > 1) break; a->knob_exh_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_ANCHORS_FAST: if (value > 1) break; a->knob_anc_fast = (uint32_t)value; return BGR_OK;
@@ -887,14 +895,11 @@ int bgr_aligner_device_results(bgr_aligner* a, void** d_results, void** d_arena,
     return BGR_OK;
 }
 
-int bgr_aligner_fetch(bgr_aligner* a, uint64_t n, int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
-    if (!a || !path_offsets || !status || (paths_cap && !paths_out)) return fail(BGR_E_ARG, "bgr_aligner_fetch: null argument");
-    if (n != a->last_n) return fail(BGR_E_ARG, "bgr_aligner_fetch: n_reads differs from the last bgr_align_device call");
-    path_offsets[0] = 0;
-    if (n == 0) return BGR_OK;
+// results -> CSR on the device in two steps: the number of path ints of the launch (fetch_total), then the dense arrays and
+// their copies into the caller's memory (fetch_copy: relative path_offsets[0..n], status[0..n), total ints at paths_out)
+static int fetch_total(bgr_aligner* a, uint64_t n, uint64_t* total_out) {
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
-    // results -> CSR on the device (launch_csr), then three plain copies into the caller's arrays
     const uint64_t nb = (n + 4095) / 4096;
     HIP_TRY(a->csr_sums.ensure(nb * 4 + 64));
     HIP_TRY(a->csr_poffs.ensure((n + 1) * 8));
@@ -908,17 +913,125 @@ int bgr_aligner_fetch(bgr_aligner* a, uint64_t n, int32_t* paths_out, uint64_t p
     HIP_TRY(hipStreamSynchronize(a->stream));
     const uint32_t* cur = reinterpret_cast<const uint32_t*>(hs);
     if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
-    const uint64_t total = hs[16];
-    if (total > paths_cap) return fail(BGR_E_CAPACITY, "bgr_aligner_fetch: paths_out too small");
+    *total_out = hs[16];
+    return BGR_OK;
+}
+static int fetch_copy(bgr_aligner* a, uint64_t n, uint64_t total, int32_t* paths_out, uint64_t* path_offsets, uint8_t* status, bool with_end = true) {
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(static_cast<char*>(a->small.p) + 128);
     HIP_TRY(a->csr_paths.ensure(total * 4 + 16));
-    e = bgr::launch_csr(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), (uint32_t)n,
-                        static_cast<uint32_t*>(a->csr_sums.p), d_total, static_cast<unsigned long long*>(a->csr_poffs.p),
-                        static_cast<int32_t*>(a->csr_paths.p), static_cast<uint8_t*>(a->csr_status.p), (uint32_t)std::min<uint64_t>(total, 0xFFFFFFFFull), 1, a->stream);
+    hipError_t e = bgr::launch_csr(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), (uint32_t)n,
+                                   static_cast<uint32_t*>(a->csr_sums.p), d_total, static_cast<unsigned long long*>(a->csr_poffs.p),
+                                   static_cast<int32_t*>(a->csr_paths.p), static_cast<uint8_t*>(a->csr_status.p), (uint32_t)std::min<uint64_t>(total, 0xFFFFFFFFull), 1, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("csr launch: ") + hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(path_offsets, a->csr_poffs.p, (n + 1) * 8, hipMemcpyDeviceToHost, a->stream));
+    // (with_end = false: entry n, the end of the last read, is left to the caller -- it is the first entry of the next piece)
+    HIP_TRY(hipMemcpyAsync(path_offsets, a->csr_poffs.p, (n + (with_end ? 1 : 0)) * 8, hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(hipMemcpyAsync(status, a->csr_status.p, n, hipMemcpyDeviceToHost, a->stream));
     if (total) HIP_TRY(hipMemcpyAsync(paths_out, a->csr_paths.p, total * 4, hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(hipStreamSynchronize(a->stream));
+    return BGR_OK;
+}
+
+int bgr_aligner_fetch(bgr_aligner* a, uint64_t n, int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
+    if (!a || !path_offsets || !status || (paths_cap && !paths_out)) return fail(BGR_E_ARG, "bgr_aligner_fetch: null argument");
+    if (n != a->last_n) return fail(BGR_E_ARG, "bgr_aligner_fetch: n_reads differs from the last bgr_align_device call");
+    path_offsets[0] = 0;
+    if (n == 0) return BGR_OK;
+    uint64_t total = 0;
+    int rc = fetch_total(a, n, &total);
+    if (rc != BGR_OK) return rc;
+    if (total > paths_cap) return fail(BGR_E_CAPACITY, "bgr_aligner_fetch: paths_out too small");
+    return fetch_copy(a, n, total, paths_out, path_offsets, status);
+}
+
+// One piece of a batch up to (not including) the copies out: H2D of the characters and offsets, the mapping launch.
+static int batch_piece_launch(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n) {
+    HIP_TRY(hipSetDevice(a->device));
+    const uint64_t base = read_offsets[0], total = read_offsets[n] - base;
+    uint32_t max_len = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t l = read_offsets[i + 1] - read_offsets[i];
+        if (l > 0x7FFFFFFFull) return fail(BGR_E_ARG, "bgr_align_batch: read longer than 2^31 bases");
+        max_len = std::max<uint32_t>(max_len, (uint32_t)l);
+    }
+    HIP_TRY(a->in_reads.ensure(total + 16));
+    HIP_TRY(a->in_offs.ensure((n + 1) * 8));
+    HIP_TRY(hipMemcpyAsync(a->in_reads.p, reads + base, total, hipMemcpyHostToDevice, a->stream));
+    if (base == 0) {
+        HIP_TRY(hipMemcpyAsync(a->in_offs.p, read_offsets, (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    } else {
+        std::vector<uint64_t> rel(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) rel[i] = read_offsets[i] - base;
+        HIP_TRY(hipMemcpyAsync(a->in_offs.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    }
+    return bgr_align_device(a, p, a->in_reads.p, a->in_offs.p, n, total, max_len);
+}
+
+// A large batch in kOverlapPieces pieces on two streams (this aligner's and its twin's, one host thread each): the copies of
+// one piece run under the kernels of the other.  A piece's place in paths_out is known once the pieces in front of it have
+// counted their path ints (fetch_total); results are those of one launch over the whole batch.
+static const uint64_t kOverlapMinReads = 512 * 1024;
+static const unsigned kOverlapPieces = 4;
+static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n,
+                                  int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
+    if (!a->twin) {
+        int rc = bgr_aligner_create(a->graph, a->device, &a->twin);
+        if (rc != BGR_OK) return rc;
+        a->twin->is_twin = true;
+    }
+    bgr_aligner* al[2] = {a, a->twin};
+    a->twin->cfg_waves = a->cfg_waves; a->twin->cfg_blocks_per_cu = a->cfg_blocks_per_cu; a->twin->cfg_lds_mphf = a->cfg_lds_mphf;
+    a->twin->knob_frame_cap = a->knob_frame_cap; a->twin->knob_search = a->knob_search; a->twin->knob_debug_stop = a->knob_debug_stop;
+    a->twin->knob_greedy_fast = a->knob_greedy_fast; a->twin->knob_exh_fast = a->knob_exh_fast; a->twin->knob_anc_fast = a->knob_anc_fast;
+    uint64_t cut[kOverlapPieces + 1];
+    for (unsigned k = 0; k <= kOverlapPieces; ++k) cut[k] = n * k / kOverlapPieces;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t totals[kOverlapPieces];
+    bool known[kOverlapPieces];
+    for (unsigned k = 0; k < kOverlapPieces; ++k) { totals[k] = 0; known[k] = false; }
+    int first_rc = BGR_OK;
+    std::string first_err;
+    auto give_up = [&](int rc, const char* msg) {
+        std::lock_guard<std::mutex> l(mu);
+        if (first_rc == BGR_OK) { first_rc = rc; first_err = msg ? msg : ""; }
+        cv.notify_all();
+    };
+    auto work = [&](unsigned t) {
+        for (unsigned k = t; k < kOverlapPieces; k += 2) {
+            { std::lock_guard<std::mutex> l(mu); if (first_rc != BGR_OK) return; }
+            const uint64_t i0 = cut[k], cnt = cut[k + 1] - cut[k];
+            uint64_t tot = 0;
+            int rc = cnt ? batch_piece_launch(al[t], p, reads, read_offsets + i0, cnt) : BGR_OK;
+            if (rc == BGR_OK && cnt) rc = fetch_total(al[t], cnt, &tot);
+            if (rc != BGR_OK) { give_up(rc, bgr_last_error()); return; }
+            uint64_t before = 0;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                totals[k] = tot;
+                known[k] = true;
+                cv.notify_all();
+                cv.wait(l, [&] { if (first_rc != BGR_OK) return true; for (unsigned j = 0; j < k; ++j) if (!known[j]) return false; return true; });
+                if (first_rc != BGR_OK) return;
+                for (unsigned j = 0; j < k; ++j) before += totals[j];
+            }
+            if (before + tot > paths_cap) { give_up(BGR_E_CAPACITY, "bgr_align_batch: paths_out too small"); return; }
+            if (cnt) {
+                rc = fetch_copy(al[t], cnt, tot, paths_out ? paths_out + before : nullptr, path_offsets + i0, status + i0, false);
+                if (rc != BGR_OK) { give_up(rc, bgr_last_error()); return; }
+                if (before) for (uint64_t i = i0; i < i0 + cnt; ++i) path_offsets[i] += before;  // (entry i0 + cnt belongs to the next piece / the end)
+            }
+        }
+    };
+    std::thread helper(work, 1u);
+    work(0u);
+    helper.join();
+    if (first_rc != BGR_OK) return fail(first_rc, first_err);
+    uint64_t all = 0;
+    for (unsigned k = 0; k < kOverlapPieces; ++k) all += totals[k];
+    path_offsets[n] = all;
+    a->last_n = 0;  // several launches: bgr_aligner_fetch has nothing to re-read
     return BGR_OK;
 }
 
@@ -948,25 +1061,9 @@ int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, cons
         a->last_n = 0;  // several launches: bgr_aligner_fetch has nothing to re-read
         return BGR_OK;
     }
-    uint32_t max_len = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        uint64_t l = read_offsets[i + 1] - read_offsets[i];
-        if (l > 0x7FFFFFFFull) return fail(BGR_E_ARG, "bgr_align_batch: read longer than 2^31 bases");
-        max_len = std::max<uint32_t>(max_len, (uint32_t)l);
-    }
-    HIP_TRY(a->in_reads.ensure(total + 16));
-    HIP_TRY(a->in_offs.ensure((n + 1) * 8));
-    HIP_TRY(hipMemcpyAsync(a->in_reads.p, reads + base, total, hipMemcpyHostToDevice, a->stream));
-    if (base == 0) {
-        HIP_TRY(hipMemcpyAsync(a->in_offs.p, read_offsets, (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
-    } else {
-        std::vector<uint64_t> rel(n + 1);
-        for (uint64_t i = 0; i <= n; ++i) rel[i] = read_offsets[i] - base;
-        HIP_TRY(hipMemcpyAsync(a->in_offs.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
-    }
-    int rc = bgr_align_device(a, p, a->in_reads.p, a->in_offs.p, n, total, max_len);
+    // a large batch: in pieces on two streams, copies under kernels (BGR_KNOB_BATCH_OVERLAP = 1 turns it off)
+    if (!a->is_twin && !a->knob_overlap && n >= kOverlapMinReads) return align_batch_overlapped(a, p, reads, read_offsets, n, paths_out, paths_cap, path_offsets, status);
+    int rc = batch_piece_launch(a, p, reads, read_offsets, n);
     if (rc != BGR_OK) return rc;
     return bgr_aligner_fetch(a, n, paths_out, paths_cap, path_offsets, status);
 }
@@ -976,6 +1073,12 @@ int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) {
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
     HIP_TRY(hipMemcpy(out, static_cast<char*>(a->small.p) + 64, 40, hipMemcpyDeviceToHost));
+    if (a->twin) {  // the pieces of overlapped batches its second stream mapped
+        uint64_t t[5];
+        HIP_TRY(hipStreamSynchronize(a->twin->stream));
+        HIP_TRY(hipMemcpy(t, static_cast<char*>(a->twin->small.p) + 64, 40, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 5; ++i) out[i] += t[i];
+    }
     return BGR_OK;
 }
 
@@ -984,6 +1087,10 @@ int bgr_aligner_reset_counters(bgr_aligner* a) {
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
     HIP_TRY(hipMemset(static_cast<char*>(a->small.p) + 64, 0, 40));
+    if (a->twin) {
+        HIP_TRY(hipStreamSynchronize(a->twin->stream));
+        HIP_TRY(hipMemset(static_cast<char*>(a->twin->small.p) + 64, 0, 40));
+    }
     return BGR_OK;
 }
 

@@ -220,6 +220,7 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
 #define BGR_KNOB_EXH_SEARCH 2u
 #define BGR_KNOB_BATCH_SPLIT_LIMIT 3u
 #define BGR_KNOB_DEBUG_STOP 4u
+#define BGR_KNOB_BATCH_OVERLAP 8u /* bgr_align_batch of >= 512 k reads: 0 = in four pieces on two streams, copies under kernels (default), 1 = one launch */
 #define BGR_KNOB_ANCHORS_FAST 7u /* anchors mode: 0 = four-reads-per-wave first pass + the one-read-per-wave kernel for the rest (default), 1 = without it */
 #define BGR_KNOB_EXH_FAST 6u    /* exhaustive mode: 0 = four-reads-per-wave first pass + the level / depth-first passes for the rest (default), 1 = without it */
 #define BGR_KNOB_GREEDY_FAST 5u /* greedy mode: 0 = eight-reads-per-wave passes + general kernel for the rest (default), 1 = general kernel only */

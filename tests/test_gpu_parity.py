@@ -474,6 +474,50 @@ def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m
     assert al.counters() == o.counters()
 
 
+@pytest.mark.parametrize("mode", [B.MODE_GREEDY, B.MODE_EXHAUSTIVE])
+def test_large_batch_in_overlapped_pieces_equals_one_launch(mode):
+    """bgr_align_batch maps a batch of >= 512 k reads in four pieces on two streams (copies of one piece under the kernels of
+    the other): rows, offsets and counters must be those of one launch over the whole batch (BGR_KNOB_BATCH_OVERLAP = 1), ragged
+    read lengths, and a paths buffer that is too small must be reported as such."""
+    k = 31
+    s = Synth(300000, 90, 2, k, 5151)
+    seqs, offs = s.unitigs()
+    n = 600001
+    reads, roffs = s.reads(0, n, 100, 2, 5252)
+    keep = np.ones(len(reads), dtype=bool)   # ragged: cut a few bases off every third read
+    lens = np.full(n, 100, dtype=np.int64)
+    lens[::3] -= np.arange(len(lens[::3])) % 37
+    idx = np.repeat(np.arange(n, dtype=np.int64) * 100, 100) + np.tile(np.arange(100, dtype=np.int64), n)
+    keep = (np.tile(np.arange(100, dtype=np.int64), n) < np.repeat(lens, 100))
+    reads = reads[keep]
+    roffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    p1, po1, st1 = al.align(reads, roffs, m=2, mode=mode)
+    c1 = al.counters()
+    al.reset_counters()
+    al.set_knob(B.KNOB_BATCH_OVERLAP, 1)
+    p2, po2, st2 = al.align(reads, roffs, m=2, mode=mode)
+    assert al.counters() == c1
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    o = oracle_py.Oracle(k, seqs, offs)
+    sub = slice(299990, 300020)            # rows around a piece boundary against the oracle
+    rs = reads[int(roffs[sub.start]):int(roffs[sub.stop])]
+    ro = (roffs[sub.start:sub.stop + 1] - roffs[sub.start]).astype(np.uint64)
+    p3, po3, st3 = o.align(rs, ro, m=2, mode=1 if mode == B.MODE_EXHAUSTIVE else 0)
+    assert np.array_equal(st1[sub], st3)
+    assert np.array_equal(p1[int(po1[sub.start]):int(po1[sub.stop])], p3)
+    if mode == B.MODE_GREEDY:   # a paths buffer that cannot hold the result: reported, not overrun
+        import ctypes as C
+        al.set_knob(B.KNOB_BATCH_OVERLAP, 0)
+        small = np.empty(1000, dtype=np.int32)
+        poffs = np.empty(n + 1, dtype=np.uint64)
+        status = np.empty(n, dtype=np.uint8)
+        prm = B.Params(mode, 2, 2, 0)
+        rc = B.lib().bgr_align_batch(al.h, C.byref(prm), reads.ctypes.data, roffs.ctypes.data, n, small.ctypes.data, len(small), poffs.ctypes.data, status.ctypes.data)
+        assert rc != 0 and b"too small" in B.lib().bgr_last_error()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 15, 17, 63, 65])
 def test_tiny_batches_through_the_many_reads_per_wave_kernels(n):
     """A single, partly filled wave (fewer reads than a wave takes, a last group alone) in all three modes."""
