@@ -233,14 +233,15 @@ __global__ void __launch_bounds__(1024, BGR_ANC_OCC) bgr_align_anchors_kernel(Bg
     }
 }
 
-// ============================ anchors mode, four reads per wavefront ===================================
+// ============================ anchors mode, several reads per wavefront ===================================
 // The kernel above gives a wave one read; per read it does a few BooPHF lookups (lane = level: a handful of the 64 lanes),
-// one placement compare and the greedy walks (a handful of lanes again).  Here a wave takes four reads, 16 lanes each:
+// one placement compare and the greedy walks (a handful of lanes again).  Here a wave takes 64 / GL reads, GL lanes each (8
+// when the index has at most 8 active levels -- eight reads per wave -- else 16):
 // lane `sub` of a group probes level `sub` of the lookup, compares bases [32 sub, 32 sub + 32) of the placement, and the
 // walks run through g4_step like the greedy kernel's.  All four groups step through the reference's loop in lockstep --
 // lookup at the current position, placement of the anchoring unitig if the lookup answered, walks, next position / next
 // strand -- which is efficient because every read does about the same work (the first `effort` answers are tried, then
-// the reverse complement).  Reads with an N, paths longer than G4_PATH ints per side and graphs with more than 16 active
+// the reverse complement).  Reads with an N, paths longer than GL ints per side and graphs with more than 16 active
 // BooPHF levels go to bgr_align_anchors_kernel (listed / not launched).
 #ifndef BGR_ANC4_OCC
 #define BGR_ANC4_OCC 5 /* 96 VGPRs: 632 Mreads/s; 4 (110 VGPRs): 574; 6 (80 VGPRs): 621 */

@@ -299,8 +299,7 @@ __device__ __forceinline__ uint32_t half_row_mirror(uint32_t x) { return (uint32
 __device__ __forceinline__ uint32_t row_ror8(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 
-// record index | canonical << 28 (| fits << 29 | found << 30 in a step result) as the four-reads-per-wave kernels pass it around
-#define G4_PATH 16  // path ints per direction the four-reads-per-wave kernels keep in registers (lane j of a group: int j)
+// record index | canonical << 28 (| fits << 29 | found << 30 in a step result) as the several-reads-per-wave kernels pass it around
 #define G4_REC_MASK 0x0FFFFFFFu
 #define G4_CANON (1u << 28)
 #define G4_FITS (1u << 29)
@@ -424,7 +423,7 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
     return true;
 }
 
-// ---- the extension step of the four-reads-per-wave kernels (greedy mode, anchors mode) ----------------------------------------
+// ---- the extension step of the several-reads-per-wave kernels (greedy mode, anchors mode) ----------------------------------------
 // One extension step for up to four walks, one per 16-lane group.  `phase` (uniform within a group): 0 = the group sits
 // out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
 // behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.

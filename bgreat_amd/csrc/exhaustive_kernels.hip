@@ -1,5 +1,5 @@
 // exhaustive_kernels.hip -- exhaustive mode (-b: alignReadExhaustive, alignerExhaustive.cpp:35-259) on gfx950.
-//   bgr_align_exhaustive4_kernel    four reads per wavefront, one node per level of the walk (x4_search)
+//   bgr_align_exhaustive4_kernel    eight reads per wavefront (8 lanes per read), one node per level of the walk (x4_search)
 //   bgr_align_exhaustive_dp_kernel  the level search (exh_dp): all nodes of a level at once, backward cost pass
 //   bgr_align_exhaustive_kernel     depth-first search in slot order (exh_search); DEEP: search state in HBM
 #include "device_common.h"
@@ -428,9 +428,10 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
     }
 }
 
-// ============================== exhaustive, four reads per wavefront ===================================
+// ============================== exhaustive, several reads per wavefront ===================================
 // The level search (exh_dp) gives a wave ONE read, and after de-duplication a level of the walk rarely holds more than one
-// node: 4 candidate slots x 4 chunk lanes = 16 of the 64 lanes work.  Here a wave takes four reads, 16 lanes each, and runs
+// node: 4 candidate slots x 4 chunk lanes = 16 of the 64 lanes work.  Here a wave takes 64 / GL reads, GL lanes each (GL = 8:
+// eight reads, 4 slots x 2 chunk lanes; written for GL = 16), and runs
 // their searches side by side, for the shape nearly every read has: every level has exactly ONE node (all candidates that go
 // on lead to the same (record, position, strand): bubbles that close again), at most 8 or 16 levels per side (chosen per launch), no N, and
 // the first anchor that can succeed does.  Per side: a forward sweep scores the node's <= 4 candidates per level (kept:
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel
 #define X4_END 1u
 #define X4_INF 0xFFFFu
 
-// One side of the search for up to four reads (act = the group takes part).  DIR 0: left of the anchor (exL), DIR 1: right
+// One side of the search for the wave's reads (act = the group takes part).  DIR 0: left of the anchor (exL), DIR 1: right
 // (exR).  On return, for the groups that took part: *cost = best total (X4_INF: none within the budget; the caller compares
 // with its budget), *n_out ints written to OUTG[o_off ...] in output order, *fb = the search left the shape this kernel
 // handles (the read goes on the list).
@@ -886,7 +887,7 @@ hipError_t launch_exhaustive(const BgrDeviceGraph& g, const BatchIO& io, const K
     return cfg.stage_mphf ? launch_one(bgr_align_exhaustive_kernel<true, false>, g, io, p, cfg, stream)
                           : launch_one(bgr_align_exhaustive_kernel<false, false>, g, io, p, cfg, stream);
 }
-const void* exhaustive_kernel_fn(uint32_t which) {  // 0 depth-first, 1 level search, 2 four reads per wave
+const void* exhaustive_kernel_fn(uint32_t which) {  // 0 depth-first, 1 level search, 2 several reads per wave
     return which == 1 ? reinterpret_cast<const void*>(&bgr_align_exhaustive_dp_kernel<false>)
          : which == 2 ? reinterpret_cast<const void*>(&bgr_align_exhaustive4_kernel<false, (int)kX4GroupLanes, 16>)
                       : reinterpret_cast<const void*>(&bgr_align_exhaustive_kernel<true, false>);
