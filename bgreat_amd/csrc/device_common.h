@@ -424,7 +424,7 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 }
 
 // ---- the extension step of the several-reads-per-wave kernels (greedy mode, anchors mode) ----------------------------------------
-// One extension step for up to four walks, one per 16-lane group.  `phase` (uniform within a group): 0 = the group sits
+// One extension step for up to 64 / GL walks, one per GL-lane group (GL = 16 or 8).  `phase` (uniform within a group): 0 = the group sits
 // out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
 // behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
 // Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
