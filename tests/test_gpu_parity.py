@@ -12,7 +12,7 @@ import pytest
 import bgreat_amd as B
 import oracle_py
 from tools.synth import Synth
-from util import GOLD, check_against_golden, golden_cases, resolve_args, run_cli
+from util import GOLD, ROOT, check_against_golden, golden_cases, resolve_args, run_cli
 
 pytestmark = pytest.mark.gpu
 
@@ -775,3 +775,33 @@ def test_tiny_and_very_long_reads_through_the_api():
     assert len(p) == 0 and list(st & 3) == [0, 0, 0, 0]
     p, po, st = al.align(short, so, mode=B.MODE_EXHAUSTIVE)
     assert len(p) == 0 and list(st & 3) == [1, 1, 1, 1]
+
+
+def test_bench_line_contract():
+    """bench.py (what the driver runs at round end) prints ONE JSON line carrying the contract's fields, the roofline and
+    cpu_baseline objects, and a parity sample that matches the oracle -- here on a small workload, without the counter passes."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads-per-step", "200000", "--e2e-reads", "200000",
+           "--pcie-steps", "1", "--cpu-sample", "20000", "--alg-sample", "4000", "--no-pmc", "--genome", "400000"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "Mreads/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is None
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "reference" and c["value"] > 0 and c["cores"] >= 1 and c["gpu_matches_cpu_records"] is True
+    assert d["parity_sample"]["gpu_equals_oracle"] is True
+    assert d["pcie_inclusive"]["value"] > 0 and d["e2e"]["value"] > 0
