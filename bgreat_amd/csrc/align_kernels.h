@@ -42,16 +42,14 @@ struct BatchIO {
     uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
-    uint32_t greedy_multi;            // greedy mode: launch the eight-reads-per-wave kernel; reads it cannot finish in this launch go on ovf_list
-                                 // (with their state in g4_state, for its next pass) or on gen_list (for the general kernel)
-    uint32_t* g4_state;          // n words: where a listed read's mapping stands (strand, anchors tried, scan position)
+    uint32_t greedy_multi;       // greedy mode: launch the eight-reads-per-wave kernel; reads it does not take go on gen_list (for the general kernel)
+    uint2* queue;                // its per-wave rings of follow-up items {read, state}: q_cap entries per wave of the grid
+    uint32_t q_cap;
     uint32_t* gen_list;          // reads for the general kernel (count at cursor[gen_ctr])
     uint32_t gen_ctr;
     uint32_t anc4;               // anchors mode: launch the four-reads-per-wave kernel (what it does not settle goes on ovf_list)
     uint32_t exh4;               // exhaustive mode: launch the several-reads-per-wave kernel (what it does not settle goes on ovf_list);
                                  //   the value = levels per side of its level table (8 or 16)
-    uint32_t list_chunk;         // entries of ovf_list a wave reserves per global atomic (4..16; the unused ones become holes = BGR_NONE)
-    uint32_t g4_last;            // last pass of the eight-reads-per-wave greedy kernel: everything unfinished goes on gen_list
     uint32_t subset_ctr, ovf_ctr; // which words of `cursor` count the reads of `subset` / collect the reads put on `ovf_list`
 };
 

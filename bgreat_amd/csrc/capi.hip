@@ -71,7 +71,7 @@ struct bgr_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
-    DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, ovf3, g4st, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, lst, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
@@ -431,7 +431,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (a->twin) { bgr_aligner_destroy(a->twin); a->twin = nullptr; }
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->ovf3.release(); a->g4st.release(); a->deep.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->lst.release(); a->deep.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
         for (int i = 0; i < kTimerRing; ++i) for (int j = 0; j <= kTimerSlots; ++j) (void)hipEventDestroy(a->ev[i][j]);
         if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -598,15 +598,13 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         if (deep_only) cfg = cfg_deep;
         mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, true, cfg_mid);
     }
-    // Greedy mode, first pass: eight reads per wave (bgr_align_greedy_multi_kernel) when a read fits one lane per word and the graph
-    // has no exception planes; what it does not settle is listed and mapped by the general kernel (cfg) right behind.
+    // Greedy mode, first pass: eight reads per wave (bgr_align_greedy_multi_kernel, the reference's retry ladder inside the launch)
+    // when a read fits one lane per word and the graph has no exception planes; what it does not take (N reads, very long paths)
+    // is listed and mapped by the general kernel (cfg) right behind.
     bgr::LaunchCfg cfg_fast;
     const uint32_t wfast = std::min<uint32_t>(words, 16);  // the many-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
     bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
                            geometry(bgr::kG4ReadsPerWave * 8 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
-    bgr::LaunchCfg cfg_fast_list = cfg_fast;  // the launches over a list are compiled for 6 waves per SIMD (80 VGPRs)
-    // (a launch over a list also keeps the reads' reverse complements: twice the words per read)
-    if (fast_pass && !geometry(bgr::kG4ReadsPerWave * 16 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, false, true, cfg_fast_list, 24)) fast_pass = false;
     // Exhaustive mode, first pass: eight reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
@@ -660,24 +658,22 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.deep_stride = (uint32_t)deep_stride;
     io.level_search = level_search ? 1u : 0u;
     io.greedy_multi = 0;
-    io.g4_state = nullptr;
+    io.queue = nullptr;
+    io.q_cap = 0;
     io.gen_list = nullptr;
     io.gen_ctr = 8;
-    io.g4_last = 0;
     io.exh4 = 0;
     io.anc4 = 0;
-    io.list_chunk = 16;
     io.subset_ctr = 2;
     io.ovf_ctr = 2;
+    // the eight-reads-per-wave greedy kernel keeps a ring of follow-up items per wave: at most one entry per read of the wave's share
+    uint32_t q_cap = 0;
     if (fast_pass) {
-        // the lists between the passes are written in per-wave slices of 16 entries (bgr::kG4ListChunk): room for the holes
-        // a wave lists up to kG4ReadsPerWave reads at a time: a slice change leaves at most that many - 1 holes, and the slice behind it
-        // is then filled at once, so at least 9 of 16 allocated entries are reads; plus the unused tail of every wave's last slice
-        const uint64_t list_cap = 2 * n_reads + (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 2 * 16 + 64;
-        HIP_TRY(a->ovf.ensure(list_cap * 4));
+        const uint64_t grid_waves = (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block;
+        const uint64_t octets = (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave;
+        q_cap = (uint32_t)((octets + grid_waves - 1) / grid_waves) * bgr::kG4ReadsPerWave;
+        HIP_TRY(a->ovf.ensure(grid_waves * q_cap * 8));
         HIP_TRY(a->ovf2.ensure(n_reads * 4));
-        HIP_TRY(a->ovf3.ensure(list_cap * 4));
-        HIP_TRY(a->g4st.ensure(n_reads * 4));
     }
     if (two_pass && !deep_only) {
         HIP_TRY(a->ovf.ensure(n_reads * 4));
@@ -712,61 +708,50 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         HIP_TRY(mark("bgr_pack_reads_kernel"));
     }
     if (fast_pass) {
-        // Three launches of the eight-reads-per-wave kernel: all reads; then twice what the launch before could not finish (the
-        // next anchors of a read whose first ones failed, then its reverse complement), densely packed four to a wave again.
-        // What is left after that -- and reads the kernel does not take at all (N, very long paths) -- is mapped from scratch
-        // by the general kernel.  All enqueued back to back: with an empty list a launch's workgroups exit at once.
-        uint32_t* lists[2] = {static_cast<uint32_t*>(a->ovf.p), static_cast<uint32_t*>(a->ovf3.p)};
-        const int kFastPasses = 3;
-        for (int ps = 0; ps < kFastPasses; ++ps) {
-            bgr::BatchIO iof = io;
-            iof.greedy_multi = 1;
-            iof.words_per_read = wfast;
-            iof.g4_state = static_cast<uint32_t*>(a->g4st.p);
-            iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
-            iof.gen_ctr = 8;
-            iof.g4_last = ps == kFastPasses - 1 ? 1u : 0u;
-            // slices of 16 list entries per atomic for big batches (a single-address atomic per read caps a launch near 300 M/s),
-            // of 4 for small ones (every wave leaves the unused tail of its last slice as holes)
-            iof.list_chunk = n_reads >= (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 256 ? 16u : std::max<uint32_t>(4u, bgr::kG4ReadsPerWave);
-            iof.subset = ps ? lists[(ps - 1) & 1] : nullptr;
-            iof.subset_ctr = 2 + (uint32_t)ps - 1;
-            iof.ovf_list = lists[ps & 1];
-            iof.ovf_ctr = 2 + (uint32_t)ps;
-            e = bgr::launch_align(a->dg, iof, kp, ps ? cfg_fast_list : cfg_fast, a->stream);
-            if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (eight-reads-per-wave pass): ") + hipGetErrorString(e));
-            HIP_TRY(mark(ps == 0 ? "bgr_align_greedy_multi_kernel pass 1 (all reads)" : ps == 1 ? "bgr_align_greedy_multi_kernel pass 2 (listed reads)" : "bgr_align_greedy_multi_kernel pass 3 (listed reads)"));
-        }
+        // ONE launch of the eight-reads-per-wave kernel: every wave maps its share of the batch and then works off its own queue of
+        // follow-up items (the next anchors of a read whose first ones failed, then its reverse complement: alignerGreedy.cpp:41-56).
+        // Reads the kernel does not take (N, very long paths) are mapped from scratch by the general kernel right behind: with an
+        // empty list its workgroups exit at once.
+        bgr::BatchIO iof = io;
+        iof.greedy_multi = 1;
+        iof.words_per_read = wfast;
+        iof.queue = static_cast<uint2*>(a->ovf.p);
+        iof.q_cap = q_cap;
+        iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
+        iof.gen_ctr = 8;
+        e = bgr::launch_align(a->dg, iof, kp, cfg_fast, a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (eight-reads-per-wave kernel): ") + hipGetErrorString(e));
+        HIP_TRY(mark("bgr_align_greedy_multi_kernel (all reads, retries in the launch)"));
         io.subset = static_cast<uint32_t*>(a->ovf2.p);
         io.subset_ctr = 8;
     }
     if (a4_pass) {
-        HIP_TRY(a->g4st.ensure(n_reads * 4));
+        HIP_TRY(a->lst.ensure(n_reads * 4));
         bgr::BatchIO ioa = io;
         ioa.anc4 = a4_lanes;
         ioa.words_per_read = wfast;
         ioa.subset = nullptr;
-        ioa.ovf_list = static_cast<uint32_t*>(a->g4st.p);
+        ioa.ovf_list = static_cast<uint32_t*>(a->lst.p);
         ioa.ovf_ctr = 5;
         e = bgr::launch_align(a->dg, ioa, kp, cfg_a4, a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (anchors, four reads per wave): ") + hipGetErrorString(e));
         HIP_TRY(mark("bgr_align_anchors4_kernel (all reads)"));
-        io.subset = static_cast<uint32_t*>(a->g4st.p);
+        io.subset = static_cast<uint32_t*>(a->lst.p);
         io.subset_ctr = 5;
     }
     if (x4_pass) {
-        HIP_TRY(a->g4st.ensure(n_reads * 4));
+        HIP_TRY(a->lst.ensure(n_reads * 4));
         bgr::BatchIO iox = io;
         iox.exh4 = x4_levels;
         iox.words_per_read = wfast;
         iox.level_search = 0;
         iox.subset = nullptr;
-        iox.ovf_list = static_cast<uint32_t*>(a->g4st.p);
+        iox.ovf_list = static_cast<uint32_t*>(a->lst.p);
         iox.ovf_ctr = 5;
         e = bgr::launch_align(a->dg, iox, kp, cfg_x4, a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (exhaustive, four reads per wave): ") + hipGetErrorString(e));
         HIP_TRY(mark("bgr_align_exhaustive4_kernel (all reads)"));
-        io.subset = static_cast<uint32_t*>(a->g4st.p);
+        io.subset = static_cast<uint32_t*>(a->lst.p);
         io.subset_ctr = 5;
     }
     e = bgr::launch_align(a->dg, io, kp, cfg, a->stream);

@@ -121,42 +121,41 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 // the compare at GL = 8), so eight slot/base load chains are in flight per wave and every wave instruction of a walk step
 // serves eight reads (a quad of reads needs max-over-4 = 3.4 steps, an octet 3.7: the instructions per read nearly halve).
 // Path ints stay in registers (lane j of a group holds int j of each direction: GL ints per direction).
-// The kernel settles the common case only -- no N in the read, first anchor extends within the budget (or there is
-// no anchor at all), at most GL path ints per direction.  Every other read (N, failed first anchor: the reference then
-// tries further anchors and the reverse complement, alignerGreedy.cpp:41-56; long paths) is put on a list and mapped by
-// bgr_align_greedy_kernel right behind, so results are the reference's for every read.
+//
+// The reference's retry ladder (alignerGreedy.cpp:41-56: the next anchors of getNOverlap's list, then once the reverse
+// complement) runs INSIDE the launch (round 3; round 2 re-launched the kernel twice over lists): an ITEM is one strand of
+// one read from one scan position on.  A wave first takes its share of the batch (items = whole reads, forward strand, position
+// 0); an item whose anchors fail leaves a follow-up item -- the same strand from behind the anchor tried last, or the reverse
+// complement from its first position -- in the wave's own queue (a ring in HBM, written and read by this wave only), and once
+// the wave's share of the batch is done it works its queue off in dense octets until nothing is left.  A reverse-complement item
+// stages reverseComplements(read) (utils.cpp:66-73) as its words, so both strands run the same code.  What the kernel does not
+// take at all -- N in the read, more than GL path ints per direction, reads of a mixed batch that are too long for one lane per
+// word -- goes on a list for bgr_align_greedy_kernel, which maps those reads from scratch right behind.
 #ifndef BGR_G4_OCC
 #define BGR_G4_OCC 8
 #endif
-#ifndef BGR_G4L_OCC
-#define BGR_G4L_OCC 6 /* the launches over a list */
-#endif
 
-
-// A read the kernel cannot finish in this launch is listed with where to go on: which strand (the reference maps the
-// reverse complement once every forward anchor has failed, alignerGreedy.cpp:54), how many anchors of that strand have
-// been tried (getNOverlap hands out the first `effort` of them) and the position the scan resumes from.
+// where an item stands: which strand (the reference maps the reverse complement once every forward anchor has failed,
+// alignerGreedy.cpp:54), how many anchors of that strand have been tried (getNOverlap hands out the first `effort` of them)
+// and the position the scan resumes from
 #define G4_ST_RC (1u << 31)
 #define G4_ST_TRIED_SHIFT 20
 #define G4_ST_POS_MASK 0xFFFFFu
 
-// LIST: the launch maps the reads an earlier launch listed (io.subset) instead of all reads of the batch.
 // GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight.
-template <bool STAGE, bool LIST, int GL>
-__global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_align_greedy_multi_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+template <bool STAGE, int GL>
+__global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     constexpr uint32_t RPW = 64 / GL;  // reads per wave
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (set by the host): one lane per word of a read
     const uint32_t K1 = g.k - 1;
-    // later passes map the reads an earlier pass listed (count in cursor[subset_ctr]), from the state it left in g4_state
-    const uint32_t total = LIST ? io.cursor[io.subset_ctr] : io.n_reads;
-    if ((uint32_t)(blockIdx.x * waves) * RPW >= total) return;  // nothing for this workgroup (before it copies the cascade into LDS)
+    const uint32_t total = io.n_reads;
+    if ((uint32_t)(blockIdx.x * waves) * RPW >= total) return;  // nothing for this workgroup (before it copies the key table into LDS)
     uint32_t ktab_words;
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
-    const uint32_t RS = LIST ? 2 * W : W;  // words per read: forward words [| reverse-complement words: only a launch over a list maps that strand]
-    u64* RD = lds + 64 + ktab_words + (u64)wave * (RPW * RS);
+    u64* RD = lds + 64 + ktab_words + (u64)wave * (RPW * W);
     const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
     const uint32_t gbase_lane = (uint32_t)lane & ~(uint32_t)(GL - 1);
     const uint32_t m = prm.max_mismatch;
@@ -164,176 +163,177 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
 
     uint32_t c_noov = 0, c_al = 0, c_na = 0;  // wave-uniform counts of the reads settled here
     uint32_t chunk_pos = 0, chunk_end = 0;    // this wave's slice of the path arena
-    uint32_t lst_pos = 0, lst_end = 0;        // this wave's slice of the list for the next pass (reserved io.list_chunk entries at a
-                                              // time: one single-address atomic per listed read caps a launch near 300 M/s)
+    // this wave's queue of follow-up items {read, state}: a ring of io.q_cap entries.  While the wave takes its share of the batch
+    // it only appends (at most one entry per read of the share: q_cap); afterwards every octet taken out makes room for what it
+    // leaves behind, so the ring never overflows.
+    const uint32_t wid = (uint32_t)(blockIdx.x * waves + wave);
+    const uint32_t q_base = wid * io.q_cap;  // (the rings of all waves hold n_reads + 8 per wave entries at most: 32-bit indices)
+    uint32_t q_rd = 0, q_wr = 0, q_cnt = 0, q_all = 0;
+    const uint32_t stride = gridDim.x * waves * RPW;
+    uint32_t ibase = wid * RPW;
 
     // (per-lane flags are kept as 0/1 words in VGPRs on purpose: as `bool`s they become 64-bit lane masks in SGPRs, and this
     // kernel is short of SGPRs, not of VGPRs)
-    for (uint32_t ibase = (blockIdx.x * waves + wave) * RPW; ibase < total; ibase += gridDim.x * waves * RPW) {
-        const uint32_t it = ibase + grp;
-        uint32_t have = it < total ? 1u : 0u;
-        uint32_t r = 0, st = 0;
-        u64 off = 0;
-        uint32_t L = 0, fast = 0;
-        if (have && LIST) {
-            r = io.subset[it];
-            if (r == BGR_NONE) have = 0;  // a hole: the unused tail of some wave's chunk of the list
-            else st = io.g4_state[r];
-        } else {
-            r = it;
+    for (;;) {
+        uint32_t r = BGR_NONE, st = 0;  // r == BGR_NONE: the group has no item
+        if (ibase < total) {  // the wave's share of the batch
+            if (ibase + grp < total) r = ibase + grp;
+            ibase += stride;
+        } else {              // then its queue
+            if (q_cnt == 0) break;
+            const uint32_t take = q_cnt < RPW ? q_cnt : RPW;
+            if (grp < take) {
+                uint32_t at = q_rd + grp;
+                if (at >= io.q_cap) at -= io.q_cap;
+                // (written by this wave some iterations ago; read past the CU's vector cache all the same)
+                r = __hip_atomic_load(&io.queue[q_base + at].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st = __hip_atomic_load(&io.queue[q_base + at].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            q_rd += take;
+            if (q_rd >= io.q_cap) q_rd -= io.q_cap;
+            q_cnt -= take;
         }
-        if (have) {
-            off = io.read_offs[r];
-            L = (uint32_t)(io.read_offs[r + 1] - off);
-            fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
-            if (((L + 31) >> 5) >= W) fast = 0;                // so does a read too long for one lane per word (a batch of mixed lengths)
-        }
-        uint32_t rc = st >> 31;
-        uint32_t tried = (st >> G4_ST_TRIED_SHIFT) & 0x7FFu;
-        uint32_t s_from = st & G4_ST_POS_MASK;
-        u64* F = RD + grp * RS;
-        for (uint32_t j = sub; j < W; j += GL) {  // stage the 2-bit words: the lanes of a group bring the words of its read
-            u64 f = 0;
-            if (fast && j < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + j];
-            F[j] = f;
+        uint32_t L = 0, act = 0;  // act: the group takes part (its item is one this kernel maps)
+        u64* F = RD + grp * W;
+        {   // stage the item's 2-bit words: the lanes of a group bring the words of its read -- or of reverseComplements(read)
+            // (utils.cpp:66-73), word j of which is the reversed complement of bases [L - 32 (j + 1), L - 32 j)
+            const u64* src = io.fw3;
+            if (r != BGR_NONE) {
+                const u64 off = io.read_offs[r];
+                L = (uint32_t)(io.read_offs[r + 1] - off);
+                act = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
+                if (((L + 31) >> 5) >= W) act = 0;               // so does a read too long for one lane per word (a batch of mixed lengths)
+                src += packed_word_offset(off, r);
+            }
+            const uint32_t Wr = (L + 31) >> 5;
+            for (uint32_t j = sub; j < W; j += GL) {
+                u64 f = 0;
+                if (act && j < Wr) {
+                    if (!(st >> 31)) f = src[j];
+                    else {
+                        const int32_t p = (int32_t)L - 32 * ((int32_t)j + 1);
+                        if (p >= 0) f = ~rev2_fast(win32(src, (u64)(uint32_t)p));
+                        else { const uint32_t v = (uint32_t)(32 + p); f = (~rev2_fast(src[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                    }
+                }
+                F[j] = f;
+            }
         }
         wave_sync();
-        uint32_t act = fast;                 // the group takes part in the current round
-        uint32_t outcome = 4, nst = 0, rc_out = rc;  // what became of the read (below); 4 = general kernel
+
+        // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each item from where its scan stands and,
+        // when it lies in the same 64 positions, the one after it; record | canonical << 28
+        uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
+        for (uint32_t q = 0; q < RPW; ++q) {
+            if (!rl32(act, (int)(GL * q))) continue;
+#ifdef BGR_PHASE_TIMING
+            if (prm.debug_stop == 1) continue;  // 1 = stops behind the staging of the reads
+#endif
+            const uint32_t Lq = rl32(L, (int)(GL * q)), stq = rl32(st, (int)(GL * q));
+            const u64* A = RD + q * W;
+            const uint32_t left_q = eff - ((stq >> G4_ST_TRIED_SHIFT) & 0x7FFu);  // anchors this strand may still try (>= 1)
+            uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
+            if (!prm.effort && npos > 1) npos = 1;
+            for (uint32_t base = stq & G4_ST_POS_MASK; base < npos; base += 64) {
+                const uint32_t i = base + (uint32_t)lane;
+                const bool valid = i < npos;
+                u64 num = 0;
+                if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
+                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid);
+                const u64 mask = __ballot(idx != BGR_NONE);
+                if (mask) {
+                    if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
+                    const int s1 = __ffsll((long long)mask) - 1;
+                    const u64 mask2 = mask & (mask - 1);
+                    const uint32_t h1 = rl32(idx, s1);
+                    uint32_t h2 = BGR_NONE, p2 = 0;
+                    if (mask2 && left_q >= 2) {  // a second anchor is tried when the first fails
+                        const int s2 = __ffsll((long long)mask2) - 1;
+                        h2 = rl32(idx, s2);
+                        p2 = base + (uint32_t)s2;
+                    }
+                    if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
+                    break;
+                }
+            }
+        }
+
+        // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), the wave's items abreast; a group whose anchor fails
+        // starts over from the next one, if the scan has seen it, while the others go on ----
+        // phase: 1 left walk, 2 first right step, 3 later right steps; 0 the walk is over (aligned, or there was no anchor),
+        // 4 the path outgrew the registers, 5 every anchor seen failed.  `tried` counts on in the item's state word.
         uint32_t nl = 0, nr = 0;
         int32_t pl = 0, pr = 0;  // lane `sub` keeps path int number `sub` of the left walk (near -> far, offset last) / right walk
-        for (uint32_t round = 0;; ++round) {
-            if (__any(act && rc)) {  // reverseComplements(read) (utils.cpp:66-73) of the groups that are on their second strand
-                if (LIST && act && rc) {
-                    for (uint32_t j = sub; j < W; j += GL) {
-                        const long long p = (long long)L - 32 * ((long long)j + 1);
-                        u64 w = 0;
-                        if (p >= 0) w = ~rev2_fast(lds_win32(F, (uint32_t)p));
-                        else if (p > -32) { const uint32_t v = (uint32_t)(32 + p); w = (~rev2_fast(F[0] >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
-                        F[W + j] = w;
-                    }
-                }
-                wave_sync();
-            }
-            const u64* FW = F + ((LIST && rc) ? W : 0);  // the strand this pass maps
-
-            // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each read from where its scan stands and,
-            // when it lies in the same 64 positions, the one after it; record | canonical << 28
-            uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
-            for (uint32_t q = 0; q < RPW; ++q) {
-                if (!rl32(act, (int)(GL * q))) continue;
-#ifdef BGR_PHASE_TIMING
-                if (prm.debug_stop == 1) continue;  // 1 = stops behind the staging of the reads
-#endif
-                const uint32_t Lq = rl32(L, (int)(GL * q));
-                const u64* A = RD + q * RS + ((LIST && rl32(rc, (int)(GL * q))) ? W : 0);
-                const uint32_t left_q = eff - rl32(tried, (int)(GL * q));  // anchors this strand may still try (>= 1)
-                uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
-                if (!prm.effort && npos > 1) npos = 1;
-                for (uint32_t base = rl32(s_from, (int)(GL * q)); base < npos; base += 64) {
-                    const uint32_t i = base + (uint32_t)lane;
-                    const bool valid = i < npos;
-                    u64 num = 0;
-                    if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
-                    const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
-                    uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid);
-                    const u64 mask = __ballot(idx != BGR_NONE);
-                    if (mask) {
-                        if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
-                        const int s1 = __ffsll((long long)mask) - 1;
-                        const u64 mask2 = mask & (mask - 1);
-                        const uint32_t h1 = rl32(idx, s1);
-                        uint32_t h2 = BGR_NONE, p2 = 0;
-                        if (mask2 && left_q >= 2) {  // a second anchor is tried when the first fails
-                            const int s2 = __ffsll((long long)mask2) - 1;
-                            h2 = rl32(idx, s2);
-                            p2 = base + (uint32_t)s2;
-                        }
-                        if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
-                        break;
-                    }
-                }
-            }
-
-            // ---- extension (alignReadGreedy's loop body, alignerGreedy.cpp:41-52), the wave's reads abreast; a group whose anchor fails
-            // starts over from the next one, if the scan has seen it, while the others go on ----
-            uint32_t phase = (act && a_rec != BGR_NONE) ? 1u : 0u;
+        uint32_t phase = (act && a_rec != BGR_NONE) ? 1u : 0u;
 #ifdef BGR_PHASE_TIMING  /* diagnostic builds (tools/phase_cost.sh): knob DEBUG_STOP = 2 stops behind the anchor scan */
-            if (prm.debug_stop == 2) phase = 0;
+        if (prm.debug_stop == 2) phase = 0;
 #endif
-            uint32_t pos = a_pos, rec = a_rec & G4_REC_MASK, canon = (a_rec >> 28) & 1u, budget = m;
-            uint32_t bad = 0, failed = 0;
-            if (act) { nl = 0; nr = 0; }
-            for (;;) {
-                if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
-                    if (sub == nl) pl = 0;
+        uint32_t pos = a_pos, rec = a_rec, budget = m;  // rec: record | canonical << 28
+        for (;;) {
+            if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
+                if (sub == nl) pl = 0;
+                ++nl;
+                phase = 2; pos = a_pos; rec = a_rec;
+            }
+            if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
+            if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
+            if ((phase == 1 && nl > GL - 2) || ((phase == 2 || phase == 3) && nr > GL - 1)) phase = 4;  // path too long for the registers
+            const uint32_t on = (phase - 1u < 3u) ? phase : 0u;
+            if (!__any(on != 0)) break;
+            uint32_t miss, ext;
+            int32_t sid;
+            const uint32_t w1 = g4_step<!STAGE, GL>(g, F, L, K1, on, rec & G4_REC_MASK, (rec >> 28) & 1u, pos, budget, lane, &miss, &ext, &sid);
+            if (on != 0) {
+                if (!(w1 & G4_FOUND)) {
+                    st += 1u << G4_ST_TRIED_SHIFT;
+                    if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
+                        a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
+                        nl = 0; nr = 0; budget = m;
+                        phase = 1; pos = a_pos; rec = a_rec;
+                    } else phase = 5;
+                } else if (phase == 1) {
+                    if (sub == nl) pl = sid;
                     ++nl;
-                    phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
-                }
-                if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
-                if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
-                if ((phase == 1 && nl > GL - 2) || (phase >= 2 && nr > GL - 1)) { bad = 1; phase = 0; }  // path too long for the registers
-                if (!__any(phase != 0)) break;
-                uint32_t miss, ext;
-                int32_t sid;
-                const uint32_t w1 = g4_step<!STAGE, GL>(g, FW, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
-                if (phase != 0) {
-                    if (!(w1 & G4_FOUND)) {
-                        ++tried;
-                        if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
-                            a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
-                            nl = 0; nr = 0; budget = m;
-                            phase = 1; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
-                        } else { failed = 1; phase = 0; }
-                    } else if (phase == 1) {
-                        if (sub == nl) pl = sid;
+                    budget -= miss;
+                    if (w1 & G4_FITS) {
+                        if (sub == nl) pl = (int32_t)(ext - pos);
                         ++nl;
-                        budget -= miss;
-                        if (w1 & G4_FITS) {
-                            if (sub == nl) pl = (int32_t)(ext - pos);
-                            ++nl;
-                            phase = 2; pos = a_pos; rec = a_rec & G4_REC_MASK; canon = (a_rec >> 28) & 1u;
-                        } else { pos -= ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; }
-                    } else {
-                        if (sub == nr) pr = sid;
-                        ++nr;
-                        budget -= miss;
-                        if (w1 & G4_FITS) phase = 0;
-                        else { pos += ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; phase = 3; }
-                    }
+                        phase = 2; pos = a_pos; rec = a_rec;
+                    } else { pos -= ext; rec = w1; }
+                } else {
+                    if (sub == nr) pr = sid;
+                    ++nr;
+                    budget -= miss;
+                    if (w1 & G4_FITS) phase = 0;
+                    else { pos += ext; rec = w1; phase = 3; }
                 }
             }
-
-            // ---- what became of each read (alignerGreedy.cpp:35-57) ---------------------------------------------------------------
-            // 0 = aligned, 1 = no anchor on this strand and none tried before (++noOverlapRead), 2 = not aligned (both strands done),
-            // 3 = goes on in a later pass with `nst`, 4 = general kernel (N in the read, path too long for the registers)
-            uint32_t o_now = 4, n_now = 0;
-            {
-                const uint32_t npos_g = (L >= K1 ? L - K1 + 1 : 0);
-                const uint32_t npos_e = (!prm.effort && npos_g > 1) ? 1u : npos_g;
-                if (bad) o_now = 4;
-                else if (a_rec != BGR_NONE && !failed) o_now = 0;
-                else if (a_rec == BGR_NONE && tried == 0) o_now = 1;
-                else {
-                    // the strand's anchors are used up when `effort` of them have been tried or the scan has passed the last position
-                    const uint32_t resume = a_pos + 1;  // (a_pos = the anchor tried last; unused when the scan found none)
-                    const uint32_t used_up = (a_rec == BGR_NONE || tried >= eff || resume >= npos_e) ? 1u : 0u;
-                    if (!used_up) { o_now = 3; n_now = (rc << 31) | (tried << G4_ST_TRIED_SHIFT) | resume; }
-                    else if (!rc) { o_now = 3; n_now = G4_ST_RC; }  // the reverse complement, from its first position
-                    else o_now = 2;
-                    if (tried > 0x7FFu) o_now = 4;
-                }
-            }
-            if (act) { outcome = o_now; nst = n_now; rc_out = rc; }
-            // A launch over a LIST goes straight on to the reverse complement of the reads whose forward anchors are used up now
-            // (most of such a launch's reads: a second round is as densely packed as the first); the launch over all reads leaves
-            // them to the next one (7 % of its reads: three of four groups would sit idle).
-            const uint32_t again = (LIST && round == 0 && act && o_now == 3 && n_now == G4_ST_RC) ? 1u : 0u;
-            if (!LIST) break;
-            if (!__any(again != 0)) break;
-            act = again; rc = 1; tried = 0; s_from = 0;
         }
-        if (outcome == 3 && io.g4_last) outcome = 4;  // no further pass of this kernel: the general kernel maps the read from scratch
+
+        // ---- what became of each item (alignerGreedy.cpp:35-57) ---------------------------------------------------------------
+        // 0 = aligned, 1 = no anchor on this strand and none tried before (++noOverlapRead), 2 = not aligned (both strands done),
+        // 3 = a follow-up item `nst` goes into the wave's queue, 4 = general kernel (N in the read, path too long for the registers)
+        uint32_t outcome = 4, nst = 0;
+        const uint32_t rc = st >> 31;
+        if (act) {
+            const uint32_t tried = (st >> G4_ST_TRIED_SHIFT) & 0x7FFu;
+            const uint32_t npos_g = (L >= K1 ? L - K1 + 1 : 0);
+            const uint32_t npos_e = (!prm.effort && npos_g > 1) ? 1u : npos_g;
+            if (phase == 4) outcome = 4;
+            else if (a_rec != BGR_NONE && phase != 5) outcome = 0;
+            else if (a_rec == BGR_NONE && tried == 0) outcome = 1;
+            else {
+                // the strand's anchors are used up when `effort` of them have been tried or the scan has passed the last position
+                const uint32_t resume = a_pos + 1;  // (a_pos = the anchor tried last; unused when the scan found none)
+                const uint32_t used_up = (a_rec == BGR_NONE || tried >= eff || resume >= npos_e) ? 1u : 0u;
+                if (!used_up) { outcome = 3; nst = (st & ~G4_ST_POS_MASK) | resume; }
+                else if (!rc) { outcome = 3; nst = G4_ST_RC; }  // the reverse complement, from its first position
+                else outcome = 2;
+                if (tried >= 0x7FEu || resume > G4_ST_POS_MASK) outcome = 4;  // (an item tries at most two anchors: the count stays inside its field)
+            }
+        }
+        const uint32_t have = r != BGR_NONE ? 1u : 0u;
 
         // ---- publish: reverse(left) ++ right into the arena ----------------------------------------------------------------------
         const uint32_t aligned = outcome == 0 ? 1u : 0u;
@@ -365,36 +365,26 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
         if (!room && lane == 0 && tot) io.cursor[1] = 1;  // overflow: reported by the host as an error
         if (sub == 0 && have) {
             if (outcome <= 2) {
-                const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc_out ? BGR_ST_RC : 0u);
+                const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc ? BGR_ST_RC : 0u);
                 io.results[r] = make_uint2(aligned ? gbase : 0u, p_n | (code << 24));
-            } else if (outcome == 3) {
-                io.g4_state[r] = nst;
-            } else {
+            } else if (outcome == 4) {
                 io.gen_list[atomicAdd(io.cursor + io.gen_ctr, 1u)] = r;
             }
         }
-        {   // the reads that go on in the next pass: appended to this wave's slice of the list -- those that start their reverse
-            // complement from the slice's front, those that resume a forward scan from its back (the next pass takes
-            // consecutive entries per wave, and only the second kind needs its second round: kept apart, few quads pay for it)
+        {   // follow-up items into the wave's queue
             const bool listed = sub == 0 && have && outcome == 3;
             const u64 lm = __ballot(listed);
             if (lm) {
-                const u64 lb = __ballot(listed && nst != G4_ST_RC);
-                const uint32_t cnt = (uint32_t)__popcll(lm), cnt_b = (uint32_t)__popcll(lb);
-                if (cnt > lst_end - lst_pos) {  // what is left of the old slice becomes holes
-                    for (uint32_t j = lst_pos + (uint32_t)lane; j < lst_end; j += 64) io.ovf_list[j] = BGR_NONE;
-                    uint32_t got = 0;
-                    if (lane == 0) got = atomicAdd(io.cursor + io.ovf_ctr, io.list_chunk);
-                    lst_pos = rl32(got, 0);
-                    lst_end = lst_pos + io.list_chunk;
-                }
-                const u64 below = (1ULL << lane) - 1;
+                const uint32_t cnt = (uint32_t)__popcll(lm);
                 if (listed) {
-                    if (nst != G4_ST_RC) io.ovf_list[lst_end - 1 - (uint32_t)__popcll(lb & below)] = r;
-                    else io.ovf_list[lst_pos + (uint32_t)__popcll(lm & ~lb & below)] = r;
+                    uint32_t at = q_wr + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));  // listed lanes below this one
+                    if (at >= io.q_cap) at -= io.q_cap;
+                    io.queue[q_base + at] = make_uint2(r, nst);
                 }
-                lst_pos += cnt - cnt_b;
-                lst_end -= cnt_b;
+                q_wr += cnt;
+                if (q_wr >= io.q_cap) q_wr -= io.q_cap;
+                q_cnt += cnt;
+                q_all += cnt;
             }
         }
         c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
@@ -402,7 +392,7 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
         c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
         wave_sync();
     }
-    for (uint32_t j = lst_pos + (uint32_t)lane; j < lst_end; j += 64) io.ovf_list[j] = BGR_NONE;
+    if (lane == 0 && q_all) atomicAdd(io.cursor + 2, q_all);  // follow-up items of the launch (bgr_aligner_pass_counts)
     if (lane == 0 && (c_al | c_noov | c_na)) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
         atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov + c_na));
@@ -416,15 +406,13 @@ __global__ void __launch_bounds__(1024, LIST ? BGR_G4L_OCC : BGR_G4_OCC) bgr_ali
 
 hipError_t launch_greedy(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     constexpr int GL = (int)kG4GroupLanes;
-    if (io.greedy_multi && io.subset) return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, true, GL>, g, io, p, cfg, stream)
-                                                       : launch_one(bgr_align_greedy_multi_kernel<false, true, GL>, g, io, p, cfg, stream);
-    if (io.greedy_multi) return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, false, GL>, g, io, p, cfg, stream)
-                                          : launch_one(bgr_align_greedy_multi_kernel<false, false, GL>, g, io, p, cfg, stream);
+    if (io.greedy_multi) return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, GL>, g, io, p, cfg, stream)
+                                               : launch_one(bgr_align_greedy_multi_kernel<false, GL>, g, io, p, cfg, stream);
     return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
                           : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
 }
 const void* greedy_kernel_fn(bool many_reads) {
-    return many_reads ? reinterpret_cast<const void*>(&bgr_align_greedy_multi_kernel<true, false, (int)kG4GroupLanes>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
+    return many_reads ? reinterpret_cast<const void*>(&bgr_align_greedy_multi_kernel<true, (int)kG4GroupLanes>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
 }
 
 }  // namespace bgr

@@ -85,6 +85,47 @@ __global__ void __launch_bounds__(256) k(uint64_t* out, uint32_t seed) {
         if (OP == 27) BODY32("v_max_u32");
         if (OP == 28) BODY32("v_subrev_u32");
         if (OP == 29) BODY32("v_ashrrev_i32");
+        // round 3: the rest of the opcodes the mapping kernels' dynamic mix contains (tools/bbcount.py prices with these)
+        if (OP == 40) asm volatile(R4("v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %8, %9, %1\n v_mad_u64_u32 %2, s[20:21], %8, %9, %2\n v_mad_u64_u32 %3, s[20:21], %8, %9, %3\n"
+                                     "v_mad_u64_u32 %4, s[20:21], %8, %9, %4\n v_mad_u64_u32 %5, s[20:21], %8, %9, %5\n v_mad_u64_u32 %6, s[20:21], %8, %9, %6\n v_mad_u64_u32 %7, s[20:21], %8, %9, %7\n")
+                                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(s), "v"(b[0]) : "s20", "s21");
+        if (OP == 41) asm volatile(R4("v_bitop3_b32 %0, %0, %8, %0 bitop3:0x48\n v_bitop3_b32 %1, %1, %8, %1 bitop3:0x48\n v_bitop3_b32 %2, %2, %8, %2 bitop3:0x48\n v_bitop3_b32 %3, %3, %8, %3 bitop3:0x48\n"
+                                     "v_bitop3_b32 %4, %4, %8, %4 bitop3:0x48\n v_bitop3_b32 %5, %5, %8, %5 bitop3:0x48\n v_bitop3_b32 %6, %6, %8, %6 bitop3:0x48\n v_bitop3_b32 %7, %7, %8, %7 bitop3:0x48\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(s));
+        if (OP == 42) BODY32_3("v_lshl_add_u32");
+        if (OP == 43) BODY32_3("v_perm_b32");
+        if (OP == 44) BODY32_1("v_ffbl_b32");
+        if (OP == 45) asm volatile(R4("v_cmp_lt_u64 vcc, %0, %1\n v_cmp_lt_u64 vcc, %1, %2\n v_cmp_lt_u64 vcc, %2, %3\n v_cmp_lt_u64 vcc, %3, %4\n"
+                                     "v_cmp_lt_u64 vcc, %4, %5\n v_cmp_lt_u64 vcc, %5, %6\n v_cmp_lt_u64 vcc, %6, %7\n v_cmp_lt_u64 vcc, %7, %0\n")
+                                  : : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "vcc");
+        if (OP == 46) asm volatile(R4("v_lshl_add_u64 %0, %0, 3, %1\n v_lshl_add_u64 %1, %1, 3, %2\n v_lshl_add_u64 %2, %2, 3, %3\n v_lshl_add_u64 %3, %3, 3, %4\n"
+                                     "v_lshl_add_u64 %4, %4, 3, %5\n v_lshl_add_u64 %5, %5, 3, %6\n v_lshl_add_u64 %6, %6, 3, %7\n v_lshl_add_u64 %7, %7, 3, %0\n")
+                                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+        if (OP == 47) asm volatile(R4("v_mov_b64 %0, %1\n v_mov_b64 %1, %2\n v_mov_b64 %2, %3\n v_mov_b64 %3, %4\n v_mov_b64 %4, %5\n v_mov_b64 %5, %6\n v_mov_b64 %6, %7\n v_mov_b64 %7, %0\n")
+                                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+        if (OP == 48) asm volatile(R4("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                                     "v_mov_b32_dpp %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n"
+                                     "v_mov_b32_dpp %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                                     "v_mov_b32_dpp %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+        if (OP == 49) asm volatile(R4("v_cndmask_b32 %0, %8, %0, vcc\n v_cndmask_b32 %1, %8, %1, vcc\n v_cndmask_b32 %2, %8, %2, vcc\n v_cndmask_b32 %3, %8, %3, vcc\n"
+                                     "v_cndmask_b32 %4, %8, %4, vcc\n v_cndmask_b32 %5, %8, %5, vcc\n v_cndmask_b32 %6, %8, %6, vcc\n v_cndmask_b32 %7, %8, %7, vcc\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(s) : "vcc");
+        if (OP == 50) asm volatile(R4("v_readfirstlane_b32 s20, %0\n v_readfirstlane_b32 s21, %1\n v_readfirstlane_b32 s22, %2\n v_readfirstlane_b32 s23, %3\n"
+                                     "v_readfirstlane_b32 s24, %4\n v_readfirstlane_b32 s25, %5\n v_readfirstlane_b32 s26, %6\n v_readfirstlane_b32 s27, %7\n")
+                                  : : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        if (OP == 51) asm volatile(R4("v_writelane_b32 %0, s28, 3\n v_writelane_b32 %1, s28, 5\n v_writelane_b32 %2, s28, 7\n v_writelane_b32 %3, s28, 9\n"
+                                     "v_writelane_b32 %4, s28, 11\n v_writelane_b32 %5, s28, 13\n v_writelane_b32 %6, s28, 15\n v_writelane_b32 %7, s28, 17\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : : "s28");
+        if (OP == 52) BODY32("v_add_co_u32_e32");   // (vcc implicit)
+        if (OP == 53) asm volatile(R4("v_max_u32_sdwa %0, %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n v_max_u32_sdwa %1, %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+                                     "v_max_u32_sdwa %2, %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n v_max_u32_sdwa %3, %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+                                     "v_max_u32_sdwa %4, %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n v_max_u32_sdwa %5, %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+                                     "v_max_u32_sdwa %6, %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n v_max_u32_sdwa %7, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n")
+                                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(s));
+        if (OP == 54) BODY32("v_and_b32_e64");      // a plain op in its 64-bit (VOP3) encoding
+        if (OP == 55) BODY32_3("v_bfi_b32");
+        if (OP == 56) BODY32("v_sub_u32_e64");
     }
     uint64_t x = 0;
     for (int i = 0; i < 8; ++i) x ^= a[i] ^ b[i];
@@ -147,5 +188,22 @@ int main() {
     run<12>("v_add_u32_dpp", d);
     run<13>("v_readlane_b32", d);
     run<17>("SALU mix", d);
+    run<40>("v_mad_u64_u32", d);
+    run<41>("v_bitop3_b32", d);
+    run<42>("v_lshl_add_u32", d);
+    run<43>("v_perm_b32", d);
+    run<44>("v_ffbl_b32", d);
+    run<45>("v_cmp_lt_u64", d);
+    run<46>("v_lshl_add_u64", d);
+    run<47>("v_mov_b64", d);
+    run<48>("v_mov_b32_dpp", d);
+    run<49>("v_cndmask e32 vcc", d);
+    run<50>("v_readfirstlane", d);
+    run<51>("v_writelane_b32", d);
+    run<52>("v_add_co_u32", d);
+    run<53>("v_max_u32_sdwa", d);
+    run<54>("v_and_b32_e64", d);
+    run<55>("v_bfi_b32", d);
+    run<56>("v_sub_u32_e64", d);
     return 0;
 }
