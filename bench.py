@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--site-spacing", type=int, default=140)
     ap.add_argument("--alleles", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the host CPU (0 disables)")
+    ap.add_argument("--cpu-sample-t1", type=int, default=100_000, help="reads of the `-t 1` leg of the CPU baseline")
     ap.add_argument("--alg-sample", type=int, default=20_000, help="reads used to count ALGORITHMIC bytes/read with the oracle")
     ap.add_argument("--lds-mphf", type=int, default=0, help="0 auto, 1 HBM/L2 only, 2 force LDS staging")
     ap.add_argument("--waves", type=int, default=0)
@@ -93,9 +94,17 @@ def parse_args():
 
 
 # ---- HBM traffic and instruction counters of one step, measured in this run ------------------------------------------------
-PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
+# (FETCH_SIZE takes 3 of the 4 TCC slots of a pass and WRITE_SIZE 2: separate passes, as MI355X_MICROARCH.md prescribes; SQ: 8 slots)
+PMC_PASSES = (("fetch", ["FETCH_SIZE", "TCC_REQ_sum", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"]),
               ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]),
-              ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"]))
+              ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"]))
+PROFILER_ENV = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARY")
+
+
+def under_profiler():
+    """True when this process already runs under rocprofv3 (its tool library is preloaded): nested counter passes would
+    inherit that environment and the inner rocprofv3 launcher would exec with the GPU initialised (forbidden on this pool)."""
+    return any("rocprof" in os.environ.get(v, "").lower() for v in PROFILER_ENV) or bool(os.environ.get("ROCPROF_OUTPUT_PATH"))
 
 
 def run_pmc_passes(args):
@@ -119,7 +128,9 @@ def run_pmc_passes(args):
         d = tempfile.mkdtemp(prefix="bgr_pmc_%s_" % tag, dir="/tmp")
         try:
             cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + fwd
-            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            env = {k: v for k, v in os.environ.items() if k not in PROFILER_ENV and not k.startswith("ROCPROF")}
+            env["TMPDIR"] = "/tmp"
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return {"error": "rocprofv3 pass '%s' failed (rc %d): %s" % (tag, p.returncode, (p.stderr or "")[-300:])}
@@ -153,7 +164,8 @@ def main():
 
     pmc = None
     if not args.pmc_child and not args.no_pmc and world == 1:
-        pmc = run_pmc_passes(args)   # child processes; this process has not initialised the GPU yet
+        # child processes; this process has not initialised the GPU yet.  Never nested inside another profiler run.
+        pmc = {"error": "already running under a profiler: counter passes skipped"} if under_profiler() else run_pmc_passes(args)
         log("pmc passes:", {k: v for k, v in pmc.items() if not k.startswith("_per")} if pmc else None)
 
     import torch
@@ -288,53 +300,94 @@ def main():
     # parity of the same sample through the GPU path (outside the timed region)
     p1, po1, st1 = al.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
     parity_ok = bool(np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2))
-    achieved = alg_bytes_per_read * R / (avg_launch_ms / 1e3) / 1e9
     kernels_ms = [{"kernel": nm, "avg_ms": round(ms / max(1, launches), 4)} for nm, ms in slots]
-    dominant = max(slots, key=lambda x: x[1])[0] if slots else None
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
-                "definition": "achieved = ALGORITHMIC bytes of the REFERENCE's control flow (SURVEY 8d: gamma-10 BooPHF probes, rank words, 24-B records, "
-                              "compared bases, path ints; oracle counter mode) x reads per launch / launch time.  This implementation moves far fewer "
-                              "bytes (its own key table is probed in LDS, or in L2 for large graphs): `traffic` is what HBM saw, `limiter` what bounds the launch",
-                "launch": "pre-pass + mapping passes of one batch, enqueued back to back on one stream (HIP events around the sequence)",
-                "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "kernels_ms": kernels_ms, "dominant_kernel": dominant,
-                "alg_bytes_per_read": round(alg_bytes_per_read, 1), "reads_per_launch": R}
+    dominant, dom_total_ms = max(slots, key=lambda x: x[1]) if slots else (None, 0.0)
+    dom_ms = dom_total_ms / max(1, launches)            # the dominant kernel's average duration (HIP events on the aligner's stream)
+    dom_short = dominant.split(" ")[0] if dominant else None
+    # ---- this implementation's OWN compulsory HBM bytes per read: what one launch must move through HBM if every
+    # re-used structure (key table, records, unitig bases: the graph blob) is read from HBM once per launch -- counted from the
+    # launch's own numbers: read lengths, path ints written (paths of this run), follow-up items queued (pass_counts)
+    blob_bytes = float(graph_info["blob_bytes"])
+    path_ints = float(len(p1)) / ns                     # per read, from the parity sample's paths
+    items = float(pass_counts[0]) / R if mode == 0 else 0.0
+    words = (L + 31) // 32
+    own = {
+        "bgr_pack_reads_kernel": {"ascii_in": L, "offsets_in": 8, "planes_out": 8 * words, "hasn_out": 0.125},
+        "mapping": {"planes_in": 8 * words * (1.0 + items), "offsets_in": 8 * (1.0 + items), "hasn_in": 0.125, "results_out": 8, "path_ints_out": 4 * path_ints,
+                    "retry_queue_rw": 16 * items, "graph_blob_once_per_launch": blob_bytes / R},
+    }
+    own_pack = sum(own["bgr_pack_reads_kernel"].values())
+    own_map = sum(own["mapping"].values())
+    dom_own = own_pack if (dom_short or "").startswith("bgr_pack") else own_map
+    hbm = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+           "compulsory_bytes_per_read": {"bgr_pack_reads_kernel": round(own_pack, 1), "mapping_kernels": round(own_map, 1), "split_mapping": {k: round(v, 2) for k, v in own["mapping"].items()}},
+           "achieved": round(dom_own * R / (dom_ms / 1e3) / 1e9, 2), "frac": round(dom_own * R / (dom_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+           "whole_launch": {"bytes_per_read": round(own_pack + own_map, 1), "achieved": round((own_pack + own_map) * R / (avg_launch_ms / 1e3) / 1e9, 2),
+                            "frac": round((own_pack + own_map) * R / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)},
+           "definition": "this implementation's compulsory HBM bytes per read of the dominant kernel (planes, offsets, results, path ints, retry queue, the graph blob once per launch) "
+                         "x reads per launch / that kernel's mean duration; `traffic` next to it is what the memory side saw (rocprofv3 PMC)"}
+    roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
+                "dominant_kernel": dominant, "dominant_kernel_ms": round(dom_ms, 4), "hbm": hbm,
+                "launch": "pre-pass + mapping kernels of one batch, enqueued back to back on one stream (HIP events around every kernel, on the aligner's stream)",
+                "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "kernels_ms": kernels_ms, "reads_per_launch": R,
+                # SURVEY 8d's figure describes the REFERENCE's control flow (gamma-10 BooPHF probes, rank words, 24-B records): kept for the
+                # record under its own keys, never as a fraction of this implementation's roofline
+                "reference_alg_bytes_per_read": round(alg_bytes_per_read, 1),
+                "reference_alg_gbps": round(alg_bytes_per_read * R / (avg_launch_ms / 1e3) / 1e9, 1),
+                "reference_alg_note": "SURVEY 8d formula counted by the oracle on %d reads of this workload: bytes the REFERENCE's algorithm would move uncached; this "
+                                      "implementation does not perform those probes (its key table is two LDS dwords per position), so this is NOT a fraction of any peak" % ns}
     if pmc and "error" not in pmc:
+        pk = pmc.get("_per_kernel", {})
+        dom_key = next((k for k in pk if dom_short and k.split("<")[0] == dom_short), None)  # (PMC rows carry the template arguments)
+        dom_pmc = pk.get(dom_key, {}) if dom_key else {}
         fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
         if fetch_kb is not None and write_kb is not None:
             raw = (fetch_kb + write_kb) * 1024.0
             corrected = (2.0 * fetch_kb + write_kb) * 1024.0  # gfx950: FETCH_SIZE tallies 128-B requests of wide reads at 64 B (upper bound for small gathers)
             roofline["traffic"] = round(corrected, 1)
             roofline["traffic_raw"] = round(raw, 1)
-            roofline["traffic_note"] = ("HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc in separate passes over a %d-launch child run of "
-                                        "this script in this run; raw = without the gfx950 x2 on FETCH_SIZE" % args.pmc_steps)
+            roofline["traffic_note"] = ("HBM-side bytes per launch (all kernels) = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc in separate passes over a %d-launch child run of "
+                                        "this script in this run; raw = without the gfx950 x2 on FETCH_SIZE (the x2 is exact for wide streaming reads, an upper bound for gathers)" % args.pmc_steps)
             roofline["traffic_frac"] = round(corrected / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
             roofline["traffic_bytes_per_read"] = round(corrected / R, 1)
+            roofline["traffic_over_compulsory"] = round(corrected / ((own_pack + own_map) * R), 3)
+            if dom_pmc.get("FETCH_SIZE") is not None and dom_pmc.get("WRITE_SIZE") is not None:
+                dt = (2.0 * dom_pmc["FETCH_SIZE"] + dom_pmc["WRITE_SIZE"]) * 1024.0
+                hbm["dominant_kernel_traffic"] = round(dt, 1)
+                hbm["dominant_kernel_traffic_frac"] = round(dt / (dom_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
         if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
             roofline["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
-        if pmc.get("SQ_INSTS_VALU") is not None:
-            simd_cycles = N_SIMD * (avg_launch_ms / 1e3) * CLOCK_GHZ * 1e9
-            roofline["valu_insts_per_read"] = round(pmc["SQ_INSTS_VALU"] / R, 1)
-            roofline["salu_insts_per_read"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / R, 1)
-            # profiles/r02_valu_rates.txt (tools/ubench/valu_rates.hip): a wave64 vector instruction occupies its SIMD for ~2.2 cycles
-            # (plain VOP1/VOP2 add/sub/and/or/xor/mov/not/right shifts, >= 2 waves on the SIMD) or ~4.1 cycles (everything else:
-            # left shifts, min/max, compares, cndmask, bfe, mul, 3-operand and 64-bit forms, DPP, readlane).  SQ_ACTIVE_INST_VALU
-            # counts 1 per instruction like SQ_INSTS_VALU (profiles/r02_valu_pmc_calibration.txt), so the counters give the
-            # instruction count only and the busy fraction is bracketed by the two prices; the static mix of the dominant kernel
-            # (tools/isa_mix.py, profiles/r02_isa_mix.txt) prices an instruction at ~3.3 cycles
-            roofline["valu_issue_frac_bounds"] = {"at_2.2_cycles": round(pmc["SQ_INSTS_VALU"] * 2.2 / simd_cycles, 4),
-                                                  "at_3.3_cycles_static_mix": round(pmc["SQ_INSTS_VALU"] * 3.3 / simd_cycles, 4),
-                                                  "at_4.1_cycles": round(pmc["SQ_INSTS_VALU"] * 4.1 / simd_cycles, 4)}
-            # what bounds the launch: the larger of the vector-issue fraction (at the static mix's price) and the HBM-side fraction
-            tf = roofline.get("traffic_frac")
-            vf = roofline["valu_issue_frac_bounds"]["at_3.3_cycles_static_mix"]
-            roofline["limiter"] = "valu_issue" if tf is None or vf >= tf else "memory (L2 fill / HBM traffic)"
-            roofline["salu_issue_frac"] = round(pmc.get("SQ_INSTS_SALU", 0.0) / (N_SIMD / 4 * (avg_launch_ms / 1e3) * CLOCK_GHZ * 1e9), 4)  # one scalar unit per CU
-            roofline["issue_note"] = ("instructions per launch from rocprofv3 SQ counters (same child runs); VALU busy fraction = SQ_INSTS_VALU x cycles per "
-                                      "instruction / (1024 SIMDs x launch time x %.1f GHz), bracketed by the two measured issue prices; SALU = SQ_INSTS_SALU / "
-                                      "(256 CUs x cycles): one scalar instruction per cycle and CU" % CLOCK_GHZ)
+        if pmc.get("TCC_REQ_sum") is not None:
+            roofline["l2_requests_per_read"] = round(pmc["TCC_REQ_sum"] / R, 2)
+        if dom_pmc.get("SQ_ACTIVE_INST_VALU") is not None and dom_pmc.get("SQ_ACTIVE_INST_VALU2") is not None:
+            # MEASURED vector-issue occupancy of the dominant kernel.  gfx950 issues one vector instruction per SIMD and 4-cycle slot, or TWO
+            # (from two waves) when both are of the plain VOP1/VOP2 class (add/sub/and/or/xor/mov/not/right shifts: the "2-cycle"
+            # class of profiles/r02_valu_rates.txt); SQ_ACTIVE_INST_VALU counts every instruction, SQ_ACTIVE_INST_VALU2 the ones that
+            # went out as the second of a pair, so (A - A2) is the number of BUSY issue slots -- calibrated on 50 single-opcode
+            # streams, profiles/r03_valu2_pmc_calibration.txt: 4 x (1 - A2/A) reproduces every stream's measured cycles per instruction.
+            busy_slots = dom_pmc["SQ_ACTIVE_INST_VALU"] - dom_pmc["SQ_ACTIVE_INST_VALU2"]        # per launch, summed over all SIMDs
+            busy_cycles_per_s = 4.0 * busy_slots / (dom_ms / 1e3)
+            peak_cycles_per_s = N_SIMD * CLOCK_GHZ * 1e9
+            valu = {"bound": "valu_issue", "unit": "G SIMD-cycles/s", "achieved": round(busy_cycles_per_s / 1e9, 2), "peak": round(peak_cycles_per_s / 1e9, 2),
+                    "frac": round(busy_cycles_per_s / peak_cycles_per_s, 4),
+                    "valu_insts_per_read": round(dom_pmc.get("SQ_INSTS_VALU", 0.0) / R, 1), "paired_share": round(dom_pmc["SQ_ACTIVE_INST_VALU2"] / max(1.0, dom_pmc["SQ_ACTIVE_INST_VALU"]), 4),
+                    "cycles_per_valu_inst": round(4.0 * busy_slots / max(1.0, dom_pmc["SQ_ACTIVE_INST_VALU"]), 3),
+                    "salu_insts_per_read": round(dom_pmc.get("SQ_INSTS_SALU", 0.0) / R, 1),
+                    "salu_issue_frac": round(dom_pmc.get("SQ_INSTS_SALU", 0.0) / (N_SIMD / 4 * (dom_ms / 1e3) * CLOCK_GHZ * 1e9), 4),
+                    "definition": "busy vector issue slots of the dominant kernel = SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 per launch (rocprofv3 PMC, child run of this "
+                                  "script), x 4 cycles / (the kernel's mean duration in the timed region) against %d SIMDs x %.1f GHz" % (N_SIMD, CLOCK_GHZ)}
+            if dom_pmc.get("SQ_BUSY_CU_CYCLES"):
+                cu_cyc = dom_pmc["SQ_BUSY_CU_CYCLES"]
+                valu["frac_of_cu_busy_cycles"] = round(busy_slots / cu_cyc, 4)   # (4 x slots) / (4 SIMDs x CU-busy cycles): needs no clock and no timer
+            roofline["valu_issue"] = valu
+            # what bounds the dominant kernel: the larger of the measured vector-issue fraction and the HBM-side fraction
+            hf = max(hbm["frac"], hbm.get("dominant_kernel_traffic_frac") or 0.0)
+            if valu["frac"] >= hf:
+                roofline.update({"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]})
+            roofline["bound_note"] = ("`bound` names the larger of the dominant kernel's measured vector-issue fraction (roofline.valu_issue) and its HBM fraction "
+                                      "(roofline.hbm: compulsory bytes, and measured traffic); integer hash + byte compare: no MFMA on this path")
         roofline["pmc_seconds"] = pmc.get("_seconds")
-        roofline["pmc_per_kernel"] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in pmc.get("_per_kernel", {}).items()}
+        roofline["pmc_per_kernel"] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in pk.items()}
     elif pmc:
         roofline["traffic_note"] = "not measured in this run: " + pmc["error"]
 
@@ -506,35 +559,59 @@ def run_pcie(args, B, g, al, syn, seed_reads, ncpu, dev):
         return {"error": "%s: %s" % (type(ex).__name__, ex)}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
+    """The compiled reference (oracle/_ref/bgreat) on a bounded sample of the workload, on this box's host cores: `-t cores` on
+    `cpu_sample` reads and `-t 1` on a tenth of them; the mapping time is the program's wall time minus an index-only run (same
+    thread count, empty read file), and the reference's own `Reads/seconds` stdout line (aligner.cpp:595) is kept beside it."""
     R, L = args.reads_per_step, args.read_len
     nc = min(args.cpu_sample, R)
+    n1 = max(1, min(nc, args.cpu_sample_t1))
     ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
     d = tempfile.mkdtemp(prefix="bgr_cpu_")
     try:
         syn.write_unitigs(os.path.join(d, "u.fa"))
         syn.write_reads(os.path.join(d, "r.fa"), 0, nc, L, args.mismatch, seed_reads)
+        with open(os.path.join(d, "r.fa"), "rb") as f, open(os.path.join(d, "r1.fa"), "wb") as o:   # the first n1 records (2 lines each)
+            for _ in range(2 * n1):
+                o.write(f.readline())
+        open(os.path.join(d, "empty.fa"), "w").close()
         cores = min(ncpu, 255)
         if os.path.exists(ref):
-            cmd, kind = [ref], "reference"
+            exe, kind = ref, "reference"
         else:
-            cmd, kind = [os.path.join(ROOT, "oracle", "bgreat_oracle")], "port"
-        cmd += ["-r", os.path.join(d, "r.fa"), "-k", str(args.k), "-g", os.path.join(d, "u.fa"), "-m", str(args.mismatch), "-e", str(args.effort), "-t", str(cores)]
-        t1 = time.perf_counter()
-        subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL)
-        wall = time.perf_counter() - t1
-        # index-only run (empty read file) to subtract the one-off indexing from the mapping time
-        open(os.path.join(d, "empty.fa"), "w").close()
-        cmd_i = list(cmd)
-        cmd_i[cmd_i.index("-r") + 1] = os.path.join(d, "empty.fa")
-        d2 = os.path.join(d, "idx")
-        os.makedirs(d2)
-        t1 = time.perf_counter()
-        subprocess.run(cmd_i, cwd=d2, check=True, stdout=subprocess.DEVNULL)
-        wall_idx = time.perf_counter() - t1
+            exe, kind = os.path.join(ROOT, "oracle", "bgreat_oracle"), "port"
+
+        def timed(reads_file, threads, sub):
+            wd = os.path.join(d, sub)
+            os.makedirs(wd)
+            cmd = [exe, "-r", os.path.join(d, reads_file), "-k", str(args.k), "-g", os.path.join(d, "u.fa"), "-m", str(args.mismatch), "-e", str(args.effort), "-t", str(threads)]
+            t1 = time.perf_counter()
+            out = subprocess.run(cmd, cwd=wd, check=True, stdout=subprocess.PIPE, text=True).stdout
+            wall = time.perf_counter() - t1
+            own = None
+            for line in out.splitlines():  # "Reads/seconds : N" = reads / (whole mapping seconds + 1), integer arithmetic (aligner.cpp:595)
+                if line.startswith("Reads/seconds"):
+                    own = line.split(":")[-1].strip()
+            return wall, own, wd
+
+        wall, own_line, wd = timed("r.fa", cores, "tN")
+        wall_idx, _, _ = timed("empty.fa", cores, "iN")
+        wall1, own_line1, _ = timed("r1.fa", 1, "t1")
+        wall_idx1, _, _ = timed("empty.fa", 1, "i1")
         map_s = max(1e-6, wall - wall_idx)
+        map_s1 = max(1e-6, wall1 - wall_idx1)
         # parity at scale: GPU records == reference records as a multiset (-t N interleaves records, SURVEY fact 0.6)
-        ref_paths = open(os.path.join(d, "paths"), "rb").read().split(b"\n")
+        ref_paths = open(os.path.join(wd, "paths"), "rb").read().split(b"\n")
         c_reads = first_host[: nc * L]
         c_offs = np.arange(nc + 1, dtype=np.uint64) * np.uint64(L)
         gp, gpo, gst = al.align(c_reads, c_offs, m=args.mismatch, effort=args.effort)
@@ -551,8 +628,12 @@ def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
                 if want != got:
                     ok = False
                     break
-        return {"value": round(nc / map_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind,
-                "sample": "first %d reads of step 0 of this workload, %s -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(cmd[0]), cores, wall, wall_idx),
+        return {"value": round(nc / map_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "host_cores_visible": len(os.sched_getaffinity(0)),
+                "sample": "first %d reads of step 0 of this workload, %s -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(exe), cores, wall, wall_idx),
+                "reference_stdout_reads_per_second": own_line,
+                "t1": {"value": round(n1 / map_s1 / 1e6, 4), "unit": "Mreads/s", "cores": 1,
+                       "sample": "first %d reads, %s -t 1, wall %.2fs minus %.2fs index-only run" % (n1, os.path.basename(exe), wall1, wall_idx1),
+                       "reference_stdout_reads_per_second": own_line1},
                 "gpu_matches_cpu_records": bool(ok)}
     except Exception as ex:
         return {"error": "%s: %s" % (type(ex).__name__, ex)}

@@ -17,6 +17,7 @@
 
 #include "../../include/bgreat_gpu.h"
 #include "align_kernels.h"
+#include "fanout.h"
 #include "fastx.h"
 #include "anchor_index.h"
 #include "graph_build.h"
@@ -297,32 +298,33 @@ bool fanout_rccl(const std::vector<int>& devs, const std::vector<void*>& ptr, ui
     return ok;
 }
 
-int fanout_peer(const std::vector<int>& devs, const std::vector<void*>& ptr, uint64_t bytes) {
-    const size_t n = devs.size();
-    for (size_t have = 1; have < n; have *= 2) {  // holders 0..have-1 each feed device i + have
-        std::vector<hipStream_t> streams;
-        std::vector<int> sdev;
-        for (size_t i = 0; i < have && i + have < n; ++i) {
-            const int src = devs[i], dst = devs[i + have];
-            HIP_TRY(hipSetDevice(src));
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, src, dst) == hipSuccess && can) {
-                hipError_t pe = hipDeviceEnablePeerAccess(dst, 0);  // direct xGMI path; without it the runtime stages through the host
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-            }
-            hipStream_t st = nullptr;
-            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            streams.push_back(st);
-            sdev.push_back(src);
-            HIP_TRY(hipMemcpyPeerAsync(ptr[i + have], dst, ptr[i], src, bytes, st));
+// one round of the doubling schedule: concurrent peer copies over disjoint links, complete on return
+bool peer_round(const std::vector<bgr::FanoutCopy>& round, uint64_t bytes, std::string& why) {
+    std::vector<hipStream_t> streams;
+    std::vector<int> sdev;
+    bool ok = true;
+    for (const bgr::FanoutCopy& c : round) {
+        if (hipSetDevice(c.src_dev) != hipSuccess) { ok = false; why = "hipSetDevice failed"; break; }
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, c.src_dev, c.dst_dev) == hipSuccess && can) {
+            hipError_t pe = hipDeviceEnablePeerAccess(c.dst_dev, 0);  // direct xGMI path; without it the runtime stages through the host
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
         }
-        for (size_t j = 0; j < streams.size(); ++j) {
-            HIP_TRY(hipSetDevice(sdev[j]));
-            HIP_TRY(hipStreamSynchronize(streams[j]));
-            HIP_TRY(hipStreamDestroy(streams[j]));
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { ok = false; why = "hipStreamCreate failed"; break; }
+        streams.push_back(st);
+        sdev.push_back(c.src_dev);
+        hipError_t e = hipMemcpyPeerAsync(c.dst, c.dst_dev, c.src, c.src_dev, bytes, st);
+        if (e != hipSuccess) { ok = false; why = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); break; }
+    }
+    for (size_t j = 0; j < streams.size(); ++j) {  // (also after a failure: nothing may still be writing when the buffers are released)
+        if (hipSetDevice(sdev[j]) == hipSuccess) {
+            hipError_t e = hipStreamSynchronize(streams[j]);
+            if (e != hipSuccess && ok) { ok = false; why = std::string("peer copy: ") + hipGetErrorString(e); }
+            (void)hipStreamDestroy(streams[j]);
         }
     }
-    return BGR_OK;
+    return ok;
 }
 
 }  // namespace
@@ -336,34 +338,22 @@ int bgr_devices_init(bgr_graph* g, int first_device, uint32_t n_devices, uint32_
     if (first_device < 0 || (uint64_t)first_device + n_devices > (uint64_t)nd) return fail(BGR_E_ARG, "bgr_devices_init: device range outside the visible devices");
     int rc = bgr_graph_upload(g, first_device);  // host -> first device (idempotent)
     if (rc != BGR_OK) return rc;
-    std::vector<int> devs(1, first_device);
-    std::vector<void*> ptr(1, g->dev[first_device].ptr);
-    for (uint32_t i = 1; i < n_devices; ++i) {
-        const int d = first_device + (int)i;
-        if (g->dev.count(d)) continue;  // already resident there
-        HIP_TRY(hipSetDevice(d));
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, g->header.blob_bytes));
-        g->dev[d] = {p, true};
-        devs.push_back(d);
-        ptr.push_back(p);
-    }
+    const uint64_t bytes = g->header.blob_bytes;
+    bgr::FanoutOps ops;
+    ops.alloc = [bytes](int dev, void** out) { return hipSetDevice(dev) == hipSuccess && hipMalloc(out, bytes) == hipSuccess; };
+    ops.release = [](int dev, void* p) { if (p && hipSetDevice(dev) == hipSuccess) (void)hipFree(p); };
+    ops.broadcast = [bytes](const std::vector<int>& devs, const std::vector<void*>& ptr, std::string& why) { return fanout_rccl(devs, ptr, bytes, why); };
+    ops.peer_round = [bytes](const std::vector<bgr::FanoutCopy>& round, std::string& why) { return peer_round(round, bytes, why); };
+    // (bookkeeping in fanout.h: new buffers are registered only once they hold the blob; after a failure they are released and
+    // g->dev is unchanged, so bgr_graph_upload / bgr_aligner_create can still bring the blob to a device on their own)
+    std::map<int, void*> resident;
+    for (auto& kv : g->dev) resident[kv.first] = kv.second.ptr;
     g->fanout_method = 0;
-    std::string why;
-    if (devs.size() == 1) {
-        // nothing to distribute.  Asked for RCCL explicitly, the call still goes through a one-rank communicator and an in-place
-        // broadcast, so that the run-time lookup of librccl and the call sequence can be checked on a single-GPU machine.
-        if (how == BGR_FANOUT_RCCL) {
-            if (!fanout_rccl(devs, ptr, g->header.blob_bytes, why)) return fail(BGR_E_HIP, "bgr_devices_init: " + why);
-            g->fanout_method = BGR_FANOUT_RCCL;
-        }
-        return BGR_OK;
-    }
-    if (how != BGR_FANOUT_PEER && fanout_rccl(devs, ptr, g->header.blob_bytes, why)) { g->fanout_method = BGR_FANOUT_RCCL; return BGR_OK; }
-    if (how == BGR_FANOUT_RCCL) return fail(BGR_E_HIP, "bgr_devices_init: " + why);
-    rc = fanout_peer(devs, ptr, g->header.blob_bytes);
-    if (rc == BGR_OK) g->fanout_method = BGR_FANOUT_PEER;
-    return rc;
+    const bgr::FanoutResult r = bgr::fanout_blob(first_device, n_devices, how, resident, ops);
+    if (!r.error.empty()) return fail(r.hip_error ? BGR_E_HIP : BGR_E_ARG, "bgr_devices_init: " + r.error);
+    for (auto& kv : resident) if (!g->dev.count(kv.first)) g->dev[kv.first] = {kv.second, true};
+    g->fanout_method = (uint32_t)r.method;
+    return BGR_OK;
 }
 
 uint32_t bgr_devices_method(const bgr_graph* g) { return g ? g->fanout_method : 0; }
@@ -1010,7 +1000,11 @@ static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const cha
         }
     };
     std::thread helper(work, 1u);
-    work(0u);
+    try {
+        work(0u);
+    } catch (...) {  // (bad_alloc in a piece: the helper must still be joined)
+        give_up(BGR_E_INTERNAL, "bgr_align_batch: out of memory");
+    }
     helper.join();
     if (first_rc != BGR_OK) return fail(first_rc, first_err);
     uint64_t all = 0;
@@ -1086,6 +1080,12 @@ int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms
     if (rc != BGR_OK) return rc;
     if (launches) *launches = a->t_launches;
     if (total_ms) *total_ms = a->t_ms;
+    if (a->twin) {  // the pieces of overlapped batches its second stream mapped
+        rc = drain_timers(a->twin);
+        if (rc != BGR_OK) return rc;
+        if (launches) *launches += a->twin->t_launches;
+        if (total_ms) *total_ms += a->twin->t_ms;
+    }
     return BGR_OK;
 }
 
@@ -1095,9 +1095,19 @@ int bgr_aligner_kernel_times(bgr_aligner* a, uint64_t* launches, double slot_ms[
     int rc = drain_timers(a);
     if (rc != BGR_OK) return rc;
     if (launches) *launches = a->t_launches;
+    if (a->twin) {
+        rc = drain_timers(a->twin);
+        if (rc != BGR_OK) return rc;
+        if (launches) *launches += a->twin->t_launches;
+    }
     for (int j = 0; j < kTimerSlots; ++j) {
         slot_ms[j] = a->t_slot_ms[j];
-        if (slot_names) slot_names[j] = a->t_slot_ms[j] > 0 ? a->t_slot_name[j] : nullptr;
+        const char* name = a->t_slot_name[j];
+        if (a->twin && a->twin->t_slot_ms[j] > 0) {  // (both streams run the same launch sequence: slot j is the same kernel)
+            slot_ms[j] += a->twin->t_slot_ms[j];
+            if (!name) name = a->twin->t_slot_name[j];
+        }
+        if (slot_names) slot_names[j] = slot_ms[j] > 0 ? name : nullptr;
     }
     return BGR_OK;
 }
@@ -1110,6 +1120,7 @@ int bgr_aligner_reset_kernel_time(bgr_aligner* a) {
     a->t_launches = 0;
     a->t_ms = 0;
     for (double& x : a->t_slot_ms) x = 0;
+    if (a->twin) return bgr_aligner_reset_kernel_time(a->twin);
     return BGR_OK;
 }
 

@@ -798,10 +798,15 @@ def test_bench_line_contract():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
+    # without the counter passes the line carries the HBM view only (own compulsory bytes of the dominant kernel / its duration):
+    # a FRACTION of the peak, <= 1; the SURVEY 8d figure of the reference's control flow sits beside it under its own keys
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is None
+    assert 0 < r["frac"] <= 1 and 0 < r["hbm"]["frac"] <= 1 and 0 < r["hbm"]["whole_launch"]["frac"] <= 1
+    assert r["reference_alg_bytes_per_read"] > 1000 and "dominant_kernel_ms" in r and r["dominant_kernel"].startswith("bgr_")
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "reference" and c["value"] > 0 and c["cores"] >= 1 and c["gpu_matches_cpu_records"] is True
+    assert c["t1"]["value"] > 0 and c["t1"]["cores"] == 1 and c["cpu_model"]
     assert d["parity_sample"]["gpu_equals_oracle"] is True
     assert d["pcie_inclusive"]["value"] > 0 and d["e2e"]["value"] > 0

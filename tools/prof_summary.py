@@ -5,7 +5,14 @@ import glob
 import os
 import sys
 
+import re
+
 out = sys.argv[1]
+
+
+def short(name):
+    m = re.search(r"(bgr_[a-z0-9_]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
 
 
 def find(sub, pattern):
@@ -23,22 +30,17 @@ for f in find("kt", "*kernel_trace.csv"):
             nm = row["Kernel_Name"]
             nm = nm[nm.find("bgr_"):][:60]
             bydur.setdefault(nm, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), row))
+kt_ms = {}
 for nm, lst in bydur.items():
     durs = [d for d, _ in lst]
     big = [d for d in durs if d * 2 >= max(durs)]
+    kt_ms[short(nm)] = sum(big) / len(big) / 1e6
     last = lst[-1][1]
     print("  %-60s dispatches %3d  full-size %3d  mean %.4f ms  (VGPR %s SGPR %s LDS %s grid %s wg %s)" % (
         nm, len(durs), len(big), sum(big) / len(big) / 1e6, last.get("VGPR_Count"), last.get("SGPR_Count"), last.get("LDS_Block_Size"),
         last.get("Grid_Size_X"), last.get("Workgroup_Size_X")))
 
 print("== PMC (mean per full-size dispatch, per kernel) ==")
-import re
-
-
-def short(name):
-    m = re.search(r"(bgr_[a-z0-9_]+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
-
 
 # full-size dispatches of a kernel = those within 2x of its longest one (the parity-sample launches are much shorter)
 vals = {}   # kernel -> counter -> mean
@@ -73,5 +75,13 @@ for k in sorted(vals):
         print("     FETCH_SIZE*1024 = %.1f MB (x2 gfx950 wide-stream correction = %.1f MB)" % (v["FETCH_SIZE"] * 1024 / 1e6, v["FETCH_SIZE"] * 2048 / 1e6))
     if "WRITE_SIZE" in v:
         print("     WRITE_SIZE*1024 = %.1f MB" % (v["WRITE_SIZE"] * 1024 / 1e6))
+    if "SQ_ACTIVE_INST_VALU" in v and "SQ_ACTIVE_INST_VALU2" in v:
+        # busy vector issue slots = instructions minus those issued as the second of a pair (profiles/r03_valu2_pmc_calibration.txt)
+        busy = v["SQ_ACTIVE_INST_VALU"] - v["SQ_ACTIVE_INST_VALU2"]
+        print("     VALU busy issue slots = ACTIVE_INST_VALU - ACTIVE_INST_VALU2 = %.4e  (x4 = %.4e SIMD-cycles; %.3f cycles per instruction)" % (busy, 4 * busy, 4 * busy / max(1.0, v["SQ_ACTIVE_INST_VALU"])))
+        if v.get("SQ_BUSY_CU_CYCLES"):
+            print("     VALU busy fraction of the CU-busy cycles = slots / SQ_BUSY_CU_CYCLES = %.4f" % (busy / v["SQ_BUSY_CU_CYCLES"]))
+        if k in kt_ms:
+            print("     VALU busy fraction at 1024 SIMDs x 2.4 GHz over the kernel's mean duration (%.4f ms, kernel trace) = %.4f" % (kt_ms[k], 4 * busy / (1024 * 2.4e9 * kt_ms[k] / 1e3)))
     if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v:
         print("     L2 hit rate = %.4f" % (v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])))
