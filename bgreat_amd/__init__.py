@@ -32,6 +32,7 @@ SYMBOLS = [
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup", "bgr_graph_key_lookup",
     "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
+    "bgr_align_fasta_text", "bgr_aligner_fetch_text", "bgr_host_cache_release", "bgr_device_local_cpus", "bgr_text_stage_create", "bgr_text_stage_destroy", "bgr_text_stage_upload",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
@@ -53,7 +54,13 @@ class Params(C.Structure):
 class RunOptions(C.Structure):
     _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
                 ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("correction", C.c_uint32),
-                ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32)]
+                ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32), ("route", C.c_uint32)]
+
+
+class TextBatch(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("text_bytes", C.c_uint64), ("want_output", C.c_uint32), ("irregular", C.c_uint32), ("paths_out", C.c_void_p),
+                ("paths_cap", C.c_uint64), ("notaligned_out", C.c_void_p), ("notaligned_cap", C.c_uint64), ("n_records", C.c_uint64),
+                ("n_accepted", C.c_uint64), ("paths_bytes", C.c_uint64), ("notaligned_bytes", C.c_uint64), ("stage", C.c_void_p)]
 
 
 class PackedReads(C.Structure):
@@ -137,6 +144,12 @@ def lib():
     L.bgr_packed_plane_words.restype = u64
     L.bgr_pack_reads.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u32)]
     L.bgr_align_batch_packed.argtypes = [vp, C.POINTER(Params), C.POINTER(PackedReads), u64, vp, u64, vp, vp]
+    L.bgr_align_fasta_text.argtypes = [vp, C.POINTER(Params), C.POINTER(TextBatch)]
+    L.bgr_aligner_fetch_text.argtypes = [vp, C.POINTER(TextBatch)]
+    L.bgr_text_stage_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.bgr_text_stage_destroy.argtypes = [vp]
+    L.bgr_text_stage_destroy.restype = None
+    L.bgr_text_stage_upload.argtypes = [vp, vp, u64]
     L.bgr_aligner_sync.argtypes = [vp]
     L.bgr_aligner_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.bgr_aligner_fetch.argtypes = [vp, u64, vp, u64, vp, vp]
@@ -328,6 +341,34 @@ class Aligner:
         _check(lib().bgr_align_batch_packed(self.h, C.byref(p), C.byref(s), n, paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
         return paths[: int(poffs[n])].copy(), poffs, status[:n]
 
+    def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False):
+        """bgr_align_fasta_text: a piece of a FASTA file (bytes) -> (paths bytes, notAligned bytes, info dict); info["irregular"] = the
+        device left the piece to the host parser (nothing mapped).  A too small `paths_cap` is grown through bgr_aligner_fetch_text."""
+        text = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else _as_u8(text)
+        n = len(text)
+        pcap = n + 64 if paths_cap is None else paths_cap
+        pout = np.empty(max(pcap, 1), dtype=np.uint8)
+        nout = np.empty(n + 64, dtype=np.uint8)
+        b = TextBatch(text.ctypes.data if n else None, n, int(want_output), 0, pout.ctypes.data, pcap, nout.ctypes.data, n + 64, 0, 0, 0, 0, None)
+        p = Params(mode, m, effort, int(partial))
+        stage = C.c_void_p()
+        if staged:  # the piece sent ahead on a copy stream of its own (bgr_text_stage_upload); the call orders itself behind it
+            _check(lib().bgr_text_stage_create(0, C.byref(stage)))
+            _check(lib().bgr_text_stage_upload(stage, text.ctypes.data if n else None, n))
+            b.stage = stage
+        try:
+            rc = lib().bgr_align_fasta_text(self.h, C.byref(p), C.byref(b))
+        finally:
+            if staged:
+                lib().bgr_text_stage_destroy(stage)
+        if rc == -4:  # BGR_E_CAPACITY: the mapping is done, the bytes did not fit
+            pout = np.empty(int(b.paths_bytes) + 64, dtype=np.uint8)
+            b.paths_out, b.paths_cap = pout.ctypes.data, len(pout)
+            rc = lib().bgr_aligner_fetch_text(self.h, C.byref(b))
+        _check(rc)
+        info = {"irregular": bool(b.irregular), "n_records": int(b.n_records), "n_accepted": int(b.n_accepted)}
+        return pout[: int(b.paths_bytes)].tobytes(), nout[: int(b.notaligned_bytes)].tobytes(), info
+
     def align_device(self, d_reads_ptr, d_offsets_ptr, n, total_bases, max_len, m=2, effort=2, mode=MODE_GREEDY, partial=False):
         p = Params(mode, m, effort, int(partial))
         _check(lib().bgr_align_device(self.h, C.byref(p), d_reads_ptr, d_offsets_ptr, n, total_bases, max_len))
@@ -391,11 +432,12 @@ class Aligner:
 
 
 def align_all(graph, reads_csv, paths_file, notaligned_file, m=2, effort=2, mode=MODE_GREEDY, partial=False, n_gpus=1, threads=1,
-              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False, correction=False, no_overlap_file=None, first_device=0):
-    """Aligner::alignAll (aligner.cpp:550-597) as one call -> (counters dict, mapping seconds)."""
+              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False, correction=False, no_overlap_file=None, first_device=0, route=0):
+    """Aligner::alignAll (aligner.cpp:550-597) as one call -> (counters dict, mapping seconds).  route: 0 = FASTA goes through the device as
+    text when it can (bgr_align_fasta_text), 1 = host parser + host formatter always."""
     p = Params(mode, m, effort, int(partial))
     o = RunOptions(n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, int(correction),
-                   no_overlap_file.encode() if no_overlap_file else None, first_device)
+                   no_overlap_file.encode() if no_overlap_file else None, first_device, route)
     out = np.zeros(5, dtype=np.uint64)
     secs = C.c_double()
     _check(lib().bgr_align_all(graph.h, C.byref(p), C.byref(o), reads_csv.encode(), paths_file.encode(), notaligned_file.encode(),

@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "device_common.h"
+#include "text_kernels.h"
 
 namespace bgr {
 
@@ -62,7 +63,9 @@ __device__ __forceinline__ u64 pack_codes(const uint32_t c[8]) {
     return (u64)hi << 32 | lo;
 }
 
-__global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* reads, const u64* read_offs, uint32_t n, u64 total_bytes, u64* fw3,
+// (src_off: null = read r's characters start at reads + read_offs[r], the reads of a batch end to end; else at reads + src_off[r]:
+// reads scattered in a FASTA text, text_kernels.hip -- read_offs still numbers the bases of the batch and addresses the planes)
+__global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* reads, const uint32_t* src_off, const u64* read_offs, uint32_t n, u64 total_bytes, u64* fw3,
                                                              u64* nmw, uint32_t* hasn, uint32_t lpr, uint32_t inv_lpr, uint32_t reads_per_block) {
     const uint32_t slot = (threadIdx.x * inv_lpr) >> 16;  // threadIdx.x / lpr (inv_lpr checked exact for 0..255 by the launcher)
     const uint32_t j0 = threadIdx.x - slot * lpr;
@@ -72,10 +75,11 @@ __global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* read
     const uint32_t L = (uint32_t)(read_offs[r + 1] - off);
     const uint32_t Wr = (L + 31) >> 5;
     const uint32_t woff = packed_word_offset(off, r);
+    const u64 src = src_off ? (u64)src_off[r] : off;
     uint32_t sawN = 0;
     for (uint32_t j = j0; j < Wr; j += lpr) {
         uint32_t xs[8], c[8];
-        load32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, xs);
+        load32(reads + src, L, j, src + 32ull * j + 32 <= total_bytes, xs);
 #pragma unroll
         for (int d = 0; d < 8; ++d) { c[d] = codes4(xs[d]); sawN |= xs[d]; }  // (bit 3 of a character: set for N only)
         fw3[woff + j] = pack_codes(c);
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* read
     if (sawN & 0x08080808u) {
         for (uint32_t j = 0; j < Wr; ++j) {
             uint32_t xs[8], c[8];
-            load32(reads + off, L, j, off + 32ull * j + 32 <= total_bytes, xs);
+            load32(reads + src, L, j, src + 32ull * j + 32 <= total_bytes, xs);
 #pragma unroll
             for (int d = 0; d < 8; ++d) c[d] = ((xs[d] >> 3) & 0x01010101u) * 3u;
             nmw[woff + j] = pack_codes(c);
@@ -94,18 +98,26 @@ __global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* read
     }
 }
 
-hipError_t launch_pack_reads(const uint8_t* reads, const uint64_t* read_offs, uint32_t n, uint64_t total_bytes, uint64_t* fw3, uint64_t* nmw,
-                             uint32_t* hasn, hipStream_t stream) {
+static hipError_t launch_pack_impl(const uint8_t* reads, const uint32_t* src_off, const uint64_t* read_offs, uint32_t n, uint64_t total_bytes, uint64_t total_bases,
+                                   uint64_t* fw3, uint64_t* nmw, uint32_t* hasn, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     // lanes per read: the mean number of 32-base words per read, rounded up (150 bp: 5), at most 16; longer reads loop
-    uint32_t lpr = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (total_bytes / n + 31) / 32));
+    uint32_t lpr = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (total_bases / n + 31) / 32));
     uint32_t inv = (65536 + lpr - 1) / lpr;
     for (uint32_t t = 0; t < 256; ++t)
         if (((t * inv) >> 16) != t / lpr) { lpr = 8; inv = 65536 / 8; break; }  // (never taken for lpr <= 16; kept as a guard)
     const uint32_t rpb = 256 / lpr;
     const uint32_t blocks = (n + rpb - 1) / rpb;
-    hipLaunchKernelGGL(bgr_pack_reads_kernel, dim3(blocks), dim3(256), 0, stream, reads, read_offs, n, total_bytes, fw3, nmw, hasn, lpr, inv, rpb);
+    hipLaunchKernelGGL(bgr_pack_reads_kernel, dim3(blocks), dim3(256), 0, stream, reads, src_off, read_offs, n, total_bytes, fw3, nmw, hasn, lpr, inv, rpb);
     return hipGetLastError();
+}
+hipError_t launch_pack_reads(const uint8_t* reads, const uint64_t* read_offs, uint32_t n, uint64_t total_bytes, uint64_t* fw3, uint64_t* nmw,
+                             uint32_t* hasn, hipStream_t stream) {
+    return launch_pack_impl(reads, nullptr, read_offs, n, total_bytes, total_bytes, fw3, nmw, hasn, stream);
+}
+hipError_t launch_pack_reads_at(const uint8_t* text, const uint32_t* src_off, const uint64_t* read_offs, uint32_t n, uint64_t text_bytes, uint64_t total_bases,
+                                uint64_t* fw3, uint64_t* nmw, uint32_t* hasn, hipStream_t stream) {
+    return launch_pack_impl(text, src_off, read_offs, n, text_bytes, total_bases, fw3, nmw, hasn, stream);
 }
 
 // plane[index[i]] = value[i]: the N-mask words of a host-packed batch (bgr_align_batch_packed)

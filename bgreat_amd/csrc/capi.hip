@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 #include "anchor_index.h"
 #include "graph_build.h"
 #include "read_pack.h"
+#include "text_kernels.h"
 
 namespace {
 
@@ -67,11 +69,25 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct bgr_text_stage {  // one piece of text on its way to / resident in a device: buffer, copy stream, "it has arrived" event
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    DevBuf buf;
+    uint64_t bytes = 0;
+};
+
 struct bgr_aligner {
     bgr_graph* graph = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
+    // the text route (bgr_align_fasta_text): the piece, its records, the formatted streams
+    DevBuf tx_in, tx_sums, tx_start, tx_rec, tx_flag, tx_len, tx_idx, tx_boff, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout;
+    uint64_t tx_n_acc = 0, tx_pbytes = 0, tx_nbytes = 0;
+    const uint8_t* tx_text = nullptr;  // where the last call's piece lies in HBM (tx_in, or the caller's stage)
+    double tx_phase_s[5] = {0, 0, 0, 0, 0};  // BGREAT_TIMING: host wall seconds to the call's four waits (mark, records, mapping + sizes, streams) + calls
+
     DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, lst, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
     uint32_t last_launch[4] = {0, 0, 0, 0};
@@ -418,11 +434,16 @@ int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out) {
 
 void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
+    if (a->tx_phase_s[4] > 0 && getenv("BGREAT_TIMING"))
+        fprintf(stderr, "bgreat: text calls %.0f on device %d: to record count %.3f s, records %.3f s, mapping + sizes %.3f s, streams out %.3f s\n", a->tx_phase_s[4], a->device,
+                a->tx_phase_s[0], a->tx_phase_s[1], a->tx_phase_s[2], a->tx_phase_s[3]);
     if (a->twin) { bgr_aligner_destroy(a->twin); a->twin = nullptr; }
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
         a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->lst.release(); a->deep.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
+        for (DevBuf* b : {&a->tx_in, &a->tx_sums, &a->tx_start, &a->tx_rec, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_offs,
+                          &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff, &a->tx_pout, &a->tx_nout}) b->release();
         for (int i = 0; i < kTimerRing; ++i) for (int j = 0; j <= kTimerSlots; ++j) (void)hipEventDestroy(a->ev[i][j]);
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
@@ -855,6 +876,162 @@ int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed
     return bgr_aligner_fetch(a, n, paths_out, paths_cap, path_offsets, status);
 }
 
+// ---- text form: FASTA bytes in, record bytes out (text_kernels.hip) -------------------------------------------------------------
+static int fetch_text_impl(bgr_aligner* a, bgr_text_batch* b) {
+    b->paths_bytes = a->tx_pbytes;
+    b->notaligned_bytes = a->tx_nbytes;
+    if (!b->want_output || a->tx_n_acc == 0) return BGR_OK;
+    if (a->tx_pbytes > b->paths_cap || a->tx_nbytes > b->notaligned_cap || (a->tx_pbytes && !b->paths_out) || (a->tx_nbytes && !b->notaligned_out))
+        return fail(BGR_E_CAPACITY, "bgr_align_fasta_text: output buffer too small (paths_bytes / notaligned_bytes say what is needed; bgr_aligner_fetch_text)");
+    HIP_TRY(a->tx_pout.ensure(a->tx_pbytes + 64));
+    HIP_TRY(a->tx_nout.ensure(a->tx_nbytes + 64));
+    hipError_t e = bgr::launch_text_write(a->tx_text, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p),
+                                          static_cast<const uint4*>(a->tx_rec.p), static_cast<const uint32_t*>(a->tx_accrec.p), (uint32_t)a->tx_n_acc,
+                                          static_cast<const uint32_t*>(a->tx_poff.p), static_cast<const uint32_t*>(a->tx_noff.p), static_cast<uint8_t*>(a->tx_pout.p),
+                                          static_cast<uint8_t*>(a->tx_nout.p), a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text write launch: ") + hipGetErrorString(e));
+    if (a->tx_pbytes) HIP_TRY(hipMemcpyAsync(b->paths_out, a->tx_pout.p, a->tx_pbytes, hipMemcpyDeviceToHost, a->stream));
+    if (a->tx_nbytes) HIP_TRY(hipMemcpyAsync(b->notaligned_out, a->tx_nout.p, a->tx_nbytes, hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    return BGR_OK;
+}
+
+int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
+    if (!a || !b) return fail(BGR_E_ARG, "bgr_aligner_fetch_text: null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    return fetch_text_impl(a, b);
+}
+
+int bgr_text_stage_create(int device, bgr_text_stage** out) {
+    if (!out) return fail(BGR_E_ARG, "bgr_text_stage_create: null argument");
+    HIP_TRY(hipSetDevice(device));
+    bgr_text_stage* s = new bgr_text_stage();
+    s->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev, hipEventDisableTiming);
+    if (e != hipSuccess) { bgr_text_stage_destroy(s); return fail(BGR_E_HIP, std::string("bgr_text_stage_create: ") + hipGetErrorString(e)); }
+    *out = s;
+    return BGR_OK;
+}
+
+void bgr_text_stage_destroy(bgr_text_stage* s) {
+    if (!s) return;
+    if (hipSetDevice(s->device) == hipSuccess) {
+        if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        if (s->ev) (void)hipEventDestroy(s->ev);
+        s->buf.release();
+    }
+    delete s;
+}
+
+int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t bytes) {
+    if (!s || (bytes && !text)) return fail(BGR_E_ARG, "bgr_text_stage_upload: null argument");
+    if (bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_text_stage_upload: piece of 2 GiB or more; cut it");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));  // (a piece still on its way: the buffer may grow, i.e. move)
+    HIP_TRY(s->buf.ensure(bytes + 64));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(s->buf.p) + bytes, 0, 64, s->stream));
+    if (bytes) HIP_TRY(hipMemcpyAsync(s->buf.p, text, bytes, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->ev, s->stream));
+    s->bytes = bytes;
+    return BGR_OK;
+}
+
+static double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b) {
+    if (!a || !p || !b || (b->text_bytes && !b->text && !b->stage)) return fail(BGR_E_ARG, "bgr_align_fasta_text: null argument");
+    double tw = wall_now();
+    auto lap = [&](int i) { const double t = wall_now(); a->tx_phase_s[i] += t - tw; tw = t; };
+    if (b->text_bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_align_fasta_text: piece of 2 GiB or more; cut it");
+    b->irregular = 0;
+    b->n_records = b->n_accepted = b->paths_bytes = b->notaligned_bytes = 0;
+    a->last_n = 0;
+    a->tx_n_acc = a->tx_pbytes = a->tx_nbytes = 0;
+    if (b->text_bytes == 0) return BGR_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    const uint32_t nbytes = (uint32_t)b->text_bytes;
+    uint32_t* info = reinterpret_cast<uint32_t*>(static_cast<char*>(a->small.p) + 192);  // TXT_INFO_WORDS u32 behind cursor / counters / CSR total
+    const uint8_t* text = nullptr;
+    HIP_TRY(hipMemsetAsync(info, 0, TXT_INFO_WORDS * 4, a->stream));
+    // 1. the piece in HBM (zero padded): uploaded ahead of this call by a stage (bgr_text_stage_upload, a copy stream of its own), or copied now
+    if (b->stage) {
+        if (b->stage->device != a->device || b->stage->bytes != b->text_bytes) return fail(BGR_E_ARG, "bgr_align_fasta_text: the stage holds another piece / lives on another device");
+        HIP_TRY(hipStreamWaitEvent(a->stream, b->stage->ev, 0));
+        text = static_cast<const uint8_t*>(b->stage->buf.p);
+    } else {
+        if (!b->text) return fail(BGR_E_ARG, "bgr_align_fasta_text: null text");
+        HIP_TRY(a->tx_in.ensure((uint64_t)nbytes + 64));
+        text = static_cast<const uint8_t*>(a->tx_in.p);
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(a->tx_in.p) + nbytes, 0, 64, a->stream));
+        HIP_TRY(hipMemcpyAsync(a->tx_in.p, b->text, nbytes, hipMemcpyHostToDevice, a->stream));
+    }
+    a->tx_text = text;
+    // 2. records: starts, extents, shape, accept test; accepted records compacted in input order.  Room for one record per 24 bytes of
+    // text (a sequencing read with its header is several times that): a piece with more record starts goes to the host parser.
+    const uint32_t R_cap = nbytes / 24 + 1024;
+    // (scratch: the marking kernel's tile sums, then room for the scans)
+    HIP_TRY(a->tx_sums.ensure(((uint64_t)bgr::text_tiles(nbytes) + bgr::scan_tiles(R_cap) + 16) * 4));
+    for (DevBuf* d : {&a->tx_start, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff})
+        HIP_TRY(d->ensure(((uint64_t)R_cap + 4) * 4));
+    HIP_TRY(a->tx_rec.ensure(((uint64_t)R_cap + 1) * 16));
+    HIP_TRY(a->tx_offs.ensure(((uint64_t)R_cap + 2) * 8));
+    uint32_t* sums2 = static_cast<uint32_t*>(a->tx_sums.p) + bgr::text_tiles(nbytes);
+    hipError_t e = bgr::launch_text_mark(text, nbytes, static_cast<uint32_t*>(a->tx_sums.p), static_cast<uint32_t*>(a->tx_start.p), R_cap, info + TXT_INFO_N_REC, a->stream);
+    if (e == hipSuccess) e = bgr::launch_text_records(text, nbytes, static_cast<const uint32_t*>(a->tx_start.p), info + TXT_INFO_N_REC, R_cap, a->dg.k, static_cast<uint4*>(a->tx_rec.p),
+                                                      static_cast<uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_len.p), info, a->stream);
+    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_idx.p), R_cap, sums2, info + TXT_INFO_N_ACC, a->stream);
+    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_len.p), static_cast<uint32_t*>(a->tx_boff.p), R_cap, sums2, info + TXT_INFO_BASES, a->stream);
+    if (e == hipSuccess) e = bgr::launch_text_compact(static_cast<const uint4*>(a->tx_rec.p), info + TXT_INFO_N_REC, R_cap, static_cast<const uint32_t*>(a->tx_idx.p),
+                                                      static_cast<const uint32_t*>(a->tx_boff.p), static_cast<uint32_t*>(a->tx_accrec.p), static_cast<uint32_t*>(a->tx_accsrc.p),
+                                                      static_cast<uint64_t*>(a->tx_offs.p), info + TXT_INFO_N_ACC, info + TXT_INFO_BASES, a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text record launches: ") + hipGetErrorString(e));
+    uint32_t h[TXT_INFO_WORDS];
+    HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    lap(0);
+    const uint32_t R = h[TXT_INFO_N_REC];
+    b->n_records = R;
+    if (R == 0 || R > R_cap) { b->irregular = 1; return BGR_OK; }  // no record start in the bytes, or far more than a read file has: the host parser decides
+    lap(1);
+    if (h[TXT_INFO_IRREGULAR]) { b->irregular = 1; return BGR_OK; }
+    const uint32_t n_acc = h[TXT_INFO_N_ACC], bases = h[TXT_INFO_BASES], max_len = h[TXT_INFO_MAX_LEN];
+    b->n_accepted = n_acc;
+    if (n_acc == 0) return BGR_OK;
+    // 3. planes, mapping launch
+    const uint64_t plane_words = (bases >> 5) + (uint64_t)n_acc + 4;
+    HIP_TRY(a->pk_fw3.ensure(plane_words * 8));
+    HIP_TRY(a->pk_nm.ensure(plane_words * 8));
+    HIP_TRY(a->pk_hasn.ensure(((uint64_t)n_acc + 31) / 32 * 4 + 4));
+    HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, ((uint64_t)n_acc + 31) / 32 * 4, a->stream));
+    e = bgr::launch_pack_reads_at(text, static_cast<const uint32_t*>(a->tx_accsrc.p), static_cast<const uint64_t*>(a->tx_offs.p), n_acc, nbytes, bases,
+                                  static_cast<uint64_t*>(a->pk_fw3.p), static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text pack launch: ") + hipGetErrorString(e));
+    int rc = align_device_impl(a, p, nullptr, a->tx_offs.p, n_acc, bases, max_len, true);
+    if (rc != BGR_OK) return rc;
+    a->last_n = 0;  // (bgr_aligner_fetch has no host read_offsets to pair its rows with: the text form hands out text)
+    a->tx_n_acc = n_acc;
+    if (!b->want_output) { HIP_TRY(hipStreamSynchronize(a->stream)); return BGR_OK; }
+    // 4. sizes of the records, stream offsets, the bytes
+    e = bgr::launch_text_sizes(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
+                               static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, static_cast<uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_nsz.p), a->stream);
+    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_poff.p), n_acc, sums2, info + TXT_INFO_PBYTES, a->stream);
+    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_noff.p), n_acc, sums2, info + TXT_INFO_NBYTES, a->stream);
+    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text size launches: ") + hipGetErrorString(e));
+    uint32_t h2[TXT_INFO_WORDS + 2];
+    HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipMemcpyAsync(h2, a->small.p, 8, hipMemcpyDeviceToHost, a->stream));  // cursor[1]: arena overflow flag
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    lap(2);
+    if (h2[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+    a->tx_pbytes = h[TXT_INFO_PBYTES];
+    a->tx_nbytes = h[TXT_INFO_NBYTES];
+    const int frc = fetch_text_impl(a, b);
+    lap(3);
+    a->tx_phase_s[4] += 1;
+    return frc;
+}
+
 int bgr_aligner_sync(bgr_aligner* a) {
     if (!a) return fail(BGR_E_ARG, "bgr_aligner_sync: null aligner");
     HIP_TRY(hipSetDevice(a->device));
@@ -1137,6 +1314,22 @@ int bgr_aligner_pass_counts(bgr_aligner* a, uint32_t out[4]) {
     uint32_t cur[16];
     HIP_TRY(hipMemcpy(cur, a->small.p, sizeof(cur), hipMemcpyDeviceToHost));
     out[0] = cur[2]; out[1] = cur[3]; out[2] = cur[5]; out[3] = cur[8];
+    return BGR_OK;
+}
+
+int bgr_device_local_cpus(int device, char* cpulist_out, uint64_t cap) {
+    if (!cpulist_out || cap < 2) return fail(BGR_E_ARG, "bgr_device_local_cpus: null argument");
+    char bus[64];
+    HIP_TRY(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device));
+    for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return fail(BGR_E_IO, "bgr_device_local_cpus: cannot read " + path);
+    const size_t got = fread(cpulist_out, 1, (size_t)cap - 1, f);
+    fclose(f);
+    cpulist_out[got] = 0;
+    for (size_t i = 0; i < got; ++i) if (cpulist_out[i] == '\n') cpulist_out[i] = 0;
+    if (!cpulist_out[0]) return fail(BGR_E_IO, "bgr_device_local_cpus: empty cpulist");
     return BGR_OK;
 }
 

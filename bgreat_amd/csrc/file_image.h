@@ -9,7 +9,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cerrno>
+#include <cstring>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -20,7 +22,9 @@ struct FileImage {
     const char* data = "";
     uint64_t size = 0;
     bool mapped = false;
+    int fd = -1;              // kept open for mapped regular files: copy_out() reads through it (pread) instead of faulting pages in
     std::vector<char> owned;  // the bytes of a stream that cannot be mapped
+    std::atomic<uint32_t> irregular_pieces{0};  // pipeline.cpp: pieces of this file the device's text route handed back to the host parser
 
     FileImage() = default;
     FileImage(const FileImage&) = delete;
@@ -36,7 +40,7 @@ struct FileImage {
             if (size == 0) { ::close(fd); return true; }
             void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (p != MAP_FAILED) {
-                ::close(fd);
+                this->fd = fd;
                 data = static_cast<const char*>(p);
                 mapped = true;
                 madvise(p, size, MADV_SEQUENTIAL);
@@ -66,8 +70,21 @@ struct FileImage {
         data = owned.empty() ? "" : owned.data();
         return true;
     }
+    // bytes [off, off + len) into dst: pread for a regular file (the kernel copies out of the page cache, ~30 GB/s per thread, no
+    // page faults on the mapping), memcpy otherwise
+    bool copy_out(char* dst, uint64_t off, uint64_t len) const {
+        if (fd < 0) { memcpy(dst, data + off, len); return true; }
+        while (len) {
+            const ssize_t r = pread(fd, dst, len, (off_t)off);
+            if (r < 0) { if (errno == EINTR) continue; return false; }
+            if (r == 0) return false;
+            dst += r; off += (uint64_t)r; len -= (uint64_t)r;
+        }
+        return true;
+    }
     ~FileImage() {
         if (mapped) munmap(const_cast<char*>(data), size);
+        if (fd >= 0) ::close(fd);
     }
 };
 

@@ -8,6 +8,8 @@
 //                                                   --write-exhaustive (-b normally writes nothing)
 //                                                   --chunk-bytes N (parser chunk size; tests use tiny chunks)
 //                                                   --no-overlap FILE (reads without any anchor go there instead of notAligned.fa)
+//                                                   --host-route (parse and format on the host always; default: FASTA goes through the
+//                                                                 device as text when the run writes the reference's two files)
 #include <getopt.h>
 
 #include <algorithm>
@@ -30,11 +32,11 @@ static void die(const char* what) {
 int main(int argc, char** argv) {
     std::string reads, unitigs("unitig.fa"), pathFile("paths"), notAlignedFile("notAligned.fa"), noOverlapFile;
     int errors = 2, threads = 1, ka = 30, effort = 2, gpus = 1;  // bgreat.cpp:56-66 defaults (k is 30, not 31)
-    long batch = 1 << 17, chunk_bytes = 0;
-    bool brute = false, incomplete = false, fastq = false, correction = false, dog = false, write_exh = false;
+    long batch = 0, chunk_bytes = 0;  // batch 0 = the pipeline's default per route
+    bool brute = false, incomplete = false, fastq = false, correction = false, dog = false, write_exh = false, host_route = false;
     static option longopts[] = {{"gpus", required_argument, nullptr, 1000}, {"batch", required_argument, nullptr, 1001},
                                 {"write-exhaustive", no_argument, nullptr, 1002}, {"chunk-bytes", required_argument, nullptr, 1003},
-                                {"no-overlap", required_argument, nullptr, 1004},
+                                {"no-overlap", required_argument, nullptr, 1004}, {"host-route", no_argument, nullptr, 1005},
                                 {nullptr, 0, nullptr, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "r:k:g:m:t:e:f:o:a:biqpcG", longopts, nullptr)) != -1) {  // bgreat.cpp:67
@@ -57,6 +59,7 @@ int main(int argc, char** argv) {
             case 1002: write_exh = true; break;
             case 1003: chunk_bytes = std::stol(optarg); break;
             case 1004: noOverlapFile = optarg; break;
+            case 1005: host_route = true; break;
             default: break;  // -o and -p are accepted and ignored, as in the reference (no `case`)
         }
     }
@@ -68,7 +71,7 @@ int main(int argc, char** argv) {
                   << "-c to output corrected reads" << std::endl;
         return 0;
     }
-    if (gpus < 1 || batch < 1) { fprintf(stderr, "bgreat: --gpus and --batch must be positive\n"); return 2; }
+    if (gpus < 1 || batch < 0) { fprintf(stderr, "bgreat: --gpus and --batch must be positive\n"); return 2; }
 
     auto t0 = std::chrono::system_clock::now();
     bgr_graph* graph = nullptr;
@@ -92,6 +95,7 @@ int main(int argc, char** argv) {
     opt.echo_files = 1;
     opt.correction = correction ? 1 : 0;
     opt.no_overlap_file = noOverlapFile.empty() ? nullptr : noOverlapFile.c_str();
+    opt.route = host_route ? 1u : 0u;
     auto start = std::chrono::system_clock::now();
     uint64_t tot[5] = {0, 0, 0, 0, 0};
     double map_secs = 0;

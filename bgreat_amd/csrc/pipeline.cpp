@@ -10,6 +10,7 @@
 // so the bytes written are the reference's `-t 1` stream whatever the thread/GPU count.  Pure host C++: talks to
 // the GPU only through the C-ABI (bgr_aligner_create, bgr_align_batch, bgr_host_alloc ...).
 #include <fcntl.h>
+#include <sched.h>
 #include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -152,9 +153,18 @@ struct HostBuf {  // grow-only host buffer; `pinned` = page-locked (20 GB/s to a
 struct Pinned {  // the page-locked buffers of one batch in flight: sources / targets of the async copies
     // reads travel as 2-bit planes (read_pack.h): fw3 words, N bitmap, and the N-mask words of the few reads with an N
     HostBuf fw3{true}, hasn{true}, nm_idx{true}, nm_val{true}, offs{true}, paths{true}, poffs{true}, status{true};
+    // text route (bgr_align_fasta_text): the piece of the file as it is, and the two record streams as they come back
+    HostBuf text{true}, ptext{true}, ntext{true};
+    std::vector<bgr_text_stage*> stages;  // per device of the run: where this set's piece waits in HBM (bgr_text_stage_upload), made on first use
     uint64_t nm_count = 0;
     uint32_t max_len = 0;
+    ~Pinned() { for (bgr_text_stage* st : stages) bgr_text_stage_destroy(st); }
 };
+
+// Page-locked buffers cost ~0.2 s per GB to allocate: a finished run leaves its sets here for the next bgr_align_all of the
+// process (bgr_host_cache_release frees them).
+std::mutex g_pin_cache_m;
+std::vector<std::unique_ptr<Pinned>> g_pin_cache;
 
 // Something the reference prints to stdout between two reads of the input order: a file name (aligner.cpp:559,576) or, in
 // exhaustive mode, the block its worker prints after every tenth getReads() call (alignerExhaustive.cpp:306-316).  A
@@ -174,6 +184,11 @@ struct Batch {
     uint64_t n = 0, bases = 0, path_cap = 0;
     std::unique_ptr<Pinned> pin;                          // attached by the gatherer, handed back by the formatter
     std::vector<RecSlice> recs;                           // flattened view of the records of this batch
+    // text route: the batch is bytes [t_begin, t_end) of `file` (a piece that starts at a header line); once mapped as text,
+    // dev_text is set and the record streams sit in pin->ptext / pin->ntext
+    bool text_piece = false, dev_text = false;
+    uint64_t t_begin = 0, t_end = 0, p_bytes = 0, n_bytes = 0;
+    unsigned dev = 0;                                     // which device of the run maps the batch (round robin in input order)
     int rc = BGR_OK;
     std::string err;
 };
@@ -395,6 +410,11 @@ bool format_range_ext(const Batch& b, uint64_t lo, uint64_t hi, const Unitigs* c
 
 }  // namespace
 
+extern "C" void bgr_host_cache_release(void) {
+    std::lock_guard<std::mutex> l(g_pin_cache_m);
+    g_pin_cache.clear();
+}
+
 extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const char* reads_csv,
                              const char* paths_file, const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds) {
     if (!graph || !prm || !opt || !reads_csv || !paths_file || !notaligned_file) return bgr::set_error(BGR_E_ARG, "bgr_align_all: null argument");
@@ -403,12 +423,17 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     // Defaults: 128k reads per batch keeps the page-locked staging small (it costs ~0.2 s per GB to allocate) and the
     // pipeline fine-grained; the parser chunk is a thread's share of a batch.
     // (one launch addresses its path arena with 32 bits: a batch stays below 4 M reads and ~1 G bases)
-    const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (1ull << 17), 4ull << 20);
+    const bool writes = prm->mode != BGR_MODE_EXHAUSTIVE || opt->write_exhaustive;
+    const bool correction = opt->correction && prm->mode != BGR_MODE_EXHAUSTIVE;  // alignPartExhaustive ignores -c
+    const bool progress_blocks = opt->echo_files && prm->mode == BGR_MODE_EXHAUSTIVE;
+    // Text route: the device parses, packs, maps and formats (bgr_align_fasta_text); the host only moves bytes.  FASTA, the
+    // reference's two output files and no -b progress blocks (those count getReads() calls, which only the host parser tracks).
+    const bool text_route = opt->route == 0 && !opt->fastq && !correction && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
+    const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (text_route ? 1ull << 18 : 1ull << 17), 4ull << 20);
+    const uint64_t piece_bytes = std::min<uint64_t>(std::max<uint64_t>(batch_reads * 170, 4096), 1ull << 30);  // text route: bytes of a batch
     const uint64_t batch_bases_cap = 1ull << 30;
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes
                                                   : std::min<uint64_t>(8ull << 20, std::max<uint64_t>(256ull << 10, batch_reads * 170 / threads));
-    const bool writes = prm->mode != BGR_MODE_EXHAUSTIVE || opt->write_exhaustive;
-    const bool correction = opt->correction && prm->mode != BGR_MODE_EXHAUSTIVE;  // alignPartExhaustive ignores -c
     Unitigs unitigs;
     if (correction) {
         if (bgr_graph_unitigs(graph, &unitigs.seqs, &unitigs.offs, &unitigs.n) != BGR_OK) return BGR_E_ARG;
@@ -433,8 +458,10 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         return bgr::set_error(BGR_E_IO, "bgr_align_all: cannot open the output files");
     }
 
-    // two aligners (streams) per device so that consecutive batches overlap copy and compute
-    const unsigned per_dev = 2;
+    // two aligners (streams) per device so that consecutive batches overlap copy and compute (text route: the piece is already on its
+    // way to the device when a worker takes the batch; measured 185 / 163 / 149 Mreads/s end to end with 2 / 3 / 4 workers per device)
+    unsigned per_dev = 2;
+    if (const char* e = getenv("BGREAT_WORKERS_PER_DEVICE")) per_dev = (unsigned)std::min(16, std::max(1, atoi(e)));  // (tuning / experiments)
     std::vector<bgr_aligner*> aligners;
     for (unsigned g = 0; g < n_gpus; ++g) {
         for (unsigned j = 0; j < per_dev; ++j) {
@@ -449,12 +476,44 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         }
     }
 
+    // The threads of this run (and the page-locked memory they allocate) on the NUMA node of the devices they feed: a copy engine
+    // reading staging buffers across the socket link runs at about half its rate.  Only when all devices of the run share a node;
+    // the caller's affinity is restored at the end (BGREAT_NUMA=0 turns it off).
+    cpu_set_t old_aff, want_aff;
+    bool aff_changed = false;
+    if (!getenv("BGREAT_NUMA") || atoi(getenv("BGREAT_NUMA")) != 0) {
+        CPU_ZERO(&want_aff);
+        bool same = true;
+        std::string first_list;
+        for (unsigned g = 0; g < n_gpus && same; ++g) {
+            char list[512];
+            if (bgr_device_local_cpus((int)(opt->first_device + g), list, sizeof(list)) != BGR_OK) { same = false; break; }
+            if (g == 0) first_list = list; else if (first_list != list) same = false;
+        }
+        if (same && !first_list.empty() && sched_getaffinity(0, sizeof(old_aff), &old_aff) == 0) {
+            int n_set = 0;
+            const char* c = first_list.c_str();
+            while (*c) {  // "a-b,c,d-e"
+                char* e = nullptr;
+                long a = strtol(c, &e, 10), b = a;
+                if (e == c) break;
+                if (*e == '-') { c = e + 1; b = strtol(c, &e, 10); }
+                for (long i = a; i <= b && i < CPU_SETSIZE; ++i) if (CPU_ISSET(i, &old_aff)) { CPU_SET(i, &want_aff); ++n_set; }
+                c = *e == ',' ? e + 1 : e;
+                if (*e != ',' && *e != 0) break;
+            }
+            if (n_set > 0 && sched_setaffinity(0, sizeof(want_aff), &want_aff) == 0) aff_changed = true;
+        }
+    }
+    struct RestoreAffinity { bool on; cpu_set_t* old; ~RestoreAffinity() { if (on) sched_setaffinity(0, sizeof(cpu_set_t), old); } } restore_aff{aff_changed, &old_aff};
     auto t_start = std::chrono::steady_clock::now();
     WorkerPool pool(threads + 2);  // + 2: the stage threads mostly wait inside run()
     // A fixed pool of batch objects circulates producer -> GPU workers -> writer -> producer, so the pinned
     // buffers are allocated once and the number of batches in flight is bounded.
     const size_t max_batches = aligners.size() * 2 + 2;
-    Channel<std::unique_ptr<Batch>> to_gather(max_batches), to_gpu(max_batches), to_out(max_batches), free_batches(max_batches);
+    Channel<std::unique_ptr<Batch>> to_gather(max_batches), to_out(max_batches), free_batches(max_batches);
+    std::vector<std::unique_ptr<Channel<std::unique_ptr<Batch>>>> to_gpu;  // one queue per device: its workers and its share of the batches
+    for (unsigned g = 0; g < n_gpus; ++g) to_gpu.push_back(std::make_unique<Channel<std::unique_ptr<Batch>>>(max_batches));
     std::atomic<size_t> created{0};
     auto take_batch = [&](std::unique_ptr<Batch>& b) {  // reuse a finished batch; create one only while below the cap
         if (free_batches.try_pop(b)) return true;
@@ -493,9 +552,18 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         const uint64_t est_bytes = std::min<uint64_t>(max_file, opt->fastq ? batch_reads * 160 : group0 * chunk_bytes);
         const uint64_t est_n = std::min<uint64_t>(batch_reads + batch_reads / 4, est_bytes / 16 + 1);
         const size_t need = est_bytes ? (size_t)std::min<uint64_t>(n_pins, (total_in + est_bytes - 1) / est_bytes + 1) : 1;
+        const uint64_t est_piece = std::min<uint64_t>(max_file, piece_bytes + piece_bytes / 16);
+        const size_t need_text = est_piece ? (size_t)std::min<uint64_t>(n_pins, (total_in + est_piece - 1) / est_piece + 1) : 1;
         for (size_t i = 0; i < n_pins; ++i) {
-            auto pn = std::make_unique<Pinned>();
-            if (i < need) {  // best effort: the stages grow what turns out too small
+            std::unique_ptr<Pinned> pn;
+            {
+                std::lock_guard<std::mutex> l(g_pin_cache_m);  // a set left by an earlier run of this process
+                if (!g_pin_cache.empty()) { pn = std::move(g_pin_cache.back()); g_pin_cache.pop_back(); }
+            }
+            if (!pn) pn = std::make_unique<Pinned>();
+            if (text_route) {  // best effort: the stages grow what turns out too small
+                if (i < need_text) (void)(pn->text.ensure(est_piece + 64) && pn->ptext.ensure(est_piece / 2 + 4096) && pn->ntext.ensure(est_piece / 2 + 4096));
+            } else if (i < need) {
                 (void)(pn->fw3.ensure(bgr::packed_plane_words(est_n, est_bytes) * 8) && pn->hasn.ensure((est_n / 32 + 2) * 4) && pn->offs.ensure((est_n + 1) * 8) &&
                        pn->paths.ensure((8 * est_n + 4096) * 4) && pn->poffs.ensure((est_n + 1) * 8) && pn->status.ensure(est_n + 1));
             }
@@ -505,7 +573,6 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     });
 
     // ---- stage 1: parse + gather -----------------------------------------------------------------------
-    const bool progress_blocks = opt->echo_files && prm->mode == BGR_MODE_EXHAUSTIVE;
     std::thread producer([&]() {
         uint64_t next_index = 0;
         std::string list(reads_csv);
@@ -518,6 +585,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             if (!take_batch(b)) return false;
             b->file = mf;
             b->bases = 0;
+            b->text_piece = b->dev_text = false;
             b->marks.clear();
             for (auto& m : pending) { m.pos = 0; b->marks.push_back(std::move(m)); }
             pending.clear();
@@ -608,6 +676,19 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 }
                 continue;
             }
+            if (text_route) {  // pieces of the file as they are: the device finds the records (the worker falls back per piece)
+                std::vector<uint64_t> cuts = bgr::split_fasta(mf->data, mf->size, piece_bytes);
+                for (size_t c = 0; c < cuts.size() && !failed && ok; ++c) {
+                    std::unique_ptr<Batch> b;
+                    if (!open_batch(b, mf)) { ok = false; break; }
+                    b->text_piece = true;
+                    b->dev_text = false;
+                    b->t_begin = cuts[c];
+                    b->t_end = c + 1 < cuts.size() ? cuts[c + 1] : mf->size;
+                    ok = emit(std::move(b));
+                }
+                continue;
+            }
             std::vector<uint64_t> starts = bgr::split_fasta(mf->data, mf->size, chunk_bytes);
             size_t c = 0;
             while (c < starts.size() && !failed && ok) {
@@ -649,73 +730,125 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     });
 
     // ---- stage 1b: gather the sequences of a batch into (pooled) pinned memory ---------------------------
-    std::thread gatherer([&]() {
-        // false = the batch could not be staged (the error is recorded); it still travels on, so that the writer sees every
-        // index and recycles every batch (a dropped batch would leave the producer waiting for a free one for ever)
-        auto gather = [&](Batch& b) {
-            uint64_t bases = 0;
-            if (!free_pins.pop(b.pin)) { fail(BGR_E_INTERNAL, "pinned buffer pool closed"); return false; }
-            const uint64_t tg0 = now_us();
-            if (!b.pin->offs.ensure((b.n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            uint64_t* offs = static_cast<uint64_t*>(b.pin->offs.p);
-            for (uint64_t i = 0; i < b.n; ++i) { offs[i] = bases; bases += b.recs[i].sl; }
-            offs[b.n] = bases;
-            b.bases = bases;
-            // typical paths are a handful of ints; the worker fetches again with the full bound if not.  A batch large enough
-            // for bgr_align_batch to map it in pieces gets the full bound at once (there is no single result to fetch again).
-            b.path_cap = 2 * (bases + 8 * b.n) >= (1ull << 31) ? bases + 8 * b.n + 8 : 8 * b.n + 4096;
-            if (!b.pin->fw3.ensure(bgr::packed_plane_words(b.n, bases) * 8) || !b.pin->hasn.ensure((b.n / 32 + 2) * 4) || !b.pin->paths.ensure(b.path_cap * 4) ||
-                !b.pin->poffs.ensure((b.n + 1) * 8) || !b.pin->status.ensure(b.n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-            uint64_t* fw3 = static_cast<uint64_t*>(b.pin->fw3.p);
-            uint32_t* hasn = static_cast<uint32_t*>(b.pin->hasn.p);
-            us_alloc += now_us() - tg0;
-            const uint64_t tg1 = now_us();
-            // pack (instead of copy) the sequences into the page-locked plane: every thread a range of whole bitmap words
-            const uint64_t per = (((b.n + threads - 1) / threads) + 31) & ~31ull;
-            Batch* bp = &b;
-            struct Part { std::vector<uint32_t> idx; std::vector<uint64_t> val; uint32_t max_len = 0; };
-            std::vector<Part> parts(threads);
-            pool.run(threads, [&](size_t t) {
-                const uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
-                if (lo >= hi) return;
-                Part& pt = parts[t];
-                std::vector<uint64_t> nm;
-                memset(hasn + lo / 32, 0, ((hi - lo + 31) / 32) * 4);
-                for (uint64_t i = lo; i < hi; ++i) {
-                    const uint32_t len = bp->recs[i].sl, words = (len + 31) >> 5;
-                    if (nm.size() < words) nm.resize(words);
-                    const uint64_t w0 = bgr::packed_word_offset(offs[i], i);
-                    pt.max_len = std::max(pt.max_len, len);
-                    if (bgr::pack_read(bp->recs[i].s, len, fw3 + w0, nm.data())) {
-                        hasn[i >> 5] |= 1u << (i & 31);
-                        for (uint32_t j = 0; j < words; ++j) { pt.idx.push_back((uint32_t)(w0 + j)); pt.val.push_back(nm[j]); }
-                    }
-                }
-            }, 2);
-            uint64_t nmc = 0;
-            b.pin->max_len = 0;
-            for (const Part& pt : parts) { nmc += pt.idx.size(); b.pin->max_len = std::max(b.pin->max_len, pt.max_len); }
-            b.pin->nm_count = nmc;
-            if (nmc) {
-                if (!b.pin->nm_idx.ensure(nmc * 4) || !b.pin->nm_val.ensure(nmc * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
-                uint64_t at = 0;
-                for (const Part& pt : parts) {
-                    if (pt.idx.empty()) continue;
-                    memcpy(static_cast<uint32_t*>(b.pin->nm_idx.p) + at, pt.idx.data(), pt.idx.size() * 4);
-                    memcpy(static_cast<uint64_t*>(b.pin->nm_val.p) + at, pt.val.data(), pt.val.size() * 8);
-                    at += pt.idx.size();
+    // false = the batch could not be staged (the error is recorded); it still travels on, so that the writer sees every
+    // index and recycles every batch (a dropped batch would leave the producer waiting for a free one for ever)
+    auto gather = [&](Batch& b) {
+        uint64_t bases = 0;
+        if (!b.pin && !free_pins.pop(b.pin)) { fail(BGR_E_INTERNAL, "pinned buffer pool closed"); return false; }
+        const uint64_t tg0 = now_us();
+        if (!b.pin->offs.ensure((b.n + 1) * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+        uint64_t* offs = static_cast<uint64_t*>(b.pin->offs.p);
+        for (uint64_t i = 0; i < b.n; ++i) { offs[i] = bases; bases += b.recs[i].sl; }
+        offs[b.n] = bases;
+        b.bases = bases;
+        // typical paths are a handful of ints; the worker fetches again with the full bound if not.  A batch large enough
+        // for bgr_align_batch to map it in pieces gets the full bound at once (there is no single result to fetch again).
+        b.path_cap = 2 * (bases + 8 * b.n) >= (1ull << 31) ? bases + 8 * b.n + 8 : 8 * b.n + 4096;
+        if (!b.pin->fw3.ensure(bgr::packed_plane_words(b.n, bases) * 8) || !b.pin->hasn.ensure((b.n / 32 + 2) * 4) || !b.pin->paths.ensure(b.path_cap * 4) ||
+            !b.pin->poffs.ensure((b.n + 1) * 8) || !b.pin->status.ensure(b.n + 1)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+        uint64_t* fw3 = static_cast<uint64_t*>(b.pin->fw3.p);
+        uint32_t* hasn = static_cast<uint32_t*>(b.pin->hasn.p);
+        us_alloc += now_us() - tg0;
+        const uint64_t tg1 = now_us();
+        // pack (instead of copy) the sequences into the page-locked plane: every thread a range of whole bitmap words
+        const uint64_t per = (((b.n + threads - 1) / threads) + 31) & ~31ull;
+        Batch* bp = &b;
+        struct Part { std::vector<uint32_t> idx; std::vector<uint64_t> val; uint32_t max_len = 0; };
+        std::vector<Part> parts(threads);
+        pool.run(threads, [&](size_t t) {
+            const uint64_t lo = t * per, hi = std::min<uint64_t>(bp->n, lo + per);
+            if (lo >= hi) return;
+            Part& pt = parts[t];
+            std::vector<uint64_t> nm;
+            memset(hasn + lo / 32, 0, ((hi - lo + 31) / 32) * 4);
+            for (uint64_t i = lo; i < hi; ++i) {
+                const uint32_t len = bp->recs[i].sl, words = (len + 31) >> 5;
+                if (nm.size() < words) nm.resize(words);
+                const uint64_t w0 = bgr::packed_word_offset(offs[i], i);
+                pt.max_len = std::max(pt.max_len, len);
+                if (bgr::pack_read(bp->recs[i].s, len, fw3 + w0, nm.data())) {
+                    hasn[i >> 5] |= 1u << (i & 31);
+                    for (uint32_t j = 0; j < words; ++j) { pt.idx.push_back((uint32_t)(w0 + j)); pt.val.push_back(nm[j]); }
                 }
             }
-            us_gather += now_us() - tg1;
-            return true;
-        };
+        }, 2);
+        uint64_t nmc = 0;
+        b.pin->max_len = 0;
+        for (const Part& pt : parts) { nmc += pt.idx.size(); b.pin->max_len = std::max(b.pin->max_len, pt.max_len); }
+        b.pin->nm_count = nmc;
+        if (nmc) {
+            if (!b.pin->nm_idx.ensure(nmc * 4) || !b.pin->nm_val.ensure(nmc * 8)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            uint64_t at = 0;
+            for (const Part& pt : parts) {
+                if (pt.idx.empty()) continue;
+                memcpy(static_cast<uint32_t*>(b.pin->nm_idx.p) + at, pt.idx.data(), pt.idx.size() * 4);
+                memcpy(static_cast<uint64_t*>(b.pin->nm_val.p) + at, pt.val.data(), pt.val.size() * 8);
+                at += pt.idx.size();
+            }
+        }
+        us_gather += now_us() - tg1;
+        return true;
+    };
+    // text route: the piece of the file into page-locked memory as it is (pread / memcpy in parallel), output buffers sized
+    auto stage_text = [&](Batch& b) {
+        if (!b.pin && !free_pins.pop(b.pin)) { fail(BGR_E_INTERNAL, "pinned buffer pool closed"); return false; }
+        const uint64_t tg0 = now_us();
+        const uint64_t bytes = b.t_end - b.t_begin;
+        if (!b.pin->text.ensure(bytes + 64) || !b.pin->ptext.ensure(bytes / 2 + 4096) || !b.pin->ntext.ensure(bytes / 2 + 4096)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+        us_alloc += now_us() - tg0;
+        const uint64_t tg1 = now_us();
+        const uint64_t part = 4ull << 20;
+        const size_t parts = (size_t)((bytes + part - 1) / part);
+        std::atomic<bool> okc{true};
+        Batch* bp = &b;
+        pool.run(parts, [&](size_t j) {
+            const uint64_t lo = j * part, len = std::min<uint64_t>(part, bytes - lo);
+            if (!bp->file->copy_out(static_cast<char*>(bp->pin->text.p) + lo, bp->t_begin + lo, len)) okc = false;
+        }, 2);
+        us_gather += now_us() - tg1;
+        if (!okc) { fail(BGR_E_IO, "read error on the read file"); return false; }
+        // ... and on towards its device at once, on the stage's own copy stream: the worker's call finds it there (or waits on the device)
+        if (b.pin->stages.size() < n_gpus) b.pin->stages.resize(n_gpus, nullptr);
+        bgr_text_stage*& st = b.pin->stages[b.dev];
+        if (!st && bgr_text_stage_create((int)(opt->first_device + b.dev), &st) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+        if (bgr_text_stage_upload(st, static_cast<const char*>(b.pin->text.p), bytes) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+        return true;
+    };
+    // a text piece through the host parser after all (the device found it irregular, or the file has shown to be): the exact
+    // getReads state machine, chunk-parallel, then the batch goes the host route (gather, bgr_align_batch_packed, host formatter)
+    auto host_parse_piece = [&](Batch& b) {
+        const uint64_t tp0 = now_us();
+        const char* base = b.file->data + b.t_begin;
+        const uint64_t bytes = b.t_end - b.t_begin;
+        std::vector<uint64_t> starts = bgr::split_fasta(base, bytes, chunk_bytes);
+        b.chunks.clear();
+        b.chunks.resize(starts.size());
+        for (auto& ch : b.chunks) ch = std::make_unique<ParsedChunk>();
+        Batch* bp = &b;
+        pool.run(starts.size(), [&](size_t j) {
+            const uint64_t e = j + 1 < starts.size() ? starts[j + 1] : bytes;
+            bgr::parse_fasta_chunk(base, starts[j], e, gi.k, *bp->chunks[j]);
+        }, 1);
+        b.recs.clear();
+        for (auto& ch : b.chunks) b.recs.insert(b.recs.end(), ch->recs.begin(), ch->recs.end());
+        b.n = b.recs.size();
+        b.dev_text = false;
+        us_parse += now_us() - tp0;
+    };
+    std::thread gatherer([&]() {
         std::unique_ptr<Batch> b;
         while (to_gather.pop(b)) {
-            if (failed || !gather(*b)) { if (!to_out.push(std::move(b))) break; continue; }
-            if (!to_gpu.push(std::move(b))) break;
+            b->dev = (unsigned)(b->index % n_gpus);
+            if (b->text_piece && b->file->irregular_pieces.load() >= 2) {  // this file is not of the device's shape: host route from here on
+                host_parse_piece(*b);
+                b->text_piece = false;
+            }
+            if (failed || !(b->text_piece ? stage_text(*b) : gather(*b))) { if (!to_out.push(std::move(b))) break; continue; }
+            const unsigned dv = b->dev;
+            if (!to_gpu[dv]->push(std::move(b))) break;
         }
         to_gather.close();  // (after a failure: unblock the producer)
-        to_gpu.close();
+        for (auto& q : to_gpu) q->close();
     });
 
     // ---- stage 2: GPU workers --------------------------------------------------------------------------
@@ -724,8 +857,44 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     for (size_t w = 0; w < aligners.size(); ++w) {
         workers.emplace_back([&, w]() {
             std::unique_ptr<Batch> b;
-            while (to_gpu.pop(b)) {
-                if (!failed) {
+            Channel<std::unique_ptr<Batch>>& my_q = *to_gpu[w / per_dev];  // (aligners are created device by device, per_dev each)
+            while (my_q.pop(b)) {
+                if (!failed && b->text_piece) {  // FASTA bytes in, record bytes out (bgr_align_fasta_text)
+                    const uint64_t tq0 = now_us();
+                    bgr_text_batch tb;
+                    memset(&tb, 0, sizeof(tb));
+                    tb.text = static_cast<const char*>(b->pin->text.p);
+                    tb.text_bytes = b->t_end - b->t_begin;
+                    tb.stage = b->pin->stages.size() > b->dev ? b->pin->stages[b->dev] : nullptr;
+                    tb.want_output = writes ? 1u : 0u;
+                    tb.paths_out = static_cast<char*>(b->pin->ptext.p);
+                    tb.paths_cap = b->pin->ptext.cap;
+                    tb.notaligned_out = static_cast<char*>(b->pin->ntext.p);
+                    tb.notaligned_cap = b->pin->ntext.cap;
+                    int rc = bgr_align_fasta_text(aligners[w], prm, &tb);
+                    if (rc == BGR_E_CAPACITY) {  // unusually long records: the same device results into larger buffers
+                        if (!b->pin->ptext.ensure(tb.paths_bytes + 64) || !b->pin->ntext.ensure(tb.notaligned_bytes + 64)) rc = BGR_E_HIP;
+                        else {
+                            tb.paths_out = static_cast<char*>(b->pin->ptext.p); tb.paths_cap = b->pin->ptext.cap;
+                            tb.notaligned_out = static_cast<char*>(b->pin->ntext.p); tb.notaligned_cap = b->pin->ntext.cap;
+                            rc = bgr_aligner_fetch_text(aligners[w], &tb);
+                        }
+                    }
+                    if (rc != BGR_OK) fail(rc, bgr_last_error());
+                    else if (tb.irregular) {
+                        b->file->irregular_pieces.fetch_add(1);
+                        host_parse_piece(*b);
+                        b->text_piece = false;
+                        if (!gather(*b)) { if (!to_out.push(std::move(b))) break; continue; }
+                    } else {
+                        b->dev_text = true;
+                        b->n = tb.n_accepted;
+                        b->p_bytes = tb.paths_bytes;
+                        b->n_bytes = tb.notaligned_bytes;
+                    }
+                    us_gpu += now_us() - tq0;
+                }
+                if (!failed && !b->text_piece) {
                     const uint64_t tq0 = now_us();
                     bgr_packed_reads pk;
                     pk.read_offsets = static_cast<const uint64_t*>(b->pin->offs.p);
@@ -754,16 +923,40 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
 
     // ---- stage 3: format (range-parallel) in batch order, stage 4: one thread writes the formatted buffers ----------
     struct OutBufs { std::vector<std::string> pb, nb, ob; };
-    Channel<std::unique_ptr<OutBufs>> to_io(2), free_bufs(4);
+    // what the writer hands to the I/O thread: formatted buffers (host route) or the batch itself, whose page-locked buffers hold the
+    // two record streams as the device wrote them (text route; the batch is recycled once they are on their way to the files)
+    struct IoItem { std::unique_ptr<OutBufs> bufs; std::unique_ptr<Batch> batch; };
+    Channel<IoItem> to_io(2);
+    Channel<std::unique_ptr<OutBufs>> free_bufs(4);
     for (int i = 0; i < 3; ++i) {
         auto ob = std::make_unique<OutBufs>();
         ob->pb.resize(threads); ob->nb.resize(threads); ob->ob.resize(threads);
         free_bufs.push(std::move(ob));
     }
+    auto recycle_batch = [&](std::unique_ptr<Batch>& b) {  // hand the batch (and its pinned buffers) back to the producer
+        if (!b) return;
+        if (b->pin) free_pins.push(std::move(b->pin));
+        b->recs.clear(); b->marks.clear(); b->chunks.clear(); b->file.reset();
+        free_batches.push(std::move(b));
+    };
     std::thread io_thread([&]() {
-        std::unique_ptr<OutBufs> o;
-        while (to_io.pop(o)) {
+        IoItem it;
+        while (to_io.pop(it)) {
             const uint64_t tw0 = now_us();
+            if (it.batch) {
+                Batch* tbp = it.batch.get();
+                pool.run(2, [&](size_t w) {  // the files are independent streams: one writer each
+                    if (w == 0) {
+                        if (tbp->p_bytes && fwrite(tbp->pin->ptext.p, 1, tbp->p_bytes, pathF) != tbp->p_bytes) fail(BGR_E_IO, "write to the paths file failed");
+                    } else {
+                        if (tbp->n_bytes && fwrite(tbp->pin->ntext.p, 1, tbp->n_bytes, notF) != tbp->n_bytes) fail(BGR_E_IO, "write to the notAligned file failed");
+                    }
+                }, 4);
+                us_write += now_us() - tw0;
+                recycle_batch(it.batch);
+                continue;
+            }
+            std::unique_ptr<OutBufs>& o = it.bufs;
             pool.run(2, [&](size_t w) {  // the files are independent streams: one writer each
                 for (unsigned t = 0; t < threads; ++t) {
                     if (w == 0) {
@@ -816,10 +1009,10 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 std::unique_ptr<Batch> cur = std::move(pending.begin()->second);
                 pending.erase(pending.begin());
                 ++want;
-                struct Recycle {  // hand the batch (and its pinned buffers) back to the producer
-                    Channel<std::unique_ptr<Batch>>& ch; Channel<std::unique_ptr<Pinned>>& pins; std::unique_ptr<Batch>& b;
-                    ~Recycle() { if (b->pin) pins.push(std::move(b->pin)); b->recs.clear(); b->marks.clear(); b->chunks.clear(); b->file.reset(); ch.push(std::move(b)); }
-                } recycle{free_batches, free_pins, cur};
+                struct Recycle {  // hand the batch (and its pinned buffers) back to the producer, unless the I/O thread got it
+                    decltype(recycle_batch)& fn; std::unique_ptr<Batch>& b;
+                    ~Recycle() { fn(b); }
+                } recycle{recycle_batch, cur};
                 if (!failed) {  // what the reference prints between reads, in input order
                     uint64_t at = 0;
                     for (const Mark& mk : cur->marks) {
@@ -829,6 +1022,12 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     if (progress_blocks) count_reads(*cur, at, cur->n);
                 }
                 if ((failed && !stop_writing_after_this) || !writes || wrote_last || cur->n == 0) continue;
+                if (cur->dev_text) {  // the record streams are ready as they are
+                    IoItem item;
+                    item.batch = std::move(cur);
+                    to_io.push(std::move(item));
+                    continue;
+                }
                 std::unique_ptr<OutBufs> o;
                 if (!free_bufs.pop(o)) continue;
                 std::vector<std::string>&pb = o->pb, &nb = o->nb, &ob = o->ob;
@@ -853,7 +1052,9 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     stop_writing_after_this = true;
                 }
                 us_format += now_us() - tf0;
-                to_io.push(std::move(o));  // the formatted records never point into the batch: it can be recycled now
+                IoItem item;
+                item.bufs = std::move(o);
+                to_io.push(std::move(item));  // the formatted records never point into the batch: it can be recycled now
                 if (stop_writing_after_this) wrote_last = true;
             }
         }
@@ -865,8 +1066,13 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     for (auto& t : workers) t.join();
     writer.join();
     io_thread.join();
-    free_pins.close();
     pin_allocator.join();
+    {   // the page-locked sets wait for the next run of this process (bgr_host_cache_release)
+        std::unique_ptr<Pinned> pn;
+        std::lock_guard<std::mutex> l(g_pin_cache_m);
+        while (free_pins.try_pop(pn)) if (g_pin_cache.size() < 8) g_pin_cache.push_back(std::move(pn));
+    }
+    free_pins.close();
     free_batches.close();
     free_bufs.close();
     fclose(pathF);

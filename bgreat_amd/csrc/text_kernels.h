@@ -1,0 +1,40 @@
+// text_kernels.h -- launch interface of text_kernels.hip (FASTA text in, formatted records out; see there).
+#ifndef BGREAT_AMD_TEXT_KERNELS_H
+#define BGREAT_AMD_TEXT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// words of the small device `info` block of a text batch
+#define TXT_INFO_N_REC 0      /* record starts found */
+#define TXT_INFO_N_ACC 1      /* records accepted (aligner.cpp:78-88) */
+#define TXT_INFO_BASES 2      /* bases of the accepted records */
+#define TXT_INFO_MAX_LEN 3
+#define TXT_INFO_IRREGULAR 4  /* the piece is not of the shape this route takes: the caller parses it on the host */
+#define TXT_INFO_PBYTES 5     /* bytes of the paths stream */
+#define TXT_INFO_NBYTES 6     /* bytes of the notAligned stream */
+#define TXT_INFO_WORDS 8
+
+namespace bgr {
+
+// exclusive scan of n u32 (out may alias in); sums: scan_tiles(n) words of scratch; *total_out = the sum
+hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, uint32_t* total_out, hipStream_t stream);
+uint32_t scan_tiles(uint32_t n);
+uint32_t text_tiles(uint32_t bytes);
+// record starts: *n_rec_out and rec_start[0 .. min(*n_rec_out, rec_cap)) (sums: text_tiles(n) words of scratch)
+hipError_t launch_text_mark(const uint8_t* text, uint32_t n, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream);
+hipError_t launch_text_records(const uint8_t* text, uint32_t n, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t max_rec, uint32_t k, uint4* rec,
+                               uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, hipStream_t stream);
+hipError_t launch_text_compact(const uint4* rec, const uint32_t* n_rec_p, uint32_t max_rec, const uint32_t* acc_idx, const uint32_t* base_off, uint32_t* acc_rec,
+                               uint32_t* acc_src, uint64_t* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p, hipStream_t stream);
+hipError_t launch_text_sizes(const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* psz, uint32_t* nsz,
+                             hipStream_t stream);
+hipError_t launch_text_write(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc,
+                             const uint32_t* poff, const uint32_t* noff, uint8_t* pout, uint8_t* nout, hipStream_t stream);
+// the pre-pass (batch_kernels.hip) over reads that lie scattered in a text: read r's characters start at reads + src_off[r]
+hipError_t launch_pack_reads_at(const uint8_t* text, const uint32_t* src_off, const uint64_t* read_offs, uint32_t n, uint64_t text_bytes, uint64_t total_bases,
+                                uint64_t* fw3, uint64_t* nmw, uint32_t* hasn, hipStream_t stream);
+
+}  // namespace bgr
+
+#endif

@@ -168,6 +168,38 @@ int bgr_pack_reads(const char* reads, const uint64_t* read_offsets, uint64_t n_r
 int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed_reads* reads, uint64_t n_reads, int32_t* paths_out,
                            uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
 
+/* Text form: one piece of a FASTA file in, the bytes to append to `paths` / `notAligned.fa` out -- the whole per-batch body of
+ * Aligner::alignPartGreedy (alignerGreedy.cpp:367-431: getReads, alignReadGreedy per read, the fwrite of a record) on the device,
+ * so a batch crosses PCIe as the file's own bytes (text_kernels.hip).  The piece must start at a header line and end behind the
+ * newline of a sequence line (or at the end of the file).  The device takes the shape nearly every piece has (header line, ONE
+ * sequence line, next header ...); for any other piece (multi-line sequences, blank lines, a last record without its newline)
+ * the call returns BGR_OK with `irregular` = 1 and NOTHING mapped: the caller then parses that piece on the host (the exact
+ * getReads state machine) and uses bgr_align_batch*, so the records are the reference's either way.
+ * BGR_E_CAPACITY: an output buffer is too small; paths_bytes / notaligned_bytes say what is needed, the mapping is done, and
+ * bgr_aligner_fetch_text delivers the same bytes into larger buffers.  Blocking; page-locked buffers recommended. */
+typedef struct bgr_text_stage bgr_text_stage;
+typedef struct {
+    const char* text;             /* in: the piece (may be NULL when `stage` holds it) */
+    uint64_t text_bytes;          /*     < 2^31 */
+    uint32_t want_output;         /*     0 = map and count only (-b without --write-exhaustive writes nothing) */
+    uint32_t irregular;           /* out */
+    char* paths_out;              /* in: where the records of mapped reads go */
+    uint64_t paths_cap;
+    char* notaligned_out;         /*     and those of the others (never more than text_bytes) */
+    uint64_t notaligned_cap;
+    uint64_t n_records, n_accepted, paths_bytes, notaligned_bytes;   /* out */
+    bgr_text_stage* stage;        /* in, optional: the piece was sent ahead with bgr_text_stage_upload (same bytes, same device): the call
+                                     waits for that copy on the device instead of making its own */
+} bgr_text_batch;
+/* A stage = a device buffer for one piece + a copy stream: bgr_text_stage_upload starts the host -> device copy and returns; the
+ * bgr_align_fasta_text call that names the stage orders itself behind it (hipStreamWaitEvent), so the copy of the next piece runs
+ * under the kernels of this one.  The host bytes must stay untouched until that call has returned. */
+int bgr_text_stage_create(int device, bgr_text_stage** out);
+void bgr_text_stage_destroy(bgr_text_stage* s);
+int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t text_bytes);
+int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b);
+int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b);
+
 /* Device-resident form: inputs already in this device's HBM (d_reads bytes, d_read_offsets uint64[n+1]);
  * results stay in aligner-owned device buffers (bgr_aligner_device_results).  Asynchronous on the
  * aligner's stream; max_read_len = longest read in the batch (< 2^24), total_bases = read_offsets[n].
@@ -248,12 +280,13 @@ int bgr_write_records(void* paths_file, void* notaligned_file, uint64_t n_reads,
 /* ---- whole run -------------------------------------------------------------------------------------
  * Batch form of Aligner::alignAll (aligner.cpp:550-597): maps every file of the comma-separated list `reads_csv`
  * and writes `paths_file` / `notaligned_file` (opened "wb" like aligner.h:85-86) with the bytes the reference
- * produces at -t 1, whatever the thread / GPU count.  Host pipeline: chunk-parallel parsing, pinned batches,
- * two streams per device, range-parallel formatting, one ordered writer.  counters_out as bgr_aligner_counters. */
+ * produces at -t 1, whatever the thread / GPU count.  Two routes per batch, same bytes: the device takes FASTA text and
+ * returns the bytes to write (`route`), or the host pipeline parses chunk-parallel, packs into pinned batches and formats
+ * range-parallel; two streams per device, one ordered writer.  counters_out as bgr_aligner_counters. */
 typedef struct {
     uint32_t n_gpus;           /* devices 0..n_gpus-1 (0 = 1)                                                  */
     uint32_t threads;          /* host threads for parsing / gathering / formatting (-t; 0 = 1)                */
-    uint64_t batch_reads;      /* target reads per device batch (0 = default 1M)                                */
+    uint64_t batch_reads;      /* target reads per device batch (0 = default: 128k on the host route, 256k as text)  */
     uint64_t chunk_bytes;      /* parser chunk size (0 = default 8 MiB)                                         */
     uint32_t fastq;            /* -q                                                                            */
     uint32_t write_exhaustive; /* exhaustive mode writes nothing in the reference; 1 = write  */
@@ -267,9 +300,19 @@ typedef struct {
                                   alignerGreedy.cpp:414-419 disables                                               */
     uint32_t first_device;     /* devices first_device .. first_device + n_gpus - 1 (one process per GPU under a launcher
                                   that does not hide the others: first_device = the rank's local index, n_gpus = 1)   */
+    uint32_t route;            /* 0 = automatic: FASTA input without -c / --no-overlap / -b progress blocks goes through the device as
+                                  text (bgr_align_fasta_text: parsing, packing, mapping and record formatting on the GPU; pieces of an
+                                  irregular shape fall back to the host parser one by one); 1 = host parser + host formatter always */
 } bgr_run_options;
+/* bgr_align_all keeps its page-locked staging buffers for the next call of the process (they cost ~0.2 s per GB to allocate);
+ * this frees them. */
+void bgr_host_cache_release(void);
 int bgr_align_all(bgr_graph* g, const bgr_params* p, const bgr_run_options* o, const char* reads_csv, const char* paths_file,
                   const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds);
+
+/* The CPUs next to a device (the `local_cpulist` of its PCI function in sysfs, e.g. "0-63,128-191"): threads that feed a GPU and the
+ * page-locked memory they allocate belong on its NUMA node.  BGR_E_IO when the platform does not say. */
+int bgr_device_local_cpus(int device, char* cpulist_out, uint64_t cap);
 
 /* Page-locked host memory for batches handed to bgr_align_batch (faster H2D/D2H); plain memory works too. */
 int bgr_host_alloc(uint64_t bytes, void** out);

@@ -19,7 +19,7 @@
 #include "fastx.h"
 
 struct bgr_graph { uint32_t k; };
-struct bgr_aligner { uint64_t counters[5] = {0, 0, 0, 0, 0}; };
+struct bgr_aligner { uint64_t counters[5] = {0, 0, 0, 0, 0}; std::string ps, ns; /* text form: the last call's streams, for bgr_aligner_fetch_text */ };
 static thread_local std::string tl_err;
 namespace bgr { int set_error(int code, const std::string& msg) { tl_err = msg; return code; } }
 extern "C" {
@@ -28,6 +28,7 @@ int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* o) { memset(o, 0, sizeo
 int bgr_graph_unitigs(const bgr_graph*, const char**, const uint64_t**, uint64_t*) { return BGR_E_ARG; }
 int bgr_aligner_create(bgr_graph*, int, bgr_aligner** out) { *out = new bgr_aligner(); return BGR_OK; }
 void bgr_aligner_destroy(bgr_aligner* a) { delete a; }
+int bgr_device_local_cpus(int, char*, uint64_t) { return BGR_E_IO; }
 int bgr_host_alloc(uint64_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? BGR_OK : BGR_E_HIP; }
 int bgr_host_free(void* p) { free(p); return BGR_OK; }
 int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) { memcpy(out, a->counters, sizeof(a->counters)); return BGR_OK; }
@@ -60,6 +61,64 @@ int bgr_align_batch_packed(bgr_aligner* a, const bgr_params*, const bgr_packed_r
 }
 }
 
+// Stand-in for the text form (bgr_align_fasta_text): the same contract on the CPU -- a piece of the regular shape (header line,
+// one sequence line, ... , ends with a newline) is "mapped" with the rule above and comes back as record bytes; any other piece is
+// handed back as irregular, untouched.
+struct bgr_text_stage { int device; std::string copy; };
+extern "C" int bgr_text_stage_create(int device, bgr_text_stage** out) { *out = new bgr_text_stage{device, std::string()}; return BGR_OK; }
+extern "C" void bgr_text_stage_destroy(bgr_text_stage* s) { delete s; }
+extern "C" int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t n) { s->copy.assign(text, n); return BGR_OK; }
+extern "C" int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
+    b->paths_bytes = a->ps.size();
+    b->notaligned_bytes = a->ns.size();
+    if (a->ps.size() > b->paths_cap || a->ns.size() > b->notaligned_cap) return BGR_E_CAPACITY;
+    memcpy(b->paths_out, a->ps.data(), a->ps.size());
+    memcpy(b->notaligned_out, a->ns.data(), a->ns.size());
+    return BGR_OK;
+}
+extern "C" int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_batch* b) {
+    b->irregular = 0; b->n_records = b->n_accepted = b->paths_bytes = b->notaligned_bytes = 0;
+    if (b->stage && (b->stage->copy.size() != b->text_bytes || (b->text_bytes && memcmp(b->stage->copy.data(), b->text, b->text_bytes) != 0))) return BGR_E_INTERNAL;  // the staged piece is this piece
+    const char* t = b->stage ? b->stage->copy.data() : b->text;
+    const uint64_t n = b->text_bytes;
+    if (n == 0) return BGR_OK;
+    std::vector<std::pair<uint64_t, uint64_t>> lines;  // [begin, end) without the newline
+    uint64_t p = 0;
+    while (p < n) {
+        const char* q = static_cast<const char*>(memchr(t + p, '\n', n - p));
+        if (!q) { b->irregular = 1; return BGR_OK; }   // last line without its newline
+        lines.push_back({p, (uint64_t)(q - t)});
+        p = (uint64_t)(q - t) + 1;
+    }
+    if (lines.size() % 2) { b->irregular = 1; return BGR_OK; }
+    for (size_t i = 0; i < lines.size(); ++i) {
+        const bool gt = lines[i].second > lines[i].first && t[lines[i].first] == '>';
+        if ((i % 2 == 0) != gt) { b->irregular = 1; return BGR_OK; }  // headers start with '>', sequence lines do not
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200 + (n * 31) % 900));
+    std::string& ps = a->ps;
+    std::string& ns = a->ns;
+    ps.clear(); ns.clear();
+    uint64_t acc = 0;
+    const uint32_t k = 5;  // (the FASTA cases of this harness run with k = 5)
+    for (size_t i = 0; i < lines.size(); i += 2) {
+        ++b->n_records;
+        const std::string h(t + lines[i].first, t + lines[i].second), r(t + lines[i + 1].first, t + lines[i + 1].second);
+        bool ok = r.size() > 2 && r.size() > k;
+        for (char c : r) if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') ok = false;
+        if (!ok) continue;
+        if (r.size() & 1) { ps += h + "\n" + std::to_string(r.size()) + ".-" + std::to_string(acc) + ".7.\n"; ++a->counters[2]; }
+        else { ns += h + "\n" + r + "\n"; ++a->counters[3]; }
+        ++a->counters[0];
+        ++acc;
+    }
+    b->n_accepted = acc;
+    b->paths_bytes = ps.size();
+    b->notaligned_bytes = ns.size();
+    if (!b->want_output) return BGR_OK;
+    return bgr_aligner_fetch_text(a, b);  // (BGR_E_CAPACITY when a stream does not fit: the pipeline grows its buffer and fetches again)
+}
+
 static std::string slurp(const std::string& p) { std::ifstream in(p, std::ios::binary); std::stringstream ss; ss << in.rdbuf(); return ss.str(); }
 
 int main(int argc, char** argv) {
@@ -79,6 +138,8 @@ int main(int argc, char** argv) {
     const Case cases[] = {{"syn_r150.fa", false}, {"edge_reads.fa", false}, {"long_r150.fq", true}, {"deg_reads.fa", false}, {"big.fq", true}};
     for (const Case& c : cases) {
         for (unsigned threads : {1u, 6u}) {
+          for (uint32_t route : {0u, 1u}) {  // FASTA: through the (stand-in) device as text, with the fall-back per irregular piece, and the host route
+            if (c.fastq && route == 0) continue;
             for (uint64_t batch : {1ull, 37ull, 100000ull}) {
                 if (std::string(c.file) == "big.fq" && batch == 1) continue;  // 50 000 one-read batches: slow under TSan, nothing new
                 const std::string in = (std::string(c.file) == "big.fq" ? tmp : gold) + "/" + c.file, pf = tmp + "/p", nf = tmp + "/n";
@@ -86,10 +147,10 @@ int main(int argc, char** argv) {
                 bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
                 bgr_run_options opt;
                 memset(&opt, 0, sizeof(opt));
-                opt.n_gpus = 2; opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 700; opt.fastq = c.fastq;
+                opt.n_gpus = 2; opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 700; opt.fastq = c.fastq; opt.route = route;
                 uint64_t tot[5]; double secs;
                 const std::string list = in + "," + in;  // two files: the batches of the second must follow the first's
-                if (bgr_align_all(&g, &prm, &opt, list.c_str(), pf.c_str(), nf.c_str(), tot, &secs) != BGR_OK) { printf("FAIL run: %s\n", bgr_last_error()); return 1; }
+                { const int rc_ = bgr_align_all(&g, &prm, &opt, list.c_str(), pf.c_str(), nf.c_str(), tot, &secs); if (rc_ != BGR_OK) { printf("FAIL run (%s threads=%u batch=%llu route=%u): rc %d %s\n", c.file, threads, (unsigned long long)batch, route, rc_, bgr_last_error()); return 1; } }
                 // expected bytes straight from the sequential parser
                 const std::string d = slurp(in);
                 bgr::ReadSet rs; bgr::parse_reads(d.data(), d.size(), c.fastq, g.k, rs);
@@ -112,11 +173,12 @@ int main(int argc, char** argv) {
                       if (!header) { size_t a = line.find('.'), b = line.find('.', a + 1); if (a == std::string::npos || b == std::string::npos) { printf("FAIL path line\n"); return 1; } line = line.substr(0, a + 1) + "#" + line.substr(b); }
                       gp2 += line + "\n"; header = !header; } }
                 if (gp2 != ep || gn != en || tot[0] != 2 * rs.count() || tot[2] != aligned) {
-                    printf("FAIL %s threads=%u batch=%llu: paths %zu/%zu notAligned %zu/%zu reads %llu/%llu\n", c.file, threads, (unsigned long long)batch,
+                    printf("FAIL %s threads=%u batch=%llu route=%u: paths %zu/%zu notAligned %zu/%zu reads %llu/%llu\n", c.file, threads, (unsigned long long)batch, route,
                            gp2.size(), ep.size(), gn.size(), en.size(), (unsigned long long)tot[0], (unsigned long long)(2 * rs.count()));
                     return 1;
                 }
             }
+          }
         }
         printf("%s ok\n", c.file);
     }

@@ -169,14 +169,16 @@ def test_cli_end_to_end_against_reference_binary(oracle_bins):
         s.write_reads(os.path.join(d, "r.fa"), 0, 200000, 150, 3, 4243)
         args = ["-r", os.path.join(d, "r.fa"), "-k", "31", "-g", os.path.join(d, "u.fa"), "-m", "2"]
         o1, p1, n1 = run_cli(ref, args + ["-t", "1"])
-        o2, p2, n2 = run_cli(B.CLI_PATH, args + ["-t", "8", "--batch", "30000", "--chunk-bytes", "1000000"])
         from util import parse_counters
-        assert parse_counters(o1) == parse_counters(o2)
-        assert p1 == p2 and n1 == n2
-        # the whole stdout, line for line, but for the three wall-clock lines (aligner.cpp:546,559,588-596)
         def timeless(o):
             return [ln for ln in o.splitlines() if "seconds" not in ln]
-        assert timeless(o1) == timeless(o2)
+        # both routes: the device takes the file as text (parse, map, format on the GPU), and the host pipeline (--host-route)
+        for extra in ([], ["--host-route"], ["--batch", "7001"]):
+            o2, p2, n2 = run_cli(B.CLI_PATH, args + ["-t", "8", "--batch", "30000", "--chunk-bytes", "1000000"] + extra)
+            assert parse_counters(o1) == parse_counters(o2), extra
+            assert p1 == p2 and n1 == n2, extra
+            # the whole stdout, line for line, but for the three wall-clock lines (aligner.cpp:546,559,588-596)
+            assert timeless(o1) == timeless(o2), extra
 
 
 @pytest.mark.parametrize("fastq", [False, True])
@@ -223,10 +225,13 @@ def test_cli_on_messy_files_against_reference_binary(oracle_bins, fastq, tmp_pat
         open(f, "wb").write(text)
         args = ["-r", f, "-k", "31", "-g", str(tmp_path / "u.fa"), "-m", "2"] + (["-q"] if fastq else [])
         o1, p1, n1 = run_cli(ref, args + ["-t", "1"])
-        o2, p2, n2 = run_cli(B.CLI_PATH, args + ["-t", "5", "--batch", "700", "--chunk-bytes", "3000"])
         from util import parse_counters
-        assert parse_counters(o1) == parse_counters(o2), it
-        assert p1 == p2 and n1 == n2, it
+        # (FASTA: by default every piece goes to the device as text first and comes back as irregular -- the fall-back per piece,
+        # then per file; --host-route: the host parser from the start)
+        for extra in ([], ["--host-route"]):
+            o2, p2, n2 = run_cli(B.CLI_PATH, args + ["-t", "5", "--batch", "700", "--chunk-bytes", "3000"] + extra)
+            assert parse_counters(o1) == parse_counters(o2), (it, extra)
+            assert p1 == p2 and n1 == n2, (it, extra)
         assert parse_counters(o1)["aligned"] > 200
 
 

@@ -1,0 +1,143 @@
+"""The text form of the C-ABI (bgr_align_fasta_text, text_kernels.hip): a piece of a FASTA file in, the bytes of `paths` and
+`notAligned.fa` out.  The device takes pieces of the regular shape (header line, one sequence line); every other piece must come
+back flagged `irregular` with nothing mapped.  Expected bytes = the host route: the exact getReads parser (bgr_readset_load) +
+bgr_align_batch (itself pinned to the oracle and the reference by test_gpu_parity.py) + the reference's record format."""
+import os
+
+import numpy as np
+import pytest
+
+import bgreat_amd as B
+from tools.synth import Synth
+from util import GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_route(al, path_or_bytes, k, tmp_path, m=2, effort=2, mode=B.MODE_GREEDY):
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        f = str(tmp_path / "piece.fa")
+        open(f, "wb").write(path_or_bytes)
+    else:
+        f = path_or_bytes
+    reads, roffs, heads, hoffs = B.load_reads(f, k)
+    n = len(roffs) - 1
+    if n == 0:
+        return b"", b"", 0
+    p, po, st = al.align(reads, roffs, m=m, effort=effort, mode=mode)
+    pb, nb = [], []
+    hb, rb = heads.tobytes(), reads.tobytes()
+    for i in range(n):
+        h = hb[int(hoffs[i]): int(hoffs[i + 1])]
+        if po[i + 1] > po[i]:   # alignerGreedy.cpp:406-411 + printPath aligner.cpp:600-609
+            pb.append(h + b"\n" + b"".join(b"%d." % v for v in p[int(po[i]): int(po[i + 1])]) + b"\n")
+        else:                   # alignerGreedy.cpp:421-427
+            nb.append(h + b"\n" + rb[int(roffs[i]): int(roffs[i + 1])] + b"\n")
+    return b"".join(pb), b"".join(nb), n
+
+
+@pytest.mark.parametrize("reads_file,unitigs,k,m", [("syn_r100.fa", "syn_unitig.fa", 31, 2), ("syn_r150.fa", "syn_unitig.fa", 31, 2), ("syn_r250.fa", "syn_unitig.fa", 31, 5),
+                                                     ("long_r150.fa", "long_unitig.fa", 31, 2), ("toy_reads.fa", "toy_unitig.fa", 4, 2)])
+def test_text_route_equals_host_route_on_golden_files(reads_file, unitigs, k, m, tmp_path):
+    g = B.Graph.from_fasta(os.path.join(GOLD, unitigs), k)
+    al = B.Aligner(g, 0)
+    text = open(os.path.join(GOLD, reads_file), "rb").read()
+    want_p, want_n, n = _host_route(al, os.path.join(GOLD, reads_file), k, tmp_path, m=m)
+    c0 = al.counters()
+    al.reset_counters()
+    got_p, got_n, info = al.align_fasta_text(text, m=m)
+    if info["irregular"]:
+        # a golden file of another shape (multi-line records ...): nothing may have been mapped
+        assert got_p == b"" and got_n == b"" and al.counters()["reads"] == 0
+        pytest.skip("piece not of the regular shape")
+    assert info["n_accepted"] == n
+    assert got_p == want_p
+    assert got_n == want_n
+    assert al.counters() == c0
+
+
+def _mixed_piece(seed, n, L, k):
+    s = Synth(120000, 90, 2, k, 4200 + seed)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, n, L, 3, 4300 + seed)
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        r = reads[i * L:(i + 1) * L].tobytes()
+        x = rng.random()
+        if x < 0.02:
+            r = r.lower()                      # not ACGTN: dropped, not counted (aligner.cpp:79-84)
+        elif x < 0.04:
+            r = r[: int(rng.integers(0, k + 1))]  # size <= k (or <= 2, or empty): dropped
+        elif x < 0.07:
+            b = bytearray(r); b[int(rng.integers(0, L))] = ord("N"); r = bytes(b)   # N is admitted
+        elif x < 0.08:
+            b = bytearray(r); b[int(rng.integers(0, L))] = 0; r = bytes(b)           # a NUL byte: dropped
+        elif x < 0.09:
+            r = r + b"\r"                      # CR before the newline: dropped
+        h = b">r%d some text > with a '>' inside %d" % (i, i) if i % 7 == 0 else b">r%d" % i
+        recs.append(h + b"\n" + r + b"\n")
+    return s, seqs, offs, b"".join(recs)
+
+
+@pytest.mark.parametrize("seed,n,L,k,mode", [(1, 40000, 150, 31, B.MODE_GREEDY), (2, 20011, 100, 21, B.MODE_GREEDY), (3, 9000, 250, 31, B.MODE_EXHAUSTIVE), (4, 5000, 40, 12, B.MODE_GREEDY),
+                                             (5, 12000, 150, 31, B.MODE_ANCHORS)])
+def test_text_route_with_dropped_records_equals_host_route(seed, n, L, k, mode, tmp_path):
+    """Regular pieces whose records the parser drops (lower case, NUL, CR, size <= k, empty sequence line) or admits (N), headers with
+    '>' inside: same bytes and counters as the host parser + bgr_align_batch."""
+    s, seqs, offs, text = _mixed_piece(seed, n, L, k)
+    g = B.Graph.build(k, seqs, offs, anchors=(mode == B.MODE_ANCHORS))
+    al = B.Aligner(g, 0)
+    want_p, want_n, n_acc = _host_route(al, text, k, tmp_path, m=2, mode=mode)
+    c0 = al.counters()
+    al.reset_counters()
+    got_p, got_n, info = al.align_fasta_text(text, m=2, mode=mode)
+    assert not info["irregular"] and info["n_records"] == n and info["n_accepted"] == n_acc and n_acc < n
+    assert got_p == want_p and got_n == want_n
+    assert al.counters() == c0
+    # too small a paths buffer: BGR_E_CAPACITY, then the same bytes through bgr_aligner_fetch_text
+    al.reset_counters()
+    got_p2, got_n2, _ = al.align_fasta_text(text, m=2, mode=mode, paths_cap=1000)
+    assert got_p2 == want_p and got_n2 == want_n and al.counters() == c0
+    # the piece sent ahead through a stage (its own copy stream)
+    al.reset_counters()
+    got_p4, got_n4, _ = al.align_fasta_text(text, m=2, mode=mode, staged=True)
+    assert got_p4 == want_p and got_n4 == want_n and al.counters() == c0
+    # counters only
+    al.reset_counters()
+    p3, n3, info3 = al.align_fasta_text(text, m=2, mode=mode, want_output=False)
+    assert p3 == b"" and n3 == b"" and info3["n_accepted"] == n_acc and al.counters() == c0
+
+
+@pytest.mark.parametrize("name,text", [
+    ("multi-line sequence", b">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\nACGTACGTACGT\n>b\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n"),
+    ("blank line", b">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n\n>b\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n"),
+    ("no final newline", b">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n>b\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT"),
+    ("dangling header", b">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n>b\n"),
+    ("header only, no newline", b">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n>b"),
+    ("does not start with a header", b"ACGT\n>a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n"),
+    ("no record at all", b"ACGTACGTACGT\nACGT\n"),
+    ("sequence line that starts with '>'", b">a\n>ACGTACGTACGTACGTACGTACGTACGTACGTACGT\n>b\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n"),
+    ("trailing blank lines", b">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n\n\n"),
+])
+def test_pieces_of_another_shape_are_left_to_the_host_parser(name, text):
+    s = Synth(60000, 75, 2, 31, 77)
+    seqs, offs = s.unitigs()
+    al = B.Aligner(B.Graph.build(31, seqs, offs), 0)
+    # such a record in the middle of many regular ones, and alone
+    many = b"".join(b">x%d\n%s\n" % (i, b"ACGT" * 40) for i in range(3000))
+    for piece in (text, many + text) if not text.startswith(b"ACGT") else (text,):
+        p, n, info = al.align_fasta_text(piece)
+        assert info["irregular"], name
+        assert p == b"" and n == b"" and al.counters()["reads"] == 0
+
+
+def test_empty_and_tiny_pieces():
+    s = Synth(60000, 75, 2, 31, 78)
+    seqs, offs = s.unitigs()
+    al = B.Aligner(B.Graph.build(31, seqs, offs), 0)
+    assert al.align_fasta_text(b"") == (b"", b"", {"irregular": False, "n_records": 0, "n_accepted": 0})
+    p, n, info = al.align_fasta_text(b">only\nACG\n")   # size <= 2: dropped, nothing to map
+    assert (p, n) == (b"", b"") and not info["irregular"] and info["n_records"] == 1 and info["n_accepted"] == 0
+    p, n, info = al.align_fasta_text(b">one\n" + b"ACGT" * 20 + b"\n")
+    assert not info["irregular"] and info["n_accepted"] == 1 and (p + n).startswith(b">one\n")
