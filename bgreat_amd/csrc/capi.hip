@@ -633,10 +633,14 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
     // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
     const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
+    // the eight-reads-per-wave greedy kernel: a wave's first chunk is its own by number and sized for its whole share of a typical batch
+    // (~6 ints per read), so that most waves never go to the cursor
+    const uint32_t arena_chunk_fast = !fast_pass ? arena_chunk
+        : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(arena_chunk, 8 * (n_reads / ((uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block) + 8)));
     const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
                                (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0) +
                                (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0) +
-                               (fast_pass ? (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk : 0) +
+                               (fast_pass ? (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk_fast : 0) +
                                (x4_pass ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk : 0) +
                                (a4_pass ? (uint64_t)cfg_a4.blocks * cfg_a4.waves_per_block * arena_chunk : 0);
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
@@ -723,8 +727,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         // follow-up items (the next anchors of a read whose first ones failed, then its reverse complement: alignerGreedy.cpp:41-56).
         // Reads the kernel does not take (N, very long paths) are mapped from scratch by the general kernel right behind: with an
         // empty list its workgroups exit at once.
+        // (the kernel's waves own the first grid x arena_chunk ints of the arena by their number: the cursor starts behind them)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->small.p), (int)((uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk_fast), 1, a->stream));
         bgr::BatchIO iof = io;
         iof.greedy_multi = 1;
+        iof.arena_chunk = arena_chunk_fast;
         iof.words_per_read = wfast;
         iof.queue = static_cast<uint2*>(a->ovf.p);
         iof.q_cap = q_cap;

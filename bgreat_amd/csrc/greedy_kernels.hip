@@ -153,6 +153,10 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     const uint32_t K1 = g.k - 1;
     const uint32_t total = io.n_reads;
     if ((uint32_t)(blockIdx.x * waves) * RPW >= total) return;  // nothing for this workgroup (before it copies the key table into LDS)
+    // the workgroup's counts of settled reads: four words at the start of the LDS (summed into HBM once per workgroup at the end: one
+    // global atomic per wave and counter, all on the same four addresses, cost a launch of 131 k reads a third of its time)
+    uint32_t* wg_counts = reinterpret_cast<uint32_t*>(lds);
+    if (threadIdx.x < 4) wg_counts[threadIdx.x] = 0;
     uint32_t ktab_words;
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     u64* RD = lds + 64 + ktab_words + (u64)wave * (RPW * W);
@@ -162,11 +166,13 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
 
     uint32_t c_noov = 0, c_al = 0, c_na = 0;  // wave-uniform counts of the reads settled here
-    uint32_t chunk_pos = 0, chunk_end = 0;    // this wave's slice of the path arena
+    // this wave's slice of the path arena: the first chunk is the wave's by its number (the host starts the cursor behind them: a
+    // returning atomic per wave on one word at the start of the launch serialises, ~90 per microsecond), later ones come from the cursor
+    const uint32_t wid = (uint32_t)(blockIdx.x * waves + wave);
+    uint32_t chunk_pos = wid * io.arena_chunk, chunk_end = chunk_pos + io.arena_chunk;
     // this wave's queue of follow-up items {read, state}: a ring of io.q_cap entries.  While the wave takes its share of the batch
     // it only appends (at most one entry per read of the share: q_cap); afterwards every octet taken out makes room for what it
     // leaves behind, so the ring never overflows.
-    const uint32_t wid = (uint32_t)(blockIdx.x * waves + wave);
     const uint32_t q_base = wid * io.q_cap;  // (the rings of all waves hold n_reads + 8 per wave entries at most: 32-bit indices)
     uint32_t q_rd = 0, q_wr = 0, q_cnt = 0, q_all = 0;
     const uint32_t stride = gridDim.x * waves * RPW;
@@ -392,13 +398,21 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
         wave_sync();
     }
-    if (lane == 0 && q_all) atomicAdd(io.cursor + 2, q_all);  // follow-up items of the launch (bgr_aligner_pass_counts)
-    if (lane == 0 && (c_al | c_noov | c_na)) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
+    if (lane == 0) {
+        if (c_al) atomicAdd(&wg_counts[0], c_al);
+        if (c_noov) atomicAdd(&wg_counts[1], c_noov);
+        if (c_na) atomicAdd(&wg_counts[2], c_na);
+        if (q_all) atomicAdd(&wg_counts[3], q_all);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov + c_na));
-        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
-        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
-        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
+        const uint32_t al = wg_counts[0], noov = wg_counts[1], na = wg_counts[2], qa = wg_counts[3];
+        if (al | noov | na) atomicAdd(&counters[0], (unsigned long long)(al + noov + na));
+        if (noov) atomicAdd(&counters[1], (unsigned long long)noov);
+        if (al) atomicAdd(&counters[2], (unsigned long long)al);
+        if (na) atomicAdd(&counters[3], (unsigned long long)na);
+        if (qa) atomicAdd(io.cursor + 2, qa);  // follow-up items of the launch (bgr_aligner_pass_counts)
     }
 }
 
