@@ -323,7 +323,10 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
     const uint32_t effort = prm.effort ? prm.effort : 1;  // getNAnchors(read, 0) still takes a hit at position 0
 
     uint32_t c_noov = 0, c_al = 0, c_na = 0;
-    uint32_t chunk_pos = 0, chunk_end = 0;
+    // (the wave's first arena chunk is its own by number: the host starts the cursor behind them, see bgr_align_greedy_multi_kernel)
+    uint32_t chunk_pos = (uint32_t)(blockIdx.x * waves + wave) * io.arena_chunk, chunk_end = chunk_pos + io.arena_chunk;
+    unsigned long long* wg_counts = wg_counts_init(lds);
+    __syncthreads();
 
     for (uint32_t rbase = (blockIdx.x * waves + wave) * RPW; rbase < io.n_reads; rbase += gridDim.x * waves * RPW) {
         const uint32_t r = rbase + grp;
@@ -523,13 +526,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
         c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
         wave_sync();
     }
-    if (lane == 0 && (c_al | c_noov | c_na)) {
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        atomicAdd(&counters[0], (unsigned long long)(c_al + c_noov + c_na));
-        if (c_noov) atomicAdd(&counters[1], (unsigned long long)c_noov);
-        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
-        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
-    }
+    wg_counts_flush(io, wg_counts, lane, c_al + c_noov + c_na, c_noov, c_al, c_na, 0);
 }
 
 }  // namespace

@@ -706,6 +706,12 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, a->knob_debug_stop};
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters
+    {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: the cursor starts behind
+        const uint64_t own = fast_pass ? (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk_fast
+                           : x4_pass   ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk
+                           : a4_pass   ? (uint64_t)cfg_a4.blocks * cfg_a4.waves_per_block * arena_chunk : 0;
+        if (own) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->small.p), (int)own, 1, a->stream));
+    }
     // HIP events on the aligner's stream: one in front of the launch, one behind every kernel of it (bgr_aligner_kernel_times)
     int marks = 0;
     auto mark = [&](const char* name) -> hipError_t {
@@ -727,8 +733,6 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         // follow-up items (the next anchors of a read whose first ones failed, then its reverse complement: alignerGreedy.cpp:41-56).
         // Reads the kernel does not take (N, very long paths) are mapped from scratch by the general kernel right behind: with an
         // empty list its workgroups exit at once.
-        // (the kernel's waves own the first grid x arena_chunk ints of the arena by their number: the cursor starts behind them)
-        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->small.p), (int)((uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk_fast), 1, a->stream));
         bgr::BatchIO iof = io;
         iof.greedy_multi = 1;
         iof.arena_chunk = arena_chunk_fast;

@@ -519,6 +519,28 @@ __device__ __forceinline__ const uint32_t* block_prologue(const BgrDeviceGraph& 
     return table;
 }
 
+// The aligner.h:68 counters of a launch ([0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned [4] overlaps) are summed per
+// workgroup in the first words of its LDS and added to HBM by one thread: one global atomic per wave and counter, all on the same
+// few addresses, cost a launch of 131 k reads a third of its time.  wg_counts_init before block_prologue (its barrier publishes the
+// zeroes); wg_counts_flush at the very end of the kernel, reached by every wave of the workgroup.
+__device__ __forceinline__ unsigned long long* wg_counts_init(u64* lds) {
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(lds);
+    if (threadIdx.x < 6) c[threadIdx.x] = 0;
+    return c;
+}
+__device__ __forceinline__ void wg_counts_flush(const BatchIO& io, unsigned long long* c, int lane, unsigned long long reads, unsigned long long noov, unsigned long long al,
+                                                unsigned long long na, unsigned long long ov) {
+    if (lane == 0) {
+        if (reads) atomicAdd(&c[0], reads);
+        if (noov) atomicAdd(&c[1], noov);
+        if (al) atomicAdd(&c[2], al);
+        if (na) atomicAdd(&c[3], na);
+        if (ov) atomicAdd(&c[4], ov);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && c[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long*>(io.cursor + 16) + threadIdx.x, c[threadIdx.x]);
+}
+
 // Arena space comes in per-wave chunks: ONE global atomic per ~50 reads instead of one per read (a
 // single-address atomic saturates near 90 M/s chip-wide, MI355X_MICROARCH.md "dequeue").
 __device__ __forceinline__ uint32_t publish_path(const BatchIO& io, const int32_t* PATH, uint32_t p_lo, uint32_t p_n,

@@ -646,6 +646,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
     const uint32_t K1 = g.k - 1;
+    unsigned long long* wg_counts = wg_counts_init(lds);
     uint32_t ktab_words;
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     // per wave: RPW x { read words W | level table XL x X4_LV_WORDS u32 | out ints 2 x (XL + 2) }  (x4_group_words, align_kernels.h)
@@ -660,7 +661,8 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
 
     uint32_t c_al = 0, c_na = 0;
     unsigned long long c_ov = 0;
-    uint32_t chunk_pos = 0, chunk_end = 0;
+    // (the wave's first arena chunk is its own by number: the host starts the cursor behind them, see bgr_align_greedy_multi_kernel)
+    uint32_t chunk_pos = (uint32_t)(blockIdx.x * waves + wave) * io.arena_chunk, chunk_end = chunk_pos + io.arena_chunk;
 
     for (uint32_t rbase = (blockIdx.x * waves + wave) * RPW; rbase < io.n_reads; rbase += gridDim.x * waves * RPW) {
         const uint32_t r = rbase + grp;
@@ -762,13 +764,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
             if ((fin >> (GL * gq)) & 1) c_ov += rl32(npos_g, (int)(GL * gq));  // overlaps += listOverlap.size() (alignerExhaustive.cpp:38)
         wave_sync();
     }
-    if (lane == 0 && (c_al | c_na)) {
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        atomicAdd(&counters[0], (unsigned long long)(c_al + c_na));
-        if (c_al) atomicAdd(&counters[2], (unsigned long long)c_al);
-        if (c_na) atomicAdd(&counters[3], (unsigned long long)c_na);
-        atomicAdd(&counters[4], c_ov);
-    }
+    wg_counts_flush(io, wg_counts, lane, c_al + c_na, 0, c_al, c_na, c_ov);
 }
 
 // Pass 1 of exhaustive mode with the level-by-level search (exh_dp); what it cannot hold goes to the overflow list and
