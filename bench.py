@@ -76,7 +76,8 @@ def parse_args():
     ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the eight-reads-per-wave passes (diagnostic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and the issue fractions become null)")
     ap.add_argument("--pmc-steps", type=int, default=3)
-    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end leg per GPU (0 disables)")
+    ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end leg per GPU (0 disables); 100 M x 150 bp = a 16 GB FASTA file: "
+                                                                          "at ~170 Mreads/s a smaller file mostly measures the start-up (page-locked staging buffers, device buffers)")
     ap.add_argument("--pcie-steps", type=int, default=3, help="timed bgr_align_batch calls of the PCIe-inclusive leg (0 disables)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--debug-stop", type=int, default=0, help="diagnostic builds of the library only (-DBGR_PHASE_TIMING, loaded through BGR_LIB_PATH): "
@@ -432,30 +433,54 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
         fsize = os.path.getsize(f)
         best = None
         runs = []
-        for rep in range(3):  # later runs have the device buffers and the pinned pool warm; the box's host cores are shared: runs vary
+        host_route = None
+        for rep in range(4):  # later runs have the page-locked staging buffers warm; the box's host cores are shared: runs vary
+            route = 1 if rep == 3 else 0   # the last run: the same file through the host parser + host formatter (the round-2 pipeline)
+            for fn in ("paths%d" % (rep - 1), "notAligned%d.fa" % (rep - 1)):
+                if rep > 1 and os.path.exists(os.path.join(d, fn)):
+                    os.unlink(os.path.join(d, fn))      # (keep run 0's outputs for the size / identity check, drop the others: disk space)
             os.sync()  # not timed: dirty pages of the input file / the previous run's outputs would throttle this run's writes
             if dist is not None:
                 dist.barrier()
             t1 = time.perf_counter()
-            cnt, secs = B.align_all(g, f, os.path.join(d, "paths%d" % rep), os.path.join(d, "notAligned%d.fa" % rep), m=args.mismatch, effort=args.effort,
-                                    threads=ncpu, n_gpus=1, first_device=dev)
+            cnt_r, secs = B.align_all(g, f, os.path.join(d, "paths%d" % rep), os.path.join(d, "notAligned%d.fa" % rep), m=args.mismatch, effort=args.effort,
+                                      threads=ncpu, n_gpus=1, first_device=dev, route=route)
             if dist is not None:
                 dist.barrier()
             wall = time.perf_counter() - t1
             if dist is not None:
                 wall = D.max_over_ranks(wall, dist, device=coll_dev)
+            if route == 1:
+                same = all(_same_file(os.path.join(d, a), os.path.join(d, b)) for a, b in (("paths0", "paths3"), ("notAligned0.fa", "notAligned3.fa")))
+                host_route = {"value": round(world * n / wall / 1e6, 3), "unit": "Mreads/s", "identical_bytes_to_the_text_route": bool(same),
+                              "what": "one run of the same file with route = 1: host parser, host packer, host formatter (bgr_align_batch_packed)"}
+                continue
+            cnt = cnt_r
             runs.append(round(world * n / wall / 1e6, 1))
             if best is None or wall < best:
                 best = wall
         out_bytes = os.path.getsize(os.path.join(d, "paths0")) + os.path.getsize(os.path.join(d, "notAligned0.fa"))
         return {"value": round(world * n / best / 1e6, 3), "unit": "Mreads/s", "reads_per_gpu": n, "n_gpus": world, "host_threads_per_gpu": ncpu, "seconds": round(best, 4),
                 "input": "FASTA, %d bytes per GPU, written just before the run: page cache" % fsize, "input_GB_per_s": round(world * fsize / best / 1e9, 2),
-                "output_bytes_per_gpu": out_bytes, "aligned": cnt["aligned"], "runs_mreads_per_s": runs,
-                "what": "bgr_align_all (the CLI's mapping phase): file -> paths + notAligned.fa; best of 3 runs (fresh output files, os.sync() before each, not timed); index build excluded"}
+                "output_bytes_per_gpu": out_bytes, "aligned": cnt["aligned"], "runs_mreads_per_s": runs, "host_route": host_route,
+                "what": "bgr_align_all (the CLI's mapping phase): file -> paths + notAligned.fa, the device taking the FASTA text and returning the record bytes "
+                        "(bgr_align_fasta_text); best of 3 runs (fresh output files, os.sync() before each, not timed); index build excluded"}
     except Exception as ex:
         return {"error": "%s: %s" % (type(ex).__name__, ex)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def _same_file(a, b, chunk=1 << 24):
+    if os.path.getsize(a) != os.path.getsize(b):
+        return False
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        while True:
+            x, y = fa.read(chunk), fb.read(chunk)
+            if x != y:
+                return False
+            if not x:
+                return True
 
 
 def run_pcie(args, B, g, al, syn, seed_reads, ncpu, dev):

@@ -72,9 +72,17 @@ struct DevBuf {
 struct bgr_text_stage {  // one piece of text on its way to / resident in a device: buffer, copy stream, "it has arrived" event
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr, ev0 = nullptr;  // ev0: BGREAT_TIMING only, start of the copy
     DevBuf buf;
     uint64_t bytes = 0;
+    bool timing = false, pending = false;
+    double copy_ms = 0, copy_bytes = 0;
+    void settle() {  // BGREAT_TIMING: duration of the last copy (it has completed)
+        if (!timing || !pending) return;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev0, ev) == hipSuccess) { copy_ms += ms; copy_bytes += (double)bytes; }
+        pending = false;
+    }
 };
 
 struct bgr_aligner {
@@ -919,7 +927,9 @@ int bgr_text_stage_create(int device, bgr_text_stage** out) {
     bgr_text_stage* s = new bgr_text_stage();
     s->device = device;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev, hipEventDisableTiming);
+    s->timing = getenv("BGREAT_TIMING") != nullptr;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev, s->timing ? hipEventDefault : hipEventDisableTiming);
+    if (e == hipSuccess && s->timing) e = hipEventCreate(&s->ev0);
     if (e != hipSuccess) { bgr_text_stage_destroy(s); return fail(BGR_E_HIP, std::string("bgr_text_stage_create: ") + hipGetErrorString(e)); }
     *out = s;
     return BGR_OK;
@@ -928,8 +938,10 @@ int bgr_text_stage_create(int device, bgr_text_stage** out) {
 void bgr_text_stage_destroy(bgr_text_stage* s) {
     if (!s) return;
     if (hipSetDevice(s->device) == hipSuccess) {
-        if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        if (s->stream) { (void)hipStreamSynchronize(s->stream); s->settle(); (void)hipStreamDestroy(s->stream); }
+        if (s->timing && s->copy_ms > 0) fprintf(stderr, "bgreat: stage on device %d: %.0f MB up in %.3f s of copies = %.1f GB/s\n", s->device, s->copy_bytes / 1e6, s->copy_ms / 1e3, s->copy_bytes / s->copy_ms / 1e6);
         if (s->ev) (void)hipEventDestroy(s->ev);
+        if (s->ev0) (void)hipEventDestroy(s->ev0);
         s->buf.release();
     }
     delete s;
@@ -940,7 +952,9 @@ int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t bytes) {
     if (bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_text_stage_upload: piece of 2 GiB or more; cut it");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));  // (a piece still on its way: the buffer may grow, i.e. move)
+    s->settle();
     HIP_TRY(s->buf.ensure(bytes + 64));
+    if (s->timing) { HIP_TRY(hipEventRecord(s->ev0, s->stream)); s->pending = true; }
     HIP_TRY(hipMemsetAsync(static_cast<char*>(s->buf.p) + bytes, 0, 64, s->stream));
     if (bytes) HIP_TRY(hipMemcpyAsync(s->buf.p, text, bytes, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev, s->stream));

@@ -510,7 +510,9 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     WorkerPool pool(threads + 2);  // + 2: the stage threads mostly wait inside run()
     // A fixed pool of batch objects circulates producer -> GPU workers -> writer -> producer, so the pinned
     // buffers are allocated once and the number of batches in flight is bounded.
-    const size_t max_batches = aligners.size() * 2 + 2;
+    size_t extra_sets = text_route ? 3 : 0;  // text route: a set is held from the read of its piece until its streams are written
+    if (const char* e = getenv("BGREAT_EXTRA_SETS")) extra_sets = (size_t)std::min(32, std::max(0, atoi(e)));
+    const size_t max_batches = aligners.size() * 2 + 2 + extra_sets;
     Channel<std::unique_ptr<Batch>> to_gather(max_batches), to_out(max_batches), free_batches(max_batches);
     std::vector<std::unique_ptr<Channel<std::unique_ptr<Batch>>>> to_gpu;  // one queue per device: its workers and its share of the batches
     for (unsigned g = 0; g < n_gpus; ++g) to_gpu.push_back(std::make_unique<Channel<std::unique_ptr<Batch>>>(max_batches));
@@ -535,7 +537,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     };
     // The page-locked buffers cost ~0.2 s per GB to allocate, so they are few (one set per batch between gather and
     // format), sized from the input up front, allocated by their own thread while the parsers already run, and reused.
-    const size_t n_pins = aligners.size() * 2 + 1;
+    const size_t n_pins = aligners.size() * 2 + 1 + extra_sets;
     Channel<std::unique_ptr<Pinned>> free_pins(n_pins + 1);
     std::thread pin_allocator([&]() {
         const uint64_t ta0 = now_us();

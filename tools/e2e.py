@@ -65,7 +65,7 @@ def main():
             line = [l for l in p.stderr.splitlines() if l.startswith("bgreat: mapping")][-1]
             secs = float(line.split()[2])
             for l in p.stderr.splitlines():
-                if "stage busy" in l or "pool CPU" in l or "text calls" in l:
+                if "stage busy" in l or "pool CPU" in l or "text calls" in l or "stage on device" in l:
                     print(l, file=sys.stderr)
             out["run%d" % rep] = {"wall_s": round(wall, 3), "mapping_s": secs, "mreads_per_s": round(args.reads / secs / 1e6, 3),
                                   "input_GB_per_s": round(fsize / secs / 1e9, 3),
