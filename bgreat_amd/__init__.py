@@ -33,6 +33,7 @@ SYMBOLS = [
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup", "bgr_graph_key_lookup",
     "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
     "bgr_align_fasta_text", "bgr_aligner_fetch_text", "bgr_host_cache_release", "bgr_device_local_cpus", "bgr_text_stage_create", "bgr_text_stage_destroy", "bgr_text_stage_upload",
+    "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
@@ -55,6 +56,10 @@ class RunOptions(C.Structure):
     _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
                 ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("correction", C.c_uint32),
                 ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32), ("route", C.c_uint32)]
+
+
+class Ticket(C.Structure):
+    _fields_ = [("aligner", C.c_void_p), ("n_reads", C.c_uint64), ("serial", C.c_uint64)]
 
 
 class TextBatch(C.Structure):
@@ -145,6 +150,9 @@ def lib():
     L.bgr_pack_reads.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u32)]
     L.bgr_align_batch_packed.argtypes = [vp, C.POINTER(Params), C.POINTER(PackedReads), u64, vp, u64, vp, vp]
     L.bgr_align_fasta_text.argtypes = [vp, C.POINTER(Params), C.POINTER(TextBatch)]
+    L.bgr_align_batch_begin.argtypes = [vp, C.POINTER(Params), vp, vp, u64, C.POINTER(Ticket)]
+    L.bgr_align_batch_test.argtypes = [C.POINTER(Ticket)]
+    L.bgr_align_batch_wait.argtypes = [C.POINTER(Ticket), vp, u64, vp, vp]
     L.bgr_aligner_fetch_text.argtypes = [vp, C.POINTER(TextBatch)]
     L.bgr_text_stage_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.bgr_text_stage_destroy.argtypes = [vp]
@@ -339,6 +347,32 @@ class Aligner:
                         len(pk["nm_index"]), pk["max_read_len"])
         p = Params(mode, m, effort, int(partial))
         _check(lib().bgr_align_batch_packed(self.h, C.byref(p), C.byref(s), n, paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
+        return paths[: int(poffs[n])].copy(), poffs, status[:n]
+
+    def align_begin(self, reads, offsets, m=2, effort=2, mode=MODE_GREEDY, partial=False):
+        """bgr_align_batch_begin: copy + launch enqueued, returns at once -> ticket (keeps the host arrays alive until align_wait)."""
+        reads = _as_u8(reads)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        t = Ticket()
+        p = Params(mode, m, effort, int(partial))
+        _check(lib().bgr_align_batch_begin(self.h, C.byref(p), reads.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(t)))
+        return (t, reads, offsets)
+
+    def align_test(self, ticket):
+        rc = lib().bgr_align_batch_test(C.byref(ticket[0]))
+        if rc < 0:
+            _check(rc)
+        return bool(rc)
+
+    def align_wait(self, ticket):
+        """bgr_align_batch_wait -> (paths, path_offsets, status) of the batch the ticket was given for."""
+        t, reads, offsets = ticket
+        n = len(offsets) - 1
+        cap = int(offsets[-1] - offsets[0]) + 8 * n + 8
+        paths = np.empty(cap, dtype=np.int32)
+        poffs = np.empty(n + 1, dtype=np.uint64)
+        status = np.empty(max(n, 1), dtype=np.uint8)
+        _check(lib().bgr_align_batch_wait(C.byref(t), paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
         return paths[: int(poffs[n])].copy(), poffs, status[:n]
 
     def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False):

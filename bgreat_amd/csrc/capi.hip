@@ -94,10 +94,14 @@ struct bgr_aligner {
     DevBuf tx_in, tx_sums, tx_start, tx_rec, tx_flag, tx_len, tx_idx, tx_boff, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout;
     uint64_t tx_n_acc = 0, tx_pbytes = 0, tx_nbytes = 0;
     const uint8_t* tx_text = nullptr;  // where the last call's piece lies in HBM (tx_in, or the caller's stage)
+    uint32_t tx_want = 0;              // its want_output (2 = correction mode: mapped reads as spelled by their paths)
     double tx_phase_s[5] = {0, 0, 0, 0, 0};  // BGREAT_TIMING: host wall seconds to the call's four waits (mark, records, mapping + sizes, streams) + calls
 
     DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, lst, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
+    uint64_t ticket_serial = 0;       // bgr_align_batch_begin: tickets handed out; the batch of the last one is in flight until its wait
+    bool ticket_open = false;
+    std::vector<uint64_t> ticket_offs;  // that batch's offsets made relative (kept alive for the asynchronous copy)
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
@@ -904,10 +908,15 @@ static int fetch_text_impl(bgr_aligner* a, bgr_text_batch* b) {
         return fail(BGR_E_CAPACITY, "bgr_align_fasta_text: output buffer too small (paths_bytes / notaligned_bytes say what is needed; bgr_aligner_fetch_text)");
     HIP_TRY(a->tx_pout.ensure(a->tx_pbytes + 64));
     HIP_TRY(a->tx_nout.ensure(a->tx_nbytes + 64));
-    hipError_t e = bgr::launch_text_write(a->tx_text, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p),
-                                          static_cast<const uint4*>(a->tx_rec.p), static_cast<const uint32_t*>(a->tx_accrec.p), (uint32_t)a->tx_n_acc,
-                                          static_cast<const uint32_t*>(a->tx_poff.p), static_cast<const uint32_t*>(a->tx_noff.p), static_cast<uint8_t*>(a->tx_pout.p),
-                                          static_cast<uint8_t*>(a->tx_nout.p), a->stream);
+    hipError_t e = a->tx_want == 2
+        ? bgr::launch_text_correct_write(a->dg, a->tx_text, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
+                                         static_cast<const uint32_t*>(a->tx_accrec.p), (uint32_t)a->tx_n_acc, static_cast<const uint32_t*>(a->tx_poff.p),
+                                         static_cast<const uint32_t*>(a->tx_noff.p), static_cast<const uint32_t*>(a->tx_idx.p), static_cast<uint8_t*>(a->tx_pout.p),
+                                         static_cast<uint8_t*>(a->tx_nout.p), a->stream)
+        : bgr::launch_text_write(a->tx_text, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p),
+                                 static_cast<const uint4*>(a->tx_rec.p), static_cast<const uint32_t*>(a->tx_accrec.p), (uint32_t)a->tx_n_acc,
+                                 static_cast<const uint32_t*>(a->tx_poff.p), static_cast<const uint32_t*>(a->tx_noff.p), static_cast<uint8_t*>(a->tx_pout.p),
+                                 static_cast<uint8_t*>(a->tx_nout.p), a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text write launch: ") + hipGetErrorString(e));
     if (a->tx_pbytes) HIP_TRY(hipMemcpyAsync(b->paths_out, a->tx_pout.p, a->tx_pbytes, hipMemcpyDeviceToHost, a->stream));
     if (a->tx_nbytes) HIP_TRY(hipMemcpyAsync(b->notaligned_out, a->tx_nout.p, a->tx_nbytes, hipMemcpyDeviceToHost, a->stream));
@@ -969,6 +978,10 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     double tw = wall_now();
     auto lap = [&](int i) { const double t = wall_now(); a->tx_phase_s[i] += t - tw; tw = t; };
     if (b->text_bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_align_fasta_text: piece of 2 GiB or more; cut it");
+    if (b->want_output > 2) return fail(BGR_E_ARG, "bgr_align_fasta_text: want_output must be 0, 1 or 2");
+    if (b->want_output == 2 && (a->graph->header.has_exc || p->mode == BGR_MODE_EXHAUSTIVE))
+        return fail(BGR_E_ARG, "bgr_align_fasta_text: correction on the device needs a graph of ACGT-only unitigs and greedy mode (format such a run on the host)");
+    a->tx_want = b->want_output;
     b->irregular = 0;
     b->n_records = b->n_accepted = b->paths_bytes = b->notaligned_bytes = 0;
     a->last_n = 0;
@@ -1038,6 +1051,12 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     a->tx_n_acc = n_acc;
     if (!b->want_output) { HIP_TRY(hipStreamSynchronize(a->stream)); return BGR_OK; }
     // 4. sizes of the records, stream offsets, the bytes
+    if (b->want_output == 2) {  // (tx_idx is free again behind the compaction: it takes the corrected reads' lengths)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(info + TXT_INFO_BUG), -1, 1, a->stream));
+        e = bgr::launch_text_correct_sizes(a->dg, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
+                                           static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, static_cast<uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_nsz.p),
+                                           static_cast<uint32_t*>(a->tx_idx.p), info + TXT_INFO_BUG, a->stream);
+    } else
     e = bgr::launch_text_sizes(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
                                static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, static_cast<uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_nsz.p), a->stream);
     if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_poff.p), n_acc, sums2, info + TXT_INFO_PBYTES, a->stream);
@@ -1049,6 +1068,11 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     HIP_TRY(hipStreamSynchronize(a->stream));
     lap(2);
     if (h2[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+    if (b->want_output == 2 && h[TXT_INFO_BUG] != 0xFFFFFFFFu) {  // a path that does not spell a walk: the reference prints "bug compaction" and exits
+        b->irregular = 2;                                          // (aligner.cpp:280-283); the caller reproduces that on the host
+        a->tx_n_acc = 0;
+        return BGR_OK;
+    }
     a->tx_pbytes = h[TXT_INFO_PBYTES];
     a->tx_nbytes = h[TXT_INFO_NBYTES];
     const int frc = fetch_text_impl(a, b);
@@ -1247,6 +1271,60 @@ int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, cons
     int rc = batch_piece_launch(a, p, reads, read_offsets, n);
     if (rc != BGR_OK) return rc;
     return bgr_aligner_fetch(a, n, paths_out, paths_cap, path_offsets, status);
+}
+
+// ---- asynchronous form over host buffers ---------------------------------------------------------------------------------------
+int bgr_align_batch_begin(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n, bgr_ticket* ticket) {
+    if (!a || !p || !ticket || (n && (!reads || !read_offsets))) return fail(BGR_E_ARG, "bgr_align_batch_begin: null argument");
+    if (a->ticket_open) return fail(BGR_E_ARG, "bgr_align_batch_begin: this aligner still has a batch in flight (wait for its ticket first)");
+    ticket->aligner = a;
+    ticket->n_reads = n;
+    ticket->serial = ++a->ticket_serial;
+    a->last_n = 0;
+    if (n == 0) { a->ticket_open = true; return BGR_OK; }
+    HIP_TRY(hipSetDevice(a->device));
+    const uint64_t base = read_offsets[0], total = read_offsets[n] - base;
+    if (n >= 0x7FFFFFFFull || 2 * (total + 8 * n) >= 0xFFFFFFFFull - (256ull << 20))
+        return fail(BGR_E_ARG, "bgr_align_batch_begin: batch too large for one launch (2 * (bases + 8 * reads) must stay below 2^32 - 2^28); bgr_align_batch cuts such a batch");
+    uint32_t max_len = 0;
+    a->ticket_offs.resize(n + 1);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t l = read_offsets[i + 1] - read_offsets[i];
+        if (l > 0x7FFFFFFFull) return fail(BGR_E_ARG, "bgr_align_batch_begin: read longer than 2^31 bases");
+        max_len = std::max<uint32_t>(max_len, (uint32_t)l);
+        a->ticket_offs[i] = read_offsets[i] - base;
+    }
+    a->ticket_offs[n] = total;
+    HIP_TRY(a->in_reads.ensure(total + 16));
+    HIP_TRY(a->in_offs.ensure((n + 1) * 8));
+    HIP_TRY(hipMemcpyAsync(a->in_reads.p, reads + base, total, hipMemcpyHostToDevice, a->stream));
+    HIP_TRY(hipMemcpyAsync(a->in_offs.p, a->ticket_offs.data(), (n + 1) * 8, hipMemcpyHostToDevice, a->stream));
+    const int rc = bgr_align_device(a, p, a->in_reads.p, a->in_offs.p, n, total, max_len);
+    if (rc != BGR_OK) return rc;
+    a->ticket_open = true;
+    return BGR_OK;
+}
+
+int bgr_align_batch_test(const bgr_ticket* t) {
+    if (!t || !t->aligner) return fail(BGR_E_ARG, "bgr_align_batch_test: null ticket");
+    bgr_aligner* a = t->aligner;
+    if (!a->ticket_open || t->serial != a->ticket_serial) return fail(BGR_E_ARG, "bgr_align_batch_test: stale ticket");
+    if (hipSetDevice(a->device) != hipSuccess) return fail(BGR_E_HIP, "hipSetDevice failed");
+    const hipError_t e = hipStreamQuery(a->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(BGR_E_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+}
+
+int bgr_align_batch_wait(const bgr_ticket* t, int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
+    if (!t || !t->aligner || !path_offsets) return fail(BGR_E_ARG, "bgr_align_batch_wait: null argument");
+    bgr_aligner* a = t->aligner;
+    if (!a->ticket_open || t->serial != a->ticket_serial) return fail(BGR_E_ARG, "bgr_align_batch_wait: stale ticket (every begin is waited for once, in order)");
+    path_offsets[0] = 0;
+    if (t->n_reads == 0) { a->ticket_open = false; return BGR_OK; }
+    const int rc = bgr_aligner_fetch(a, t->n_reads, paths_out, paths_cap, path_offsets, status);
+    if (rc != BGR_E_CAPACITY) a->ticket_open = false;  // (too small a paths buffer: the results stay, wait again with a larger one)
+    return rc;
 }
 
 int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) {

@@ -428,7 +428,10 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     const bool progress_blocks = opt->echo_files && prm->mode == BGR_MODE_EXHAUSTIVE;
     // Text route: the device parses, packs, maps and formats (bgr_align_fasta_text); the host only moves bytes.  FASTA, the
     // reference's two output files and no -b progress blocks (those count getReads() calls, which only the host parser tracks).
-    const bool text_route = opt->route == 0 && !opt->fastq && !correction && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
+    // Correction mode too (the device spells the reads from its 2-bit unitig store) unless the graph has non-ACGT unitig characters.
+    bgr_graph_info_t gi_route;
+    if (bgr_graph_info(graph, &gi_route) != BGR_OK) return BGR_E_ARG;
+    const bool text_route = opt->route == 0 && !opt->fastq && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
     const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (text_route ? 1ull << 18 : 1ull << 17), 4ull << 20);
     const uint64_t piece_bytes = std::min<uint64_t>(std::max<uint64_t>(batch_reads * 170, 4096), 1ull << 30);  // text route: bytes of a batch
     const uint64_t batch_bases_cap = 1ull << 30;
@@ -868,7 +871,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     tb.text = static_cast<const char*>(b->pin->text.p);
                     tb.text_bytes = b->t_end - b->t_begin;
                     tb.stage = b->pin->stages.size() > b->dev ? b->pin->stages[b->dev] : nullptr;
-                    tb.want_output = writes ? 1u : 0u;
+                    tb.want_output = writes ? (correction ? 2u : 1u) : 0u;
                     tb.paths_out = static_cast<char*>(b->pin->ptext.p);
                     tb.paths_cap = b->pin->ptext.cap;
                     tb.notaligned_out = static_cast<char*>(b->pin->ntext.p);
@@ -883,8 +886,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                         }
                     }
                     if (rc != BGR_OK) fail(rc, bgr_last_error());
-                    else if (tb.irregular) {
-                        b->file->irregular_pieces.fetch_add(1);
+                    else if (tb.irregular) {  // (2 = correction mode met a path that spells no walk: the host formatter reproduces the reference's exit)
+                        if (tb.irregular == 1) b->file->irregular_pieces.fetch_add(1);
                         host_parse_piece(*b);
                         b->text_piece = false;
                         if (!gather(*b)) { if (!to_out.push(std::move(b))) break; continue; }

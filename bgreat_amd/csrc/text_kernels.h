@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "graph_layout.h"
+
 // words of the small device `info` block of a text batch
 #define TXT_INFO_N_REC 0      /* record starts found */
 #define TXT_INFO_N_ACC 1      /* records accepted (aligner.cpp:78-88) */
@@ -13,6 +15,7 @@
 #define TXT_INFO_IRREGULAR 4  /* the piece is not of the shape this route takes: the caller parses it on the host */
 #define TXT_INFO_PBYTES 5     /* bytes of the paths stream */
 #define TXT_INFO_NBYTES 6     /* bytes of the notAligned stream */
+#define TXT_INFO_BUG 7        /* correction mode: the first accepted read whose path does not spell a walk ("bug compaction"), else ~0 */
 #define TXT_INFO_WORDS 8
 
 namespace bgr {
@@ -31,6 +34,11 @@ hipError_t launch_text_sizes(const uint2* results, const int32_t* arena, const u
                              hipStream_t stream);
 hipError_t launch_text_write(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc,
                              const uint32_t* poff, const uint32_t* noff, uint8_t* pout, uint8_t* nout, hipStream_t stream);
+// correction mode (-c): mapped reads are written as header + the read spelled by its path (recoverPath, aligner.cpp:270-290)
+hipError_t launch_text_correct_sizes(const BgrDeviceGraph& g, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* psz,
+                                     uint32_t* nsz, uint32_t* clen, uint32_t* bug, hipStream_t stream);
+hipError_t launch_text_correct_write(const BgrDeviceGraph& g, const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc,
+                                     const uint32_t* poff, const uint32_t* noff, const uint32_t* clen, uint8_t* pout, uint8_t* nout, hipStream_t stream);
 // the pre-pass (batch_kernels.hip) over reads that lie scattered in a text: read r's characters start at reads + src_off[r]
 hipError_t launch_pack_reads_at(const uint8_t* text, const uint32_t* src_off, const uint64_t* read_offs, uint32_t n, uint64_t text_bytes, uint64_t total_bases,
                                 uint64_t* fw3, uint64_t* nmw, uint32_t* hasn, hipStream_t stream);

@@ -320,6 +320,132 @@ __global__ void __launch_bounds__(256) bgr_text_write_kernel(const uint8_t* text
     }
 }
 
+// ---- correction mode (-c) on the device: the read as spelled by its path ----------------------------------------------------------
+// recoverPath (aligner.cpp:270-290): walk = getUnitig(path[1]); for every further int: compactionEnd(walk, getUnitig(path[i]), k-1)
+// (utils.cpp:171-179) glues the unitig on when the walk's last k-1 characters equal its first k-1 -- as oriented by its sign or,
+// failing that, reverse complemented -- else "bug compaction"; then walk.substr(path[0], read size), reverse complemented when the
+// path was found on the read's reverse complement (alignerGreedy.cpp:394-404).  Graphs without exception planes only (every unitig
+// character is one of ACGT, so the 2-bit store spells it); the caller formats such a batch on the host otherwise.
+struct WalkIter {   // the oriented unitigs of a path, one after the other
+    const BgrDeviceGraph& g;
+    const int32_t* path;
+    uint32_t np, K1;
+    uint32_t i = 1;          // path int of the current unitig
+    u64 base = 0;            // where its oriented bases start in seq
+    uint32_t len = 0, skip = 0;  // its length; bases of it that belong to the overlap with its predecessor (0 for the first, else k-1)
+    bool bad = false;
+    __device__ WalkIter(const BgrDeviceGraph& g_, const int32_t* p, uint32_t n) : g(g_), path(p), np(n), K1(g_.k - 1) {}
+    __device__ u64 kmer_at(u64 b) const { return win32(g.seq, b) >> (64 - 2 * K1); }
+    __device__ bool load() {  // unitig i as its sign orients it; false when the id is out of range (getUnitig of a bad int)
+        const int32_t s = path[i];
+        const uint32_t id = (uint32_t)(s < 0 ? -(int64_t)s : (int64_t)s);
+        if (id == 0 || id > (uint32_t)g.hdr->n_unitigs) return false;
+        const BgrUnitigMeta m = g.meta[id];
+        len = m.len;
+        base = m.F + (s < 0 ? m.len : 0);
+        return true;
+    }
+    __device__ bool first() { skip = 0; i = 1; if (np < 2 || !load()) { bad = true; return false; } return true; }
+    __device__ bool next() {   // false: no further unitig (or bad set: bug compaction)
+        if (i + 1 >= np) return false;
+        const u64 tail = kmer_at(base + len - K1);
+        ++i;
+        if (!load()) { bad = true; return false; }
+        if (kmer_at(base) != tail) {  // compactionEnd's second try: the reverse complement (the other strand of the store)
+            const int32_t s = path[i];
+            const uint32_t id = (uint32_t)(s < 0 ? -(int64_t)s : (int64_t)s);
+            const BgrUnitigMeta m = g.meta[id];
+            const u64 other = m.F + (s < 0 ? 0 : m.len);
+            if (kmer_at(other) != tail) { bad = true; return false; }
+            base = other;
+        }
+        skip = K1;
+        return true;
+    }
+};
+
+// sizes: mapped read -> header + '\n' + min(read size, walk size - offset) + '\n' in the paths stream; *bug (atomicMin) = the first
+// accepted read whose path does not spell a walk
+__global__ void __launch_bounds__(256) bgr_text_correct_sizes_kernel(BgrDeviceGraph g, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec,
+                                                                     uint32_t n_acc, uint32_t* psz, uint32_t* nsz, uint32_t* clen, uint32_t* bug) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_acc) return;
+    const uint2 res = results[a];
+    const uint4 r = rec[acc_rec[a]];
+    const uint32_t np = res.y & 0xFFFFFFu, L = r.w & 0x7FFFFFFFu;
+    uint32_t ps = 0, ns = 0, cl = 0;
+    if (np) {
+        WalkIter w(g, arena + res.x, np);
+        u64 total = 0;
+        if (w.first()) { total = w.len; while (w.next()) total += w.len - w.skip; }
+        const int32_t off = arena[res.x];
+        if (w.bad || off < 0 || (u64)off > total) atomicMin(bug, a);
+        else {
+            const u64 left = total - (u64)off;
+            cl = left < L ? (uint32_t)left : L;
+        }
+        ps = r.y + 2 + cl;
+    } else {
+        ns = r.y + L + 2;
+    }
+    psz[a] = ps;
+    nsz[a] = ns;
+    clen[a] = cl;
+}
+
+__device__ __forceinline__ uint8_t base_char(uint32_t code) { return (uint8_t)((0x54474341u >> (8 * code)) & 0xFF); }  // "ACGT"
+
+// one 16-lane group per accepted read; a mapped read's record is header + '\n' + the corrected read + '\n'
+__global__ void __launch_bounds__(256) bgr_text_correct_write_kernel(BgrDeviceGraph g, const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec,
+                                                                     const uint32_t* acc_rec, uint32_t n_acc, const uint32_t* poff, const uint32_t* noff, const uint32_t* clen,
+                                                                     uint8_t* pout, uint8_t* nout) {
+    const uint32_t a = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (a >= n_acc) return;
+    const uint2 res = results[a];
+    const uint4 r = rec[acc_rec[a]];
+    const uint32_t np = res.y & 0xFFFFFFu, hl = r.y;
+    if (!np) {   // alignerGreedy.cpp:421-427: header + '\n' + read + '\n'
+        uint8_t* d = nout + noff[a];
+        const uint32_t L = r.w & 0x7FFFFFFFu;
+        group_copy(d, text + r.x, hl, sub);
+        if (sub == 0) d[hl] = '\n';
+        group_copy(d + hl + 1, text + r.z, L, sub);
+        if (sub == 0) d[hl + 1 + L] = '\n';
+        return;
+    }
+    uint8_t* d = pout + poff[a];
+    group_copy(d, text + r.x, hl, sub);
+    if (sub == 0) d[hl] = '\n';
+    const uint32_t cl = clen[a];
+    uint8_t* o = d + hl + 1;
+    if (sub == 0) o[cl] = '\n';
+    const bool rc = ((res.y >> 24) & BGR_ST_RC) != 0;
+    // every lane walks the path (a handful of unitigs) and spells the characters j = sub, sub + 16, ... of walk[off, off + cl)
+    const uint32_t off = (uint32_t)arena[res.x];
+    WalkIter w(g, arena + res.x, np);
+    if (!w.first()) return;
+    u64 start = 0;  // walk position of the current unitig's first NEW base (behind the overlap)
+    for (;;) {
+        const u64 new_len = w.len - w.skip, end = start + new_len;   // walk positions [start, end) come from this unitig at oriented offsets skip + (p - start)
+        // walk positions wanted: off + j, j < cl
+        if (end > off && start < (u64)off + cl) {
+            const u64 lo = start > off ? start : off, hi = end < (u64)off + cl ? end : (u64)off + cl;
+            // j with off + j in [lo, hi), j = sub mod 16
+            uint32_t j = (uint32_t)(lo - off);
+            j += (sub + 16 - (j & 15)) & 15;
+            for (; (u64)off + j < hi; j += 16) {
+                const u64 p = w.base + w.skip + ((u64)off + j - start);
+                const uint32_t code = (uint32_t)(g.seq[p >> 5] >> (62 - 2 * (p & 31))) & 3u;
+                if (!rc) o[j] = base_char(code);
+                else o[cl - 1 - j] = base_char(3u - code);  // reverseComplements(corrected) (utils.cpp:66-73; ACGT only here)
+            }
+        }
+        start = end;
+        if (start >= (u64)off + cl) break;
+        if (!w.next()) break;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, uint32_t* total_out, hipStream_t stream) {
@@ -365,6 +491,20 @@ hipError_t launch_text_write(const uint8_t* text, const uint2* results, const in
                              const uint32_t* poff, const uint32_t* noff, uint8_t* pout, uint8_t* nout, hipStream_t stream) {
     if (n_acc == 0) return hipSuccess;
     hipLaunchKernelGGL(bgr_text_write_kernel, dim3((n_acc + 15) / 16), dim3(256), 0, stream, text, results, arena, rec, acc_rec, n_acc, poff, noff, pout, nout);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_correct_sizes(const BgrDeviceGraph& g, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* psz,
+                                     uint32_t* nsz, uint32_t* clen, uint32_t* bug, hipStream_t stream) {
+    if (n_acc == 0) return hipSuccess;
+    hipLaunchKernelGGL(bgr_text_correct_sizes_kernel, dim3((n_acc + 255) / 256), dim3(256), 0, stream, g, results, arena, rec, acc_rec, n_acc, psz, nsz, clen, bug);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_correct_write(const BgrDeviceGraph& g, const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc,
+                                     const uint32_t* poff, const uint32_t* noff, const uint32_t* clen, uint8_t* pout, uint8_t* nout, hipStream_t stream) {
+    if (n_acc == 0) return hipSuccess;
+    hipLaunchKernelGGL(bgr_text_correct_write_kernel, dim3((n_acc + 15) / 16), dim3(256), 0, stream, g, text, results, arena, rec, acc_rec, n_acc, poff, noff, clen, pout, nout);
     return hipGetLastError();
 }
 

@@ -168,6 +168,23 @@ int bgr_pack_reads(const char* reads, const uint64_t* read_offsets, uint64_t n_r
 int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed_reads* reads, uint64_t n_reads, int32_t* paths_out,
                            uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
 
+/* Asynchronous form over host buffers ("asynchronous variant with a stream/ticket for double-buffering"):
+ * bgr_align_batch_begin starts the copy of the batch to the device and enqueues the mapping launch on the aligner's stream, then
+ * returns a ticket WITHOUT waiting; bgr_align_batch_wait blocks until that launch has finished and delivers its results (same
+ * output contract as bgr_align_batch); bgr_align_batch_test polls (1 = finished, 0 = still running).  One batch in flight per
+ * aligner: one host thread double-buffers with two aligners -- begin(A, b0); begin(B, b1); wait(A); begin(A, b2); wait(B); ... --
+ * where the blocking calls need two threads.  `reads` / `read_offsets` (page-locked memory recommended) must stay untouched until
+ * the wait has returned.  The batch must fit one launch (2 * (bases + 8 * reads) < 2^32 - 2^28): larger ones go through
+ * bgr_align_batch, which cuts them. */
+typedef struct {
+    bgr_aligner* aligner;
+    uint64_t n_reads;
+    uint64_t serial;      /* which begin of that aligner this ticket belongs to */
+} bgr_ticket;
+int bgr_align_batch_begin(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n_reads, bgr_ticket* ticket);
+int bgr_align_batch_test(const bgr_ticket* ticket);
+int bgr_align_batch_wait(const bgr_ticket* ticket, int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status);
+
 /* Text form: one piece of a FASTA file in, the bytes to append to `paths` / `notAligned.fa` out -- the whole per-batch body of
  * Aligner::alignPartGreedy (alignerGreedy.cpp:367-431: getReads, alignReadGreedy per read, the fwrite of a record) on the device,
  * so a batch crosses PCIe as the file's own bytes (text_kernels.hip).  The piece must start at a header line and end behind the
@@ -181,8 +198,11 @@ typedef struct bgr_text_stage bgr_text_stage;
 typedef struct {
     const char* text;             /* in: the piece (may be NULL when `stage` holds it) */
     uint64_t text_bytes;          /*     < 2^31 */
-    uint32_t want_output;         /*     0 = map and count only (-b without --write-exhaustive writes nothing) */
-    uint32_t irregular;           /* out */
+    uint32_t want_output;         /*     0 = map and count only (-b without --write-exhaustive writes nothing), 1 = the reference's records,
+                                         2 = correction mode (-c, alignerGreedy.cpp:394-404): a mapped read's record is header + the read as
+                                         spelled by its path (recoverPath, aligner.cpp:270-290); greedy modes, ACGT-only unitigs */
+    uint32_t irregular;           /* out: 1 = piece left to the host parser; 2 = (want_output 2) a path of this piece does not spell a walk --
+                                         the reference's "bug compaction" exit, which the caller reproduces on the host */
     char* paths_out;              /* in: where the records of mapped reads go */
     uint64_t paths_cap;
     char* notaligned_out;         /*     and those of the others (never more than text_bytes) */

@@ -617,6 +617,41 @@ def test_batch_of_mixed_lengths_keeps_the_fast_pass(mode, m):
         assert listed[2] >= li   # the long reads went on the list of the first pass
 
 
+def test_asynchronous_tickets_double_buffer_on_one_thread():
+    """bgr_align_batch_begin / _wait: one host thread keeps two aligners busy (begin A, begin B, wait A, begin A, wait B ...); every
+    batch's rows, offsets and status equal the blocking call's, counters add up, stale tickets and a second begin are refused."""
+    s = Synth(200000, 100, 2, 31, 911)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(31, seqs, offs)
+    a1, a2, ref = B.Aligner(g, 0), B.Aligner(g, 0), B.Aligner(g, 0)
+    batches = [s.reads(i * 30000, 30000 - 7 * i, 150, 3, 912) for i in range(6)]
+    want = [ref.align(r, o, m=2, effort=2) for r, o in batches]
+    als = [a1, a2]
+    tickets = [None, None]
+    got = [None] * len(batches)
+    for i, (r, o) in enumerate(batches):
+        j = i & 1
+        if tickets[j] is not None:
+            got[tickets[j][1]] = als[j].align_wait(tickets[j][0])
+        tickets[j] = (als[j].align_begin(r, o, m=2, effort=2), i)
+        if i == 2:
+            with pytest.raises(B.BgrError):
+                als[j].align_begin(r, o)      # one batch in flight per aligner
+    for j in range(2):
+        als[j].align_test(tickets[j][0])
+        got[tickets[j][1]] = als[j].align_wait(tickets[j][0])
+        with pytest.raises(B.BgrError):
+            als[j].align_wait(tickets[j][0])  # a ticket is waited for once
+    for (p1, po1, st1), (p2, po2, st2) in zip(got, want):
+        assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    c1, c2, cr = a1.counters(), a2.counters(), ref.counters()
+    assert {k: c1[k] + c2[k] for k in cr} == cr
+    # an empty batch
+    t = a1.align_begin(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    p, po, st = a1.align_wait(t)
+    assert len(p) == 0 and list(po) == [0]
+
+
 def test_ragged_and_empty_batches():
     s = Synth(60000, 75, 2, 31, 77)
     seqs, offs = s.unitigs()

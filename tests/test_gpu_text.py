@@ -141,3 +141,28 @@ def test_empty_and_tiny_pieces():
     assert (p, n) == (b"", b"") and not info["irregular"] and info["n_records"] == 1 and info["n_accepted"] == 0
     p, n, info = al.align_fasta_text(b">one\n" + b"ACGT" * 20 + b"\n")
     assert not info["irregular"] and info["n_accepted"] == 1 and (p + n).startswith(b">one\n")
+
+
+def _cli_pair(args, extra_a, extra_b):
+    from util import run_cli
+    oa, pa, na = run_cli(B.CLI_PATH, args + extra_a)
+    ob, pb, nb = run_cli(B.CLI_PATH, args + extra_b)
+    return (oa, pa, na), (ob, pb, nb)
+
+
+@pytest.mark.parametrize("seed,L,k,m", [(1, 150, 31, 2), (2, 100, 21, 3), (3, 250, 31, 5), (4, 60, 12, 1)])
+def test_cli_correction_mode_on_the_device_equals_the_host_formatter(seed, L, k, m, tmp_path):
+    """-c through the text route (the device spells every mapped read from its path and the 2-bit unitig store, reverse complemented
+    when the path was found on the other strand) == -c with --host-route (recover_path on the host, itself pinned to the reference's
+    goldens): same bytes, same stdout."""
+    s = Synth(150000, 3 * k, 3, k, 8100 + seed)
+    s.write_unitigs(str(tmp_path / "u.fa"))
+    s.write_reads(str(tmp_path / "r.fa"), 0, 30000, L, m + 1, 8200 + seed)
+    args = ["-r", str(tmp_path / "r.fa"), "-k", str(k), "-g", str(tmp_path / "u.fa"), "-m", str(m), "-c", "-t", "4"]
+    (oa, pa, na), (ob, pb, nb) = _cli_pair(args, [], ["--host-route"])
+    assert pa == pb and na == nb
+    assert [l for l in oa.splitlines() if "seconds" not in l] == [l for l in ob.splitlines() if "seconds" not in l]
+    assert pa.count(b"\n") > 20000   # most reads map: header + corrected read
+    # a corrected read is as long as its read (the walk covers it) and made of ACGT
+    lines = pa.split(b"\n")
+    assert all(len(x) == L and set(x) <= set(b"ACGT") for x in lines[1:2000:2])
