@@ -460,9 +460,34 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
             if best is None or wall < best:
                 best = wall
         out_bytes = os.path.getsize(os.path.join(d, "paths0")) + os.path.getsize(os.path.join(d, "notAligned0.fa"))
+        # N > 1: the CLI's own form as well -- ONE process feeding all N devices (bgr_devices_init: one upload, then device to device over
+        # xGMI; bgr_align_all with n_gpus = N: one producer, per-device queues and workers, one ordered writer), rank 0's file, the other
+        # ranks waiting.  What a future scaling run reads as "does the CLI scale", next to the per-rank figure above.
+        one_process = None
+        if world > 1:
+            if dist is not None:
+                dist.barrier()
+            if rank == 0:
+                try:
+                    import torch
+                    n_dev = min(world, B.device_count(), max(1, torch.cuda.device_count()))
+                    how = g.devices_init(0, n_dev, 0)
+                    t1 = time.perf_counter()
+                    cnt1, _ = B.align_all(g, f, os.path.join(d, "paths_1p"), os.path.join(d, "notAligned_1p.fa"), m=args.mismatch, effort=args.effort,
+                                          threads=min(len(os.sched_getaffinity(0)), ncpu * n_dev), n_gpus=n_dev, first_device=0)
+                    w1 = time.perf_counter() - t1
+                    one_process = {"value": round(n / w1 / 1e6, 3), "unit": "Mreads/s", "n_gpus": n_dev, "reads": n, "host_threads": min(len(os.sched_getaffinity(0)), ncpu * n_dev),
+                                   "fanout_method": {0: "none", 1: "rccl broadcast", 2: "peer copies"}.get(how, str(how)),
+                                   "identical_bytes_to_one_gpu": bool(_same_file(os.path.join(d, "paths0"), os.path.join(d, "paths_1p")) and
+                                                                      _same_file(os.path.join(d, "notAligned0.fa"), os.path.join(d, "notAligned_1p.fa"))),
+                                   "what": "bgr_align_all(n_gpus = N) in ONE process on rank 0's file while the other ranks wait"}
+                except Exception as ex:
+                    one_process = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            if dist is not None:
+                dist.barrier()
         return {"value": round(world * n / best / 1e6, 3), "unit": "Mreads/s", "reads_per_gpu": n, "n_gpus": world, "host_threads_per_gpu": ncpu, "seconds": round(best, 4),
                 "input": "FASTA, %d bytes per GPU, written just before the run: page cache" % fsize, "input_GB_per_s": round(world * fsize / best / 1e9, 2),
-                "output_bytes_per_gpu": out_bytes, "aligned": cnt["aligned"], "runs_mreads_per_s": runs, "host_route": host_route,
+                "output_bytes_per_gpu": out_bytes, "aligned": cnt["aligned"], "runs_mreads_per_s": runs, "host_route": host_route, "one_process_all_gpus": one_process,
                 "what": "bgr_align_all (the CLI's mapping phase): file -> paths + notAligned.fa, the device taking the FASTA text and returning the record bytes "
                         "(bgr_align_fasta_text); best of 3 runs (fresh output files, os.sync() before each, not timed); index build excluded"}
     except Exception as ex:
