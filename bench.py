@@ -74,6 +74,10 @@ def parse_args():
     ap.add_argument("--gamma", type=float, default=0.0, help="overlap key table slots per key (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the eight-reads-per-wave passes (diagnostic)")
+    ap.add_argument("--exh-first-pass-off", action="store_true", help="exhaustive: skip the eight-reads-per-wave pass, every read goes through the search kernels (diagnostic)")
+    ap.add_argument("--anc-first-pass-off", action="store_true", help="anchors: skip the several-reads-per-wave pass (diagnostic)")
+    ap.add_argument("--exh-search", type=int, default=0, help="exhaustive: 0 = choose, 1 = depth-first search, 2 = level search (diagnostic)")
+    ap.add_argument("--exh-frame-cap", type=int, default=0, help="exhaustive: search frames / levels per wave (a tiny cap pushes reads through the later passes; diagnostic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and the issue fractions become null)")
     ap.add_argument("--pmc-steps", type=int, default=3)
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end leg per GPU (0 disables); 100 M x 150 bp = a 16 GB FASTA file: "
@@ -120,9 +124,10 @@ def run_pmc_passes(args):
            "--genome", str(args.genome), "--site-spacing", str(args.site_spacing), "--alleles", str(args.alleles), "--lds-mphf", str(args.lds_mphf),
            "--waves", str(args.waves), "--blocks-per-cu", str(args.blocks_per_cu), "--gamma", str(args.gamma), "--cpu-threads", str(args.cpu_threads),
            "--debug-stop", str(args.debug_stop)]
-    for flag in ("exhaustive", "anchors", "general_kernel_only"):
+    for flag in ("exhaustive", "anchors", "general_kernel_only", "exh_first_pass_off", "anc_first_pass_off"):
         if getattr(args, flag):
             fwd.append("--" + flag.replace("_", "-"))
+    fwd += ["--exh-search", str(args.exh_search), "--exh-frame-cap", str(args.exh_frame_cap)]
     totals, per_kernel = {}, {}
     t0 = time.time()
     for tag, counters in PMC_PASSES:
@@ -221,6 +226,14 @@ def main():
         al.set_knob(B.KNOB_GREEDY_FAST, 1)
     if args.debug_stop:
         al.set_knob(B.KNOB_DEBUG_STOP, args.debug_stop)
+    if args.exh_first_pass_off:
+        al.set_knob(B.KNOB_EXH_FAST, 1)
+    if args.anc_first_pass_off:
+        al.set_knob(B.KNOB_ANCHORS_FAST, 1)
+    if args.exh_search:
+        al.set_knob(B.KNOB_EXH_SEARCH, args.exh_search)
+    if args.exh_frame_cap:
+        al.set_knob(B.KNOB_EXH_FRAME_CAP, args.exh_frame_cap)
     if rank == 0:
         log("graph: %s  (%.1fs)" % (graph_info, time.time() - t0))
 

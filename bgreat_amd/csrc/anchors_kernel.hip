@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                 // ---- alignReadGreedyAnchors loop body for this anchor (alignerGreedy.cpp:68-161): place the unitig on the read ----
                 u64 pv = 0;
                 BgrUnitigMeta mt;
-                mt.len = 0; mt.flags = 0; mt.rec_beg = 0; mt.rec_end = 0; mt.F = 0; mt.pad = 0;
+                mt.len = 0; mt.flags = 0; mt.rec_beg = 0; mt.rec_end = 0; mt.F = 0; mt.hw[0] = mt.hw[1] = 0;
                 if (found) { pv = av.pos[idx]; mt = g.meta[(uint32_t)(pv >> 32)]; }
                 const uint32_t un = (uint32_t)(pv >> 32);
                 uint32_t pU = (uint32_t)pv;
@@ -385,9 +385,14 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                 if (returned) { fo += len; pU = len - K - pU; }
                 const int32_t uid = returned ? -(int32_t)un : (int32_t)un;
                 // the oriented unitig's end (k-1)-mers as neighbour records (what str2num + getEnd/getBegin find)
-                const uint32_t rec_b = returned ? mt.rec_end : mt.rec_beg, rec_e = returned ? mt.rec_beg : mt.rec_end;
                 const uint32_t can_b = (mt.flags & (returned ? BGR_META_CANON_RCEND : BGR_META_CANON_BEG)) ? 1u : 0u;
                 const uint32_t can_e = (mt.flags & (returned ? BGR_META_CANON_RCBEG : BGR_META_CANON_END)) ? 1u : 0u;
+                // (as the HALVES the first steps read: getEnd for the left walk, getBegin for the right one -- handles, graph_layout.h)
+                uint32_t rec_b = G4_REC_MASK, rec_e = G4_REC_MASK;
+                if (found && okp) {
+                    rec_b = half_handle(g, returned ? mt.rec_end : mt.rec_beg, can_b != 0, true);
+                    rec_e = half_handle(g, returned ? mt.rec_beg : mt.rec_end, can_e != 0, false);
+                }
                 const uint32_t c12 = pR >= pU ? 1u : 0u;                       // the unitig starts inside the read (cases 1, 2)
                 const uint32_t longr = (L - pR >= len - pU) ? 1u : 0u;         // the read reaches the unitig's end (cases 1, 3)
                 const uint32_t start = pR - pU, uoff = pU - pR;               // (whichever the case uses)

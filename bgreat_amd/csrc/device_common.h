@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u6
             const bool first = c1 != 0;
             const uint32_t c = first ? c1 : c2;
             const uint32_t idx = (first ? b1 : b2) * 4 + ((uint32_t)(__ffs((int)c) - 1) >> 3);
-            if (g.keys[idx] == key) { res = idx; c1 = 0; c2 = 0; }
+            if (g.keys[idx].key == key) { res = idx; c1 = 0; c2 = 0; }
             else if (first) c1 &= c1 - 1;
             else c2 &= c2 - 1;
         }
@@ -124,6 +124,14 @@ __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u6
         }
     }
     return res;
+}
+
+// The half of key entry `idx` a walk step reads (graph_layout.h: handles): getEnd(bin) -- a step to the LEFT -- reads the right table
+// when bin is canonical, else the left one; getBegin(bin) -- a step to the right -- the other way round (aligner.cpp:147-267).
+__device__ __forceinline__ uint32_t half_handle(const BgrDeviceGraph& g, uint32_t idx, bool canon, bool left) {
+    if (idx == BGR_NONE) return BGR_HNONE;
+    const uint2 h = *reinterpret_cast<const uint2*>(&g.keys[idx].hL);
+    return canon == left ? h.y : h.x;
 }
 
 // ---- stage A: the read's 2-bit words, from the planes the pre-pass (bgr_pack_reads_kernel) or the host packer wrote ----
@@ -230,22 +238,22 @@ __device__ __forceinline__ uint32_t ham_near(const u64* CMP, u64 near, bool left
     return __popcll(mm);
 }
 
+// `hnd` = handle of the half to read (half_handle / a slot's nx word without its flag bit); the half's slots follow each other,
+// the last one flagged (candidate lanes behind it see whatever comes next in the array and are masked off)
 template <int DIR>
 __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L,
-                                                   uint32_t K1, uint32_t rec, bool canon, uint32_t pos, int lane) {
+                                                   uint32_t K1, uint32_t hnd, bool canon, uint32_t pos, int lane) {
     Scored sc;
     const int c = lane >> 4, sub = lane & 15;
-    // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
-    const bool useR = (DIR == 0) ? canon : !canon;
     const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
     // one 32-byte slot per candidate (graph_layout.h BgrSlot): id + orientation bits, length, sequence address |
-    // the unitig's flags and end records (what the NEXT step needs)
-    const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + (useR ? 4u : 0u) + (uint32_t)c) * 2;
+    // where the walk goes on behind the unitig (what the NEXT step needs)
+    const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(hnd + (uint32_t)c) * 2;
     const uint4 sl = sp[0];
-    const uint4 m0 = sp[1];  // x = BGR_META_* flags, y = rec_beg, z = rec_end
+    const uint4 m0 = sp[1];  // y = nx0, z = nx1: next half | canonical << 28, reached by a canonical / non-canonical query
     const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
-    const u64 zmask = __ballot(id == 0);
-    sc.first_zero = zmask ? (__ffsll((long long)zmask) - 1) >> 4 : 4;
+    const u64 lmask = __ballot((sl.w & BGR_SLOT_LAST) != 0) & 0x0001000100010001ULL;  // lane 0 of each candidate's 16
+    sc.first_zero = ((__ffsll((long long)lmask) - 1) >> 4) + 1;  // candidates = slots up to and including the first flagged one
     const bool valid = c < sc.first_zero;
     const bool fwd = (sl.x & fbit) != 0;
     const uint32_t len = valid ? sl.y : 0;
@@ -260,8 +268,6 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
         n = fits ? pos : sc.ext;
         ustart = fits ? sc.ext - pos : 0;
         rstart = fits ? 0 : pos - sc.ext;
-        sc.nrec = fwd ? m0.y : m0.z;
-        sc.info = (fits ? 1u : 0u) | ((m0.x & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) ? 2u : 0u);
     } else {
         if (DIR == 1) {
             const uint32_t rl = L - pos - K1;
@@ -276,8 +282,11 @@ __device__ __forceinline__ Scored score_candidates(const BgrDeviceGraph& g, cons
             ustart = 0;
             rstart = pos;
         }
-        sc.nrec = fwd ? m0.z : m0.y;
-        sc.info = (fits ? 1u : 0u) | ((m0.x & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) ? 2u : 0u);
+    }
+    {
+        const uint32_t nx = canon ? m0.y : m0.z;
+        sc.nrec = nx & BGR_HNONE;
+        sc.info = (fits ? 1u : 0u) | ((nx & BGR_H_CANON) ? 2u : 0u);
     }
     if (!valid) n = 0;
     // (requesting the next step's slot line here, ahead of the choice, was measured: 1-4 % slower on all workloads)
@@ -317,7 +326,7 @@ __device__ __forceinline__ Step greedy_step(const BgrDeviceGraph& g, const u64* 
                                             uint32_t K1, uint32_t rec, bool canon, uint32_t pos, uint32_t budget, int lane) {
     Step out;
     out.found = false; out.fits = false; out.sid = 0; out.miss = 0; out.ext = 0; out.next_rec = BGR_NONE; out.next_canon = false;
-    if (rec == BGR_NONE) return out;  // key not in the table: getBegin/getEnd return an empty list
+    if (rec == BGR_HNONE) return out;  // no such half: getBegin/getEnd return an empty list  (`rec` = the HANDLE of the half to read)
     const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, rec, canon, pos, lane);
     // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min"):
     // the minimum of (miss << 2 | slot) over the candidates
@@ -347,6 +356,7 @@ __device__ __forceinline__ bool walk_left(const BgrDeviceGraph& g, const u64* CM
                                           uint32_t rec, bool canon, uint32_t pos, uint32_t* budget, int32_t* PATH, uint32_t mid,
                                           uint32_t* nl_out, int lane) {
     uint32_t nl = 0;
+    rec = half_handle(g, rec, canon, true);  // (the caller names the key entry; the steps pass handles on)
     for (;;) {
         if (pos == 0) { if (lane == 0) PATH[mid - 1 - nl] = 0; ++nl; break; }
         Step s = greedy_step<0>(g, CMP, NM, useN, L, K1, rec, canon, pos, *budget, lane);
@@ -367,6 +377,7 @@ __device__ __forceinline__ bool walk_right(const BgrDeviceGraph& g, const u64* C
                                            uint32_t* nr_out, int lane) {
     uint32_t nr = 0;
     bool first = true;
+    rec = half_handle(g, rec, canon, false);
     for (;;) {
         if (first) { if (L - pos - K1 == 0) break; } else { if (L - pos < K1 + 1) break; }
         Step s = first ? greedy_step<1>(g, CMP, NM, useN, L, K1, rec, canon, pos, *budget, lane)
@@ -392,7 +403,7 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
     // spilled registers)
     const uint32_t mid = a_pos + 2;  // left pushes grow downwards from mid-1 (at most a_pos+1 of them), right upwards from mid
     uint32_t nl = 0, nr = 0, budget = m;
-    uint32_t pos = a_pos, rec = a_rec;
+    uint32_t pos = a_pos, rec = half_handle(g, a_rec, a_canon, true);  // (a_rec: the anchor's key entry; the walks pass handles on)
     bool canon = a_canon;
     for (;;) {  // left walk
         if (pos == 0) { if (lane == 0) PATH[mid - 1 - nl] = 0; ++nl; break; }
@@ -404,7 +415,7 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
         if (s.fits) { if (lane == 0) PATH[mid - 1 - nl] = (int32_t)(s.ext - pos); ++nl; break; }
         pos -= s.ext; rec = s.next_rec; canon = s.next_canon;
     }
-    pos = a_pos; rec = a_rec; canon = a_canon;
+    pos = a_pos; rec = half_handle(g, a_rec, a_canon, false); canon = a_canon;
     bool first = true;
     for (;;) {  // right walk
         if (first) { if (L - pos - K1 == 0) break; } else { if (L - pos < K1 + 1) break; }
@@ -434,18 +445,19 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     constexpr uint32_t QL = GL / 4;  // lanes per candidate slot: each takes 32 bases per round of the compare
     const uint32_t c = ((uint32_t)lane / QL) & 3u, q = (uint32_t)lane % QL;
     const uint32_t left = phase == 1 ? 1u : 0u;
-    // getEnd(bin): bin<=rc ? rightIndices : leftIndices ; getBegin(bin): bin<=rc ? leftIndices : rightIndices
-    const uint32_t useR = canon == left ? 1u : 0u;
-    uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
+    // `rec` = the HANDLE of the half to read (G4_REC_MASK == BGR_HNONE: none): its slots follow each other, the last one flagged; lanes
+    // of candidates behind it see whatever comes next in the array and are masked off
+    uint4 sl = make_uint4(0, 0, 0, BGR_SLOT_LAST), m0 = make_uint4(0, 0, 0, 0);
     if (phase != 0 && rec != G4_REC_MASK) {
-        const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + useR * 4u + c) * 2;
+        const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec + c) * 2;
         sl = sp[0];
         m0 = sp[1];
     }
-    const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
-    const u64 zmask = __ballot(id == 0);  // (all lanes of a candidate agree; a group that sits out reads as "no candidate")
-    const uint32_t nb = (uint32_t)(zmask >> ((uint32_t)lane & (64u - GL))) & (GL == 16 ? 0x1111u : 0x55u);
-    const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) / QL : 4u;  // the reference stops at the first empty slot
+    const uint32_t id = (phase != 0 && rec != G4_REC_MASK) ? sl.x & BGR_SLOT_ID_MASK : 0u;
+    const u64 lmask = __ballot((sl.w & BGR_SLOT_LAST) != 0);  // (all lanes of a candidate agree)
+    const uint32_t nb = (uint32_t)(lmask >> ((uint32_t)lane & (64u - GL))) & (GL == 16 ? 0x1111u : 0x55u);
+    // candidates = the slots up to and including the first flagged one (a group that sits out, or whose half is empty: none)
+    const uint32_t n_cand = (phase != 0 && rec != G4_REC_MASK && nb) ? (uint32_t)(__ffs((int)nb) - 1) / QL + 1u : 0u;
     const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
     const uint32_t len = sl.y;
     const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwd ? 0u : len);
@@ -458,9 +470,8 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     uint32_t n = fits ? rl : (span < rl ? span : rl);  // (later right steps: read.substr(pos, |u|) is clipped at |read|)
     const uint32_t ustart = left ? ext - n : kk;
     const uint32_t rstart = left ? rl - n : pos + kk;
-    const uint32_t nrec = fwd == left ? m0.y : m0.z;
-    const uint32_t cbit = left ? (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND) : (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
-    if (c >= first_zero) n = 0;
+    const uint32_t nx = canon ? m0.y : m0.z;  // next half | canonical << 28 (graph_layout.h nx0 / nx1)
+    if (c >= n_cand) n = 0;
     // at most 32 bases next to the overlap: they sit in the slot itself (graph_layout.h `near`), no load from seq.  Not for the
     // later right steps (they compare the overlap as well, alignerGreedy.cpp:222,243) nor for a unitig that hangs on the overlap both ways
     const uint32_t both = BGR_SLOT_F0 | BGR_SLOT_F1;
@@ -474,13 +485,13 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     cnt += quad_xor1(cnt);
     if (QL == 4) cnt += quad_xor2(cnt);
     // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
-    uint32_t key = c < first_zero ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
+    uint32_t key = c < n_cand ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
     uint32_t o = GL == 16 ? row_ror4(key) : quad_xor2(key);   // 16 lanes: slots sit 4 lanes apart; 8 lanes: 2 apart
     key = o < key ? o : key;
     o = GL == 16 ? row_ror8(key) : half_row_mirror(key);      // (lane 7 - l of the half row: the other two slots)
     key = o < key ? o : key;
     const uint32_t src = ((uint32_t)lane & (64u - GL)) | ((key & 3u) * QL);
-    const uint32_t pk = nrec | ((m0.x & cbit) ? G4_CANON : 0u) | (fits ? G4_FITS : 0u);
+    const uint32_t pk = (nx & (G4_REC_MASK | G4_CANON)) | (fits ? G4_FITS : 0u);
     const uint32_t w1 = lane_get(pk, src);
     *ext_o = lane_get(ext, src);
     *sid_o = (int32_t)lane_get(fwd ? id : 0u - id, src);
@@ -501,6 +512,9 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
 #endif
 #ifndef BGR_EXH_OCC
 #define BGR_EXH_OCC 6 /* waves per SIMD the exhaustive kernel is compiled for */
+#endif
+#ifndef BGR_EXH_DEEP_OCC
+#define BGR_EXH_DEEP_OCC BGR_EXH_OCC /* ... its variant with the search state in HBM */
 #endif
 
 // ================================================ kernels ===============================================

@@ -30,7 +30,10 @@ __device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u6
     uint32_t best = budget + 1;
     *best_n = 0;
     int depth = 0;
-    if (lane == 0) { FR[0] = a_rec; FR[1] = a_pos; FR[2] = 0; FR[3] = a_canon ? (1u << 17) : 0u; }
+    {   // (a frame names the HALF its candidates come from -- a handle, graph_layout.h; the anchor is a key entry)
+        const uint32_t h0 = half_handle(g, a_rec, a_canon, DIR == 0);
+        if (lane == 0) { FR[0] = h0; FR[1] = a_pos; FR[2] = 0; FR[3] = a_canon ? (1u << 17) : 0u; }
+    }
     wave_sync();
     while (depth >= 0) {
         uint32_t* F = FR + (uint32_t)depth * FR_WORDS;
@@ -58,7 +61,7 @@ __device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u6
                 continue;
             }
             uint32_t ncand = 0;
-            if (rec != BGR_NONE) {
+            if (rec != BGR_HNONE) {
                 const bool canon = (ctl >> 17) & 1u;
                 const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, rec, canon, pos, lane);
                 ncand = (uint32_t)sc.first_zero;
@@ -151,7 +154,10 @@ __device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* C
     const int i = lane >> 4, c = (lane >> 2) & 3, sub = lane & 3, k = lane >> 2;
     const bool leader = sub == 0;
     *best_n = 0;
-    if (lane == 0) { T[0] = a_rec; T[1] = a_pos; T[2] = a_canon ? 1u : 0u; T[3] = 0; }
+    {   // (a node names the HALF its candidates come from -- a handle, graph_layout.h; the anchor is a key entry)
+        const uint32_t h0 = half_handle(g, a_rec, a_canon, DIR == 0);
+        if (lane == 0) { T[0] = h0; T[1] = a_pos; T[2] = a_canon ? 1u : 0u; T[3] = 0; }
+    }
     wave_sync();
     uint32_t n_cur = 1, lvl = 0;
     for (; n_cur; ++lvl) {
@@ -161,19 +167,19 @@ __device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* C
         const uint32_t rec = nd.x, pos = nd.y, prefix = nd.w;
         const bool canon = (nd.z & 1u) != 0;
         const bool end_here = nvalid && ((DIR == 0) ? (pos == 0) : (L - pos - K1 == 0));
-        const bool has_rec = nvalid && !end_here && rec != BGR_NONE;
-        const bool useR = (DIR == 0) ? canon : !canon;
+        const bool has_rec = nvalid && !end_here && rec != BGR_HNONE;
         const uint32_t fbit = canon ? BGR_SLOT_F0 : BGR_SLOT_F1;
         uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
         if (has_rec) {
-            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + (useR ? 4u : 0u) + (uint32_t)c) * 2;
+            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec + (uint32_t)c) * 2;
             sl = sp[0];
             m0 = sp[1];
         }
         const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
-        const u64 zmask = __ballot(leader && (!has_rec || id == 0));
-        const uint32_t nb = (uint32_t)(zmask >> (16 * i)) & 0x1111u;
-        const uint32_t first_zero = nb ? (uint32_t)(__ffs((int)nb) - 1) >> 2 : 4u;  // the reference stops at the first empty slot
+        const u64 lmask = __ballot(leader && has_rec && (sl.w & BGR_SLOT_LAST) != 0);
+        const uint32_t nb = (uint32_t)(lmask >> (16 * i)) & 0x1111u;
+        // candidates = the half's slots up to and including the first flagged one (the reference stops at the first empty slot)
+        const uint32_t first_zero = nb ? ((uint32_t)(__ffs((int)nb) - 1) >> 2) + 1u : 0u;
         if (DIR == 1 && partial && lvl == 0) {  // alignerExhaustive.cpp:217-221 (-i): nothing starts here, nothing to pay
             const bool none = rl32(first_zero, 0) == 0 && !(rl32(end_here ? 1u : 0u, 0));
             if (none) { wave_sync(); return 0; }
@@ -192,16 +198,17 @@ __device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* C
             n = fits ? pos : ext;
             ustart = fits ? ext - pos : 0;
             rstart = fits ? 0 : pos - ext;
-            nrec = fwd ? m0.y : m0.z;
-            ncanon = (m0.x & (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND)) != 0;
         } else {
             const uint32_t rl = L - pos - K1;
             fits = ext >= rl;
             n = fits ? rl : ext;
             ustart = K1;
             rstart = pos + K1;
-            nrec = fwd ? m0.z : m0.y;
-            ncanon = (m0.x & (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG)) != 0;
+        }
+        {
+            const uint32_t nx = canon ? m0.y : m0.z;  // next half | canonical << 28 (graph_layout.h nx0 / nx1)
+            nrec = nx & BGR_HNONE;
+            ncanon = (nx & BGR_H_CANON) != 0;
         }
         if (!valid) n = 0;
         uint32_t cnt = 0;
@@ -330,7 +337,7 @@ __device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* C
 // DEEP (pass 2): the search state (OUT | CUR | BEST | frames) of every wave lives in HBM (io.deep_scratch) instead
 // of LDS, sized for the worst case, so neither the depth of the search nor the read length is bounded by LDS.
 template <bool STAGE, bool DEEP>
-__global__ void __launch_bounds__(1024, BGR_EXH_OCC) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
+__global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -460,7 +467,9 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
     const uint32_t c = ((uint32_t)lane / QL) & 3u, q = (uint32_t)lane % QL, sub = (uint32_t)lane % GL;
     const uint32_t gl0 = (uint32_t)lane & (64u - GL);  // first lane of the group
     uint32_t fwd = act, fb = 0, lvl = 0, nlev = 0, prefix = 0;
-    uint32_t pos = a_pos, rec = a_rec, canon = a_canon;
+    // rec: the HANDLE of the half the level's candidates come from (graph_layout.h); the anchor a_rec is a key entry
+    uint32_t pos = a_pos, canon = a_canon, rec = G4_REC_MASK;
+    if (act && a_rec != G4_REC_MASK) rec = half_handle(g, a_rec, a_canon != 0, DIR == 0);
     // ---- forward: one node per level ----
     for (;;) {
         if (fwd && lvl >= XL) { fb = 1; fwd = 0; }
@@ -471,30 +480,29 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
             fwd = 0;
         }
         if (!__any(fwd != 0)) break;
-        const uint32_t useR = ((DIR == 0) ? canon : (canon ^ 1u));
         uint4 sl = make_uint4(0, 0, 0, 0), m0 = make_uint4(0, 0, 0, 0);
-        if (fwd && rec != G4_REC_MASK) {
-            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec * 8u + useR * 4u + c) * 2;
+        const bool reads = fwd && rec != G4_REC_MASK;
+        if (reads) {
+            const uint4* sp = reinterpret_cast<const uint4*>(g.recs) + (size_t)(rec + c) * 2;
             sl = sp[0];
             m0 = sp[1];
         }
-        const uint32_t id = sl.x & BGR_SLOT_ID_MASK;
-        const u64 zmask = __ballot(id == 0);
-        const uint32_t zb = (uint32_t)(zmask >> gl0) & Q0;
-        const uint32_t first_zero = zb ? (uint32_t)(__ffs((int)zb) - 1) / QL : 4u;  // the reference stops at the first empty slot
+        const uint32_t id = reads ? sl.x & BGR_SLOT_ID_MASK : 0u;
+        const u64 lmask = __ballot(reads && (sl.w & BGR_SLOT_LAST) != 0);
+        const uint32_t zb = (uint32_t)(lmask >> gl0) & Q0;
+        // candidates = the half's slots up to and including the first flagged one (the reference stops at the first empty slot)
+        const uint32_t first_zero = (reads && zb) ? (uint32_t)(__ffs((int)zb) - 1) / QL + 1u : 0u;
         const uint32_t valid = c < first_zero ? 1u : 0u;
         const uint32_t fwdu = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
         const uint32_t len = sl.y;
         const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwdu ? 0u : len);
         const uint32_t ext = len - K1;
-        uint32_t fits, n, ustart, rstart, nrec, cbit, aux, npos;
+        uint32_t fits, n, ustart, rstart, aux, npos;
         if (DIR == 0) {
             fits = ext >= pos ? 1u : 0u;
             n = fits ? pos : ext;
             ustart = fits ? ext - pos : 0;
             rstart = fits ? 0 : pos - ext;
-            nrec = fwdu ? m0.y : m0.z;
-            cbit = fwdu ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND;
             aux = ext - pos;   // offset in the last unitig (:126,:175)
             npos = pos - ext;
         } else {
@@ -503,8 +511,6 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
             n = fits ? rl : ext;
             ustart = K1;
             rstart = pos + K1;
-            nrec = fwdu ? m0.z : m0.y;
-            cbit = fwdu ? BGR_META_CANON_END : BGR_META_CANON_RCBEG;
             aux = L - pos;     // |readLeft| + k-1 (:99,:231)
             npos = pos + ext;
         }
@@ -535,7 +541,7 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         const u64 nmask = __ballot(need && q == 0 && fwd);
         const uint32_t nb = (uint32_t)(nmask >> gl0) & Q0;
         const uint32_t src = gl0 | (nb ? (uint32_t)(__ffs((int)nb) - 1) : 0u);
-        const uint32_t kpk = nrec | ((m0.x & cbit) ? G4_CANON : 0u);
+        const uint32_t kpk = (canon ? m0.y : m0.z) & (G4_REC_MASK | G4_CANON);  // next half | canonical << 28 (graph_layout.h nx0 / nx1)
         const uint32_t k_rec = lane_get(kpk, src), k_pos = lane_get(npos, src);
         const u64 dmask = __ballot(need && fwd && (kpk != k_rec || npos != k_pos));
         uint32_t pmin = need ? ptotal : 0xFFFFFFFFu;

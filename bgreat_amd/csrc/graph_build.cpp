@@ -123,8 +123,8 @@ inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m, const ui
     s[j].Fw = (uint32_t)(m.F >> 5);
     s[j].Fo_x = (uint32_t)(m.F & 31) | ((uint32_t)((near >> 32) & 15u) << 8);
     s[j].mflags_x = (m.flags & 15u) | (uint32_t)((near >> 32) & 0xFFFFFFF0u);
-    s[j].rec_beg = m.rec_beg;
-    s[j].rec_end = m.rec_end;
+    s[j].nx0 = m.rec_beg;   // (temporary: the unitig's end KEYS; compact_slots() turns them into the handles of the next halves)
+    s[j].nx1 = m.rec_end;
     s[j].near_lo = (uint32_t)near;
 }
 
@@ -132,7 +132,7 @@ inline void fill_slot(BgrSlot* s, uint32_t idf, const BgrUnitigMeta& m, const ui
 
 uint32_t host_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key) {
     const uint32_t* table = reinterpret_cast<const uint32_t*>(base + h->off_table);
-    const uint64_t* keys = reinterpret_cast<const uint64_t*>(base + h->off_keys);
+    const BgrKeyEntry* keys = reinterpret_cast<const BgrKeyEntry*>(base + h->off_keys);
     const uint32_t nb = (uint32_t)h->n_buckets;
     const uint64_t m = bgr_mix64(key);
     const uint32_t bk[2] = {bgr_tab_bucket((uint32_t)m, nb), bgr_tab_bucket((uint32_t)(m >> 32), nb)};
@@ -141,7 +141,7 @@ uint32_t host_lookup(const BgrBlobHeader* h, const uint8_t* base, uint64_t key) 
         if (c == 1 && bk[1] == bk[0]) break;
         for (uint32_t z = bgr_zero_bytes(table[bk[c]] ^ f4); z; z &= z - 1) {
             const uint32_t idx = bk[c] * 4 + ((uint32_t)__builtin_ctz(z) >> 3);
-            if (keys[idx] == key) return idx;
+            if (keys[idx].key == key) return idx;
         }
     }
     if (h->n_fallback) {
@@ -157,7 +157,7 @@ void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGr
     const uint8_t* base = static_cast<const uint8_t*>(basev);
     memset(&dg, 0, sizeof(dg));
     dg.table = reinterpret_cast<const uint32_t*>(base + h->off_table);
-    dg.keys = reinterpret_cast<const uint64_t*>(base + h->off_keys);
+    dg.keys = reinterpret_cast<const BgrKeyEntry*>(base + h->off_keys);
     dg.recs = reinterpret_cast<const BgrSlot*>(base + h->off_recs);
     dg.meta = reinterpret_cast<const BgrUnitigMeta*>(base + h->off_meta);
     dg.seq = reinterpret_cast<const uint64_t*>(base + h->off_seq);
@@ -182,7 +182,8 @@ bool validate_blob_header(const BgrBlobHeader* h, uint64_t bytes, std::string& e
         return count <= (bytes - off) / size;
     };
     if (h->n_keys >= 0x0FFFFFFFull || h->n_unitigs > 0x40000000ull || h->n_buckets == 0 || h->n_buckets >= (1ull << 26)) { err = "corrupt blob header (counts)"; return false; }
-    if (!inside(h->off_table, h->n_buckets, 4) || !inside(h->off_keys, h->n_keys, 8) || !inside(h->off_recs, h->n_keys, sizeof(BgrSlot) * 8) ||
+    if (h->n_slots >= BGR_HNONE - 8) { err = "corrupt blob header (slots)"; return false; }
+    if (!inside(h->off_table, h->n_buckets, 4) || !inside(h->off_keys, h->n_keys, sizeof(BgrKeyEntry)) || !inside(h->off_recs, h->n_slots + 4, sizeof(BgrSlot)) ||
         !inside(h->off_meta, h->n_unitigs + 1, sizeof(BgrUnitigMeta)) || !inside(h->off_seq, h->seq_words, 8)) { err = "blob section outside the blob"; return false; }
     if (h->n_fallback && !inside(h->off_fallback, h->n_fallback, 8)) { err = "blob section outside the blob"; return false; }
     if (h->n_keys != 4 * h->n_buckets + h->n_fallback || h->n_placed > 4 * h->n_buckets) { err = "corrupt blob header (key counts)"; return false; }
@@ -404,8 +405,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     uint64_t off = align256(4096);
     static_assert(sizeof(BgrBlobHeader) <= 4096, "header must fit its 4 KiB slot");
     h.off_table = off;    off = align256(off + h.n_buckets * 4 + 16);
-    h.off_keys = off;     off = align256(off + h.n_keys * 8 + 8);
-    h.off_recs = off;     off = align256(off + h.n_keys * sizeof(BgrSlot) * 8 + 256);
+    h.off_keys = off;     off = align256(off + h.n_keys * sizeof(BgrKeyEntry) + 16);
     h.off_meta = off;     off = align256(off + (n + 1) * sizeof(BgrUnitigMeta));
     h.off_seq = off;      off = align256(off + seq_words * 8);
     if (has_exc) {
@@ -426,6 +426,12 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         h.off_anc_final = off; off = align256(off + h.anc_n_final * 16 + 16);
         h.off_anc_pos = off;   off = align256(off + h.anc_n * 8 + 8);
     }
+    // the compact slots come last: their number is known once the records are filled (at most two per unitig: one per end); the
+    // blob is allocated for that bound (untouched zero pages cost nothing) and blob_bytes set to what is used
+    h.off_recs = off;
+    const uint64_t slots_bound = 2 * n + 4;
+    if (slots_bound >= BGR_HNONE - 8) { err = "too many unitigs for the slot handles (limit 2^27-8)"; return false; }
+    off = align256(off + slots_bound * sizeof(BgrSlot));
     h.blob_bytes = off;
 
     if (!out.blob.reset(off / 8)) { err = "out of memory for the graph blob"; return false; }  // zero pages, touched below in parallel
@@ -460,17 +466,17 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     tm.lap("pack");
 
     // keys by table slot (~0 = empty slot), then the fallback list's; every key must now be found where it was put
-    uint64_t* kout = reinterpret_cast<uint64_t*>(base + h.off_keys);
+    BgrKeyEntry* kout = reinterpret_cast<BgrKeyEntry*>(base + h.off_keys);
     parallel_ranges(T, 4 * h.n_buckets, [&](uint64_t b, uint64_t e, unsigned) {
-        for (uint64_t j = b; j < e; ++j) kout[j] = tab.who[j] == BGR_NONE ? BGR_EMPTY_KEY : keys[tab.who[j]];
+        for (uint64_t j = b; j < e; ++j) { kout[j].key = tab.who[j] == BGR_NONE ? BGR_EMPTY_KEY : keys[tab.who[j]]; kout[j].hL = kout[j].hR = BGR_HNONE; }
     });
-    for (uint64_t j = 0; j < h.n_fallback; ++j) kout[4 * h.n_buckets + j] = tab.fallback[j];
+    for (uint64_t j = 0; j < h.n_fallback; ++j) { kout[4 * h.n_buckets + j].key = tab.fallback[j]; kout[4 * h.n_buckets + j].hL = kout[4 * h.n_buckets + j].hR = BGR_HNONE; }
     const BgrBlobHeader* hp = reinterpret_cast<const BgrBlobHeader*>(base);
     std::atomic<bool> bad{false};
     parallel_ranges(T, keys.size(), [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t j = b; j < e; ++j) {
             const uint32_t idx = host_lookup(hp, base, keys[j]);
-            if (idx == BGR_NONE || idx >= h.n_keys || kout[idx] != keys[j]) { bad.store(true); return; }
+            if (idx == BGR_NONE || idx >= h.n_keys || kout[idx].key != keys[j]) { bad.store(true); return; }
             if (idx < 4 * h.n_buckets) {  // what find_key<LAZY2> relies on: a key sits in its bucket 2 only when its bucket 1 is full
                 const uint32_t b1 = bgr_tab_bucket((uint32_t)bgr_mix64(keys[j]), (uint32_t)h.n_buckets);
                 if (idx / 4 != b1 && bgr_zero_bytes(tab.buckets[b1]) != 0) { bad.store(true); return; }
@@ -483,7 +489,11 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     // ---- slot fill in unitig order (aligner.cpp:466-533) + orientation bits ---------------------
     // Pass 1 (parallel over unitigs): record indices and flags.  Pass 2: the fill order within a record is the
     // unitig order, so every thread walks all unitigs in order and fills only the records of its own index range.
-    BgrSlot* recs = reinterpret_cast<BgrSlot*>(base + h.off_recs);
+    // the records are filled the round-2 way -- 8 slots per key (left-table slots 0..3, right-table slots 4..7), in a scratch buffer
+    // -- and compacted into the blob afterwards (compact_slots below)
+    ZeroPages dense;
+    if (!dense.reset(h.n_keys * 8 * sizeof(BgrSlot) / 8 + 8)) { err = "out of memory for the record scratch"; return false; }
+    BgrSlot* recs = reinterpret_cast<BgrSlot*>(dense.data());
     BgrUnitigMeta* mout = reinterpret_cast<BgrUnitigMeta*>(base + h.off_meta);
     parallel_ranges(T, n, [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t i = b + 1; i <= e; ++i) {
@@ -536,6 +546,64 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         BgrBlobHeader* hw = reinterpret_cast<BgrBlobHeader*>(base);
         hw->slot_fill_x100 = hh ? (uint32_t)(100 * f / hh) : 100;
         if (getenv("BGREAT_TIMING")) fprintf(stderr, "[build] slot fill %.2f per non-empty half record\n", hw->slot_fill_x100 / 100.0);
+    }
+    {   // ---- compaction: the filled slots of every half next to each other, handles in the key entries and in the slots ----
+        const uint64_t nh = 2 * nk;
+        std::vector<uint32_t> hoff(nh + 1);
+        parallel_ranges(T, nh, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t j = b; j < e; ++j) {  // the reference's nested ifs stop at the first empty slot (aligner.cpp:160-203)
+                const BgrSlot* sl4 = recs + j * 4;
+                uint32_t c = 0;
+                while (c < 4 && sl4[c].idf) ++c;
+                hoff[j + 1] = c;
+            }
+        });
+        hoff[0] = 0;
+        for (uint64_t j = 0; j < nh; ++j) hoff[j + 1] += hoff[j];
+        const uint64_t n_slots = hoff[nh];
+        if (n_slots > slots_bound - 4) { err = "internal: more slots than unitig ends"; return false; }
+        auto handle = [&](uint64_t half) { return hoff[half + 1] == hoff[half] ? (uint32_t)BGR_HNONE : hoff[half]; };
+        parallel_ranges(T, nk, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t j = b; j < e; ++j) { kout[j].hL = handle(2 * j); kout[j].hR = handle(2 * j + 1); }
+        });
+        BgrSlot* cs = reinterpret_cast<BgrSlot*>(base + h.off_recs);
+        parallel_ranges(T, nh, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t j = b; j < e; ++j) {
+                const uint32_t cnt = hoff[j + 1] - hoff[j];
+                const uint32_t side = (uint32_t)(j & 1);  // 0 = the key's left-table slots, 1 = its right-table slots
+                for (uint32_t q = 0; q < cnt; ++q) {
+                    BgrSlot sl = recs[j * 4 + q];
+                    const uint32_t rec_beg = sl.nx0, rec_end = sl.nx1, mflags = sl.mflags_x & 15u;
+                    // Where the walk goes on behind this unitig, for the two ways the slot can be reached.  A query for key x on side
+                    // `side` that is canonical (c = 1) or not (c = 0): getBegin(bin) reads the left table when bin <= rc(bin), else the
+                    // right one; getEnd(bin) the other way round (aligner.cpp:147-267) -- so the walk goes LEFT exactly when c == side.
+                    // The unitig's orientation is bit F0 (c = 1) / F1 (c = 0); its far end in walking direction names the next key
+                    // (forward unitig walking left: its beg key; ...), the canonical flag of that far-end (k-1)-mer the side of the NEXT
+                    // query: again left walk <-> side == canonical.
+                    uint32_t nx[2];
+                    for (uint32_t c = 0; c < 2; ++c) {
+                        const bool left = c == side;
+                        const bool fwd = (sl.idf & (c ? BGR_SLOT_F0 : BGR_SLOT_F1)) != 0;
+                        const uint32_t nrec = fwd == left ? rec_beg : rec_end;
+                        const uint32_t cbit = left ? (fwd ? BGR_META_CANON_BEG : BGR_META_CANON_RCEND) : (fwd ? BGR_META_CANON_END : BGR_META_CANON_RCBEG);
+                        const bool cn = (mflags & cbit) != 0;
+                        const bool next_right_table = cn == left;
+                        const uint32_t hd = nrec < nk ? handle(2 * (uint64_t)nrec + (next_right_table ? 1 : 0)) : (uint32_t)BGR_HNONE;
+                        nx[c] = hd | (cn ? BGR_H_CANON : 0u);
+                    }
+                    sl.nx0 = nx[1];
+                    sl.nx1 = nx[0];
+                    if (q + 1 == cnt) sl.Fo_x |= BGR_SLOT_LAST;
+                    cs[hoff[j] + q] = sl;
+                }
+            }
+        });
+        BgrBlobHeader* hw = reinterpret_cast<BgrBlobHeader*>(base);
+        hw->n_slots = n_slots;
+        hw->blob_bytes = align256(h.off_recs + (n_slots + 4) * sizeof(BgrSlot));
+        h.n_slots = n_slots;
+        h.blob_bytes = hw->blob_bytes;
+        dense.release();
     }
     tm.lap("slots");
 

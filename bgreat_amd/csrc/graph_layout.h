@@ -24,13 +24,17 @@
 //          most read positions are not overlaps -- so the 8-byte key load is left to the members and a few false matches.
 //          About 8.6 bits per key at the default fill (0.935): the table of an E. coli-scale graph fits LDS twice per CU.
 //          Keys that found no slot after the eviction budget (in practice none) go to a sorted fallback list.
-//   keys   u64 key per table slot, ~0 for an empty slot (membership check, aligner.cpp:158,219,353,361).
-//   recs   256 B per table slot: the 4 "left table" slots (one 128-byte line) and the 4 "right table" slots (the
-//          next line) of that key (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite,
-//          aligner.cpp:466-533).  A slot is 32 B: {id | orientation bits, len, F as seq word + base-in-word} --
-//          everything a walk step needs to start streaming the candidate's bases -- plus the unitig's own end
-//          records and canonical flags, i.e. where the walk goes NEXT.  So a step is slot -> bases (two dependent
-//          loads, no per-unitig meta fetch beside the bases).  Bits 30/31 of the id word carry
+//   keys   16 B per table slot: the u64 key (~0 for an empty slot: membership check, aligner.cpp:158,219,353,361) and the
+//          HANDLES of the key's two halves -- where its "left table" slots and its "right table" slots start in `slots`.
+//   slots  the neighbour records, COMPACT (round 3; round 2 kept 256 B per table slot, 8 x 32 B of which 1-3 were filled
+//          and 45 % of the table slots of a large graph hold no key at all: 1.2 of the chr1-scale blob's 1.6 GB): the
+//          filled "left table" slots of a key (aligner.h:49-55 indice1..4, filled in unitig order with slot-4 overwrite,
+//          aligner.cpp:466-533) stand next to each other, the last one flagged; likewise its "right table" slots; a half
+//          without any slot has no storage (handle BGR_HNONE).  A slot is 32 B: {id | orientation bits, len, F as seq
+//          word + base-in-word} -- everything a walk step needs to start streaming the candidate's bases -- plus where
+//          the walk goes NEXT: the handle (and canonical flag) of the half the following step reads, one for each of
+//          the two ways a slot can be reached (by a canonical or a non-canonical query), so a step is slot -> bases
+//          (two dependent loads) and never goes back to the key table.  Bits 30/31 of the id word carry
 //          the orientation the reference recomputes by string compare at query time (aligner.cpp:174,235).
 #ifndef BGREAT_AMD_GRAPH_LAYOUT_H
 #define BGREAT_AMD_GRAPH_LAYOUT_H
@@ -44,10 +48,12 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 10u /* 10: slots carry the 32 bases next to the overlap; 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
+#define BGR_BLOB_VERSION 11u /* 11: compact slots + half handles; 10: slots carry the 32 bases next to the overlap; 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
 #define BGR_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL /* keys[] of an empty table slot: no (k-1)-mer, k <= 32, has bit 62 or 63 set */
 #define BGR_NONE 0xFFFFFFFFu
 #define BGR_SLOT_ID_MASK 0x3FFFFFFFu
+#define BGR_HNONE 0x0FFFFFFFu      /* handle of a half without slots (28 bits; bit 28 of a handle word = "the query is canonical") */
+#define BGR_H_CANON (1u << 28)
 // slot flag bits (see graph_build.cpp fill_records):
 //   left-table slot : bit30 = unitig forward when asked "who BEGINS with key"      (getBegin(key))
 //                     bit31 = unitig forward when asked "who ENDS with rc(key)"    (getEnd(rc key))
@@ -65,29 +71,35 @@
 typedef struct {
     uint32_t len;     // bases
     uint32_t flags;   // BGR_META_*
-    uint32_t rec_beg; // table slot of canonical(first k-1 bases)
-    uint32_t rec_end; // table slot of canonical(last k-1 bases)
+    uint32_t rec_beg; // key index (table slot) of canonical(first k-1 bases)
+    uint32_t rec_end; // key index of canonical(last k-1 bases)
     uint64_t F;       // base offset of the forward strand in `seq` (reverse complement at F + len)
-    uint64_t pad;
-} BgrUnitigMeta;      // 32 B; the first 16 B are what a walk step needs about the unitig it has chosen
+    uint32_t hw[2];   // unused (0)
+} BgrUnitigMeta;      // 32 B (anchors mode and the correction formatter read it; a walk step does not)
 
 typedef struct {
     uint32_t idf;     // unitig id | BGR_SLOT_F0 | BGR_SLOT_F1 ; 0 = empty slot
     uint32_t len;
     uint32_t Fw;      // forward strand starts at base Fo of seq word Fw  (F = 32*Fw + Fo): 32-bit address arithmetic
     uint32_t Fo_x;    //   in the kernels (seq must stay below 4 GiB = 2^34 bases, checked at build time).  Bits 0..4 = Fo,
-                      //   bits 8..11 = bits 0..3 of `near` (below)
+                      //   bit 5 = BGR_SLOT_LAST (the last slot of its half), bits 8..11 = bits 0..3 of `near` (below)
     uint32_t mflags_x;// bits 0..3 = BGR_META_* of this unitig; bits 4..31 = bits 4..31 of `near`'s high word
-    uint32_t rec_beg; // == meta[id].rec_beg / rec_end: the neighbour records at the unitig's two ends
-    uint32_t rec_end;
+    uint32_t nx0;     // where the walk goes on behind this unitig: handle | BGR_H_CANON of the half the NEXT step reads, when this
+    uint32_t nx1;     //   slot was reached by a canonical query (nx0) / by a non-canonical one (nx1) -- the direction of the walk and the
+                      //   unitig's orientation follow from (table side, canonical or not), see graph_build.cpp next_half()
     uint32_t near_lo; // `near` (64 bits, bgr_slot_near): the <= 32 unitig bases NEXT TO the overlap this slot hangs on, outside it,
                       //   read away from the overlap in the orientation in which the unitig BEGINS with the key (or with the
                       //   key's reverse complement), first base most significant, zero beyond the unitig's end.  A walk to the
                       //   right compares exactly these bases, a walk to the left their reverse complement, so a step over
                       //   a short unitig (or a short rest of the read) never touches `seq`.  Valid when exactly one of F0/F1
                       //   is set (a hairpin unitig hangs on its overlap both ways) and the graph has no exception planes.
-} BgrSlot;            // 32 B; a neighbour record is BgrSlot[8]: left-table slots 0..3, right-table slots 4..7
+} BgrSlot;            // 32 B
 #define BGR_SLOT_FO_MASK 31u
+#define BGR_SLOT_LAST 32u
+typedef struct {
+    uint64_t key;     // BGR_EMPTY_KEY for an empty table slot
+    uint32_t hL, hR;  // handles of the key's left-table / right-table slots in `slots` (BGR_HNONE: none)
+} BgrKeyEntry;        // 16 B per table slot (and per fallback key)
 BGR_HD uint64_t bgr_slot_near(uint32_t Fo_x, uint32_t mflags_x, uint32_t near_lo) {
     return ((uint64_t)((mflags_x & 0xFFFFFFF0u) | ((Fo_x >> 8) & 15u)) << 32) | near_lo;
 }
@@ -122,11 +134,12 @@ typedef struct {
     uint64_t seq_words;     // u64 words in seq (incl. 2 trailing pad words)
     uint64_t total_bases;   // 2 * sum(len)
     uint64_t n_buckets;     // 4-slot buckets (one dword each) of the key table
-    uint64_t off_table, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback;
+    uint64_t off_table, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback;  // off_recs: the compact `slots`
     uint32_t reserved0, has_exc;
     uint64_t max_unitig_len;
     uint64_t n_left_keys, n_right_keys;  // sizes of the reference's two key sets (informational)
     uint32_t slot_fill_x100, pad0;       // 100 x mean number of filled slots per non-empty half record (how branchy the graph is)
+    uint64_t n_slots;       // entries of `slots` (filled slots of all halves; 4 zero entries follow them)
     double gamma;           // table slots per key
     // anchors index (all zero when the graph was built without it)
     uint64_t anc_n;          // anchors = k-mers of all unitigs but each unitig's last, repeats included (aligner.cpp:434-442)
@@ -145,8 +158,8 @@ typedef struct {
 #define BGR_GF_HAS_FALLBACK 2u
 typedef struct {
     const uint32_t* table;   // n_buckets dwords: 4 one-byte fingerprints each (slot s = byte s), 0 = empty
-    const uint64_t* keys;
-    const BgrSlot* recs;     // n_keys * 8 slots (L0..L3, R0..R3)
+    const BgrKeyEntry* keys; // n_keys entries
+    const BgrSlot* recs;     // n_slots compact slots
     const BgrUnitigMeta* meta;
     const uint64_t* seq;
     const BgrBlobHeader* hdr;

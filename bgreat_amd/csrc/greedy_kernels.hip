@@ -275,12 +275,19 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
 #ifdef BGR_PHASE_TIMING  /* diagnostic builds (tools/phase_cost.sh): knob DEBUG_STOP = 2 stops behind the anchor scan */
         if (prm.debug_stop == 2) phase = 0;
 #endif
-        uint32_t pos = a_pos, rec = a_rec, budget = m;  // rec: record | canonical << 28
+        // rec: the half the next step reads (handle | canonical << 28).  An anchor is a key entry: its walks start from the half that
+        // getEnd (left) / getBegin (right) reads for it (half_handle: one 8-byte load at each start)
+        auto start_half = [&](uint32_t anchor, bool left) -> uint32_t {
+            if (anchor == BGR_NONE) return G4_REC_MASK;
+            const bool cn = (anchor >> 28) & 1u;
+            return half_handle(g, anchor & G4_REC_MASK, cn, left) | (cn ? G4_CANON : 0u);
+        };
+        uint32_t pos = a_pos, rec = phase ? start_half(a_rec, true) : G4_REC_MASK, budget = m;
         for (;;) {
             if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
                 if (sub == nl) pl = 0;
                 ++nl;
-                phase = 2; pos = a_pos; rec = a_rec;
+                phase = 2; pos = a_pos; rec = start_half(a_rec, false);
             }
             if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
             if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                     if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
                         a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
                         nl = 0; nr = 0; budget = m;
-                        phase = 1; pos = a_pos; rec = a_rec;
+                        phase = 1; pos = a_pos; rec = start_half(a_rec, true);
                     } else phase = 5;
                 } else if (phase == 1) {
                     if (sub == nl) pl = sid;
@@ -305,7 +312,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                     if (w1 & G4_FITS) {
                         if (sub == nl) pl = (int32_t)(ext - pos);
                         ++nl;
-                        phase = 2; pos = a_pos; rec = a_rec;
+                        phase = 2; pos = a_pos; rec = start_half(a_rec, false);
                     } else { pos -= ext; rec = w1; }
                 } else {
                     if (sub == nr) pr = sid;

@@ -79,6 +79,9 @@ def test_blob_validation_refuses_corrupt_headers():
         B.Graph.from_blob(blob[:-256])           # truncated
 
 
+_HDR_N_SLOTS = 23   # BgrBlobHeader.n_slots as a uint64 index (graph_layout.h: ... max_unitig_len 19, n_left_keys 20, n_right_keys 21, slot_fill 22, n_slots 23)
+
+
 def _canonical_end_kmers(seqs, offs, k):
     """The reference's overlap key set (aligner.cpp:466-533): canonical first and last (k-1)-mers of every unitig."""
     code = {65: 0, 67: 1, 71: 2, 84: 3}
@@ -122,7 +125,9 @@ def test_overlap_key_table(gamma, no_evictions):
     hdr = blob[:4096].view(np.uint64)
     n_buckets, off_table, off_keys = int(hdr[9]), int(hdr[10]), int(hdr[11])
     table = blob[off_table:off_table + 4 * n_buckets]
-    kslot = blob[off_keys:off_keys + 8 * (4 * n_buckets + info["n_fallback"])].view(np.uint64)
+    kent = blob[off_keys:off_keys + 16 * (4 * n_buckets + info["n_fallback"])]   # 16 B per entry: key, handle of the left half, of the right half
+    kslot = kent.view(np.uint64)[0::2]
+    khand = kent.view(np.uint32).reshape(-1, 4)[:, 2:4]
     assert int((table != 0).sum()) == len(keys) - info["n_fallback"]
     assert np.array_equal(table == 0, kslot[:4 * n_buckets] == np.uint64(0xFFFFFFFFFFFFFFFF))
     full = (table.reshape(-1, 4) != 0).all(axis=1)
@@ -140,6 +145,50 @@ def test_overlap_key_table(gamma, no_evictions):
             assert full[b1]
     if not no_evictions and gamma in (0.0, 1.03):
         assert 4 * n_buckets <= 1.08 * len(keys) + 4  # the tight fill small graphs are staged in LDS with
+    # the neighbour records, compact (graph_layout.h): the slots of a key's left / right half stand next to each other from its handle
+    # on, the last one flagged, ids in the reference's fill order (first free of indice1..3, later ones overwrite indice4:
+    # aligner.cpp:466-533), nothing else in the array; every slot's two "where the walk goes on" words name the start of a half
+    off_recs, n_slots = int(hdr[12]), int(blob[:4096].view(np.uint64)[_HDR_N_SLOTS])
+    sl = blob[off_recs:off_recs + 32 * (n_slots + 4)].view(np.uint32).reshape(-1, 8)
+    assert not sl[n_slots:].any()                      # four zero slots behind the last one
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    K1 = k - 1
+    left, right = {}, {}
+
+    def attach(tab, key, i):
+        lst = tab.setdefault(key, [])
+        if len(lst) < 3:
+            lst.append(i)
+        elif len(lst) == 3:
+            lst.append(i)
+        else:
+            lst[3] = i
+    for i in range(len(offs) - 1):
+        u = bytes(seqs[int(offs[i]):int(offs[i + 1])])
+        if len(u) < k:
+            break
+        enc = lambda w: (sum(code.get(ch, 3) << (2 * (K1 - 1 - j)) for j, ch in enumerate(w)), sum((3 - code.get(ch, 3)) << (2 * j) for j, ch in enumerate(w)))
+        beg, rcbeg = enc(u[:K1])
+        end, rcend = enc(u[-K1:])
+        attach(left, beg, i + 1) if beg <= rcbeg else attach(right, rcbeg, i + 1)
+        attach(right, end, i + 1) if end <= rcend else attach(left, rcend, i + 1)
+    HNONE, LAST = 0x0FFFFFFF, 32
+    starts, seen = set(), 0
+    for x, slot in zip(keys, slots):
+        for side, tab in ((0, left), (1, right)):
+            want = tab.get(x, [])
+            h = int(khand[slot, side])
+            assert (h == HNONE) == (not want)
+            if not want:
+                continue
+            starts.add(h)
+            got = sl[h:h + len(want)]
+            assert [int(v) & 0x3FFFFFFF for v in got[:, 0]] == want
+            assert [bool(int(v) & LAST) for v in got[:, 3]] == [False] * (len(want) - 1) + [True]
+            seen += len(want)
+    assert seen == n_slots
+    nxt = np.concatenate([sl[:n_slots, 5], sl[:n_slots, 6]]) & HNONE
+    assert all(int(v) == HNONE or int(v) in starts for v in nxt)
 
 
 def test_graph_build_rejects_bad_k():
