@@ -180,6 +180,7 @@ struct Batch {
     std::vector<Mark> marks;                              // ascending pos
     std::shared_ptr<MappedFile> file;                     // keeps header/sequence slices valid
     std::vector<std::unique_ptr<ParsedChunk>> chunks;
+    std::shared_ptr<std::vector<std::unique_ptr<ParsedChunk>>> shared_chunks;  // a chunk group cut into several batches (base cap): its storage, shared
     std::vector<std::pair<const ParsedChunk*, std::pair<uint32_t, uint32_t>>> spans;  // chunk, [first, last) records
     uint64_t n = 0, bases = 0, path_cap = 0;
     std::unique_ptr<Pinned> pin;                          // attached by the gatherer, handed back by the formatter
@@ -434,7 +435,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     const bool text_route = opt->route == 0 && !opt->fastq && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
     const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (text_route ? 1ull << 18 : 1ull << 17), 4ull << 20);
     const uint64_t piece_bytes = std::min<uint64_t>(std::max<uint64_t>(batch_reads * 170, 4096), 1ull << 30);  // text route: bytes of a batch
-    const uint64_t batch_bases_cap = 1ull << 30;
+    uint64_t batch_bases_cap = 1ull << 30;
+    if (const char* e = getenv("BGREAT_TEST_BASES_CAP")) batch_bases_cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // (tests: walk the cut with small inputs)
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes
                                                   : std::min<uint64_t>(8ull << 20, std::max<uint64_t>(256ull << 10, batch_reads * 170 / threads));
     Unitigs unitigs;
@@ -602,7 +604,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             return to_gather.push(std::move(b));
         };
         auto drop = [&](std::unique_ptr<Batch> b) {  // an opened batch that got neither reads nor marks
-            b->chunks.clear(); b->file.reset(); b->recs.clear();
+            b->chunks.clear(); b->shared_chunks.reset(); b->file.reset(); b->recs.clear();
             free_batches.push(std::move(b));
         };
         bool ok = true;
@@ -713,18 +715,36 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 size_t total = 0;
                 for (auto& ch : b->chunks) total += ch->recs.size();
                 b->recs.reserve(total);
-                for (auto& ch : b->chunks) {
+                // (one launch addresses its path arena with 32 bits: a group of chunks with very long records -- a large --chunk-bytes,
+                // many threads -- is handed on in pieces of at most ~1 G bases, like the FASTQ feeder does)
+                // every batch cut from the group keeps the group's storage alive (the records point into it)
+                auto keep = std::make_shared<std::vector<std::unique_ptr<ParsedChunk>>>(std::move(b->chunks));
+                b->chunks.clear();
+                b->shared_chunks = keep;
+                for (auto& ch : *keep) {
                     marker.chunk(*ch, file_iters, mark_idx);
                     file_iters += ch->iters;
-                    for (uint64_t mi : mark_idx) b->marks.push_back({b->recs.size() + mi, 0, ""});
-                    b->recs.insert(b->recs.end(), ch->recs.begin(), ch->recs.end());
+                    size_t mi = 0;
+                    for (size_t ri = 0; ri <= ch->recs.size() && ok; ++ri) {
+                        for (; mi < mark_idx.size() && mark_idx[mi] == ri; ++mi) b->marks.push_back({b->recs.size(), 0, ""});
+                        if (ri == ch->recs.size()) break;
+                        b->recs.push_back(ch->recs[ri]);
+                        b->bases += ch->recs[ri].sl;
+                        if (b->bases >= batch_bases_cap) {  // hand this piece on, go on in a fresh batch
+                            ok = emit(std::move(b));
+                            if (!ok || !open_batch(b, mf)) { ok = false; break; }
+                            b->shared_chunks = keep;
+                        }
+                    }
+                    if (!ok) break;
                 }
                 us_parse += now_us() - tp0;
                 c = c_end;
+                if (!ok) break;
                 if (c >= starts.size())
                     for (unsigned d = marker.end_file(std::max<uint64_t>(1, file_iters)); d; --d) b->marks.push_back({b->recs.size(), 0, ""});
                 if (b->recs.empty() && b->marks.empty()) { drop(std::move(b)); continue; }
-                ok = emit(std::move(b));
+                ok = ok && emit(std::move(b));
             }
         }
         if (ok && !failed && !pending.empty()) {  // what is printed after the last read: an empty batch carries it to the writer
@@ -941,7 +961,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     auto recycle_batch = [&](std::unique_ptr<Batch>& b) {  // hand the batch (and its pinned buffers) back to the producer
         if (!b) return;
         if (b->pin) free_pins.push(std::move(b->pin));
-        b->recs.clear(); b->marks.clear(); b->chunks.clear(); b->file.reset();
+        b->recs.clear(); b->marks.clear(); b->chunks.clear(); b->shared_chunks.reset(); b->file.reset();
         free_batches.push(std::move(b));
     };
     std::thread io_thread([&]() {
