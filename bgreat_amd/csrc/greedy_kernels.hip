@@ -165,7 +165,6 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     const uint32_t m = prm.max_mismatch;
     const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
 
-    uint32_t c_noov = 0, c_al = 0, c_na = 0;  // wave-uniform counts of the reads settled here
     // this wave's slice of the path arena: the first chunk is the wave's by its number (the host starts the cursor behind them: a
     // returning atomic per wave on one word at the start of the launch serialises, ~90 per microsecond), later ones come from the cursor
     const uint32_t wid = (uint32_t)(blockIdx.x * waves + wave);
@@ -174,7 +173,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     // it only appends (at most one entry per read of the share: q_cap); afterwards every octet taken out makes room for what it
     // leaves behind, so the ring never overflows.
     const uint32_t q_base = wid * io.q_cap;  // (the rings of all waves hold n_reads + 8 per wave entries at most: 32-bit indices)
-    uint32_t q_rd = 0, q_wr = 0, q_cnt = 0, q_all = 0;
+    uint32_t q_rd = 0, q_wr = 0, q_cnt = 0;
     const uint32_t stride = gridDim.x * waves * RPW;
     uint32_t ibase = wid * RPW;
 
@@ -397,24 +396,16 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                 q_wr += cnt;
                 if (q_wr >= io.q_cap) q_wr -= io.q_cap;
                 q_cnt += cnt;
-                q_all += cnt;
             }
         }
-        c_al += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 0));
-        c_noov += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 1));
-        c_na += (uint32_t)__popcll(__ballot(sub == 0 && have && outcome == 2));
+        // what became of the read: counted per workgroup in LDS (wg_counts[outcome]: aligned, no anchor, not aligned, follow-up item)
+        if (sub == 0 && have && outcome <= 3) atomicAdd(&wg_counts[outcome], 1u);
         wave_sync();
-    }
-    if (lane == 0) {
-        if (c_al) atomicAdd(&wg_counts[0], c_al);
-        if (c_noov) atomicAdd(&wg_counts[1], c_noov);
-        if (c_na) atomicAdd(&wg_counts[2], c_na);
-        if (q_all) atomicAdd(&wg_counts[3], q_all);
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);
-        const uint32_t al = wg_counts[0], noov = wg_counts[1], na = wg_counts[2], qa = wg_counts[3];
+        const uint32_t al = wg_counts[0], noov = wg_counts[1], na = wg_counts[2], qa = wg_counts[3];  // (indexed by `outcome`)
         if (al | noov | na) atomicAdd(&counters[0], (unsigned long long)(al + noov + na));
         if (noov) atomicAdd(&counters[1], (unsigned long long)noov);
         if (al) atomicAdd(&counters[2], (unsigned long long)al);
