@@ -95,6 +95,12 @@ __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u6
     const uint32_t b1 = __umulhi((uint32_t)m, g.n_buckets), b2 = __umulhi((uint32_t)(m >> 32), g.n_buckets);
     uint32_t w1 = 0, w2 = 0;
     if (LAZY2) {
+        // large graph: one bit of a Bloom filter that lives in L2 turns most positions (no overlaps) away before the table -- whose
+        // probes miss the L2 half of the time -- is touched; a member always passes, and the key compare below decides as before
+        if (g.bloom && active) {
+            const uint32_t bit = bgr_bloom_bit(m, g.bloom_mask);
+            active = (g.bloom[bit >> 5] >> (bit & 31)) & 1u;
+        }
         if (active) w1 = tab[b1];
         if (active && bgr_zero_bytes(w1) == 0) w2 = tab[b2];
     } else if (active) { w1 = tab[b1]; w2 = tab[b2]; }

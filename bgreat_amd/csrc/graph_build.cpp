@@ -166,6 +166,8 @@ void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGr
     dg.n_buckets = (uint32_t)h->n_buckets;
     dg.flags = (h->has_exc ? BGR_GF_HAS_EXC : 0u) | (h->n_fallback ? BGR_GF_HAS_FALLBACK : 0u);
     dg.table_bytes = (uint32_t)(h->n_buckets * 4);
+    dg.bloom = h->bloom_bits ? reinterpret_cast<const uint32_t*>(base + h->off_bloom) : nullptr;
+    dg.bloom_mask = h->bloom_bits ? (uint32_t)(h->bloom_bits - 1) : 0u;
 }
 
 // Everything the kernels later trust about a blob can be checked on its header alone (section extents, level table):
@@ -186,6 +188,7 @@ bool validate_blob_header(const BgrBlobHeader* h, uint64_t bytes, std::string& e
     if (!inside(h->off_table, h->n_buckets, 4) || !inside(h->off_keys, h->n_keys, sizeof(BgrKeyEntry)) || !inside(h->off_recs, h->n_slots + 4, sizeof(BgrSlot)) ||
         !inside(h->off_meta, h->n_unitigs + 1, sizeof(BgrUnitigMeta)) || !inside(h->off_seq, h->seq_words, 8)) { err = "blob section outside the blob"; return false; }
     if (h->n_fallback && !inside(h->off_fallback, h->n_fallback, 8)) { err = "blob section outside the blob"; return false; }
+    if (h->bloom_bits && ((h->bloom_bits & (h->bloom_bits - 1)) || h->bloom_bits < 64 || h->bloom_bits > (1ull << 32) || !inside(h->off_bloom, h->bloom_bits / 32, 4))) { err = "corrupt blob header (Bloom filter)"; return false; }
     if (h->n_keys != 4 * h->n_buckets + h->n_fallback || h->n_placed > 4 * h->n_buckets) { err = "corrupt blob header (key counts)"; return false; }
     if (h->seq_words < 2 || h->total_bases > (h->seq_words - 2) * 32 || h->seq_words * 8 >= (1ull << 32)) { err = "corrupt blob header (sequence store)"; return false; }
     if (h->has_exc) {  // one bit per base, read 64 bits at a time one word past the addressed one
@@ -413,6 +416,14 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         h.off_excn = off; off = align256(off + exc_words * 8);
     }
     h.off_fallback = off; off = align256(off + h.n_fallback * 8 + 8);
+    // a table too large for LDS staging gets a Bloom filter in front (4-8 bits per key, one hash; BGREAT_BLOOM=0 builds without)
+    const bool want_bloom = (double)keys.size() * 1.07 > 73000.0 && !(getenv("BGREAT_BLOOM") && atoi(getenv("BGREAT_BLOOM")) == 0);
+    if (want_bloom) {
+        uint64_t bits = 64;
+        while (bits < 4 * keys.size()) bits <<= 1;
+        h.bloom_bits = bits;
+        h.off_bloom = off; off = align256(off + bits / 8 + 16);
+    }
     if (flags & BGR_BUILD_ANCHORS) {
         h.anc_n = anc.n;
         h.anc_last_rank = anc.last_rank;
@@ -439,6 +450,16 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     memcpy(base, &h, sizeof(h));
     memcpy(base + h.off_table, tab.buckets.data(), tab.buckets.size() * 4);
     if (h.n_fallback) memcpy(base + h.off_fallback, tab.fallback.data(), h.n_fallback * 8);
+    if (h.bloom_bits) {
+        uint32_t* bl = reinterpret_cast<uint32_t*>(base + h.off_bloom);
+        const uint32_t mask = (uint32_t)(h.bloom_bits - 1);
+        parallel_ranges(T, keys.size(), [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t i = b; i < e; ++i) {
+                const uint32_t bit = bgr_bloom_bit(bgr_mix64(keys[i]), mask);
+                __atomic_fetch_or(&bl[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED);
+            }
+        });
+    }
 
     // ---- pack both strands into the blob; non-ACGT exceptions of the forward strand -----------------
     uint64_t* seq = reinterpret_cast<uint64_t*>(base + h.off_seq);

@@ -48,7 +48,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 11u /* 11: compact slots + half handles; 10: slots carry the 32 bases next to the overlap; 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
+#define BGR_BLOB_VERSION 12u /* 12: Bloom filter in front of large key tables; 11: compact slots + half handles; 10: slots carry the 32 bases next to the overlap; 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
 #define BGR_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL /* keys[] of an empty table slot: no (k-1)-mer, k <= 32, has bit 62 or 63 set */
 #define BGR_NONE 0xFFFFFFFFu
 #define BGR_SLOT_ID_MASK 0x3FFFFFFFu
@@ -140,6 +140,9 @@ typedef struct {
     uint64_t n_left_keys, n_right_keys;  // sizes of the reference's two key sets (informational)
     uint32_t slot_fill_x100, pad0;       // 100 x mean number of filled slots per non-empty half record (how branchy the graph is)
     uint64_t n_slots;       // entries of `slots` (filled slots of all halves; 4 zero entries follow them)
+    uint64_t off_bloom;     // large graphs (key table probed in L2, not staged in LDS): a one-hash Bloom filter over the keys, 4-8 bits per
+    uint64_t bloom_bits;    //   key, a power of two (0 = none) -- small enough to live in an XCD's L2, so most read positions (no overlaps)
+                            //   are turned away by one L2 hit instead of a table probe that misses the L2 half of the time
     double gamma;           // table slots per key
     // anchors index (all zero when the graph was built without it)
     uint64_t anc_n;          // anchors = k-mers of all unitigs but each unitig's last, repeats included (aligner.cpp:434-442)
@@ -164,6 +167,9 @@ typedef struct {
     const uint64_t* seq;
     const BgrBlobHeader* hdr;
     uint32_t k, n_buckets, flags, table_bytes;  // table_bytes = 4 * n_buckets (LDS staging)
+    const uint32_t* bloom;   // null = none
+    uint32_t bloom_mask;     // bloom_bits - 1
+    uint32_t pad1;
 } BgrDeviceGraph;
 
 // ---- hashing shared by the host builder and the device lookup ---------------------------------------
@@ -176,6 +182,7 @@ BGR_HD uint64_t bgr_mix64(uint64_t x) {
     return x * 0x9E3779B97F4A7C15ULL;
 }
 BGR_HD uint32_t bgr_tab_bucket(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((uint64_t)h * (uint64_t)n_buckets) >> 32); }
+BGR_HD uint32_t bgr_bloom_bit(uint64_t m, uint32_t mask) { return (uint32_t)(m >> 20) & mask; }  // (bits of both words of the hash)
 BGR_HD uint32_t bgr_tab_fp(uint64_t m) { const uint32_t f = (uint32_t)(m >> 32) & 0xFFu; return f ? f : 1u; }
 // bit 7 of every byte of x that is zero (exact: no borrow between bytes)
 BGR_HD uint32_t bgr_zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }

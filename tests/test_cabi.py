@@ -191,6 +191,35 @@ def test_overlap_key_table(gamma, no_evictions):
     assert all(int(v) == HNONE or int(v) in starts for v in nxt)
 
 
+def test_large_tables_get_a_bloom_filter_that_passes_every_key():
+    """A key table too large for LDS staging is built with a one-hash Bloom filter in front (graph_layout.h): a power of two of
+    4-8 bits per key, every key's bit set (a member is never turned away), not saturated."""
+    k = 31
+    s = Synth(2_600_000, 60, 2, k, 23)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(k, seqs, offs)
+    keys = _canonical_end_kmers(seqs, offs, k)
+    assert len(keys) * 1.07 > 73000
+    blob = np.array(g.blob())
+    hdr = blob[:4096].view(np.uint64)
+    off_bloom, bits = int(hdr[24]), int(hdr[25])
+    assert bits & (bits - 1) == 0 and 4 * len(keys) <= bits < 8 * len(keys)
+    bl = blob[off_bloom:off_bloom + bits // 8].view(np.uint32)
+    M = (1 << 64) - 1
+    for x in keys:
+        y = x ^ (x >> 32)
+        m = (y * 0x9E3779B97F4A7C15) & M               # bgr_mix64
+        bit = (m >> 20) & (bits - 1)                   # bgr_bloom_bit
+        assert (int(bl[bit >> 5]) >> (bit & 31)) & 1
+    ones = int(np.unpackbits(bl.view(np.uint8)).sum())
+    assert 0.1 * bits < ones <= len(keys)
+    # a small graph (table staged in LDS) has none
+    s2 = Synth(60000, 45, 3, k, 17)
+    sq, of = s2.unitigs()
+    h2 = np.array(B.Graph.build(k, sq, of).blob())[:4096].view(np.uint64)
+    assert int(h2[25]) == 0
+
+
 def test_graph_build_rejects_bad_k():
     seqs = np.frombuffer(b"ACGTACGTAC", dtype=np.uint8)
     offs = np.array([0, 10], dtype=np.uint64)
