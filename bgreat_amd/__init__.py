@@ -65,7 +65,8 @@ class Ticket(C.Structure):
 class TextBatch(C.Structure):
     _fields_ = [("text", C.c_void_p), ("text_bytes", C.c_uint64), ("want_output", C.c_uint32), ("irregular", C.c_uint32), ("paths_out", C.c_void_p),
                 ("paths_cap", C.c_uint64), ("notaligned_out", C.c_void_p), ("notaligned_cap", C.c_uint64), ("n_records", C.c_uint64),
-                ("n_accepted", C.c_uint64), ("paths_bytes", C.c_uint64), ("notaligned_bytes", C.c_uint64), ("stage", C.c_void_p)]
+                ("n_accepted", C.c_uint64), ("paths_bytes", C.c_uint64), ("notaligned_bytes", C.c_uint64), ("stage", C.c_void_p),
+                ("fastq", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PackedReads(C.Structure):
@@ -375,15 +376,16 @@ class Aligner:
         _check(lib().bgr_align_batch_wait(C.byref(t), paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
         return paths[: int(poffs[n])].copy(), poffs, status[:n]
 
-    def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False):
+    def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False, fastq=False):
         """bgr_align_fasta_text: a piece of a FASTA file (bytes) -> (paths bytes, notAligned bytes, info dict); info["irregular"] = the
-        device left the piece to the host parser (nothing mapped).  A too small `paths_cap` is grown through bgr_aligner_fetch_text."""
+        device left the piece to the host parser (nothing mapped).  fastq: the piece is whole four-line FASTQ records instead.  A too small `paths_cap` is grown through bgr_aligner_fetch_text."""
         text = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else _as_u8(text)
         n = len(text)
         pcap = n + 64 if paths_cap is None else paths_cap
         pout = np.empty(max(pcap, 1), dtype=np.uint8)
         nout = np.empty(n + 64, dtype=np.uint8)
         b = TextBatch(text.ctypes.data if n else None, n, int(want_output), 0, pout.ctypes.data, pcap, nout.ctypes.data, n + 64, 0, 0, 0, 0, None)
+        b.fastq = int(bool(fastq))
         p = Params(mode, m, effort, int(partial))
         stage = C.c_void_p()
         if staged:  # the piece sent ahead on a copy stream of its own (bgr_text_stage_upload); the call orders itself behind it

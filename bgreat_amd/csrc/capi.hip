@@ -983,6 +983,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     auto lap = [&](int i) { const double t = wall_now(); a->tx_phase_s[i] += t - tw; tw = t; };
     if (b->text_bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_align_fasta_text: piece of 2 GiB or more; cut it");
     if (b->want_output > 2) return fail(BGR_E_ARG, "bgr_align_fasta_text: want_output must be 0, 1 or 2");
+    if (b->fastq && b->text_bytes && b->text && b->text[b->text_bytes - 1] != '\n' && !b->stage)
+        return fail(BGR_E_ARG, "bgr_align_fasta_text: a FASTQ piece holds whole four-line records and ends with a newline");
     if (b->want_output == 2 && (a->graph->header.has_exc || p->mode == BGR_MODE_EXHAUSTIVE))
         return fail(BGR_E_ARG, "bgr_align_fasta_text: correction on the device needs a graph of ACGT-only unitigs and greedy mode (format such a run on the host)");
     a->tx_want = b->want_output;
@@ -1019,8 +1021,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     HIP_TRY(a->tx_rec.ensure(((uint64_t)R_cap + 1) * 16));
     HIP_TRY(a->tx_offs.ensure(((uint64_t)R_cap + 2) * 8));
     uint32_t* sums2 = static_cast<uint32_t*>(a->tx_sums.p) + bgr::text_tiles(nbytes);
-    hipError_t e = bgr::launch_text_mark(text, nbytes, static_cast<uint32_t*>(a->tx_sums.p), static_cast<uint32_t*>(a->tx_start.p), R_cap, info + TXT_INFO_N_REC, a->stream);
-    if (e == hipSuccess) e = bgr::launch_text_records(text, nbytes, static_cast<const uint32_t*>(a->tx_start.p), info + TXT_INFO_N_REC, R_cap, a->dg.k, static_cast<uint4*>(a->tx_rec.p),
+    hipError_t e = bgr::launch_text_mark(text, nbytes, b->fastq != 0, static_cast<uint32_t*>(a->tx_sums.p), static_cast<uint32_t*>(a->tx_start.p), R_cap, info + TXT_INFO_N_REC, a->stream);
+    if (e == hipSuccess) e = bgr::launch_text_records(text, nbytes, b->fastq != 0, static_cast<const uint32_t*>(a->tx_start.p), info + TXT_INFO_N_REC, R_cap, a->dg.k, static_cast<uint4*>(a->tx_rec.p),
                                                       static_cast<uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_len.p), info, a->stream);
     if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_idx.p), R_cap, sums2, info + TXT_INFO_N_ACC, a->stream);
     if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_len.p), static_cast<uint32_t*>(a->tx_boff.p), R_cap, sums2, info + TXT_INFO_BASES, a->stream);

@@ -271,6 +271,45 @@ bool FastqPlan::parse_chunk(size_t c, ParsedChunk& out) {  // pass 2: chunk c ow
     return true;
 }
 
+uint64_t FastqPlan::record_offset(uint64_t rec) const {
+    const uint64_t T = 4 * rec;  // line T starts behind the T-th newline
+    if (T == 0) return 0;
+    // the chunk that holds the T-th newline: nl_[c] < T <= nl_[c + 1]
+    size_t lo = 0, hi = nc_;
+    while (lo + 1 < hi) { const size_t mid = (lo + hi) / 2; if (nl_[mid] < T) lo = mid; else hi = mid; }
+    const uint64_t b = lo * chunk_bytes_, e = std::min<uint64_t>(size_, b + chunk_bytes_);
+    uint64_t need = T - nl_[lo];
+    const char* p = data_ + b;
+    const char* end = data_ + e;
+    while (p < end && (p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))))) { ++p; if (--need == 0) return (uint64_t)(p - data_); }
+    return size_;
+}
+
+void parse_fastq_records(const char* data, uint64_t begin, uint64_t end, ParsedChunk& out) {
+    std::string none;
+    uint64_t pos = begin;
+    while (pos < end) {
+        ++out.iters;
+        const char* h = data + pos;
+        const char* hq = static_cast<const char*>(memchr(h, '\n', (size_t)(end - pos)));
+        if (!hq) break;
+        const char* s = hq + 1;
+        bool ok;
+        const char* sq = scan_line(s, data + end, ok);
+        Slice hs; hs.p = h; hs.n = (uint64_t)(hq - h);
+        const uint64_t sn = (uint64_t)(sq - s);
+        if (sn > 2 && ok) push(out, hs, s, sn, false, none);
+        pos = (uint64_t)(sq - data) + 1;
+        for (int l = 0; l < 2 && pos < end; ++l) {  // the '+' line and the quality line
+            const char* q = static_cast<const char*>(memchr(data + pos, '\n', (size_t)(end - pos)));
+            if (!q) { pos = end; break; }
+            pos = (uint64_t)(q - data) + 1;
+        }
+    }
+}
+
+void parse_fastq_from(const char* data, uint64_t begin, uint64_t size, ParsedChunk& out) { parse_fastq_range(data, begin, size, out); }
+
 bool FastqPlan::parse_tail(ParsedChunk& out) {
     uint64_t tstart = size_;
     for (size_t c = 0; c < nc_; ++c) if (tail_start_[c] != UINT64_MAX) { tstart = tail_start_[c]; break; }

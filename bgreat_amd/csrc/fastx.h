@@ -80,6 +80,10 @@ public:
     bool sequential_only() const { return complete_ == 0 || par_records_ == 0; }  // everything goes through parse_tail
     bool parse_chunk(size_t c, ParsedChunk& out);
     bool parse_tail(ParsedChunk& out);
+    // (text route) records 0 .. par_records()-1 are plain four-line records in front of the file's last getReads() call boundary;
+    // record_offset(r), r <= par_records(): the byte where line 4r starts (finish_counts() must have run)
+    uint64_t par_records() const { return par_records_; }
+    uint64_t record_offset(uint64_t rec) const;
 private:
     const char* data_;
     uint64_t size_, chunk_bytes_;
@@ -87,6 +91,11 @@ private:
     std::vector<uint64_t> nl_, tail_start_;
     uint64_t complete_ = 0, par_records_ = 0;
 };
+// Whole four-line records in [begin, end) (end = the start of a record): header line + sequence line, kept iff size > 2 and ACGTN
+// (what every getReads() call but a file's last one does, aligner.cpp:51-68).
+void parse_fastq_records(const char* data, uint64_t begin, uint64_t end, ParsedChunk& out);
+// The sequential state machine from `begin` to the end of the image (a getReads() call boundary): phantom record, truncated tails.
+void parse_fastq_from(const char* data, uint64_t begin, uint64_t size, ParsedChunk& out);
 // Parallel whole-file parse into a ReadSet (threads >= 1); identical result to parse_reads().
 void parse_reads_parallel(const char* data, uint64_t size, bool fastq, uint32_t k, unsigned threads, uint64_t chunk_bytes, ReadSet& out);
 

@@ -187,7 +187,7 @@ struct Batch {
     std::vector<RecSlice> recs;                           // flattened view of the records of this batch
     // text route: the batch is bytes [t_begin, t_end) of `file` (a piece that starts at a header line); once mapped as text,
     // dev_text is set and the record streams sit in pin->ptext / pin->ntext
-    bool text_piece = false, dev_text = false;
+    bool text_piece = false, dev_text = false, fastq_piece = false;
     uint64_t t_begin = 0, t_end = 0, p_bytes = 0, n_bytes = 0;
     unsigned dev = 0;                                     // which device of the run maps the batch (round robin in input order)
     int rc = BGR_OK;
@@ -432,7 +432,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     // Correction mode too (the device spells the reads from its 2-bit unitig store) unless the graph has non-ACGT unitig characters.
     bgr_graph_info_t gi_route;
     if (bgr_graph_info(graph, &gi_route) != BGR_OK) return BGR_E_ARG;
-    const bool text_route = opt->route == 0 && !opt->fastq && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
+    const bool text_route = opt->route == 0 && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
     const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (text_route ? 1ull << 18 : 1ull << 17), 4ull << 20);
     const uint64_t piece_bytes = std::min<uint64_t>(std::max<uint64_t>(batch_reads * 170, 4096), 1ull << 30);  // text route: bytes of a batch
     uint64_t batch_bases_cap = 1ull << 30;
@@ -559,7 +559,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         const uint64_t est_bytes = std::min<uint64_t>(max_file, opt->fastq ? batch_reads * 160 : group0 * chunk_bytes);
         const uint64_t est_n = std::min<uint64_t>(batch_reads + batch_reads / 4, est_bytes / 16 + 1);
         const size_t need = est_bytes ? (size_t)std::min<uint64_t>(n_pins, (total_in + est_bytes - 1) / est_bytes + 1) : 1;
-        const uint64_t est_piece = std::min<uint64_t>(max_file, piece_bytes + piece_bytes / 16);
+        const uint64_t est_piece = std::min<uint64_t>(max_file, opt->fastq ? batch_reads * 330 : piece_bytes + piece_bytes / 16);
         const size_t need_text = est_piece ? (size_t)std::min<uint64_t>(n_pins, (total_in + est_piece - 1) / est_piece + 1) : 1;
         for (size_t i = 0; i < n_pins; ++i) {
             std::unique_ptr<Pinned> pn;
@@ -592,7 +592,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             if (!take_batch(b)) return false;
             b->file = mf;
             b->bases = 0;
-            b->text_piece = b->dev_text = false;
+            b->text_piece = b->dev_text = b->fastq_piece = false;
             b->marks.clear();
             for (auto& m : pending) { m.pos = 0; b->marks.push_back(std::move(m)); }
             pending.clear();
@@ -628,6 +628,50 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 plan.finish_counts();
                 us_parse += now_us() - tp0;
                 std::unique_ptr<Batch> b;
+                if (text_route && !plan.sequential_only()) {
+                    // text route: every record in front of the file's last getReads() call boundary is a plain four-line record -- pieces of
+                    // whole records go to the device as they are; the rest of the file (the phantom record at its end, truncated tails:
+                    // aligner.cpp:51-68) goes through the sequential state machine on the host, behind them
+                    const uint64_t par = plan.par_records();
+                    uint64_t r0 = 0, o0 = 0;
+                    while (r0 < par && ok && !failed) {
+                        uint64_t r1 = std::min<uint64_t>(par, r0 + batch_reads), o1 = plan.record_offset(r1);
+                        while (o1 - o0 > (1ull << 30) && r1 > r0 + 1) {  // long reads: a piece stays under the 2 GiB of one call
+                            r1 = r0 + (r1 - r0) / 2;
+                            o1 = plan.record_offset(r1);
+                        }
+                        std::unique_ptr<Batch> tb;
+                        if (!open_batch(tb, mf)) { ok = false; break; }
+                        tb->text_piece = o1 - o0 < (1ull << 31);  // (one record of 2 GiB: the host parser takes it)
+                        tb->fastq_piece = true;
+                        tb->t_begin = o0; tb->t_end = o1;
+                        if (!tb->text_piece) {
+                            tb->chunks.clear();
+                            tb->chunks.push_back(std::make_unique<ParsedChunk>());
+                            bgr::parse_fastq_records(mf->data, o0, o1, *tb->chunks[0]);
+                            tb->recs = tb->chunks[0]->recs;
+                        }
+                        ok = emit(std::move(tb));
+                        r0 = r1; o0 = o1;
+                    }
+                    if (ok && !failed) {
+                        ParsedChunk tl;
+                        tp0 = now_us();
+                        bgr::parse_fastq_from(mf->data, o0, mf->size, tl);
+                        us_parse += now_us() - tp0;
+                        const std::vector<RecSlice>& rs = tl.recs;
+                        size_t lo = 0;
+                        while (lo < rs.size() && ok) {
+                            std::unique_ptr<Batch> hb;
+                            if (!open_batch(hb, mf)) { ok = false; break; }
+                            const size_t take = std::min<size_t>(rs.size() - lo, (size_t)batch_reads);
+                            hb->recs.assign(rs.begin() + lo, rs.begin() + lo + take);
+                            lo += take;
+                            ok = emit(std::move(hb));
+                        }
+                    }
+                    continue;
+                }
                 auto feed = [&](const ParsedChunk& ch) {  // slices point into the file image only (no joined storage)
                     const std::vector<RecSlice>& rs = ch.recs;
                     marker.chunk(ch, file_iters, mark_idx);
@@ -845,6 +889,16 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         const uint64_t tp0 = now_us();
         const char* base = b.file->data + b.t_begin;
         const uint64_t bytes = b.t_end - b.t_begin;
+        if (b.fastq_piece) {  // whole four-line records
+            b.chunks.clear();
+            b.chunks.push_back(std::make_unique<ParsedChunk>());
+            bgr::parse_fastq_records(base, 0, bytes, *b.chunks[0]);
+            b.recs = b.chunks[0]->recs;
+            b.n = b.recs.size();
+            b.dev_text = false;
+            us_parse += now_us() - tp0;
+            return;
+        }
         std::vector<uint64_t> starts = bgr::split_fasta(base, bytes, chunk_bytes);
         b.chunks.clear();
         b.chunks.resize(starts.size());
@@ -864,7 +918,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         std::unique_ptr<Batch> b;
         while (to_gather.pop(b)) {
             b->dev = (unsigned)(b->index % n_gpus);
-            if (b->text_piece && b->file->irregular_pieces.load() >= 2) {  // this file is not of the device's shape: host route from here on
+            if (b->text_piece && !b->fastq_piece && b->file->irregular_pieces.load() >= 2) {  // this file is not of the device's shape: host route from here on
                 host_parse_piece(*b);
                 b->text_piece = false;
             }
@@ -891,6 +945,7 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     tb.text = static_cast<const char*>(b->pin->text.p);
                     tb.text_bytes = b->t_end - b->t_begin;
                     tb.stage = b->pin->stages.size() > b->dev ? b->pin->stages[b->dev] : nullptr;
+                    tb.fastq = b->fastq_piece ? 1u : 0u;
                     tb.want_output = writes ? (correction ? 2u : 1u) : 0u;
                     tb.paths_out = static_cast<char*>(b->pin->ptext.p);
                     tb.paths_cap = b->pin->ptext.cap;

@@ -90,12 +90,25 @@ __device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t pat) { return 
 
 // phase 0: record starts per 16 KB tile -> sums[tile]; phase 1: rec_start[] (byte offsets, ascending) from the scanned sums
 // (rec_cap: room in rec_start; a piece with more record starts than that is left to the host, the caller sees it from the count)
-template <int PHASE>
+// FASTQ (-q): record j is lines 4j .. 4j+3 whatever they contain (aligner.cpp:51-68), so the marks are the NEWLINES; the byte behind
+// every fourth one starts a record (the piece holds whole records and starts at one: the caller cuts it so)
+template <int PHASE, bool FASTQ>
 __global__ void __launch_bounds__(kTxtThreads) bgr_text_mark_kernel(const uint8_t* text, uint32_t n, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap) {
     __shared__ uint32_t lw[16];
     const uint32_t pos = blockIdx.x * kTxtTile + threadIdx.x * 16;
-    uint32_t rs = 0;  // bit i: byte pos + i starts a record
-    if (pos < n) {
+    uint32_t rs = 0;  // bit i: byte pos + i starts a record (FASTQ: is a newline)
+    if (FASTQ) {
+        if (pos < n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(text + pos);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t nl = eq_bytes(w[d], 0x0A0A0A0Au) >> 7;
+                rs |= (((nl & 1u) | ((nl >> 7) & 2u) | ((nl >> 14) & 4u) | ((nl >> 21) & 8u)) << (4 * d));
+            }
+            if (pos + 16 > n) rs &= (1u << (n - pos)) - 1u;
+        }
+    } else if (pos < n) {
         const uint4 v = *reinterpret_cast<const uint4*>(text + pos);  // (the buffer is zero padded: a zero byte is neither '>' nor '\n')
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t prev_nl = pos == 0 ? 1u : (text[pos - 1] == '\n' ? 1u : 0u);
@@ -116,14 +129,18 @@ __global__ void __launch_bounds__(kTxtThreads) bgr_text_mark_kernel(const uint8_
         if (threadIdx.x == 0) sums[blockIdx.x] = total;
     } else {
         uint32_t at = sums[blockIdx.x] + ex;
+        if (FASTQ && blockIdx.x == 0 && threadIdx.x == 0 && n) rec_start[0] = 0;
         while (rs) {
             const uint32_t i = (uint32_t)__ffs((int)rs) - 1;
             rs &= rs - 1;
-            if (at < rec_cap) rec_start[at] = pos + i;
+            if (!FASTQ) { if (at < rec_cap) rec_start[at] = pos + i; }
+            else if (((at + 1) & 3u) == 0 && ((at + 1) >> 2) < rec_cap && pos + i + 1 < n) rec_start[(at + 1) >> 2] = pos + i + 1;  // behind the 4th, 8th ... newline
             ++at;
         }
     }
 }
+// FASTQ: newlines counted -> records (a piece of whole records ends with a newline: 4 per record)
+__global__ void bgr_text_fastq_count_kernel(uint32_t* n_rec) { *n_rec = *n_rec >> 2; }
 
 // ---- records: header / sequence extents, shape check, accept test ------------------------------------------------------------
 // min over the 16 lanes of a row, result in every lane
@@ -164,6 +181,9 @@ __device__ __forceinline__ uint32_t mask16(const uint32_t w[4], uint32_t pat) {
 // One 16-lane group per record j: bytes [rec_start[j], rec_start[j+1] or n).  The shape this route takes: exactly two
 // newlines, the second one the record's last byte (header line + one sequence line).  Anything else sets *irregular.
 // rec[j] = {header offset, header length, sequence offset, sequence length | accepted << 31}
+// FASTQ: a record is four lines; header = the first, read = the second; accepted when size > 2 and ACGTN only (aligner.cpp:54-66: no
+// size > k test), and there is no "other shape" -- record j is lines 4j .. 4j+3 whatever they hold.
+template <bool FASTQ>
 __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* text, uint32_t n, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t k,
                                                                uint4* rec, uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, uint32_t rec_cap) {
     const uint32_t R = *n_rec_p;
@@ -188,9 +208,10 @@ __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* te
             if (m && mine == first) m &= m - 1;  // the lane that holds it looks past it; every other newline lies behind it anyway
         }
         if (first != 0xFFFFFFFFu && second == 0xFFFFFFFFu) second = row16_min(m ? at + (uint32_t)__ffs((int)m) - 1 : 0xFFFFFFFFu);
-        if (count > 2) break;
+        if (count > 2 || (FASTQ && count >= 2)) break;
     }
-    const bool regular = count == 2 && second == q - 1 && (j != 0 || p == 0);  // (bytes in front of the piece's first record start: not this route's shape)
+    const bool regular = FASTQ ? (first != 0xFFFFFFFFu && second != 0xFFFFFFFFu)
+                               : (count == 2 && second == q - 1 && (j != 0 || p == 0));  // (bytes in front of the piece's first record start: not this route's shape)
     uint32_t hl = 0, so = 0, L = 0, ok = 0;
     if (regular) {
         hl = first - p;
@@ -213,7 +234,7 @@ __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* te
             }
         }
         bad = row16_sum(bad ? 1u : 0u);
-        ok = (L > 2 && bad == 0 && L > k) ? 1u : 0u;  // aligner.cpp:78-88: size > 2, alphabet, size > k
+        ok = (L > 2 && bad == 0 && (FASTQ || L > k)) ? 1u : 0u;  // aligner.cpp:78-88: size > 2, alphabet, size > k (FASTA only)
     }
     if (sub == 0) {
         if (!regular && !__hip_atomic_load(&info[TXT_INFO_IRREGULAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&info[TXT_INFO_IRREGULAR], 1u);
@@ -458,18 +479,26 @@ hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32
 uint32_t scan_tiles(uint32_t n) { return std::max<uint32_t>(1, (n + kScanTile - 1) / kScanTile); }
 uint32_t text_tiles(uint32_t bytes) { return std::max<uint32_t>(1, (bytes + kTxtTile - 1) / kTxtTile); }
 
-hipError_t launch_text_mark(const uint8_t* text, uint32_t n, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream) {
+hipError_t launch_text_mark(const uint8_t* text, uint32_t n, bool fastq, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream) {
     const uint32_t nb = text_tiles(n);
-    hipLaunchKernelGGL(bgr_text_mark_kernel<0>, dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-    hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, n_rec_out);
-    hipLaunchKernelGGL(bgr_text_mark_kernel<1>, dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+    if (fastq) {
+        hipLaunchKernelGGL((bgr_text_mark_kernel<0, true>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, n_rec_out);
+        hipLaunchKernelGGL((bgr_text_mark_kernel<1, true>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        hipLaunchKernelGGL(bgr_text_fastq_count_kernel, dim3(1), dim3(1), 0, stream, n_rec_out);
+    } else {
+        hipLaunchKernelGGL((bgr_text_mark_kernel<0, false>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, n_rec_out);
+        hipLaunchKernelGGL((bgr_text_mark_kernel<1, false>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_text_records(const uint8_t* text, uint32_t n, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t max_rec, uint32_t k, uint4* rec,
+hipError_t launch_text_records(const uint8_t* text, uint32_t n, bool fastq, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t max_rec, uint32_t k, uint4* rec,
                                uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, hipStream_t stream) {
     if (max_rec == 0) return hipSuccess;
-    hipLaunchKernelGGL(bgr_text_records_kernel, dim3((max_rec + 15) / 16), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
+    if (fastq) hipLaunchKernelGGL(bgr_text_records_kernel<true>, dim3((max_rec + 15) / 16), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
+    else hipLaunchKernelGGL(bgr_text_records_kernel<false>, dim3((max_rec + 15) / 16), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
     return hipGetLastError();
 }
 

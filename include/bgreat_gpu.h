@@ -210,6 +210,10 @@ typedef struct {
     uint64_t n_records, n_accepted, paths_bytes, notaligned_bytes;   /* out */
     bgr_text_stage* stage;        /* in, optional: the piece was sent ahead with bgr_text_stage_upload (same bytes, same device): the call
                                      waits for that copy on the device instead of making its own */
+    uint32_t fastq;               /* in: 1 = the piece is FASTQ (-q): whole four-line records (record j = lines 4j .. 4j+3 whatever they hold,
+                                     aligner.cpp:51-68), ending with a newline; the reference's end-of-file behaviour (its phantom record)
+                                     stays with the caller: bgr_align_all maps the file's last getReads() call through the host parser */
+    uint32_t reserved;
 } bgr_text_batch;
 /* A stage = a device buffer for one piece + a copy stream: bgr_text_stage_upload starts the host -> device copy and returns; the
  * bgr_align_fasta_text call that names the stage orders itself behind it (hipStreamWaitEvent), so the copy of the next piece runs

@@ -14,13 +14,13 @@ from util import GOLD
 pytestmark = pytest.mark.gpu
 
 
-def _host_route(al, path_or_bytes, k, tmp_path, m=2, effort=2, mode=B.MODE_GREEDY):
+def _host_route(al, path_or_bytes, k, tmp_path, m=2, effort=2, mode=B.MODE_GREEDY, fastq=False):
     if isinstance(path_or_bytes, (bytes, bytearray)):
         f = str(tmp_path / "piece.fa")
         open(f, "wb").write(path_or_bytes)
     else:
         f = path_or_bytes
-    reads, roffs, heads, hoffs = B.load_reads(f, k)
+    reads, roffs, heads, hoffs = B.load_reads(f, k, fastq=fastq)
     n = len(roffs) - 1
     if n == 0:
         return b"", b"", 0
@@ -141,6 +141,73 @@ def test_empty_and_tiny_pieces():
     assert (p, n) == (b"", b"") and not info["irregular"] and info["n_records"] == 1 and info["n_accepted"] == 0
     p, n, info = al.align_fasta_text(b">one\n" + b"ACGT" * 20 + b"\n")
     assert not info["irregular"] and info["n_accepted"] == 1 and (p + n).startswith(b">one\n")
+
+
+def _fastq_records(seed, n, L, k):
+    s = Synth(120000, 90, 2, k, 5200 + seed)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, n, L, 3, 5300 + seed)
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        r = reads[i * L:(i + 1) * L].tobytes()
+        x = rng.random()
+        if x < 0.02:
+            r = r.lower()                                  # not ACGTN: dropped (aligner.cpp:56-65)
+        elif x < 0.04:
+            r = r[: int(rng.integers(0, 3))]               # size <= 2 (or empty): dropped
+        elif x < 0.06:
+            r = r[: int(rng.integers(3, k + 1))]           # 2 < size <= k: KEPT in FASTQ (no size > k test there), never anchored
+        elif x < 0.09:
+            b = bytearray(r); b[int(rng.integers(0, L))] = ord("N"); r = bytes(b)
+        elif x < 0.10:
+            r = r + b"\r"
+        h = [b"@q%d" % i, b"@q%d 1:N:0 @ > + text" % i, b"", b">not an at sign %d" % i][0 if i % 11 else (i // 11) % 4]
+        plus = b"+" if i % 5 else b"+q%d" % i
+        qual = bytes(rng.integers(33, 74, len(r)).astype(np.uint8)) if i % 13 else b"@" * len(r)   # '@', '+', '>' are quality characters too
+        recs.append(h + b"\n" + r + b"\n" + plus + b"\n" + qual + b"\n")
+    return s, seqs, offs, recs
+
+
+@pytest.mark.parametrize("seed,n,L,k,mode", [(1, 40000, 150, 31, B.MODE_GREEDY), (2, 20000, 100, 21, B.MODE_GREEDY), (3, 10000, 250, 31, B.MODE_EXHAUSTIVE)])
+def test_fastq_pieces_equal_the_host_route(seed, n, L, k, mode, tmp_path):
+    """-q: a piece of whole four-line records (n a multiple of the reference's 10000-record getReads() call, so that the host parser sees
+    no phantom record at the end of the file): header = line 0 whatever it holds, read = line 1, kept iff size > 2 and ACGTN."""
+    s, seqs, offs, recs = _fastq_records(seed, n, L, k)
+    text = b"".join(recs)
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    want_p, want_n, n_acc = _host_route(al, text, k, tmp_path, m=2, mode=mode, fastq=True)
+    c0 = al.counters()
+    al.reset_counters()
+    got_p, got_n, info = al.align_fasta_text(text, m=2, mode=mode, fastq=True)
+    assert not info["irregular"] and info["n_records"] == n and info["n_accepted"] == n_acc and n_acc < n
+    assert got_p == want_p and got_n == want_n
+    assert al.counters() == c0
+    al.reset_counters()
+    got_p2, got_n2, _ = al.align_fasta_text(text, m=2, mode=mode, fastq=True, staged=True, paths_cap=500)
+    assert got_p2 == want_p and got_n2 == want_n and al.counters() == c0
+    # a piece that is not whole records is refused (the pipeline cuts at record starts)
+    with pytest.raises(B.BgrError):
+        al.align_fasta_text(text[:-1], fastq=True)
+
+
+@pytest.mark.parametrize("n,batch,extra", [(25003, 0, []), (25003, 7000, ["-c"]), (30000, 4096, []), (10001, 0, ["-G"]), (9999, 0, [])])
+def test_cli_fastq_text_route_equals_host_route(n, batch, extra, tmp_path):
+    """-q through the text route (device pieces up to the file's last getReads() boundary, the tail with its phantom record on the
+    host) == -q with --host-route, two files in a row."""
+    k, L = 31, 120
+    s, seqs, offs, recs = _fastq_records(7, n, L, k)
+    s.write_unitigs(str(tmp_path / "u.fa"))
+    open(tmp_path / "a.fq", "wb").write(b"".join(recs))
+    open(tmp_path / "b.fq", "wb").write(b"".join(recs[: n // 3]) + b"@last\nACGTACGTAC")   # truncated tail
+    args = ["-r", "%s,%s" % (tmp_path / "a.fq", tmp_path / "b.fq"), "-q", "-k", str(k), "-g", str(tmp_path / "u.fa"), "-m", "2", "-t", "4"] + extra
+    if batch:
+        args += ["--batch", str(batch)]
+    (oa, pa, na), (ob, pb, nb) = _cli_pair(args, [], ["--host-route"])
+    assert pa == pb and na == nb
+    assert [l for l in oa.splitlines() if "seconds" not in l] == [l for l in ob.splitlines() if "seconds" not in l]
+    assert pa.count(b"\n") > n
 
 
 def _cli_pair(args, extra_a, extra_b):

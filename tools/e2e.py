@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--site-spacing", type=int, default=140)
     ap.add_argument("--fastq", action="store_true")
+    ap.add_argument("--extra", default="", help="further CLI flags, space separated (e.g. \"-c\", \"-G\", \"-b --write-exhaustive\", \"--host-route\")")
     ap.add_argument("--tmp", default=None)
     args = ap.parse_args()
     cli = os.path.join(ROOT, "bgreat_amd", "bin", "bgreat")
@@ -52,6 +53,7 @@ def main():
             base += ["--chunk-bytes", str(args.chunk_bytes)]
         if args.fastq:
             base.append("-q")
+        base += args.extra.split()
         env = dict(os.environ, BGREAT_TIMING="1")
         out = {}
         for rep in range(2):  # second run: page cache warm, device warm
@@ -70,19 +72,19 @@ def main():
             out["run%d" % rep] = {"wall_s": round(wall, 3), "mapping_s": secs, "mreads_per_s": round(args.reads / secs / 1e6, 3),
                                   "input_GB_per_s": round(fsize / secs / 1e9, 3),
                                   "cpu_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "cpu_sys_s": round(ru1.ru_stime - ru0.ru_stime, 2)}
-        res = {"reads": args.reads, "read_len": args.read_len, "threads": args.threads, "gpus": args.gpus, "input_bytes": fsize,
+        res = {"reads": args.reads, "read_len": args.read_len, "threads": args.threads, "gpus": args.gpus, "input_bytes": fsize, "extra": args.extra, "fastq": args.fastq,
                "generate_s": round(gen_s, 1), **out}
         if args.check and os.path.exists(ref):
             n = min(args.check, args.reads)
             s.write_reads(os.path.join(d, "c." + ext), 0, n, args.read_len, 2, 77, fastq=args.fastq, threads=args.threads)
-            cargs = ["-r", os.path.join(d, "c." + ext), "-k", "31", "-g", os.path.join(d, "u.fa"), "-m", "2"] + (["-q"] if args.fastq else [])
+            cargs = ["-r", os.path.join(d, "c." + ext), "-k", "31", "-g", os.path.join(d, "u.fa"), "-m", "2"] + (["-q"] if args.fastq else []) + [x for x in args.extra.split() if x in ("-c", "-G")]
             ra, rb = os.path.join(d, "ca"), os.path.join(d, "cb")
             os.makedirs(ra)
             os.makedirs(rb)
             t0 = time.time()
             subprocess.run([ref] + cargs + ["-t", "1"], cwd=ra, check=True, stdout=subprocess.DEVNULL)
             ref_s = time.time() - t0
-            subprocess.run([cli] + cargs + ["-t", str(args.threads)], cwd=rb, check=True, stdout=subprocess.DEVNULL)
+            subprocess.run([cli] + cargs + ["-t", str(args.threads)] + [x for x in args.extra.split() if x == "--host-route"], cwd=rb, check=True, stdout=subprocess.DEVNULL)
             same = all(hashlib.sha256(open(os.path.join(ra, f), "rb").read()).digest() == hashlib.sha256(open(os.path.join(rb, f), "rb").read()).digest()
                        for f in ("paths", "notAligned.fa"))
             res["check"] = {"reads": n, "identical_to_reference_t1": bool(same), "reference_t1_wall_s": round(ref_s, 2)}
