@@ -394,13 +394,13 @@ class Aligner:
             b.stage = stage
         try:
             rc = lib().bgr_align_fasta_text(self.h, C.byref(p), C.byref(b))
+            if rc == -4:  # BGR_E_CAPACITY: the mapping is done, the bytes did not fit (the stage still holds the text the records are cut from)
+                pout = np.empty(int(b.paths_bytes) + 64, dtype=np.uint8)
+                b.paths_out, b.paths_cap = pout.ctypes.data, len(pout)
+                rc = lib().bgr_aligner_fetch_text(self.h, C.byref(b))
         finally:
             if staged:
                 lib().bgr_text_stage_destroy(stage)
-        if rc == -4:  # BGR_E_CAPACITY: the mapping is done, the bytes did not fit
-            pout = np.empty(int(b.paths_bytes) + 64, dtype=np.uint8)
-            b.paths_out, b.paths_cap = pout.ctypes.data, len(pout)
-            rc = lib().bgr_aligner_fetch_text(self.h, C.byref(b))
         _check(rc)
         info = {"irregular": bool(b.irregular), "n_records": int(b.n_records), "n_accepted": int(b.n_accepted)}
         return pout[: int(b.paths_bytes)].tobytes(), nout[: int(b.notaligned_bytes)].tobytes(), info

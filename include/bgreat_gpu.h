@@ -217,7 +217,8 @@ typedef struct {
 } bgr_text_batch;
 /* A stage = a device buffer for one piece + a copy stream: bgr_text_stage_upload starts the host -> device copy and returns; the
  * bgr_align_fasta_text call that names the stage orders itself behind it (hipStreamWaitEvent), so the copy of the next piece runs
- * under the kernels of this one.  The host bytes must stay untouched until that call has returned. */
+ * under the kernels of this one.  The host bytes must stay untouched until that call has returned, and the stage keeps the piece
+ * (no new upload, no destroy) until the records have been fetched: after BGR_E_CAPACITY, bgr_aligner_fetch_text still cuts them from it. */
 int bgr_text_stage_create(int device, bgr_text_stage** out);
 void bgr_text_stage_destroy(bgr_text_stage* s);
 int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t text_bytes);

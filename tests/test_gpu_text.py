@@ -207,7 +207,7 @@ def test_cli_fastq_text_route_equals_host_route(n, batch, extra, tmp_path):
     (oa, pa, na), (ob, pb, nb) = _cli_pair(args, [], ["--host-route"])
     assert pa == pb and na == nb
     assert [l for l in oa.splitlines() if "seconds" not in l] == [l for l in ob.splitlines() if "seconds" not in l]
-    assert pa.count(b"\n") > n
+    assert pa.count(b"\n") > n // 4
 
 
 def _cli_pair(args, extra_a, extra_b):
