@@ -89,17 +89,24 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 // bucket 2 is only read by the lanes whose bucket 1 is full -- the builder fills bucket 1 first and never empties a slot, so
 // a key can sit in bucket 2 only then.  At the sparse fill such graphs are built with (0.55) that is one lane in five:
 // 1.2 instead of 2 requests per position (chr1-scale graph: 749 -> 930 Mreads/s).
+// (mblock: the key's block of the minimizer filter, from the caller -- the scans work it out across lanes, wave_window_max below;
+// callers that cannot pass a graph without filter)
 template <bool LAZY2 = false, typename TP>
-__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u64 key, bool active) {
+__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u64 key, bool active, uint32_t mblock = 0) {
     const u64 m = bgr_mix64(key);
     const uint32_t b1 = __umulhi((uint32_t)m, g.n_buckets), b2 = __umulhi((uint32_t)(m >> 32), g.n_buckets);
     uint32_t w1 = 0, w2 = 0;
     if (LAZY2) {
-        // large graph: one bit of a Bloom filter that lives in L2 turns most positions (no overlaps) away before the table -- whose
-        // probes miss the L2 half of the time -- is touched; a member always passes, and the key compare below decides as before
+        // large graph: a filter turns most positions (no overlaps) away before the table -- every probe of which is a cache line of
+        // its own -- is touched; a member always passes, and the key compare below decides as before
         if (g.bloom && active) {
-            const uint32_t bit = bgr_bloom_bit(m, g.bloom_mask);
-            active = (g.bloom[bit >> 5] >> (bit & 31)) & 1u;
+            if (g.filter_kind == BGR_FILTER_MINIMIZER) {
+                const uint32_t bits = bgr_mmx_bits(m);
+                active = (g.bloom[(mblock << 4) + bgr_mmx_word(m)] & bits) == bits;
+            } else {
+                const uint32_t bit = bgr_bloom_bit(m, g.bloom_mask);
+                active = (g.bloom[bit >> 5] >> (bit & 31)) & 1u;
+            }
         }
         if (active) w1 = tab[b1];
         if (active && bgr_zero_bytes(w1) == 0) w2 = tab[b2];
@@ -130,6 +137,47 @@ __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u6
         }
     }
     return res;
+}
+
+// Minimizer filter, scan side.  h = bgr_mmx_hash of the 16-mer that starts at the lane's read position (0 where the read has none).
+// Returns, for the (k-1)-mer that starts there, the largest h over its W = k-16 16-mers -- bgr_mmx_of_key of it -- in lanes
+// 0 .. 64-W (the lanes behind lack their right neighbours: a scan advances by 65-W positions per step).  Whole-wave DPP shifts
+// (wave_shl:1: lane i takes lane i+1, lane 63 takes 0 -- neutral for a maximum): a shift by d is d moves, the last one folded into
+// the v_max; k = 31: 14 VALU instructions, no LDS (profiles/r03_wave_shift_dpp.txt: 4.2 cycles each, a ds_bpermute is 24).
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true); }
+template <int D>
+__device__ __forceinline__ uint32_t wave_shl(uint32_t x) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) x = wave_shl1(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_window_max(uint32_t h, uint32_t W) {
+    if (W == 15 || W == 16) {  // k = 31 / 32, straight-line (the loops below cost three scalar instructions per shift)
+        uint32_t r = umax(h, wave_shl<1>(h));
+        r = umax(r, wave_shl<2>(r));
+        r = umax(r, wave_shl<4>(r));
+        return W == 15 ? umax(r, wave_shl<7>(r)) : umax(r, wave_shl<8>(r));
+    }
+    uint32_t r = h, w = 1;
+    while (2 * w <= W) {  // r: maximum over w positions -> over 2w
+        uint32_t t = r;
+        for (uint32_t s = 0; s < w; ++s) t = wave_shl1(t);
+        r = t > r ? t : r;
+        w *= 2;
+    }
+    if (w < W) {          // two windows of w that overlap
+        uint32_t t = r;
+        for (uint32_t s = 0; s < W - w; ++s) t = wave_shl1(t);
+        r = t > r ? t : r;
+    }
+    return r;
+}
+
+// the filter block of the (k-1)-mer at the lane's position: win = the 32 bases from there (left aligned), has16 = a 16-mer starts there
+__device__ __forceinline__ uint32_t scan_mblock(const BgrDeviceGraph& g, u64 win, bool has16, uint32_t W) {
+    const uint32_t h = has16 ? bgr_mmx_hash((uint32_t)(win >> 32)) : 0u;
+    return bgr_mmx_block(wave_window_max(h, W), g.bloom_mask);
 }
 
 // The half of key entry `idx` a walk step reads (graph_layout.h: handles): getEnd(bin) -- a step to the LEFT -- reads the right table

@@ -167,7 +167,10 @@ void resolve_device_graph(const BgrBlobHeader* h, const void* basev, BgrDeviceGr
     dg.flags = (h->has_exc ? BGR_GF_HAS_EXC : 0u) | (h->n_fallback ? BGR_GF_HAS_FALLBACK : 0u);
     dg.table_bytes = (uint32_t)(h->n_buckets * 4);
     dg.bloom = h->bloom_bits ? reinterpret_cast<const uint32_t*>(base + h->off_bloom) : nullptr;
-    dg.bloom_mask = h->bloom_bits ? (uint32_t)(h->bloom_bits - 1) : 0u;
+    dg.filter_kind = h->bloom_bits ? h->filter_kind : BGR_FILTER_NONE;
+    dg.bloom_mask = 0;
+    if (dg.filter_kind == BGR_FILTER_FLAT) dg.bloom_mask = (uint32_t)(h->bloom_bits - 1);
+    if (dg.filter_kind == BGR_FILTER_MINIMIZER) { uint32_t lg = 0; while ((512ull << lg) < h->bloom_bits) ++lg; dg.bloom_mask = 32 - lg; }
 }
 
 // Everything the kernels later trust about a blob can be checked on its header alone (section extents, level table):
@@ -188,7 +191,11 @@ bool validate_blob_header(const BgrBlobHeader* h, uint64_t bytes, std::string& e
     if (!inside(h->off_table, h->n_buckets, 4) || !inside(h->off_keys, h->n_keys, sizeof(BgrKeyEntry)) || !inside(h->off_recs, h->n_slots + 4, sizeof(BgrSlot)) ||
         !inside(h->off_meta, h->n_unitigs + 1, sizeof(BgrUnitigMeta)) || !inside(h->off_seq, h->seq_words, 8)) { err = "blob section outside the blob"; return false; }
     if (h->n_fallback && !inside(h->off_fallback, h->n_fallback, 8)) { err = "blob section outside the blob"; return false; }
-    if (h->bloom_bits && ((h->bloom_bits & (h->bloom_bits - 1)) || h->bloom_bits < 64 || h->bloom_bits > (1ull << 32) || !inside(h->off_bloom, h->bloom_bits / 32, 4))) { err = "corrupt blob header (Bloom filter)"; return false; }
+    if (h->bloom_bits && ((h->bloom_bits & (h->bloom_bits - 1)) || h->bloom_bits < 64 || !inside(h->off_bloom, h->bloom_bits / 32, 4))) { err = "corrupt blob header (filter)"; return false; }
+    if (h->bloom_bits && h->filter_kind == BGR_FILTER_FLAT && h->bloom_bits > (1ull << 32)) { err = "corrupt blob header (flat filter size)"; return false; }
+    // (minimizer blocks: at least 2 of them, so that the block shift stays below 32; at most 2^27 = 8 GiB)
+    if (h->bloom_bits && h->filter_kind == BGR_FILTER_MINIMIZER && (h->bloom_bits < 1024 || h->bloom_bits > (512ull << 27) || h->k - 1 < BGR_MMX_MIN_K1)) { err = "corrupt blob header (minimizer filter)"; return false; }
+    if (h->bloom_bits && h->filter_kind != BGR_FILTER_FLAT && h->filter_kind != BGR_FILTER_MINIMIZER) { err = "corrupt blob header (filter kind)"; return false; }
     if (h->n_keys != 4 * h->n_buckets + h->n_fallback || h->n_placed > 4 * h->n_buckets) { err = "corrupt blob header (key counts)"; return false; }
     if (h->seq_words < 2 || h->total_bases > (h->seq_words - 2) * 32 || h->seq_words * 8 >= (1ull << 32)) { err = "corrupt blob header (sequence store)"; return false; }
     if (h->has_exc) {  // one bit per base, read 64 bits at a time one word past the addressed one
@@ -416,11 +423,16 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         h.off_excn = off; off = align256(off + exc_words * 8);
     }
     h.off_fallback = off; off = align256(off + h.n_fallback * 8 + 8);
-    // a table too large for LDS staging gets a Bloom filter in front (4-8 bits per key, one hash; BGREAT_BLOOM=0 builds without)
-    const bool want_bloom = (double)keys.size() * 1.07 > 73000.0 && !(getenv("BGREAT_BLOOM") && atoi(getenv("BGREAT_BLOOM")) == 0);
-    if (want_bloom) {
-        uint64_t bits = 64;
-        while (bits < 4 * keys.size()) bits <<= 1;
+    // a table too large for LDS staging gets a filter in front: minimizer-blocked when k-1 >= 20 (24-48 bits per key), else one hash
+    // (4-8 bits per key).  BGREAT_BLOOM=0 builds without, =1 the one-hash kind, =2 the minimizer kind whatever the table size (tests)
+    const int filter_env = getenv("BGREAT_BLOOM") ? atoi(getenv("BGREAT_BLOOM")) : -1;
+    const bool large_table = (double)keys.size() * 1.07 > 73000.0;
+    if (filter_env != 0 && !keys.empty() && (large_table || filter_env == 2)) {
+        const bool minimizer = k - 1 >= BGR_MMX_MIN_K1 && filter_env != 1;
+        uint64_t bits = minimizer ? 1024 : 64;
+        while (bits < (minimizer ? 24 : 4) * keys.size()) bits <<= 1;
+        if (minimizer && bits > (512ull << 27)) bits = 512ull << 27;
+        h.filter_kind = minimizer ? BGR_FILTER_MINIMIZER : BGR_FILTER_FLAT;
         h.bloom_bits = bits;
         h.off_bloom = off; off = align256(off + bits / 8 + 16);
     }
@@ -453,10 +465,19 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     if (h.bloom_bits) {
         uint32_t* bl = reinterpret_cast<uint32_t*>(base + h.off_bloom);
         const uint32_t mask = (uint32_t)(h.bloom_bits - 1);
+        uint32_t lg = 0;
+        while ((512ull << lg) < h.bloom_bits) ++lg;
+        const bool minimizer = h.filter_kind == BGR_FILTER_MINIMIZER;
         parallel_ranges(T, keys.size(), [&](uint64_t b, uint64_t e, unsigned) {
             for (uint64_t i = b; i < e; ++i) {
-                const uint32_t bit = bgr_bloom_bit(bgr_mix64(keys[i]), mask);
-                __atomic_fetch_or(&bl[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED);
+                const uint64_t m = bgr_mix64(keys[i]);
+                if (minimizer) {
+                    const uint64_t w = ((uint64_t)bgr_mmx_block(bgr_mmx_of_key(keys[i], k - 1), 32 - lg) << 4) + bgr_mmx_word(m);
+                    __atomic_fetch_or(&bl[w], bgr_mmx_bits(m), __ATOMIC_RELAXED);
+                } else {
+                    const uint32_t bit = bgr_bloom_bit(m, mask);
+                    __atomic_fetch_or(&bl[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED);
+                }
             }
         });
     }

@@ -48,7 +48,7 @@
 #endif
 
 #define BGR_MAGIC 0x3130484752474742ULL /* "BGGRGH01" */
-#define BGR_BLOB_VERSION 12u /* 12: Bloom filter in front of large key tables; 11: compact slots + half handles; 10: slots carry the 32 bases next to the overlap; 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
+#define BGR_BLOB_VERSION 13u /* 13: minimizer-blocked filter in front of large key tables; 12: one-hash Bloom filter there; 11: compact slots + half handles; 10: slots carry the 32 bases next to the overlap; 9: fingerprint key table instead of the MPHF cascade; 8: slot_fill_x100; 7: anchors levels with division magic */
 #define BGR_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL /* keys[] of an empty table slot: no (k-1)-mer, k <= 32, has bit 62 or 63 set */
 #define BGR_NONE 0xFFFFFFFFu
 #define BGR_SLOT_ID_MASK 0x3FFFFFFFu
@@ -135,14 +135,16 @@ typedef struct {
     uint64_t total_bases;   // 2 * sum(len)
     uint64_t n_buckets;     // 4-slot buckets (one dword each) of the key table
     uint64_t off_table, off_keys, off_recs, off_meta, off_seq, off_exc, off_excn, off_fallback;  // off_recs: the compact `slots`
-    uint32_t reserved0, has_exc;
+    uint32_t filter_kind, has_exc;       // filter_kind: BGR_FILTER_* of the section at off_bloom
     uint64_t max_unitig_len;
     uint64_t n_left_keys, n_right_keys;  // sizes of the reference's two key sets (informational)
     uint32_t slot_fill_x100, pad0;       // 100 x mean number of filled slots per non-empty half record (how branchy the graph is)
     uint64_t n_slots;       // entries of `slots` (filled slots of all halves; 4 zero entries follow them)
-    uint64_t off_bloom;     // large graphs (key table probed in L2, not staged in LDS): a one-hash Bloom filter over the keys, 4-8 bits per
-    uint64_t bloom_bits;    //   key, a power of two (0 = none) -- small enough to live in an XCD's L2, so most read positions (no overlaps)
-                            //   are turned away by one L2 hit instead of a table probe that misses the L2 half of the time
+    uint64_t off_bloom;     // large graphs (key table probed in L2/HBM, not staged in LDS): a filter over the keys in front of the table, so
+    uint64_t bloom_bits;    //   that most read positions (no overlaps) are turned away before a table probe; bits = a power of two, 0 = none.
+                            //   BGR_FILTER_MINIMIZER (k-1 >= 20): 64-byte blocks chosen by the (k-1)-mer's minimizer -- consecutive read
+                            //   positions share it, so the lanes of a scan read a few lines instead of one line each (see bgr_mmx_*);
+                            //   BGR_FILTER_FLAT (shorter k): one hash, 4-8 bits per key
     double gamma;           // table slots per key
     // anchors index (all zero when the graph was built without it)
     uint64_t anc_n;          // anchors = k-mers of all unitigs but each unitig's last, repeats included (aligner.cpp:434-442)
@@ -168,8 +170,8 @@ typedef struct {
     const BgrBlobHeader* hdr;
     uint32_t k, n_buckets, flags, table_bytes;  // table_bytes = 4 * n_buckets (LDS staging)
     const uint32_t* bloom;   // null = none
-    uint32_t bloom_mask;     // bloom_bits - 1
-    uint32_t pad1;
+    uint32_t bloom_mask;     // BGR_FILTER_FLAT: bloom_bits - 1; BGR_FILTER_MINIMIZER: 32 - log2(number of blocks)
+    uint32_t filter_kind;
 } BgrDeviceGraph;
 
 // ---- hashing shared by the host builder and the device lookup ---------------------------------------
@@ -183,6 +185,44 @@ BGR_HD uint64_t bgr_mix64(uint64_t x) {
 }
 BGR_HD uint32_t bgr_tab_bucket(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((uint64_t)h * (uint64_t)n_buckets) >> 32); }
 BGR_HD uint32_t bgr_bloom_bit(uint64_t m, uint32_t mask) { return (uint32_t)(m >> 20) & mask; }  // (bits of both words of the hash)
+// ---- the minimizer-blocked filter (BGR_FILTER_MINIMIZER) ------------------------------------------------------------------
+// A scan asks for the (k-1)-mers at ~120 consecutive positions of a read and nearly all of them are no keys.  With one hashed bit per
+// key every one of those probes is its own cache line of a table far larger than the L2 (52-80 G probes/s on an MI355X whatever
+// the kernel does, profiles/r03_probe_locality.txt).  Here the 64-byte block of a key is chosen by the key's MINIMIZER: of the
+// k-16 16-mers of the (k-1)-mer (canonical form: the smaller of the 16-mer and its reverse complement, so both strands agree), the one
+// with the largest hash.  Neighbouring positions share their minimizer (runs of ~(k-14)/2 positions), so the lanes of a scan touch a
+// handful of lines (x5-10 probes/s).  Inside the block: one of 16 words and two of its 32 bits, from the key's own hash.
+#define BGR_FILTER_NONE 0u
+#define BGR_FILTER_FLAT 1u
+#define BGR_FILTER_MINIMIZER 2u
+#define BGR_MMX_BASES 16u      // bases of a minimizer
+#define BGR_MMX_MIN_K1 20u     // shortest (k-1)-mer the filter is built for (window of at least 5 16-mers)
+BGR_HD uint32_t bgr_rc16(uint32_t x) {  // reverse complement of 16 bases (2-bit codes A0 C1 G2 T3: complement = ~code)
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __builtin_bitreverse32(x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+#else
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = (x >> 24) | ((x >> 8) & 0xFF00u) | ((x << 8) & 0xFF0000u) | (x << 24);
+#endif
+    return ~x;
+}
+BGR_HD uint32_t bgr_mmx_hash(uint32_t x) {  // of the 16-mer x; never 0 (0 = "no 16-mer here" in the device's window maximum)
+    const uint32_t r = bgr_rc16(x);
+    return ((x < r ? x : r) * 0x9E3779B1u) | 1u;
+}
+BGR_HD uint32_t bgr_mmx_of_key(uint64_t key, uint32_t K1) {  // key: K1 bases, right aligned (either strand gives the same value)
+    uint32_t best = 0;
+    for (uint32_t j = 0; j + BGR_MMX_BASES <= K1; ++j) {
+        const uint32_t h = bgr_mmx_hash((uint32_t)(key >> (2 * (K1 - BGR_MMX_BASES - j))));
+        best = h > best ? h : best;
+    }
+    return best;
+}
+BGR_HD uint32_t bgr_mmx_block(uint32_t mh, uint32_t shift) { return (mh * 0x85EBCA6Bu) >> shift; }  // 2^(32 - shift) blocks
+BGR_HD uint32_t bgr_mmx_word(uint64_t m) { return (uint32_t)(m >> 8) & 15u; }                       // m = bgr_mix64(key)
+BGR_HD uint32_t bgr_mmx_bits(uint64_t m) { return (1u << ((uint32_t)(m >> 12) & 31u)) | (1u << ((uint32_t)(m >> 17) & 31u)); }
 BGR_HD uint32_t bgr_tab_fp(uint64_t m) { const uint32_t f = (uint32_t)(m >> 32) & 0xFFu; return f ? f : 1u; }
 // bit 7 of every byte of x that is zero (exact: no borrow between bytes)
 BGR_HD uint32_t bgr_zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }

@@ -46,6 +46,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #ifdef BGR_PHASE_TIMING  /* diagnostic builds: env BGR_DEBUG_STOP = 1 stops after packing, 2 after the position scan */
         if (prm.debug_stop == 1) npos = 0;
 #endif
+        // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
+        const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+        const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
         for (int pass = 0; pass < 2; ++pass) {
             if ((pass == 1 || hasN) && !derived) { derive_streams(L, W, K1, FW3, FWQ, RCW, NM, lane); derived = true; }
             // A read without N: FWQ == FW3 and the rolling reverse k-mer == rcb(forward k-mer), so pass 0 needs FW3 only.
@@ -56,16 +59,21 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
             const bool useN = (pass == 0) && hasN;
             uint32_t tried = 0;
             bool done = false;
-            for (uint32_t base = 0; base < npos && !done && tried < effort; base += 64) {
+            for (uint32_t base = 0; base < npos && !done && tried < effort; base += scan_step) {
                 const uint32_t i = base + lane;
-                const bool valid = i < npos;
-                u64 num = 0, rcn = 0;
+                const bool valid = i < npos && (uint32_t)lane < scan_step;
+                u64 num = 0, rcn = 0, win = 0;
+                if (valid || (mmx_w && i + BGR_MMX_BASES <= L)) win = lds_win32(A, i);
                 if (valid) {
-                    num = lds_win32(A, i) >> (64 - 2 * K1);
+                    num = win >> (64 - 2 * K1);
                     rcn = plain ? rcb_fast(num, K1) : lds_win32(B, L - K1 - i) >> (64 - 2 * K1);
                 }
                 const u64 rep = num < rcn ? num : rcn;
-                const uint32_t idx = find_key<!STAGE>(g, ktab, rep, valid);
+                uint32_t mblock = 0;
+                if (!STAGE && mmx_w) {  // (a read with an N: the key looked up need not be the canonical form of the window -- its own 16-mers then)
+                    mblock = plain ? scan_mblock(g, win, i + BGR_MMX_BASES <= L, mmx_w) : bgr_mmx_block(bgr_mmx_of_key(rep, K1), g.bloom_mask);
+                }
+                const uint32_t idx = find_key<!STAGE>(g, ktab, rep, valid, mblock);
                 u64 mask = __ballot(idx != BGR_NONE);
 #ifdef BGR_PHASE_TIMING
                 if (prm.debug_stop == 2) { if (mask) { ++tried; done = true; p_n = 0; } mask = 0; }
@@ -82,7 +90,10 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
                     // getBegin/getEnd recompute rc = rcb(num) (aligner.cpp:149,211); it differs from the
                     // rolling rcnum only when an N was rolled into the window.
                     const u64 rc2 = rcb_fast(a_num, K1);
-                    if (rc2 != a_rcn) a_rec = find_key<!STAGE>(g, ktab, a_num < rc2 ? a_num : rc2, true);
+                    if (rc2 != a_rcn) {
+                        const u64 key2 = a_num < rc2 ? a_num : rc2;
+                        a_rec = find_key<!STAGE>(g, ktab, key2, true, (!STAGE && mmx_w) ? bgr_mmx_block(bgr_mmx_of_key(key2, K1), g.bloom_mask) : 0u);
+                    }
                     if (greedy_from_anchor(g, CMP, NM, useN, L, K1, a_rec, a_num <= rc2, a_pos, prm.max_mismatch, PATH, &p_lo, &p_n, lane)) {
                         done = true;
                         break;
@@ -164,6 +175,9 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     const uint32_t gbase_lane = (uint32_t)lane & ~(uint32_t)(GL - 1);
     const uint32_t m = prm.max_mismatch;
     const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
+    // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
+    const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+    const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
 
     // this wave's slice of the path arena: the first chunk is the wave's by its number (the host starts the cursor behind them: a
     // returning atomic per wave on one word at the start of the launch serialises, ~90 per microsecond), later ones come from the cursor
@@ -239,13 +253,15 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
             const uint32_t left_q = eff - ((stq >> G4_ST_TRIED_SHIFT) & 0x7FFu);  // anchors this strand may still try (>= 1)
             uint32_t npos = Lq >= K1 ? Lq - K1 + 1 : 0;
             if (!prm.effort && npos > 1) npos = 1;
-            for (uint32_t base = stq & G4_ST_POS_MASK; base < npos; base += 64) {
+            for (uint32_t base = stq & G4_ST_POS_MASK; base < npos; base += scan_step) {
                 const uint32_t i = base + (uint32_t)lane;
-                const bool valid = i < npos;
-                u64 num = 0;
-                if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                const bool valid = i < npos && (uint32_t)lane < scan_step;
+                u64 num = 0, win = 0;
+                if (valid || (mmx_w && i + BGR_MMX_BASES <= Lq)) win = lds_win32(A, i);
+                if (valid) num = win >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
-                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid);
+                const uint32_t mblock = (!STAGE && mmx_w) ? scan_mblock(g, win, i + BGR_MMX_BASES <= Lq, mmx_w) : 0u;
+                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid, mblock);
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {
                     if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;

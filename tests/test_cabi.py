@@ -191,32 +191,81 @@ def test_overlap_key_table(gamma, no_evictions):
     assert all(int(v) == HNONE or int(v) in starts for v in nxt)
 
 
-def test_large_tables_get_a_bloom_filter_that_passes_every_key():
-    """A key table too large for LDS staging is built with a one-hash Bloom filter in front (graph_layout.h): a power of two of
-    4-8 bits per key, every key's bit set (a member is never turned away), not saturated."""
-    k = 31
-    s = Synth(2_600_000, 60, 2, k, 23)
+def _rc16(x):
+    y = 0
+    for _ in range(16):
+        y = (y << 2) | (3 - (x & 3))
+        x >>= 2
+    return y
+
+
+def _mmx_hash(x):
+    c = min(x, _rc16(x))
+    return ((c * 0x9E3779B1) & 0xFFFFFFFF) | 1        # bgr_mmx_hash
+
+
+def _mmx_of_key(key, K1):
+    return max(_mmx_hash((key >> (2 * (K1 - 16 - j))) & 0xFFFFFFFF) for j in range(K1 - 15))   # bgr_mmx_of_key
+
+
+def _filter_passes(bl, kind, bits, key, K1):
+    M = (1 << 64) - 1
+    y = key ^ (key >> 32)
+    m = (y * 0x9E3779B97F4A7C15) & M                   # bgr_mix64
+    if kind == 1:
+        bit = (m >> 20) & (bits - 1)                   # bgr_bloom_bit
+        return (int(bl[bit >> 5]) >> (bit & 31)) & 1
+    shift = 32 - ((bits // 512).bit_length() - 1)
+    blk = ((_mmx_of_key(key, K1) * 0x85EBCA6B) & 0xFFFFFFFF) >> shift          # bgr_mmx_block
+    want = (1 << ((m >> 12) & 31)) | (1 << ((m >> 17) & 31))                   # bgr_mmx_bits
+    return (int(bl[blk * 16 + ((m >> 8) & 15)]) & want) == want                # bgr_mmx_word
+
+
+@pytest.mark.parametrize("k,env,kind", [(31, None, 2), (21, None, 2), (32, None, 2), (20, None, 1), (31, "1", 1), (25, "2", 2)])
+def test_large_tables_get_a_filter_that_passes_every_key(k, env, kind, monkeypatch):
+    """A key table too large for LDS staging is built with a filter in front (graph_layout.h): minimizer-blocked for k-1 >= 20 (24-48
+    bits per key in 64-byte blocks chosen by the key's minimizer), one hash (4-8 bits per key) for shorter k; every key passes (a member
+    is never turned away), the filter is not saturated, and both strands of a key choose the same block."""
+    if env is not None:
+        monkeypatch.setenv("BGREAT_BLOOM", env)
+    small = env == "2"
+    s = Synth(60000 if small else 2_600_000, 60, 2, k, 23)
     seqs, offs = s.unitigs()
     g = B.Graph.build(k, seqs, offs)
     keys = _canonical_end_kmers(seqs, offs, k)
-    assert len(keys) * 1.07 > 73000
+    assert small or len(keys) * 1.07 > 73000
     blob = np.array(g.blob())
     hdr = blob[:4096].view(np.uint64)
     off_bloom, bits = int(hdr[24]), int(hdr[25])
-    assert bits & (bits - 1) == 0 and 4 * len(keys) <= bits < 8 * len(keys)
+    assert int(hdr[18]) & 0xFFFFFFFF == kind
+    lo, hi = (24, 48) if kind == 2 else (4, 8)
+    assert bits & (bits - 1) == 0 and (lo * len(keys) <= bits < hi * len(keys) or bits == 1024)
     bl = blob[off_bloom:off_bloom + bits // 8].view(np.uint32)
-    M = (1 << 64) - 1
-    for x in keys:
-        y = x ^ (x >> 32)
-        m = (y * 0x9E3779B97F4A7C15) & M               # bgr_mix64
-        bit = (m >> 20) & (bits - 1)                   # bgr_bloom_bit
-        assert (int(bl[bit >> 5]) >> (bit & 31)) & 1
+    K1 = k - 1
+    rng = np.random.default_rng(5)
+    for x in list(keys)[:20000]:
+        assert _filter_passes(bl, kind, bits, x, K1)
+    if kind == 2:   # strand symmetry of the minimizer: the reverse complement of a key has the same 16-mer set
+        for x in list(keys)[:200]:
+            rc = 0
+            t = x
+            for _ in range(K1):
+                rc = (rc << 2) | (3 - (t & 3))
+                t >>= 2
+            assert _mmx_of_key(x, K1) == _mmx_of_key(rc, K1)
+    # random non-keys are mostly turned away
+    keyset = set(keys)
+    non = [int(v) for v in rng.integers(0, 1 << (2 * K1), 4000, dtype=np.uint64) if int(v) not in keyset]
+    passed = sum(1 for v in non if _filter_passes(bl, kind, bits, v, K1))
+    assert passed < (0.05 if kind == 2 else 0.3) * len(non)
     ones = int(np.unpackbits(bl.view(np.uint8)).sum())
-    assert 0.1 * bits < ones <= len(keys)
-    # a small graph (table staged in LDS) has none
-    s2 = Synth(60000, 45, 3, k, 17)
+    assert 0.01 * bits < ones <= 2 * len(keys)
+
+
+def test_small_tables_get_no_filter():
+    s2 = Synth(60000, 45, 3, 31, 17)
     sq, of = s2.unitigs()
-    h2 = np.array(B.Graph.build(k, sq, of).blob())[:4096].view(np.uint64)
+    h2 = np.array(B.Graph.build(31, sq, of).blob())[:4096].view(np.uint64)
     assert int(h2[25]) == 0
 
 

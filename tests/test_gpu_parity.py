@@ -479,6 +479,44 @@ def test_four_reads_per_wave_pass_equals_general_kernel_and_oracle(seed, k, L, m
     assert al.counters() == o.counters()
 
 
+@pytest.mark.parametrize("seed,k,L,m,e,nfrac", [(1, 31, 150, 2, 2, 0.0), (2, 21, 100, 3, 1, 0.002), (3, 32, 250, 5, 4, 0.001), (4, 25, 60, 1, 3, 0.0), (5, 31, 40, 0, 0, 0.0),
+                                                (6, 27, 400, 4, 6, 0.0), (7, 31, 31, 2, 2, 0.0), (8, 22, 150, 2, 2, 0.0)])
+def test_minimizer_filter_in_front_of_the_key_table(seed, k, L, m, e, nfrac, monkeypatch):
+    """The filter of large graphs (graph_layout.h bgr_mmx_*: block chosen by the (k-1)-mer's minimizer, worked out across the lanes of a scan
+    with whole-wave DPP shifts, 65 - (k-16) positions per scan step) forced onto a small graph whose table is probed in memory: eight-reads-
+    per-wave kernel and general kernel (N reads: per-key minimizer) against the oracle, and against the same graph without filter."""
+    monkeypatch.setenv("BGREAT_BLOOM", "2")
+    s = Synth(150000, 3 * k, 3, k, 9100 + seed)
+    seqs, offs = s.unitigs()
+    n = 20000
+    reads, roffs = s.reads(0, n, L, m + 1, 9200 + seed)
+    if nfrac:
+        reads = _inject_n(reads, np.random.default_rng(seed), nfrac)
+    g = B.Graph.build(k, seqs, offs)
+    hdr = np.array(g.blob())[:4096].view(np.uint64)
+    assert int(hdr[18]) & 0xFFFFFFFF == 2 and int(hdr[25]) >= 1024
+    al = B.Aligner(g, 0)
+    al.configure(lds_mphf=1)   # table not staged in LDS: the filter is in use
+    o = oracle_py.Oracle(k, seqs, offs)
+    p2, po2, st2 = o.align(reads, roffs, m=m, effort=e)
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=e)
+    assert not al.launch_info()["mphf_in_lds"] and al.launch_info()["four_reads_per_wave"]
+    assert np.array_equal(st1, st2), np.nonzero(st1 != st2)[0][:10]
+    assert np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    assert al.counters() == o.counters()
+    assert ((st1 & 3) == B.ST_ALIGNED).sum() > n // 100
+    al.reset_counters()
+    al.set_knob(B.KNOB_GREEDY_FAST, 1)   # general kernel only
+    p3, po3, st3 = al.align(reads, roffs, m=m, effort=e)
+    assert np.array_equal(st3, st2) and np.array_equal(po3, po2) and np.array_equal(p3, p2)
+    assert al.counters() == o.counters()
+    # exhaustive mode runs without the filter (capi.hip): still the oracle's rows
+    al.set_knob(B.KNOB_GREEDY_FAST, 0)
+    p4, po4, st4 = al.align(reads[: int(roffs[2000])], roffs[:2001], m=m, effort=e, mode=B.MODE_EXHAUSTIVE)
+    p5, po5, st5 = o.align(reads[: int(roffs[2000])], roffs[:2001], m=m, effort=e, mode=1)
+    assert np.array_equal(st4, st5) and np.array_equal(po4, po5) and np.array_equal(p4, p5)
+
+
 @pytest.mark.parametrize("mode", [B.MODE_GREEDY, B.MODE_EXHAUSTIVE])
 def test_large_batch_in_overlapped_pieces_equals_one_launch(mode):
     """bgr_align_batch maps a batch of >= 512 k reads in four pieces on two streams (copies of one piece under the kernels of
