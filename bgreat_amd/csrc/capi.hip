@@ -104,6 +104,7 @@ struct bgr_aligner {
     std::vector<uint64_t> ticket_offs;  // that batch's offsets made relative (kept alive for the asynchronous copy)
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
+    bool exh_filter = getenv("BGREAT_EXH_FILTER") && atoi(getenv("BGREAT_EXH_FILTER")) != 0;  // exhaustive mode through the minimizer filter too (diagnostic)
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
     uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0;
     uint64_t knob_split_limit = 0;
@@ -716,10 +717,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.arena = static_cast<int32_t*>(a->arena.p);
     io.cursor = static_cast<uint32_t*>(a->small.p);
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, a->knob_debug_stop};
-    // the Bloom filter in front of a large key table pays where every read position is probed (greedy and anchors scans: chr1-scale graph
-    // 1 025 -> 1 072 Mreads/s, HBM-side traffic 5.6 -> 3.6 KB per read); the exhaustive scan stops at its first hit (4-allele graph 705 vs 681)
+    // the filter in front of a large key table pays where many read positions are probed per anchor (greedy scans: chr1-scale graph
+    // 1 020 -> 1 184 Mreads/s, L2 requests per read 135 -> 28); the exhaustive scan of a branchy graph meets its first hit within a few
+    // positions (4-allele graph: 697 without, 664 with) and runs without it unless BGREAT_EXH_FILTER=1 (the minimizer kind only)
     BgrDeviceGraph dgl = a->dg;
-    if (p->mode == BGR_MODE_EXHAUSTIVE) dgl.bloom = nullptr;
+    if (p->mode == BGR_MODE_EXHAUSTIVE && !(dgl.filter_kind == BGR_FILTER_MINIMIZER && a->exh_filter)) dgl.bloom = nullptr;
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters
     {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: the cursor starts behind

@@ -374,13 +374,19 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
         uint32_t p_n = 0;
         const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         bool done = false, overflow = false;
-        for (uint32_t base = 0; base < npos && !done && !overflow; base += 64) {
+        // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
+        const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+        const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
+        for (uint32_t base = 0; base < npos && !done && !overflow; base += scan_step) {
             const uint32_t i = base + lane;
-            const bool valid = i < npos;
-            u64 num = 0;
-            if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            const bool valid = i < npos && (uint32_t)lane < scan_step;
+            u64 num = 0, win = 0;
+            if (valid || (mmx_w && i + BGR_MMX_BASES <= L)) win = lds_win32(ROLL, i);
+            if (valid) num = win >> (64 - 2 * K1);             // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
-            const uint32_t idx = find_key<!STAGE>(g, ktab, num < rc ? num : rc, valid);
+            // (the key is the canonical form of the window of ROLL itself, so its 16-mers are the windows' leading 16 bases)
+            const uint32_t mblock = (!STAGE && mmx_w) ? scan_mblock(g, win, i + BGR_MMX_BASES <= L, mmx_w) : 0u;
+            const uint32_t idx = find_key<!STAGE>(g, ktab, num < rc ? num : rc, valid, mblock);
             u64 mask = __ballot(idx != BGR_NONE);
             if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
             while (mask) {
@@ -652,6 +658,9 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
     const uint32_t K1 = g.k - 1;
+    // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
+    const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+    const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
     unsigned long long* wg_counts = wg_counts_init(lds);
     uint32_t ktab_words;
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
@@ -696,13 +705,15 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
             const uint32_t Lq = rl32(L, (int)(GL * qq));
             const u64* A = WV + qq * grp_words;
             const uint32_t npos = Lq - K1 + 1;
-            for (uint32_t base = 0; base < npos; base += 64) {
+            for (uint32_t base = 0; base < npos; base += scan_step) {
                 const uint32_t i = base + (uint32_t)lane;
-                const bool valid = i < npos;
-                u64 num = 0;
-                if (valid) num = lds_win32(A, i) >> (64 - 2 * K1);
+                const bool valid = i < npos && (uint32_t)lane < scan_step;
+                u64 num = 0, win = 0;
+                if (valid || (mmx_w && i + BGR_MMX_BASES <= Lq)) win = lds_win32(A, i);
+                if (valid) num = win >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);
-                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid);
+                const uint32_t mblock = (!STAGE && mmx_w) ? scan_mblock(g, win, i + BGR_MMX_BASES <= Lq, mmx_w) : 0u;
+                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid, mblock);
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {
                     if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
@@ -812,13 +823,19 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
         uint32_t p_n = 0;
         const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         bool done = false, overflow = false;
-        for (uint32_t base = 0; base < npos && !done && !overflow; base += 64) {
+        // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
+        const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+        const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
+        for (uint32_t base = 0; base < npos && !done && !overflow; base += scan_step) {
             const uint32_t i = base + lane;
-            const bool valid = i < npos;
-            u64 num = 0;
-            if (valid) num = lds_win32(ROLL, i) >> (64 - 2 * K1);  // the rolling `num` (aligner.cpp:321,334)
+            const bool valid = i < npos && (uint32_t)lane < scan_step;
+            u64 num = 0, win = 0;
+            if (valid || (mmx_w && i + BGR_MMX_BASES <= L)) win = lds_win32(ROLL, i);
+            if (valid) num = win >> (64 - 2 * K1);             // the rolling `num` (aligner.cpp:321,334)
             const u64 rc = rcb_fast(num, K1);                  // getBegin/getEnd use rcb(num) (aligner.cpp:149,211)
-            const uint32_t idx = find_key<!STAGE>(g, ktab, num < rc ? num : rc, valid);
+            // (the key is the canonical form of the window of ROLL itself, so its 16-mers are the windows' leading 16 bases)
+            const uint32_t mblock = (!STAGE && mmx_w) ? scan_mblock(g, win, i + BGR_MMX_BASES <= L, mmx_w) : 0u;
+            const uint32_t idx = find_key<!STAGE>(g, ktab, num < rc ? num : rc, valid, mblock);
             u64 mask = __ballot(idx != BGR_NONE);
             if (base == 0) mask |= 1;  // position 0: the left side is trivially [0] whatever the k-mer
             while (mask) {

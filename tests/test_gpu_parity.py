@@ -486,6 +486,7 @@ def test_minimizer_filter_in_front_of_the_key_table(seed, k, L, m, e, nfrac, mon
     with whole-wave DPP shifts, 65 - (k-16) positions per scan step) forced onto a small graph whose table is probed in memory: eight-reads-
     per-wave kernel and general kernel (N reads: per-key minimizer) against the oracle, and against the same graph without filter."""
     monkeypatch.setenv("BGREAT_BLOOM", "2")
+    monkeypatch.setenv("BGREAT_EXH_FILTER", "1")   # (exhaustive mode skips the filter by default: slower with it on branchy graphs)
     s = Synth(150000, 3 * k, 3, k, 9100 + seed)
     seqs, offs = s.unitigs()
     n = 20000
@@ -510,11 +511,15 @@ def test_minimizer_filter_in_front_of_the_key_table(seed, k, L, m, e, nfrac, mon
     p3, po3, st3 = al.align(reads, roffs, m=m, effort=e)
     assert np.array_equal(st3, st2) and np.array_equal(po3, po2) and np.array_equal(p3, p2)
     assert al.counters() == o.counters()
-    # exhaustive mode runs without the filter (capi.hip): still the oracle's rows
+    # exhaustive mode: the eight-reads-per-wave pass, then the depth-first and the level search alone
     al.set_knob(B.KNOB_GREEDY_FAST, 0)
-    p4, po4, st4 = al.align(reads[: int(roffs[2000])], roffs[:2001], m=m, effort=e, mode=B.MODE_EXHAUSTIVE)
-    p5, po5, st5 = o.align(reads[: int(roffs[2000])], roffs[:2001], m=m, effort=e, mode=1)
-    assert np.array_equal(st4, st5) and np.array_equal(po4, po5) and np.array_equal(p4, p5)
+    sub_r, sub_o = reads[: int(roffs[3000])], roffs[:3001]
+    p5, po5, st5 = o.align(sub_r, sub_o, m=m, effort=e, mode=1)
+    for fast_off, search in ((0, B.SEARCH_AUTO), (1, B.SEARCH_DEPTH_FIRST), (1, B.SEARCH_BY_LEVEL)):
+        al.set_knob(B.KNOB_EXH_FAST, fast_off)
+        al.set_knob(B.KNOB_EXH_SEARCH, search)
+        p4, po4, st4 = al.align(sub_r, sub_o, m=m, effort=e, mode=B.MODE_EXHAUSTIVE)
+        assert np.array_equal(st4, st5) and np.array_equal(po4, po5) and np.array_equal(p4, p5), (fast_off, search)
 
 
 @pytest.mark.parametrize("mode", [B.MODE_GREEDY, B.MODE_EXHAUSTIVE])
