@@ -10,11 +10,14 @@
 
 namespace bgr {
 
-// lanes per read of the many-reads-per-wave greedy kernel (bgr_align_greedy_multi_kernel): 16 = four reads per wave, 8 = eight
+// lanes per read of the many-reads-per-wave greedy kernel (bgr_align_greedy_multi_kernel): 16 = four reads per wave, 8 = eight, 4 = sixteen
+// (sixteen: the step instructions of a wave serve twice the reads and twice as many walks wait on memory at once: E. coli-scale 1 772 -> 1 877
+// Mreads/s, chr1-scale 1 202 -> 1 320, configs[1] 1 791 -> 2 035)
 #ifndef BGR_G4_GROUP_LANES
-#define BGR_G4_GROUP_LANES 8
+#define BGR_G4_GROUP_LANES 4
 #endif
 constexpr uint32_t kG4GroupLanes = BGR_G4_GROUP_LANES, kG4ReadsPerWave = 64 / BGR_G4_GROUP_LANES;
+constexpr uint32_t kG4PathInts = 16;  // path ints of a read's row in the arena: 8 of the left walk (offset included), 8 of the right; longer paths go to the general kernel
 // the same for the exhaustive first pass (bgr_align_exhaustive4_kernel); its level table holds one level per lane of a read's group
 #ifndef BGR_X4_GROUP_LANES
 #define BGR_X4_GROUP_LANES 8

@@ -543,7 +543,8 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // grid of exactly CUs x b workgroups avoids a partial last round.
     const uint32_t cap_default = std::max<uint32_t>(4, bgr::resident_waves_per_cu(level_search ? 3u : p->mode));  // 3: the level-search kernel
     const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
-    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bool allow_stage, bgr::LaunchCfg& cfg, uint32_t cap_override = 0) -> bool {
+    // (stage_pct: the staged grouping is taken when it keeps at least this share of the resident waves of the best grouping without staging)
+    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bool allow_stage, bgr::LaunchCfg& cfg, uint32_t cap_override = 0, uint32_t stage_pct = 100) -> bool {
         const uint32_t cap = cap_override ? cap_override : cap_default;
         uint32_t waves = 0, bpc = 0;
         bool stage = false;
@@ -585,7 +586,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             // one wave per SIMD and workgroup schedules best (8-wave workgroups measured 87 vs 123 Mreads/s at 24 vs 20
             // resident waves): take that grouping unless it gives up more than a fifth of the resident waves
             if (w4 == 4 && b4 * w4 * 5 >= res_n * 4) { res_n = b4 * w4; wn = w4; bn = b4; }
-            if (!allow_stage || a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n > best_res)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
+            if (!allow_stage || a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n * stage_pct > best_res * 100)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
             if (best_res == 0) waves = 0;
         }
         if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return false;
@@ -628,7 +629,8 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     bgr::LaunchCfg cfg_fast;
     const uint32_t wfast = std::min<uint32_t>(words, 16);  // the many-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
     bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
-                           geometry(bgr::kG4ReadsPerWave * 8 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)));
+                           geometry(bgr::kG4ReadsPerWave * 8 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)),
+                                    50);  // sixteen reads per wave, E. coli-scale table (72 KB): 2 x 12 waves with the table in LDS 1 877 Mreads/s, 1 x 16: 1 543, 32 waves probing it in L2: 1 381
     // Exhaustive mode, first pass: eight reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
@@ -646,17 +648,16 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
     // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
     const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
-    // the eight-reads-per-wave greedy kernel: a wave's first chunk is its own by number and sized for its whole share of a typical batch
-    // (~6 ints per read), so that most waves never go to the cursor
-    const uint32_t arena_chunk_fast = !fast_pass ? arena_chunk
-        : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(arena_chunk, 8 * (n_reads / ((uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block) + 8)));
+    // the several-reads-per-wave greedy kernel writes a read's path ints where they are found, into the read's own row of kG4PathInts ints
+    // at the start of the arena (no per-wave chunks, no copy at the end of a walk); the cursor-served chunks of the other kernels follow
+    const uint64_t fast_rows = fast_pass ? n_reads * bgr::kG4PathInts : 0;
     const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
                                (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0) +
                                (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0) +
-                               (fast_pass ? (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk_fast : 0) +
+                               fast_rows +
                                (x4_pass ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk : 0) +
                                (a4_pass ? (uint64_t)cfg_a4.blocks * cfg_a4.waves_per_block * arena_chunk : 0);
-    if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 8*reads) must stay below 2^32); split it");
+    if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 16*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf | (level_search && !deep_only ? 2u : 0u) | (fast_pass ? 4u : 0u);
     if (a4_pass) { a->last_launch[0] = cfg_a4.blocks; a->last_launch[1] = cfg_a4.waves_per_block * 64; a->last_launch[2] = cfg_a4.lds_bytes; a->last_launch[3] = 4u; }
@@ -725,7 +726,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters
     {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: the cursor starts behind
-        const uint64_t own = fast_pass ? (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * arena_chunk_fast
+        const uint64_t own = fast_pass ? fast_rows
                            : x4_pass   ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk
                            : a4_pass   ? (uint64_t)cfg_a4.blocks * cfg_a4.waves_per_block * arena_chunk : 0;
         if (own) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->small.p), (int)own, 1, a->stream));
@@ -753,7 +754,6 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         // empty list its workgroups exit at once.
         bgr::BatchIO iof = io;
         iof.greedy_multi = 1;
-        iof.arena_chunk = arena_chunk_fast;
         iof.words_per_read = wfast;
         iof.queue = static_cast<uint2*>(a->ovf.p);
         iof.q_cap = q_cap;
@@ -874,8 +874,8 @@ int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed
     if (n == 0) return BGR_OK;
     if (pk->read_offsets[0] != 0) return fail(BGR_E_ARG, "bgr_align_batch_packed: read_offsets must start at 0 (they address the planes)");
     const uint64_t total = pk->read_offsets[n];
-    if (n >= 0x7FFFFFFFull || 2 * (total + 8 * n) >= 0xFFFFFFFFull - (256ull << 20))
-        return fail(BGR_E_ARG, "bgr_align_batch_packed: batch too large for one launch (2*(bases + 8*reads) must stay below 2^32); pack it in pieces");
+    if (n >= 0x7FFFFFFFull || 2 * (total + 16 * n) >= 0xFFFFFFFFull - (256ull << 20))
+        return fail(BGR_E_ARG, "bgr_align_batch_packed: batch too large for one launch (2*(bases + 16*reads) must stay below 2^32 - 2^28); pack it in pieces");
     HIP_TRY(hipSetDevice(a->device));
     const uint64_t plane_words = bgr::packed_plane_words(n, total);
     HIP_TRY(a->in_offs.ensure((n + 1) * 8));
@@ -1259,11 +1259,11 @@ int bgr_align_batch(bgr_aligner* a, const bgr_params* p, const char* reads, cons
     // One launch addresses its path arena with 32 bits: a batch beyond that (~13 M reads of 150 bp) is mapped in pieces.
     // (BGR_KNOB_BATCH_SPLIT_LIMIT: tests lower the limit to walk this path with small inputs)
     const uint64_t lim = a->knob_split_limit ? std::max<uint64_t>(4096, a->knob_split_limit) : 0xFFFFFFFFull - (256ull << 20);
-    if (n > 1 && (2 * (total + 8 * n) >= lim || n >= 0x7FFFFFFFull)) {
+    if (n > 1 && (2 * (total + 16 * n) >= lim || n >= 0x7FFFFFFFull)) {
         uint64_t w = 0;
         for (uint64_t i0 = 0; i0 < n;) {
             uint64_t i1 = i0 + 1;  // longest piece below half the limit (at least one read)
-            while (i1 < n && 2 * ((read_offsets[i1 + 1] - read_offsets[i0]) + 8 * (i1 + 1 - i0)) < lim / 2 && i1 + 1 - i0 < (1ull << 30)) ++i1;
+            while (i1 < n && 2 * ((read_offsets[i1 + 1] - read_offsets[i0]) + 16 * (i1 + 1 - i0)) < lim / 2 && i1 + 1 - i0 < (1ull << 30)) ++i1;
             int rc = bgr_align_batch(a, p, reads, read_offsets + i0, i1 - i0, paths_out ? paths_out + w : nullptr, paths_cap - w, path_offsets + i0, status + i0);
             if (rc != BGR_OK) return rc;
             const uint64_t got = path_offsets[i1];
@@ -1292,8 +1292,8 @@ int bgr_align_batch_begin(bgr_aligner* a, const bgr_params* p, const char* reads
     if (n == 0) { a->ticket_open = true; return BGR_OK; }
     HIP_TRY(hipSetDevice(a->device));
     const uint64_t base = read_offsets[0], total = read_offsets[n] - base;
-    if (n >= 0x7FFFFFFFull || 2 * (total + 8 * n) >= 0xFFFFFFFFull - (256ull << 20))
-        return fail(BGR_E_ARG, "bgr_align_batch_begin: batch too large for one launch (2 * (bases + 8 * reads) must stay below 2^32 - 2^28); bgr_align_batch cuts such a batch");
+    if (n >= 0x7FFFFFFFull || 2 * (total + 16 * n) >= 0xFFFFFFFFull - (256ull << 20))
+        return fail(BGR_E_ARG, "bgr_align_batch_begin: batch too large for one launch (2 * (bases + 16 * reads) must stay below 2^32 - 2^28); bgr_align_batch cuts such a batch");
     uint32_t max_len = 0;
     a->ticket_offs.resize(n + 1);
     for (uint64_t i = 0; i < n; ++i) {

@@ -489,7 +489,7 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 }
 
 // ---- the extension step of the several-reads-per-wave kernels (greedy mode, anchors mode) ----------------------------------------
-// One extension step for up to 64 / GL walks, one per GL-lane group (GL = 16 or 8).  `phase` (uniform within a group): 0 = the group sits
+// One extension step for up to 64 / GL walks, one per GL-lane group (GL = 16, 8 or 4: four, two or one lane per candidate slot).  `phase` (uniform within a group): 0 = the group sits
 // out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
 // behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
 // Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
@@ -509,7 +509,7 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     }
     const uint32_t id = (phase != 0 && rec != G4_REC_MASK) ? sl.x & BGR_SLOT_ID_MASK : 0u;
     const u64 lmask = __ballot((sl.w & BGR_SLOT_LAST) != 0);  // (all lanes of a candidate agree)
-    const uint32_t nb = (uint32_t)(lmask >> ((uint32_t)lane & (64u - GL))) & (GL == 16 ? 0x1111u : 0x55u);
+    const uint32_t nb = (uint32_t)(lmask >> ((uint32_t)lane & (64u - GL))) & (GL == 16 ? 0x1111u : GL == 8 ? 0x55u : 0xFu);
     // candidates = the slots up to and including the first flagged one (a group that sits out, or whose half is empty: none)
     const uint32_t n_cand = (phase != 0 && rec != G4_REC_MASK && nb) ? (uint32_t)(__ffs((int)nb) - 1) / QL + 1u : 0u;
     const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
@@ -536,13 +536,13 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     if (NEAR && near_ok && n && q == 0) cnt = ham_near(FW, bgr_slot_near(sl.w, m0.x, m0.w), left != 0, n, rstart);
     for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 32 * QL)
         if (b < n && !near_ok) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
-    cnt += quad_xor1(cnt);
+    if (QL >= 2) cnt += quad_xor1(cnt);
     if (QL == 4) cnt += quad_xor2(cnt);
     // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
     uint32_t key = c < n_cand ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
-    uint32_t o = GL == 16 ? row_ror4(key) : quad_xor2(key);   // 16 lanes: slots sit 4 lanes apart; 8 lanes: 2 apart
+    uint32_t o = GL == 16 ? row_ror4(key) : GL == 8 ? quad_xor2(key) : quad_xor1(key);   // 16 lanes: slots sit 4 lanes apart; 8 lanes: 2 apart; 4: neighbours
     key = o < key ? o : key;
-    o = GL == 16 ? row_ror8(key) : half_row_mirror(key);      // (lane 7 - l of the half row: the other two slots)
+    o = GL == 16 ? row_ror8(key) : GL == 8 ? half_row_mirror(key) : quad_xor2(key);       // (8: lane 7 - l of the half row: the other two slots)
     key = o < key ? o : key;
     const uint32_t src = ((uint32_t)lane & (64u - GL)) | ((key & 3u) * QL);
     const uint32_t pk = (nx & (G4_REC_MASK | G4_CANON)) | (fits ? G4_FITS : 0u);

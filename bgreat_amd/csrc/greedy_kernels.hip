@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #define G4_ST_TRIED_SHIFT 20
 #define G4_ST_POS_MASK 0xFFFFFu
 
-// GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight.
+// GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight, 4 = sixteen.
 template <bool STAGE, int GL>
 __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     constexpr uint32_t RPW = 64 / GL;  // reads per wave
@@ -172,17 +172,16 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     u64* RD = lds + 64 + ktab_words + (u64)wave * (RPW * W);
     const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
-    const uint32_t gbase_lane = (uint32_t)lane & ~(uint32_t)(GL - 1);
     const uint32_t m = prm.max_mismatch;
     const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
     // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
     const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
     const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
 
-    // this wave's slice of the path arena: the first chunk is the wave's by its number (the host starts the cursor behind them: a
-    // returning atomic per wave on one word at the start of the launch serialises, ~90 per microsecond), later ones come from the cursor
+    // Path ints go straight into the arena: read r owns the row arena[r * kG4PathInts ...] (the host keeps n_reads rows in front of the
+    // chunks the cursor serves to the other kernels).  Left int number i (near -> far, offset last) at row[PH - 1 - i], right int number
+    // i at row[PH + i], so reverse(left) ++ right is the slice row[PH - nl, PH + nr) -- no allocation, no copy when a walk ends.
     const uint32_t wid = (uint32_t)(blockIdx.x * waves + wave);
-    uint32_t chunk_pos = wid * io.arena_chunk, chunk_end = chunk_pos + io.arena_chunk;
     // this wave's queue of follow-up items {read, state}: a ring of io.q_cap entries.  While the wave takes its share of the batch
     // it only appends (at most one entry per read of the share: q_cap); afterwards every octet taken out makes room for what it
     // leaves behind, so the ring never overflows.
@@ -285,7 +284,8 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         // phase: 1 left walk, 2 first right step, 3 later right steps; 0 the walk is over (aligned, or there was no anchor),
         // 4 the path outgrew the registers, 5 every anchor seen failed.  `tried` counts on in the item's state word.
         uint32_t nl = 0, nr = 0;
-        int32_t pl = 0, pr = 0;  // lane `sub` keeps path int number `sub` of the left walk (near -> far, offset last) / right walk
+        constexpr uint32_t PH = kG4PathInts / 2;
+        int32_t* PT = io.arena + (size_t)(r == BGR_NONE ? 0u : r) * kG4PathInts;  // the read's row; written by the group's first lane (only while the group walks)
         uint32_t phase = (act && a_rec != BGR_NONE) ? 1u : 0u;
 #ifdef BGR_PHASE_TIMING  /* diagnostic builds (tools/phase_cost.sh): knob DEBUG_STOP = 2 stops behind the anchor scan */
         if (prm.debug_stop == 2) phase = 0;
@@ -300,13 +300,13 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         uint32_t pos = a_pos, rec = phase ? start_half(a_rec, true) : G4_REC_MASK, budget = m;
         for (;;) {
             if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
-                if (sub == nl) pl = 0;
+                if (sub == 0) PT[PH - 1 - nl] = 0;
                 ++nl;
                 phase = 2; pos = a_pos; rec = start_half(a_rec, false);
             }
             if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
             if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
-            if ((phase == 1 && nl > GL - 2) || ((phase == 2 || phase == 3) && nr > GL - 1)) phase = 4;  // path too long for the registers
+            if ((phase == 1 && nl > PH - 2) || ((phase == 2 || phase == 3) && nr > PH - 1)) phase = 4;  // path too long for the row (a left step may push two ints)
             const uint32_t on = (phase - 1u < 3u) ? phase : 0u;
             if (!__any(on != 0)) break;
             uint32_t miss, ext;
@@ -321,16 +321,16 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                         phase = 1; pos = a_pos; rec = start_half(a_rec, true);
                     } else phase = 5;
                 } else if (phase == 1) {
-                    if (sub == nl) pl = sid;
+                    if (sub == 0) PT[PH - 1 - nl] = sid;
                     ++nl;
                     budget -= miss;
                     if (w1 & G4_FITS) {
-                        if (sub == nl) pl = (int32_t)(ext - pos);
+                        if (sub == 0) PT[PH - 1 - nl] = (int32_t)(ext - pos);
                         ++nl;
                         phase = 2; pos = a_pos; rec = start_half(a_rec, false);
                     } else { pos -= ext; rec = w1; }
                 } else {
-                    if (sub == nr) pr = sid;
+                    if (sub == 0) PT[PH + nr] = sid;
                     ++nr;
                     budget -= miss;
                     if (w1 & G4_FITS) phase = 0;
@@ -363,34 +363,10 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         }
         const uint32_t have = r != BGR_NONE ? 1u : 0u;
 
-        // ---- publish: reverse(left) ++ right into the arena ----------------------------------------------------------------------
+        // ---- publish: the path is the slice [PH - nl, PH + nr) of the read's row ----------------------------------------------------
         const uint32_t aligned = outcome == 0 ? 1u : 0u;
         const uint32_t p_n = aligned ? nl + nr : 0;
-        uint32_t tot = 0, before = 0;  // ints of the whole wave / of the groups in front of this one
-#pragma unroll
-        for (uint32_t i = 0; i < RPW; ++i) {
-            const uint32_t ni = rl32(p_n, (int)(GL * i));
-            if (grp > i) before += ni;
-            tot += ni;
-        }
-        if (tot > chunk_end - chunk_pos) {  // one global atomic per ~50 reads (see publish_path)
-            const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
-            uint32_t got = 0;
-            if (lane == 0) got = atomicAdd(io.cursor, want);
-            chunk_pos = rl32(got, 0);
-            chunk_end = chunk_pos + want;
-        }
-        const uint32_t gbase = chunk_pos + before;
-        const bool room = chunk_pos + tot <= io.arena_cap;
-        chunk_pos += tot;
-#pragma unroll
-        for (uint32_t jj = 0; jj < 2; ++jj) {
-            const uint32_t j = sub + GL * jj;
-            const uint32_t vl = lane_get((uint32_t)pl, gbase_lane | ((nl - 1 - j) & (GL - 1)));
-            const uint32_t vr = lane_get((uint32_t)pr, gbase_lane | ((j - nl) & (GL - 1)));
-            if (j < p_n && room) io.arena[gbase + j] = (int32_t)(j < nl ? vl : vr);
-        }
-        if (!room && lane == 0 && tot) io.cursor[1] = 1;  // overflow: reported by the host as an error
+        const uint32_t gbase = (r == BGR_NONE ? 0u : r) * kG4PathInts + PH - nl;
         if (sub == 0 && have) {
             if (outcome <= 2) {
                 const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc ? BGR_ST_RC : 0u);

@@ -174,7 +174,7 @@ int bgr_align_batch_packed(bgr_aligner* a, const bgr_params* p, const bgr_packed
  * output contract as bgr_align_batch); bgr_align_batch_test polls (1 = finished, 0 = still running).  One batch in flight per
  * aligner: one host thread double-buffers with two aligners -- begin(A, b0); begin(B, b1); wait(A); begin(A, b2); wait(B); ... --
  * where the blocking calls need two threads.  `reads` / `read_offsets` (page-locked memory recommended) must stay untouched until
- * the wait has returned.  The batch must fit one launch (2 * (bases + 8 * reads) < 2^32 - 2^28): larger ones go through
+ * the wait has returned.  The batch must fit one launch (2 * (bases + 16 * reads) < 2^32 - 2^28): larger ones go through
  * bgr_align_batch, which cuts them. */
 typedef struct {
     bgr_aligner* aligner;
