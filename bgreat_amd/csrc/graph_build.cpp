@@ -278,6 +278,9 @@ bool read_unitig_fasta(const std::string& path, uint32_t k, std::vector<char>& s
     return true;
 }
 
+// LDS a CU has for key table copies next to 16 waves of sixteen 150-bp reads each (160 KB - 64, 512 B fixed per workgroup, 768 B per wave)
+static const double kStageTwice = (163776.0 / 2 - 512 - 16 * 768), kStageOnce = (163776.0 - 512 - 16 * 768);
+
 bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* offs, double gamma, uint32_t flags, HostGraph& out, std::string& err) {
     if (k < 2 || k > 32) { err = "k must be in [2,32] (kmer is uint64_t, utils.h:27)"; return false; }
     if (gamma != 0.0 && !(gamma >= 1.03 && gamma <= 64.0)) { err = "gamma (key table slots per key) must be in [1.03,64] (0 = choose)"; return false; }
@@ -360,7 +363,18 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     // larger one is probed in L2, where the request rate is the limit: built sparse (1.8 slots per key) few first buckets
     // are full and few lanes need the second probe (find_key, device_common.h; chr1-scale graph, slots per key 1.07 / 1.4 /
     // 1.8 / 2.5: 800 / 900 / 930 / 870 Mreads/s -- beyond 2 the table outgrows the L2).
-    if (gamma == 0.0) gamma = (double)keys.size() * 1.07 <= 73000.0 ? 1.07 : 1.8;
+    // Staging has two break points (capi.hip geometry; sixteen 150-bp reads per wave = 768 B of LDS per wave): a table of at most
+    // kStageTwice bytes fits twice per CU next to 16 waves each (32 resident waves), one of at most kStageOnce bytes once (16 waves).
+    // A key count just above a break point at 1.07 is built tighter, down to 1.03 slots per key (E. coli-scale graph, 66 k keys:
+    // 2 x 12 waves at 1.07 -> 1 881 Mreads/s, 2 x 16 at 1.03 -> 2 030).
+    if (gamma == 0.0) {
+        const double n = (double)keys.size();
+        if (n * 1.07 <= kStageTwice) gamma = 1.07;
+        else if (n * 1.03 <= kStageTwice) gamma = std::max(1.03, (kStageTwice - 64) / n);  // (64: the bucket count and the staged copy round up)
+        else if (n * 1.07 <= kStageOnce) gamma = 1.07;
+        else if (n * 1.03 <= kStageOnce) gamma = std::max(1.03, (kStageOnce - 64) / n);
+        else gamma = 1.8;
+    }
     KeyTable tab;
     build_key_table(keys, gamma, T, !(flags & BGR_BUILD_NO_EVICTIONS), tab);
     tm.lap("keytable");
@@ -426,7 +440,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     // a table too large for LDS staging gets a filter in front: minimizer-blocked when k-1 >= 20 (24-48 bits per key), else one hash
     // (4-8 bits per key).  BGREAT_BLOOM=0 builds without, =1 the one-hash kind, =2 the minimizer kind whatever the table size (tests)
     const int filter_env = getenv("BGREAT_BLOOM") ? atoi(getenv("BGREAT_BLOOM")) : -1;
-    const bool large_table = (double)keys.size() * 1.07 > 73000.0;
+    const bool large_table = (double)tab.buckets.size() * 4.0 > kStageTwice;  // (may be probed in memory: always beyond kStageOnce, below it with long reads)
     if (filter_env != 0 && !keys.empty() && (large_table || filter_env == 2)) {
         const bool minimizer = k - 1 >= BGR_MMX_MIN_K1 && filter_env != 1;
         uint64_t bits = minimizer ? 1024 : 64;
