@@ -154,6 +154,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #define G4_ST_POS_MASK 0xFFFFFu
 
 // GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight, 4 = sixteen.
+#ifndef BGR_G4_NEAR_UNSTAGED
+#define BGR_G4_NEAR_UNSTAGED 0  /* 1: a graph probed in memory compares against the 32 bases a slot carries instead of loading them from seq.  With sixteen walks per wave waiting on memory at once the launch is bound by instruction issue, not by that load: chr1-scale 1 331 with, 1 359 Mreads/s without; 12 Mb genome 1 402 / 1 455 */
+#endif
 template <bool STAGE, int GL>
 __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     constexpr uint32_t RPW = 64 / GL;  // reads per wave
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
             if (!__any(on != 0)) break;
             uint32_t miss, ext;
             int32_t sid;
-            const uint32_t w1 = g4_step<!STAGE, GL>(g, F, L, K1, on, rec & G4_REC_MASK, (rec >> 28) & 1u, pos, budget, lane, &miss, &ext, &sid);
+            const uint32_t w1 = g4_step<BGR_G4_NEAR_UNSTAGED && !STAGE, GL>(g, F, L, K1, on, rec & G4_REC_MASK, (rec >> 28) & 1u, pos, budget, lane, &miss, &ext, &sid);
             if (on != 0) {
                 if (!(w1 & G4_FOUND)) {
                     st += 1u << G4_ST_TRIED_SHIFT;
