@@ -149,7 +149,8 @@ int main(int argc, char** argv) {
                 bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
                 bgr_run_options opt;
                 memset(&opt, 0, sizeof(opt));
-                opt.n_gpus = 2; opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 700; opt.fastq = c.fastq; opt.route = route == 2 ? 1u : route;
+                opt.n_gpus = (batch == 37 && threads == 6) ? 8 : 2;  // (eight stand-in devices = 16 stream workers, per-device queues: order and bytes as with two)
+                opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 700; opt.fastq = c.fastq; opt.route = route == 2 ? 1u : route;
                 uint64_t tot[5]; double secs;
                 const std::string list = in + "," + in;  // two files: the batches of the second must follow the first's
                 { const int rc_ = bgr_align_all(&g, &prm, &opt, list.c_str(), pf.c_str(), nf.c_str(), tot, &secs); if (rc_ != BGR_OK) { printf("FAIL run (%s threads=%u batch=%llu route=%u): rc %d %s\n", c.file, threads, (unsigned long long)batch, route, rc_, bgr_last_error()); return 1; } }
