@@ -87,6 +87,9 @@ __device__ __forceinline__ u64 rcb_fast(u64 x, uint32_t n) {
 
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
+#ifndef BGR_DIRECT_BUCKETS
+#define BGR_DIRECT_BUCKETS 1  /* behind the minimizer filter: compare a bucket's four keys directly (0 = fingerprints first, as everywhere else) */
+#endif
 // Key table lookup for one key per lane (graph_layout.h): the slot of `key` -- its index into keys[] and recs[] -- or
 // BGR_NONE when the key is no overlap of the graph (the membership test of aligner.cpp:158,219,353,361).  A byte that
 // equals the fingerprint is confirmed against keys[].  Most read positions are no overlaps and match no byte, so the loop
@@ -102,35 +105,59 @@ template <bool LAZY2 = false, typename TP>
 __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u64 key, bool active, uint32_t mblock = 0) {
     const u64 m = bgr_mix64(key);
     const uint32_t b1 = __umulhi((uint32_t)m, g.n_buckets), b2 = __umulhi((uint32_t)(m >> 32), g.n_buckets);
-    uint32_t w1 = 0, w2 = 0;
-    if (LAZY2) {
-        // large graph: a filter turns most positions (no overlaps) away before the table -- every probe of which is a cache line of
-        // its own -- is touched; a member always passes, and the key compare below decides as before
-        if (g.bloom && active) {
-            if (g.filter_kind == BGR_FILTER_MINIMIZER) {
-                const uint32_t bits = bgr_mmx_bits(m);
-                active = (g.bloom[(mblock << 4) + bgr_mmx_word(m)] & bits) == bits;
-            } else {
-                const uint32_t bit = bgr_bloom_bit(m, g.bloom_mask);
-                active = (g.bloom[bit >> 5] >> (bit & 31)) & 1u;
+    uint32_t res = BGR_NONE;
+    if (LAZY2 && BGR_DIRECT_BUCKETS && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) {
+        // large graph behind the minimizer filter: the few lanes it lets through (members and ~1 % of the rest) compare the four keys of
+        // their bucket directly -- keys[4 b .. 4 b + 3] share one 64-byte line -- instead of fingerprints first: one dependent miss
+        // less per member (filter block -> bucket keys instead of filter block -> fingerprints -> key entry)
+        if (active) {
+            const uint32_t bits = bgr_mmx_bits(m);
+            active = (g.bloom[(mblock << 4) + bgr_mmx_word(m)] & bits) == bits;
+        }
+        if (wave_any(active)) {
+            if (active) {
+                const BgrKeyEntry* e = g.keys + (size_t)b1 * 4;
+                u64 k0 = e[0].key, k1 = e[1].key, k2 = e[2].key, k3 = e[3].key;
+                uint32_t hit = k0 == key ? 0u : k1 == key ? 1u : k2 == key ? 2u : k3 == key ? 3u : 4u;
+                if (hit < 4) res = b1 * 4 + hit;
+                else if (((k0 | k1 | k2 | k3) >> 62) == 0) {  // no empty slot (an empty one holds ~0; a key has its top two bits clear): bucket 2
+                    e = g.keys + (size_t)b2 * 4;
+                    k0 = e[0].key; k1 = e[1].key; k2 = e[2].key; k3 = e[3].key;
+                    hit = k0 == key ? 0u : k1 == key ? 1u : k2 == key ? 2u : k3 == key ? 3u : 4u;
+                    if (hit < 4) res = b2 * 4 + hit;
+                }
             }
         }
-        if (active) w1 = tab[b1];
-        if (active && bgr_zero_bytes(w1) == 0) w2 = tab[b2];
-    } else if (active) { w1 = tab[b1]; w2 = tab[b2]; }
-    const uint32_t f4 = bgr_tab_fp(m) * 0x01010101u;  // (an empty slot is 0 and the fingerprint is not: lanes that sit out match nothing)
-    // (b2 == b1, one key in ~n_buckets: the second word then repeats the first one's matches, and the loop below re-checks a slot it has
-    // already ruled out -- harmless; testing for it cost six instructions per scan step)
-    uint32_t c1 = bgr_zero_bytes(w1 ^ f4), c2 = bgr_zero_bytes(w2 ^ f4);
-    uint32_t res = BGR_NONE;
-    while (wave_any((c1 | c2) != 0)) {
-        if (c1 | c2) {
-            const bool first = c1 != 0;
-            const uint32_t c = first ? c1 : c2;
-            const uint32_t idx = (first ? b1 : b2) * 4 + ((uint32_t)(__ffs((int)c) - 1) >> 3);
-            if (g.keys[idx].key == key) { res = idx; c1 = 0; c2 = 0; }
-            else if (first) c1 &= c1 - 1;
-            else c2 &= c2 - 1;
+    } else {
+        uint32_t w1 = 0, w2 = 0;
+        if (LAZY2) {
+            // large graph: a filter turns most positions (no overlaps) away before the table -- every probe of which is a cache line of
+            // its own -- is touched; a member always passes, and the key compare below decides as before
+            if (g.bloom && active) {
+                if (g.filter_kind == BGR_FILTER_MINIMIZER) {
+                    const uint32_t bits = bgr_mmx_bits(m);
+                    active = (g.bloom[(mblock << 4) + bgr_mmx_word(m)] & bits) == bits;
+                } else {
+                    const uint32_t bit = bgr_bloom_bit(m, g.bloom_mask);
+                    active = (g.bloom[bit >> 5] >> (bit & 31)) & 1u;
+                }
+            }
+            if (active) w1 = tab[b1];
+            if (active && bgr_zero_bytes(w1) == 0) w2 = tab[b2];
+        } else if (active) { w1 = tab[b1]; w2 = tab[b2]; }
+        const uint32_t f4 = bgr_tab_fp(m) * 0x01010101u;  // (an empty slot is 0 and the fingerprint is not: lanes that sit out match nothing)
+        // (b2 == b1, one key in ~n_buckets: the second word then repeats the first one's matches, and the loop below re-checks a slot it has
+        // already ruled out -- harmless; testing for it cost six instructions per scan step)
+        uint32_t c1 = bgr_zero_bytes(w1 ^ f4), c2 = bgr_zero_bytes(w2 ^ f4);
+        while (wave_any((c1 | c2) != 0)) {
+            if (c1 | c2) {
+                const bool first = c1 != 0;
+                const uint32_t c = first ? c1 : c2;
+                const uint32_t idx = (first ? b1 : b2) * 4 + ((uint32_t)(__ffs((int)c) - 1) >> 3);
+                if (g.keys[idx].key == key) { res = idx; c1 = 0; c2 = 0; }
+                else if (first) c1 &= c1 - 1;
+                else c2 &= c2 - 1;
+            }
         }
     }
     if ((g.flags & BGR_GF_HAS_FALLBACK) && wave_any(active && res == BGR_NONE)) {

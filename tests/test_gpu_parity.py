@@ -737,10 +737,15 @@ def test_mphf_in_lds_and_in_hbm_agree(stage, gamma):
 
 
 @pytest.mark.parametrize("mode", [B.MODE_GREEDY, B.MODE_EXHAUSTIVE])
-@pytest.mark.parametrize("stage", [1, 2])
-def test_keys_in_the_fallback_list_are_found(mode, stage):
+@pytest.mark.parametrize("stage", [1, 2, 3])
+def test_keys_in_the_fallback_list_are_found(mode, stage, monkeypatch):
     """BUILD_NO_EVICTIONS (test hook) leaves the keys whose two buckets were full in the sorted fallback list: the kernels'
-    bisection path, which ordinary graphs never take."""
+    bisection path, which ordinary graphs never take.  stage 3 = table in memory behind the (forced) minimizer filter, where the
+    lanes the filter lets through compare their bucket's four keys directly."""
+    if stage == 3:
+        monkeypatch.setenv("BGREAT_BLOOM", "2")
+        monkeypatch.setenv("BGREAT_EXH_FILTER", "1")
+        stage = 1
     s = Synth(120000, 60, 3, 31, 91)
     seqs, offs = s.unitigs()
     reads, roffs = s.reads(0, 12000, 120, 3, 92)
