@@ -2,6 +2,7 @@
 // and stream management, launch geometry; the algorithm lives in graph_build.cpp (index) and
 // the *_kernels.hip files (mapping; launch interface align_kernels.h).  There is no CPU mapping path in this library.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -1444,9 +1445,33 @@ int bgr_device_local_cpus(int device, char* cpulist_out, uint64_t cap) {
     return BGR_OK;
 }
 
+// Page-locked host memory.  hipHostMalloc pins 4 KB pages at ~4.4 GB/s on this platform, from any number of threads; an anonymous
+// mapping with transparent huge pages asked for, touched once per 2 MB and then registered pins at ~26 GB/s (tools/ubench/pin_alloc.hip) --
+// bgr_align_all takes ~0.7 GB of staging sets while its pipeline ramps up, 0.17 s of a 0.6 s run of 100 M reads.  Buffers of 2 MB and
+// more go that way (hipHostMalloc when anything in it fails); the registry tells bgr_host_free how a pointer was obtained.
+// (never destroyed: the pipeline's cache of staging sets frees its buffers from a static destructor of its own, in whatever order)
+static std::mutex& g_host_m = *new std::mutex;
+static std::map<void*, uint64_t>& g_host_mapped = *new std::map<void*, uint64_t>;  // registered anonymous mappings: pointer -> mapped bytes
+
 int bgr_host_alloc(uint64_t bytes, void** out) {
     if (!out) return fail(BGR_E_ARG, "bgr_host_alloc: null argument");
     void* p = nullptr;
+    if (bytes >= (2ull << 20) && !getenv("BGREAT_NO_HUGE_PINNED")) {
+        const uint64_t len = (bytes + (2ull << 20) - 1) & ~((2ull << 20) - 1);
+        void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            (void)madvise(m, len, MADV_HUGEPAGE);
+            for (uint64_t o = 0; o < len; o += 2ull << 20) static_cast<volatile char*>(m)[o] = 0;  // fault the (huge) pages in before they are pinned
+            if (hipHostRegister(m, len, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> l(g_host_m);
+                g_host_mapped[m] = len;
+                *out = m;
+                return BGR_OK;
+            }
+            (void)hipGetLastError();
+            munmap(m, len);
+        }
+    }
     hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     *out = p;
@@ -1455,6 +1480,18 @@ int bgr_host_alloc(uint64_t bytes, void** out) {
 
 int bgr_host_free(void* p) {
     if (!p) return BGR_OK;
+    uint64_t len = 0;
+    {
+        std::lock_guard<std::mutex> l(g_host_m);
+        auto it = g_host_mapped.find(p);
+        if (it != g_host_mapped.end()) { len = it->second; g_host_mapped.erase(it); }
+    }
+    if (len) {
+        hipError_t e = hipHostUnregister(p);
+        munmap(p, len);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e));
+        return BGR_OK;
+    }
     hipError_t e = hipHostFree(p);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
     return BGR_OK;
