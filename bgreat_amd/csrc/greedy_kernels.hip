@@ -293,19 +293,22 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
 #ifdef BGR_PHASE_TIMING  /* diagnostic builds (tools/phase_cost.sh): knob DEBUG_STOP = 2 stops behind the anchor scan */
         if (prm.debug_stop == 2) phase = 0;
 #endif
-        // rec: the half the next step reads (handle | canonical << 28).  An anchor is a key entry: its walks start from the half that
-        // getEnd (left) / getBegin (right) reads for it (half_handle: one 8-byte load at each start)
-        auto start_half = [&](uint32_t anchor, bool left) -> uint32_t {
-            if (anchor == BGR_NONE) return G4_REC_MASK;
-            const bool cn = (anchor >> 28) & 1u;
-            return half_handle(g, anchor & G4_REC_MASK, cn, left) | (cn ? G4_CANON : 0u);
+        // rec: the half the next step reads (handle | canonical << 28).  An anchor is a key entry: its left walk starts from the half that
+        // getEnd reads for it, its right walk from the one getBegin reads -- both handles sit in the key entry, fetched by ONE 8-byte load
+        // when the anchor is taken up (a_right waits for the left walk to end: a load at that point would stall all sixteen walks)
+        uint32_t a_right = G4_REC_MASK;
+        auto take_anchor = [&](uint32_t anchor) -> uint32_t {  // -> the left start; sets a_right
+            const uint32_t cn = (anchor >> 28) & 1u;
+            const uint2 h = *reinterpret_cast<const uint2*>(&g.keys[anchor & G4_REC_MASK].hL);
+            a_right = (cn ? h.x : h.y) | (cn ? G4_CANON : 0u);
+            return (cn ? h.y : h.x) | (cn ? G4_CANON : 0u);
         };
-        uint32_t pos = a_pos, rec = phase ? start_half(a_rec, true) : G4_REC_MASK, budget = m;
+        uint32_t pos = a_pos, rec = phase ? take_anchor(a_rec) : G4_REC_MASK, budget = m;
         for (;;) {
             if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0, then the right side of the anchor
                 if (sub == 0) PT[PH - 1 - nl] = 0;
                 ++nl;
-                phase = 2; pos = a_pos; rec = start_half(a_rec, false);
+                phase = 2; pos = a_pos; rec = a_right;
             }
             if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the anchor: aligned
             if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k: aligned
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                     if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
                         a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
                         nl = 0; nr = 0; budget = m;
-                        phase = 1; pos = a_pos; rec = start_half(a_rec, true);
+                        phase = 1; pos = a_pos; rec = take_anchor(a_rec);
                     } else phase = 5;
                 } else if (phase == 1) {
                     if (sub == 0) PT[PH - 1 - nl] = sid;
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                     if (w1 & G4_FITS) {
                         if (sub == 0) PT[PH - 1 - nl] = (int32_t)(ext - pos);
                         ++nl;
-                        phase = 2; pos = a_pos; rec = start_half(a_rec, false);
+                        phase = 2; pos = a_pos; rec = a_right;
                     } else { pos -= ext; rec = w1; }
                 } else {
                     if (sub == 0) PT[PH + nr] = sid;
