@@ -533,7 +533,7 @@ template <bool NEAR = false, int GL = 16>
 __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t phase, uint32_t rec, uint32_t canon,
                                             uint32_t pos, uint32_t budget, int lane, uint32_t* miss, uint32_t* ext_o, int32_t* sid_o) {
     constexpr uint32_t QL = GL / 4;  // lanes per candidate slot: each takes 32 bases per round of the compare
-    const uint32_t c = ((uint32_t)lane / QL) & 3u, q = (uint32_t)lane % QL;
+    uint32_t c = ((uint32_t)lane / QL) & 3u, q = (uint32_t)lane % QL, ql = QL;
     const uint32_t left = phase == 1 ? 1u : 0u;
     // `rec` = the HANDLE of the half to read (G4_REC_MASK == BGR_HNONE: none): its slots follow each other, the last one flagged; lanes
     // of candidates behind it see whatever comes next in the array and are masked off
@@ -543,11 +543,23 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
         sl = sp[0];
         m0 = sp[1];
     }
-    const uint32_t id = (phase != 0 && rec != G4_REC_MASK) ? sl.x & BGR_SLOT_ID_MASK : 0u;
     const u64 lmask = __ballot((sl.w & BGR_SLOT_LAST) != 0);  // (all lanes of a candidate agree)
     const uint32_t nb = (uint32_t)(lmask >> ((uint32_t)lane & (64u - GL))) & (GL == 16 ? 0x1111u : GL == 8 ? 0x55u : 0xFu);
     // candidates = the slots up to and including the first flagged one (a group that sits out, or whose half is empty: none)
     const uint32_t n_cand = (phase != 0 && rec != G4_REC_MASK && nb) ? (uint32_t)(__ffs((int)nb) - 1) / QL + 1u : 0u;
+    // four lanes per read: a half with one or two candidates (nearly every half of a graph of 2-allele sites) gives the lanes of candidates
+    // 2 and 3 to candidates 0 and 1 -- they take the slot over (DPP, lanes 0 1 0 1 of the quad) and compare every other 32-base chunk, so
+    // the compare loop below runs half the rounds (each round costs the whole wave ~100 instructions)
+    uint32_t two = 0;
+    if (GL == 4) {
+        two = (n_cand - 1u < 2u) ? 1u : 0u;
+        const bool take = two && ((uint32_t)lane & 2u);
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)sl.x, 0x44, 0xF, 0xF, true), t1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)sl.y, 0x44, 0xF, 0xF, true),
+                       t2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)sl.z, 0x44, 0xF, 0xF, true), t3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)sl.w, 0x44, 0xF, 0xF, true);
+        if (take) { sl.x = t0; sl.y = t1; sl.z = t2; sl.w = t3; }
+        if (two) { c = (uint32_t)lane & 1u; q = ((uint32_t)lane >> 1) & 1u; ql = 2; }
+    }
+    const uint32_t id = (phase != 0 && rec != G4_REC_MASK) ? sl.x & BGR_SLOT_ID_MASK : 0u;
     const uint32_t fwd = (sl.x & (canon ? BGR_SLOT_F0 : BGR_SLOT_F1)) ? 1u : 0u;
     const uint32_t len = sl.y;
     const uint32_t fw = sl.z, fo = (sl.w & BGR_SLOT_FO_MASK) + (fwd ? 0u : len);
@@ -570,10 +582,11 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     const bool near_ok = NEAR && n <= 32 && phase != 3 && (sl.x & both) != both && !(g.flags & BGR_GF_HAS_EXC);
     uint32_t cnt = 0;
     if (NEAR && near_ok && n && q == 0) cnt = ham_near(FW, bgr_slot_near(sl.w, m0.x, m0.w), left != 0, n, rstart);
-    for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 32 * QL)
+    for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 32 * ql)
         if (b < n && !near_ok) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
     if (QL >= 2) cnt += quad_xor1(cnt);
     if (QL == 4) cnt += quad_xor2(cnt);
+    if (GL == 4) { const uint32_t o2 = quad_xor2(cnt); if (two) cnt += o2; }  // (the two lanes of a candidate: l and l ^ 2)
     // best = smallest miss, lowest slot on ties, only if miss <= budget (== "first zero wins, else strict min")
     uint32_t key = c < n_cand ? ((cnt > 0x0FFFFFFFu ? 0x0FFFFFFFu : cnt) << 2) | c : 0xFFFFFFFFu;
     uint32_t o = GL == 16 ? row_ror4(key) : GL == 8 ? quad_xor2(key) : quad_xor1(key);   // 16 lanes: slots sit 4 lanes apart; 8 lanes: 2 apart; 4: neighbours
