@@ -3,6 +3,9 @@
 //   bgr_align_exhaustive_dp_kernel  the level search (exh_dp): all nodes of a level at once, backward cost pass
 //   bgr_align_exhaustive_kernel     depth-first search in slot order (exh_search); DEEP: search state in HBM
 #include "device_common.h"
+#ifndef BGR_EXH_MMX
+#define BGR_EXH_MMX 1
+#endif
 
 namespace bgr {
 namespace {
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
         const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         bool done = false, overflow = false;
         // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
-        const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+        const uint32_t mmx_w = (BGR_EXH_MMX && !STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
         const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
         for (uint32_t base = 0; base < npos && !done && !overflow; base += scan_step) {
             const uint32_t i = base + lane;
@@ -659,7 +662,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
     const uint32_t K1 = g.k - 1;
     // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
-    const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+    const uint32_t mmx_w = (BGR_EXH_MMX && !STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
     const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
     unsigned long long* wg_counts = wg_counts_init(lds);
     uint32_t ktab_words;
@@ -824,7 +827,7 @@ __global__ void __launch_bounds__(1024, BGR_DP_OCC) bgr_align_exhaustive_dp_kern
         const uint32_t npos = L >= K1 ? L - K1 + 1 : 0;
         bool done = false, overflow = false;
         // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
-        const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
+        const uint32_t mmx_w = (BGR_EXH_MMX && !STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
         const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
         for (uint32_t base = 0; base < npos && !done && !overflow; base += scan_step) {
             const uint32_t i = base + lane;
