@@ -636,7 +636,8 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
     const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && !a->graph->header.has_exc && p->max_mismatch < 0x7FFF &&
-                         geometry(bgr::kX4ReadsPerWave * 8 * (wfast + bgr::x4_group_words(x4_levels)), (n_reads + bgr::kX4ReadsPerWave - 1) / bgr::kX4ReadsPerWave, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)));
+                         geometry(bgr::kX4ReadsPerWave * 8 * (wfast + bgr::x4_group_words(x4_levels)), (n_reads + bgr::kX4ReadsPerWave - 1) / bgr::kX4ReadsPerWave, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)),
+                                  50);  // (E. coli-scale table, 150 bp: one staged workgroup of 16 waves 1 496 Mreads/s, 28 waves probing the table in L2 1 395)
     // Anchors mode, first pass: four reads per wave (bgr_align_anchors4_kernel); reads with an N and very long paths are listed
     // for the one-read-per-wave kernel.
     bgr::LaunchCfg cfg_a4;
