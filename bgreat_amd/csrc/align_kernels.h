@@ -17,6 +17,7 @@ namespace bgr {
 #define BGR_G4_GROUP_LANES 4
 #endif
 constexpr uint32_t kG4GroupLanes = BGR_G4_GROUP_LANES, kG4ReadsPerWave = 64 / BGR_G4_GROUP_LANES;
+constexpr uint32_t kA4PathInts = 20;  // ... of the several-reads-per-wave anchors kernel: 8 left + [offset,] unitig + 8 right (9 + 2 + 9 slots)
 constexpr uint32_t kG4PathInts = 16;  // path ints of a read's row in the arena: 8 of the left walk (offset included), 8 of the right; longer paths go to the general kernel
 // the same for the exhaustive first pass (bgr_align_exhaustive4_kernel); its level table holds one level per lane of a read's group
 #ifndef BGR_X4_GROUP_LANES

@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
     const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
     const uint32_t K = g.k, K1 = g.k - 1;
-    const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL, gb = (uint32_t)lane & (64u - GL);
+    const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
     u64* RD = lds + 64 + (u64)wave * (RPW * 2 * W);  // the reads of this wave: forward words | reverse-complement words
     u64* F = RD + grp * (2 * W);
     const AncView av = anc_view(g, (int)sub);
@@ -323,8 +323,10 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
     const uint32_t effort = prm.effort ? prm.effort : 1;  // getNAnchors(read, 0) still takes a hit at position 0
 
     uint32_t c_noov = 0, c_al = 0, c_na = 0;
-    // (the wave's first arena chunk is its own by number: the host starts the cursor behind them, see bgr_align_greedy_multi_kernel)
-    uint32_t chunk_pos = (uint32_t)(blockIdx.x * waves + wave) * io.arena_chunk, chunk_end = chunk_pos + io.arena_chunk;
+    // Path ints go straight into the arena, as in bgr_align_greedy_multi_kernel: read r owns the row arena[r * kA4PathInts ...]; left int
+    // number i (near -> far, offset last) at row[LH - 1 - i], then the anchoring unitig ([offset,] id) from row[LH] on, the right ints
+    // behind it: reverse(left) ++ [offset,] unitig ++ right is the slice row[LH - nl, LH + nmid + nr)
+    constexpr uint32_t LH = kA4PathInts / 2 - 1;
     unsigned long long* wg_counts = wg_counts_init(lds);
     __syncthreads();
 
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
         u64 rcnum = rcb_fast(num, K);
         uint32_t i = 0, tried = 0;
         uint32_t nl = 0, nr = 0, nmid = 0;
-        int32_t pl = 0, pr = 0, mid0 = 0, mid1 = 0;
+        int32_t* PT = io.arena + (size_t)(have ? r : 0u) * kA4PathInts;  // the read's row; written by the group's first lane
         while (__any(active != 0)) {
             const u64* S = F + (rc ? W : 0);  // the characters of this pass's read (reverseComplements: N -> 'A')
             // ---- one lookup per group at its current position ----
@@ -413,17 +415,17 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                 uint32_t wfail = 0;
                 if (found) {
                     nl = 0; nr = 0;
-                    if (c12) { mid0 = uid; nmid = 1; } else { mid0 = (int32_t)uoff; mid1 = uid; nmid = 2; }
+                    if (c12) { if (sub == 0) PT[LH] = uid; nmid = 1; } else { if (sub == 0) { PT[LH] = (int32_t)uoff; PT[LH + 1] = uid; } nmid = 2; }
                 }
                 for (;;) {
                     if (phase == 1 && pos == 0) {  // the left walk reached the read's first base: push 0
-                        if (sub == nl) pl = 0;
+                        if (sub == 0) PT[LH - 1 - nl] = 0;
                         ++nl;
                         phase = want_right ? 2u : 0u; pos = r_pos; rec = rec_e; canon = can_e;
                     }
                     if (phase == 2 && L - pos - K1 == 0) phase = 0;  // nothing right of the unitig
                     if (phase == 3 && L - pos < K1 + 1) phase = 0;   // |readLeft| < k
-                    if ((phase == 1 && nl > GL - 2) || (phase >= 2 && nr > GL - 1)) { bad = 1; phase = 0; }  // path too long for the registers
+                    if ((phase == 1 && nl > LH - 2) || (phase >= 2 && nr > LH - 1)) { bad = 1; phase = 0; }  // path too long for the row (a left step may push two ints)
                     if (!__any(phase != 0)) break;
                     uint32_t miss, ext;
                     int32_t sid;
@@ -431,16 +433,16 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                     if (phase != 0) {
                         if (!(w1 & G4_FOUND)) { wfail = 1; phase = 0; }
                         else if (phase == 1) {
-                            if (sub == nl) pl = sid;
+                            if (sub == 0) PT[LH - 1 - nl] = sid;
                             ++nl;
                             budget -= miss;
                             if (w1 & G4_FITS) {
-                                if (sub == nl) pl = (int32_t)(ext - pos);
+                                if (sub == 0) PT[LH - 1 - nl] = (int32_t)(ext - pos);
                                 ++nl;
                                 phase = want_right ? 2u : 0u; pos = r_pos; rec = rec_e; canon = can_e;
                             } else { pos -= ext; rec = w1 & G4_REC_MASK; canon = (w1 >> 28) & 1u; }
                         } else {
-                            if (sub == nr) pr = sid;
+                            if (sub == 0) PT[LH + nmid + nr] = sid;
                             ++nr;
                             budget -= miss;
                             if (w1 & G4_FITS) phase = 0;
@@ -487,37 +489,10 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                 }
             }
         }
-        // ---- publish: reverse(left) ++ [offset,] unitig ++ right ----
+        // ---- publish: the path is a slice of the read's row ----
         const uint32_t aligned = (have && outcome == 0) ? 1u : 0u;
         const uint32_t p_n = aligned ? nl + nmid + nr : 0;
-        uint32_t tot = 0, before = 0;
-#pragma unroll
-        for (uint32_t i2 = 0; i2 < RPW; ++i2) {
-            const uint32_t ni = rl32(p_n, (int)(GL * i2));
-            if (grp > i2) before += ni;
-            tot += ni;
-        }
-        if (tot > chunk_end - chunk_pos) {
-            const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
-            uint32_t got = 0;
-            if (lane == 0) got = atomicAdd(io.cursor, want);
-            chunk_pos = rl32(got, 0);
-            chunk_end = chunk_pos + want;
-        }
-        const uint32_t gbase = chunk_pos + before;
-        const bool room = chunk_pos + tot <= io.arena_cap;
-        chunk_pos += tot;
-#pragma unroll
-        for (uint32_t jj = 0; jj < 3; ++jj) {  // up to GL + 2 + GL ints
-            const uint32_t j = sub + GL * jj;
-            const uint32_t vl = lane_get((uint32_t)pl, gb | ((nl - 1 - j) & (GL - 1)));
-            const uint32_t vr = lane_get((uint32_t)pr, gb | ((j - nl - nmid) & (GL - 1)));
-            int32_t v = (int32_t)vr;
-            if (j < nl) v = (int32_t)vl;
-            else if (j < nl + nmid) v = (j == nl) ? mid0 : mid1;
-            if (j < p_n && room) io.arena[gbase + j] = v;
-        }
-        if (!room && lane == 0 && tot) io.cursor[1] = 1;
+        const uint32_t gbase = (have ? r : 0u) * kA4PathInts + LH - nl;
         if (sub == 0 && have) {
             if (outcome <= 2) {
                 const uint32_t code = (outcome == 0 ? BGR_ST_ALIGNED : outcome == 1 ? BGR_ST_NOANCHOR : BGR_ST_FAILED) | (rc ? BGR_ST_RC : 0u);

@@ -658,7 +658,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
                                (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0) +
                                fast_rows +
                                (x4_pass ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk : 0) +
-                               (a4_pass ? (uint64_t)cfg_a4.blocks * cfg_a4.waves_per_block * arena_chunk : 0);
+                               (a4_pass ? n_reads * bgr::kA4PathInts : 0);  // (per-read rows, as for the greedy kernel)
     if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 16*reads) must stay below 2^32); split it");
     HIP_TRY(a->arena.ensure(arena_cap * 4));
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf | (level_search && !deep_only ? 2u : 0u) | (fast_pass ? 4u : 0u);
@@ -730,7 +730,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: the cursor starts behind
         const uint64_t own = fast_pass ? fast_rows
                            : x4_pass   ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk
-                           : a4_pass   ? (uint64_t)cfg_a4.blocks * cfg_a4.waves_per_block * arena_chunk : 0;
+                           : a4_pass   ? n_reads * bgr::kA4PathInts : 0;
         if (own) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->small.p), (int)own, 1, a->stream));
     }
     // HIP events on the aligner's stream: one in front of the launch, one behind every kernel of it (bgr_aligner_kernel_times)
