@@ -105,7 +105,7 @@ struct bgr_aligner {
     std::vector<uint64_t> ticket_offs;  // that batch's offsets made relative (kept alive for the asynchronous copy)
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
-    bool exh_filter = getenv("BGREAT_EXH_FILTER") && atoi(getenv("BGREAT_EXH_FILTER")) != 0;  // exhaustive mode through the minimizer filter too (diagnostic)
+    bool exh_filter = !(getenv("BGREAT_EXH_FILTER") && atoi(getenv("BGREAT_EXH_FILTER")) == 0);  // exhaustive mode through the minimizer filter too (BGREAT_EXH_FILTER=0: without)
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
     uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0;
     uint64_t knob_split_limit = 0;
@@ -721,8 +721,10 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.cursor = static_cast<uint32_t*>(a->small.p);
     bgr::KernelParams kp = {p->max_mismatch, p->effort, p->partial, p->mode, a->knob_debug_stop};
     // the filter in front of a large key table pays where many read positions are probed per anchor (greedy scans: chr1-scale graph
-    // 1 020 -> 1 184 Mreads/s, L2 requests per read 135 -> 28); the exhaustive scan of a branchy graph meets its first hit within a few
-    // positions (4-allele graph: 697 without, 664 with) and runs without it unless BGREAT_EXH_FILTER=1 (the minimizer kind only)
+    // 1 020 -> 1 184 Mreads/s, L2 requests per read 135 -> 28).  The exhaustive scan meets its first hit within a few positions; with
+    // fingerprints behind it the filter cost it more than it saved (4-allele graph: 697 without, 664 with), with the bucket's keys compared
+    // directly behind it, it pays there too (4-allele graph 702 -> 720, chr1-scale graph 1 111 -> 1 231): on by default for the minimizer
+    // kind (BGREAT_EXH_FILTER=0: without); the one-hash kind of short k stays off in exhaustive mode
     BgrDeviceGraph dgl = a->dg;
     if (p->mode == BGR_MODE_EXHAUSTIVE && !(dgl.filter_kind == BGR_FILTER_MINIMIZER && a->exh_filter)) dgl.bloom = nullptr;
 
