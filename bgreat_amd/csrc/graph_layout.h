@@ -200,7 +200,7 @@ BGR_HD uint32_t bgr_bloom_bit(uint64_t m, uint32_t mask) { return (uint32_t)(m >
 BGR_HD uint32_t bgr_rc16(uint32_t x) {  // reverse complement of 16 bases (2-bit codes A0 C1 G2 T3: complement = ~code)
 #if defined(__HIP_DEVICE_COMPILE__)
     x = __builtin_bitreverse32(x);
-    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    return (uint32_t)__builtin_amdgcn_bitop3_b32((int)(x >> 1), (int)(x << 1), 0x55555555, 0x1B);  // pairs swapped and complemented: ~(mask ? a : b)
 #else
     x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
     x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
