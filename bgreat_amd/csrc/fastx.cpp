@@ -226,8 +226,14 @@ void FastqPlan::count_chunk(size_t c) {  // pass 1: newlines in chunk c
     nl_[c + 1] = n;
 }
 
+void FastqPlan::extend_counts(size_t c_end) {  // chunks [0, c_end) have been counted: their prefix sums
+    if (c_end > nc_) c_end = nc_;
+    for (size_t c = summed_; c < c_end; ++c) nl_[c + 1] += nl_[c];  // nl_[c] = newlines before chunk c = index of the line containing its first byte
+    if (c_end > summed_) summed_ = c_end;
+}
+
 void FastqPlan::finish_counts() {
-    for (size_t c = 0; c < nc_; ++c) nl_[c + 1] += nl_[c];  // nl_[c] = newlines before chunk c = index of the line containing its first byte
+    extend_counts(nc_);
     complete_ = nc_ ? nl_[nc_] / 4 : 0;                      // records whose four lines all end with a newline
     par_records_ = complete_ ? ((complete_ - 1) / kBatch) * kBatch : 0;  // a getReads() call boundary
 }
@@ -274,8 +280,9 @@ bool FastqPlan::parse_chunk(size_t c, ParsedChunk& out) {  // pass 2: chunk c ow
 uint64_t FastqPlan::record_offset(uint64_t rec) const {
     const uint64_t T = 4 * rec;  // line T starts behind the T-th newline
     if (T == 0) return 0;
-    // the chunk that holds the T-th newline: nl_[c] < T <= nl_[c + 1]
-    size_t lo = 0, hi = nc_;
+    // the chunk that holds the T-th newline: nl_[c] < T <= nl_[c + 1] (among the chunks summed so far)
+    if (T > nl_[summed_]) return size_;
+    size_t lo = 0, hi = summed_;
     while (lo + 1 < hi) { const size_t mid = (lo + hi) / 2; if (nl_[mid] < T) lo = mid; else hi = mid; }
     const uint64_t b = lo * chunk_bytes_, e = std::min<uint64_t>(size_, b + chunk_bytes_);
     uint64_t need = T - nl_[lo];

@@ -77,6 +77,10 @@ public:
     size_t chunks() const { return nc_; }
     void count_chunk(size_t c);
     void finish_counts();
+    // (streaming: once chunks 0 .. c_end-1 are counted, extend_counts(c_end) makes record_offset() usable for the records that end in them;
+    // records_counted() of them are complete so far, and every getReads() call boundary at or below records_counted() - 1 is final)
+    void extend_counts(size_t c_end);
+    uint64_t records_counted() const { return nl_[summed_] / 4; }
     bool sequential_only() const { return complete_ == 0 || par_records_ == 0; }  // everything goes through parse_tail
     bool parse_chunk(size_t c, ParsedChunk& out);
     bool parse_tail(ParsedChunk& out);
@@ -87,7 +91,7 @@ public:
 private:
     const char* data_;
     uint64_t size_, chunk_bytes_;
-    size_t nc_ = 0;
+    size_t nc_ = 0, summed_ = 0;
     std::vector<uint64_t> nl_, tail_start_;
     uint64_t complete_ = 0, par_records_ = 0;
 };

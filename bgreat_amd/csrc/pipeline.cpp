@@ -624,35 +624,46 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 bgr::FastqPlan plan(mf->data, mf->size, chunk_bytes);
                 const size_t nc = plan.chunks();
                 uint64_t tp0 = now_us();
-                pool.run(nc, [&](size_t c) { plan.count_chunk(c); }, 1);
-                plan.finish_counts();
-                us_parse += now_us() - tp0;
                 std::unique_ptr<Batch> b;
-                if (text_route && !plan.sequential_only()) {
+                if (text_route) {
                     // text route: every record in front of the file's last getReads() call boundary is a plain four-line record -- pieces of
-                    // whole records go to the device as they are; the rest of the file (the phantom record at its end, truncated tails:
-                    // aligner.cpp:51-68) goes through the sequential state machine on the host, behind them
-                    const uint64_t par = plan.par_records();
+                    // whole records go to the device as they are, cut while the newline counts of the chunks behind them are still being
+                    // taken (a boundary is final once the records counted so far reach beyond it); the rest of the file (the phantom record
+                    // at its end, truncated tails: aligner.cpp:51-68) goes through the sequential state machine on the host, behind them
+                    const size_t wave = std::max<size_t>((size_t)threads * 8, 64);
                     uint64_t r0 = 0, o0 = 0;
-                    while (r0 < par && ok && !failed) {
-                        uint64_t r1 = std::min<uint64_t>(par, r0 + batch_reads), o1 = plan.record_offset(r1);
-                        while (o1 - o0 > (1ull << 30) && r1 > r0 + 1) {  // long reads: a piece stays under the 2 GiB of one call
-                            r1 = r0 + (r1 - r0) / 2;
-                            o1 = plan.record_offset(r1);
+                    for (size_t c_done = 0; ok && !failed;) {
+                        const size_t c_end = std::min(nc, c_done + wave);
+                        tp0 = now_us();
+                        if (c_end > c_done) pool.run(c_end - c_done, [&](size_t c) { plan.count_chunk(c_done + c); }, 1);
+                        plan.extend_counts(c_end);
+                        c_done = c_end;
+                        const bool last = c_done >= nc;
+                        if (last) plan.finish_counts();
+                        us_parse += now_us() - tp0;
+                        const uint64_t counted = plan.records_counted();
+                        const uint64_t limit = last ? plan.par_records() : (counted ? ((counted - 1) / 10000) * 10000 : 0);
+                        while (ok && !failed && r0 < limit && (last || r0 + batch_reads <= limit)) {
+                            uint64_t r1 = std::min<uint64_t>(limit, r0 + batch_reads), o1 = plan.record_offset(r1);
+                            while (o1 - o0 > (1ull << 30) && r1 > r0 + 1) {  // long reads: a piece stays under the 2 GiB of one call
+                                r1 = r0 + (r1 - r0) / 2;
+                                o1 = plan.record_offset(r1);
+                            }
+                            std::unique_ptr<Batch> tb;
+                            if (!open_batch(tb, mf)) { ok = false; break; }
+                            tb->text_piece = o1 - o0 < (1ull << 31);  // (one record of 2 GiB: the host parser takes it)
+                            tb->fastq_piece = true;
+                            tb->t_begin = o0; tb->t_end = o1;
+                            if (!tb->text_piece) {
+                                tb->chunks.clear();
+                                tb->chunks.push_back(std::make_unique<ParsedChunk>());
+                                bgr::parse_fastq_records(mf->data, o0, o1, *tb->chunks[0]);
+                                tb->recs = tb->chunks[0]->recs;
+                            }
+                            ok = emit(std::move(tb));
+                            r0 = r1; o0 = o1;
                         }
-                        std::unique_ptr<Batch> tb;
-                        if (!open_batch(tb, mf)) { ok = false; break; }
-                        tb->text_piece = o1 - o0 < (1ull << 31);  // (one record of 2 GiB: the host parser takes it)
-                        tb->fastq_piece = true;
-                        tb->t_begin = o0; tb->t_end = o1;
-                        if (!tb->text_piece) {
-                            tb->chunks.clear();
-                            tb->chunks.push_back(std::make_unique<ParsedChunk>());
-                            bgr::parse_fastq_records(mf->data, o0, o1, *tb->chunks[0]);
-                            tb->recs = tb->chunks[0]->recs;
-                        }
-                        ok = emit(std::move(tb));
-                        r0 = r1; o0 = o1;
+                        if (last) break;
                     }
                     if (ok && !failed) {
                         ParsedChunk tl;
@@ -672,6 +683,11 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                     }
                     continue;
                 }
+                // FASTQ: newline counts first (they fix which line of a record every chunk starts in), then the chunks
+                // group by group, so that the later stages already work on the first batches while the rest is parsed
+                pool.run(nc, [&](size_t c) { plan.count_chunk(c); }, 1);
+                plan.finish_counts();
+                us_parse += now_us() - tp0;
                 auto feed = [&](const ParsedChunk& ch) {  // slices point into the file image only (no joined storage)
                     const std::vector<RecSlice>& rs = ch.recs;
                     marker.chunk(ch, file_iters, mark_idx);
