@@ -486,7 +486,7 @@ def test_minimizer_filter_in_front_of_the_key_table(seed, k, L, m, e, nfrac, mon
     with whole-wave DPP shifts, 65 - (k-16) positions per scan step) forced onto a small graph whose table is probed in memory: eight-reads-
     per-wave kernel and general kernel (N reads: per-key minimizer) against the oracle, and against the same graph without filter."""
     monkeypatch.setenv("BGREAT_BLOOM", "2")
-    monkeypatch.setenv("BGREAT_EXH_FILTER", "1")   # (exhaustive mode skips the filter by default: slower with it on branchy graphs)
+    monkeypatch.setenv("BGREAT_EXH_FILTER", "1")   # (the default; spelled out: exhaustive mode goes through the filter as well)
     s = Synth(150000, 3 * k, 3, k, 9100 + seed)
     seqs, offs = s.unitigs()
     n = 20000
