@@ -46,7 +46,7 @@ struct BatchIO {
     uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
-    uint32_t greedy_multi;       // greedy mode: launch the eight-reads-per-wave kernel; reads it does not take go on gen_list (for the general kernel)
+    uint32_t greedy_multi;       // greedy mode: launch the sixteen-reads-per-wave kernel; reads it does not take go on gen_list (for the general kernel)
     uint2* queue;                // its per-wave rings of follow-up items {read, state}: q_cap entries per wave of the grid
     uint32_t q_cap;
     uint32_t* gen_list;          // reads for the general kernel (count at cursor[gen_ctr])
@@ -101,7 +101,7 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
 }
 
 // Waves of the mapping kernel that one CU can keep resident (register-limited; mode 0 greedy, 1 exhaustive depth-first,
-// 2 anchors, 3 exhaustive level search, 4 greedy eight-reads-per-wave, 5 exhaustive four-reads-per-wave, 6 anchors four-reads-per-wave).
+// 2 anchors, 3 exhaustive level search, 4 greedy sixteen-reads-per-wave, 5 exhaustive eight-reads-per-wave, 6 anchors four-reads-per-wave).
 uint32_t resident_waves_per_cu(uint32_t mode);
 
 // (results, arena) of the last mapping launch -> input-ordered CSR on the device.  phase 0: block_sums[ceil(n/4096)] and

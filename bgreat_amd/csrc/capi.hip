@@ -624,7 +624,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         if (deep_only) cfg = cfg_deep;
         mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, true, cfg_mid);
     }
-    // Greedy mode, first pass: eight reads per wave (bgr_align_greedy_multi_kernel, the reference's retry ladder inside the launch)
+    // Greedy mode, first pass: sixteen reads per wave (bgr_align_greedy_multi_kernel, the reference's retry ladder inside the launch)
     // when a read fits one lane per word and the graph has no exception planes; what it does not take (N reads, very long paths)
     // is listed and mapped by the general kernel (cfg) right behind.
     bgr::LaunchCfg cfg_fast;
@@ -697,7 +697,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.anc4 = 0;
     io.subset_ctr = 2;
     io.ovf_ctr = 2;
-    // the eight-reads-per-wave greedy kernel keeps a ring of follow-up items per wave: at most one entry per read of the wave's share
+    // the sixteen-reads-per-wave greedy kernel keeps a ring of follow-up items per wave: at most one entry per read of the wave's share
     uint32_t q_cap = 0;
     if (fast_pass) {
         const uint64_t grid_waves = (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block;
@@ -752,7 +752,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         HIP_TRY(mark("bgr_pack_reads_kernel"));
     }
     if (fast_pass) {
-        // ONE launch of the eight-reads-per-wave kernel: every wave maps its share of the batch and then works off its own queue of
+        // ONE launch of the sixteen-reads-per-wave kernel: every wave maps its share of the batch and then works off its own queue of
         // follow-up items (the next anchors of a read whose first ones failed, then its reverse complement: alignerGreedy.cpp:41-56).
         // Reads the kernel does not take (N, very long paths) are mapped from scratch by the general kernel right behind: with an
         // empty list its workgroups exit at once.
@@ -764,7 +764,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
         iof.gen_ctr = 8;
         e = bgr::launch_align(dgl, iof, kp, cfg_fast, a->stream);
-        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (eight-reads-per-wave kernel): ") + hipGetErrorString(e));
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (sixteen-reads-per-wave kernel): ") + hipGetErrorString(e));
         HIP_TRY(mark("bgr_align_greedy_multi_kernel (all reads, retries in the launch)"));
         io.subset = static_cast<uint32_t*>(a->ovf2.p);
         io.subset_ctr = 8;

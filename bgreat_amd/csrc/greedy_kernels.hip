@@ -1,5 +1,5 @@
 // greedy_kernels.hip -- greedy mode (alignReadGreedy, alignerGreedy.cpp:35-57,167-364) on gfx950.
-//   bgr_align_greedy_multi_kernel  eight reads per wavefront (lanes per read: a template parameter): the position scans one after the
+//   bgr_align_greedy_multi_kernel  sixteen reads per wavefront (lanes per read: a template parameter): the position scans one after the
 //                             other on all 64 lanes, the extensions side by side, 8 lanes each; settles the common shapes, lists the rest
 //   bgr_align_greedy_kernel   the general kernel: one read per wavefront, every anchor, both strands, N planes, any path length
 #include "device_common.h"
@@ -126,21 +126,22 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 // ================================= greedy, several reads per wavefront ====================================
 // bgr_align_greedy_kernel above walks one read per wave: a walk step is two dependent loads (slot, bases) scored by at
 // most 4 candidates x a few 32-base chunks, i.e. a handful of the 64 lanes, and per read there are ~3 such steps in a row.
-// Here a wave takes 64 / GL reads, GL lanes each (GL = 8: EIGHT reads; round 2 started with GL = 16, four reads): their
-// position scans still run one after the other on all 64 lanes (a scan is lane-efficient: one (k-1)-mer per lane), then
-// the extensions run side by side, GL lanes each (4 candidate slots x GL/4 chunk lanes of 32 bases: 64 bases per round of
-// the compare at GL = 8), so eight slot/base load chains are in flight per wave and every wave instruction of a walk step
-// serves eight reads (a quad of reads needs max-over-4 = 3.4 steps, an octet 3.7: the instructions per read nearly halve).
-// Path ints stay in registers (lane j of a group holds int j of each direction: GL ints per direction).
+// Here a wave takes 64 / GL reads, GL lanes each (GL = 4: SIXTEEN reads; round 2 started with GL = 16, four reads, and ended with 8):
+// their position scans still run one after the other on all 64 lanes (a scan is lane-efficient: one (k-1)-mer per lane), then
+// the extensions run side by side, GL lanes each (4 candidate slots x GL/4 chunk lanes of 32 bases; at GL = 4 one lane per slot, two
+// when a half has at most two candidates), so sixteen slot/base load chains are in flight per wave and every wave instruction of a
+// walk step serves sixteen reads (a quad of reads needs max-over-4 = 3.4 steps, an octet 3.7: the instructions per read nearly halve
+// with every doubling).  Path ints go straight into the read's own row of the arena (kG4PathInts ints: left walk downwards from the
+// middle, right walk upwards), so there are no path registers, no per-wave arena chunks and no copy when a walk ends.
 //
 // The reference's retry ladder (alignerGreedy.cpp:41-56: the next anchors of getNOverlap's list, then once the reverse
 // complement) runs INSIDE the launch (round 3; round 2 re-launched the kernel twice over lists): an ITEM is one strand of
 // one read from one scan position on.  A wave first takes its share of the batch (items = whole reads, forward strand, position
 // 0); an item whose anchors fail leaves a follow-up item -- the same strand from behind the anchor tried last, or the reverse
 // complement from its first position -- in the wave's own queue (a ring in HBM, written and read by this wave only), and once
-// the wave's share of the batch is done it works its queue off in dense octets until nothing is left.  A reverse-complement item
+// the wave's share of the batch is done it works its queue off in dense groups until nothing is left.  A reverse-complement item
 // stages reverseComplements(read) (utils.cpp:66-73) as its words, so both strands run the same code.  What the kernel does not
-// take at all -- N in the read, more than GL path ints per direction, reads of a mixed batch that are too long for one lane per
+// take at all -- N in the read, more than kG4PathInts / 2 path ints per direction, reads of a mixed batch that are too long for one lane per
 // word -- goes on a list for bgr_align_greedy_kernel, which maps those reads from scratch right behind.
 #ifndef BGR_G4_OCC
 #define BGR_G4_OCC 8
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     // i at row[PH + i], so reverse(left) ++ right is the slice row[PH - nl, PH + nr) -- no allocation, no copy when a walk ends.
     const uint32_t wid = (uint32_t)(blockIdx.x * waves + wave);
     // this wave's queue of follow-up items {read, state}: a ring of io.q_cap entries.  While the wave takes its share of the batch
-    // it only appends (at most one entry per read of the share: q_cap); afterwards every octet taken out makes room for what it
+    // it only appends (at most one entry per read of the share: q_cap); afterwards every group taken out makes room for what it
     // leaves behind, so the ring never overflows.
     const uint32_t q_base = wid * io.q_cap;  // (the rings of all waves hold n_reads + 8 per wave entries at most: 32-bit indices)
     uint32_t q_rd = 0, q_wr = 0, q_cnt = 0;

@@ -254,11 +254,11 @@ int bgr_aligner_reset_kernel_time(bgr_aligner* a);
 int bgr_aligner_kernel_times(bgr_aligner* a, uint64_t* launches, double slot_ms[8], const char* slot_names[8]);
 /* Launch geometry of the last mapping kernel (for logs): blocks, threads per block, dynamic LDS bytes, and flags:
  * bit 0 = the overlap key table was staged in LDS, bit 1 = exhaustive mode ran its level search (else depth-first),
- * bit 2 = the mode ran its several-reads-per-wave first pass (eight in greedy mode, four in the others; the numbers then
+ * bit 2 = the mode ran its several-reads-per-wave first pass (sixteen in greedy mode, eight or four in the others; the numbers then
  * describe that launch). */
 int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
 /* How the last mapping launch went through its passes.  Greedy mode: out[0..2] = reads the first / second / third launch of
- * the eight-reads-per-wave kernel handed on to the next one, counted in list entries (lists are written in per-wave slices,
+ * the sixteen-reads-per-wave kernel handed on to the next one, counted in list entries (lists are written in per-wave slices,
  * so the figure includes a few unused entries; out[2] is 0: the third launch hands everything to the general kernel),
  * out[3] = reads mapped by the general kernel.  Exhaustive mode: out[2] = reads the four-reads-per-wave pass left to the level
  * / depth-first search, out[0] = reads that search listed for its second pass, out[1] = for its third.  Synchronises the stream. */
@@ -280,7 +280,7 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
 #define BGR_KNOB_BATCH_OVERLAP 8u /* bgr_align_batch of >= 512 k reads: 0 = in four pieces on two streams, copies under kernels (default), 1 = one launch */
 #define BGR_KNOB_ANCHORS_FAST 7u /* anchors mode: 0 = four-reads-per-wave first pass + the one-read-per-wave kernel for the rest (default), 1 = without it */
 #define BGR_KNOB_EXH_FAST 6u    /* exhaustive mode: 0 = four-reads-per-wave first pass + the level / depth-first passes for the rest (default), 1 = without it */
-#define BGR_KNOB_GREEDY_FAST 5u /* greedy mode: 0 = eight-reads-per-wave passes + general kernel for the rest (default), 1 = general kernel only */
+#define BGR_KNOB_GREEDY_FAST 5u /* greedy mode: 0 = sixteen-reads-per-wave pass + general kernel for the rest (default), 1 = general kernel only */
 int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value);
 
 /* ---- read files (host) ----------------------------------------------------------------------------
