@@ -865,6 +865,32 @@ def test_tiny_and_very_long_reads_through_the_api():
     assert len(p) == 0 and list(st & 3) == [1, 1, 1, 1]
 
 
+@pytest.mark.parametrize("nbytes,env", [(8 << 20, None), (3 << 20, None), (4096, None), (8 << 20, "1")])
+def test_page_locked_host_buffers(nbytes, env, monkeypatch):
+    """bgr_host_alloc: buffers of 2 MB and more come from huge-page mappings registered with the runtime, smaller ones (and all of them
+    under BGREAT_NO_HUGE_PINNED=1) from hipHostMalloc; either kind is writable, feeds a batch call and is freed by bgr_host_free."""
+    import ctypes
+    if env:
+        monkeypatch.setenv("BGREAT_NO_HUGE_PINNED", env)
+    L = B.lib()
+    p = ctypes.c_void_p()
+    B._check(L.bgr_host_alloc(nbytes, ctypes.byref(p)))
+    assert p.value
+    buf = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+    s = Synth(60000, 75, 2, 31, 5)
+    seqs, offs = s.unitigs()
+    n = min(2000, nbytes // 200)
+    reads, roffs = s.reads(0, n, 150, 2, 6)
+    buf[: len(reads)] = reads                      # the reads live in the page-locked buffer
+    al = B.Aligner(B.Graph.build(31, seqs, offs), 0)
+    p1 = al.align(buf[: len(reads)], roffs)
+    p2 = al.align(reads, roffs)
+    for x, y in zip(p1, p2):
+        assert np.array_equal(x, y)
+    del buf
+    B._check(L.bgr_host_free(p))
+
+
 def test_bench_line_contract():
     """bench.py (what the driver runs at round end) prints ONE JSON line carrying the contract's fields, the roofline and
     cpu_baseline objects, and a parity sample that matches the oracle -- here on a small workload, without the counter passes."""
