@@ -192,7 +192,8 @@ def test_fastq_pieces_equal_the_host_route(seed, n, L, k, mode, tmp_path):
         al.align_fasta_text(text[:-1], fastq=True)
 
 
-@pytest.mark.parametrize("n,batch,extra", [(25003, 0, []), (25003, 7000, ["-c"]), (30000, 4096, []), (10001, 0, ["-G"]), (9999, 0, [])])
+@pytest.mark.parametrize("n,batch,extra", [(25003, 0, []), (25003, 7000, ["-c"]), (30000, 4096, []), (10001, 0, ["-G"]), (9999, 0, []),
+                                           (45003, 3000, ["--chunk-bytes", "20000"])])   # (the last: pieces cut while later chunks are still being counted)
 def test_cli_fastq_text_route_equals_host_route(n, batch, extra, tmp_path):
     """-q through the text route (device pieces up to the file's last getReads() boundary, the tail with its phantom record on the
     host) == -q with --host-route, two files in a row."""
