@@ -439,6 +439,17 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
     """bgr_align_all on a FASTA file written just before (so it is read from the page cache): mmap + chunk-parallel parse +
     gather into pinned batches + H2D + launch + CSR + D2H + format + write, `ncpu` host threads per GPU.  Index build excluded."""
     n, L = args.e2e_reads, args.read_len
+    # every rank writes its own input (L + 14 bytes per read) and keeps up to three output pairs (~55 bytes per read each) in the node's
+    # temporary directory: with N ranks that is N x ~33 GB at the default size.  Cut the per-rank read count to what half of the free
+    # space admits -- the same number on every rank (minimum over the ranks), so that all ranks pass the same barriers
+    free = shutil.disk_usage(tempfile.gettempdir()).free
+    cap = int(0.5 * free / (world * (L + 14 + 3 * 60)))
+    if dist is not None:
+        cap = int(-D.max_over_ranks(-float(cap), dist, device=coll_dev))
+    if cap < n:
+        n = cap
+    if n < 100_000:
+        return {"error": "not enough free space under %s for the end-to-end leg (%d bytes free, %d ranks)" % (tempfile.gettempdir(), free, world)}
     d = tempfile.mkdtemp(prefix="bgr_e2e_r%d_" % rank)
     try:
         f = os.path.join(d, "reads.fa")
