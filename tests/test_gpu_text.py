@@ -163,13 +163,16 @@ def _fastq_records(seed, n, L, k):
         elif x < 0.10:
             r = r + b"\r"
         h = [b"@q%d" % i, b"@q%d 1:N:0 @ > + text" % i, b"", b">not an at sign %d" % i][0 if i % 11 else (i // 11) % 4]
+        if seed == 4 and i % 17 == 0:
+            h = b"@long header " + b"x" * int(rng.integers(200, 700)) + b" %d" % i   # a header line longer than one pass of the record scan
         plus = b"+" if i % 5 else b"+q%d" % i
         qual = bytes(rng.integers(33, 74, len(r)).astype(np.uint8)) if i % 13 else b"@" * len(r)   # '@', '+', '>' are quality characters too
         recs.append(h + b"\n" + r + b"\n" + plus + b"\n" + qual + b"\n")
     return s, seqs, offs, recs
 
 
-@pytest.mark.parametrize("seed,n,L,k,mode", [(1, 40000, 150, 31, B.MODE_GREEDY), (2, 20000, 100, 21, B.MODE_GREEDY), (3, 10000, 250, 31, B.MODE_EXHAUSTIVE)])
+@pytest.mark.parametrize("seed,n,L,k,mode", [(1, 40000, 150, 31, B.MODE_GREEDY), (2, 20000, 100, 21, B.MODE_GREEDY), (3, 10000, 250, 31, B.MODE_EXHAUSTIVE),
+                                             (4, 10000, 600, 31, B.MODE_GREEDY)])
 def test_fastq_pieces_equal_the_host_route(seed, n, L, k, mode, tmp_path):
     """-q: a piece of whole four-line records (n a multiple of the reference's 10000-record getReads() call, so that the host parser sees
     no phantom record at the end of the file): header = line 0 whatever it holds, read = line 1, kept iff size > 2 and ACGTN."""
