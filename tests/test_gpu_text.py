@@ -76,12 +76,14 @@ def _mixed_piece(seed, n, L, k):
         elif x < 0.09:
             r = r + b"\r"                      # CR before the newline: dropped
         h = b">r%d some text > with a '>' inside %d" % (i, i) if i % 7 == 0 else b">r%d" % i
+        if seed == 6 and i % 13 == 0:
+            h = b">long header " + b"y" * int(rng.integers(200, 900)) + b" %d" % i   # longer than one pass of the record scan
         recs.append(h + b"\n" + r + b"\n")
     return s, seqs, offs, b"".join(recs)
 
 
 @pytest.mark.parametrize("seed,n,L,k,mode", [(1, 40000, 150, 31, B.MODE_GREEDY), (2, 20011, 100, 21, B.MODE_GREEDY), (3, 9000, 250, 31, B.MODE_EXHAUSTIVE), (4, 5000, 40, 12, B.MODE_GREEDY),
-                                             (5, 12000, 150, 31, B.MODE_ANCHORS)])
+                                             (5, 12000, 150, 31, B.MODE_ANCHORS), (6, 6000, 600, 31, B.MODE_GREEDY)])
 def test_text_route_with_dropped_records_equals_host_route(seed, n, L, k, mode, tmp_path):
     """Regular pieces whose records the parser drops (lower case, NUL, CR, size <= k, empty sequence line) or admits (N), headers with
     '>' inside: same bytes and counters as the host parser + bgr_align_batch."""
