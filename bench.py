@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end leg per GPU (0 disables); 100 M x 150 bp = a 16 GB FASTA file: "
                                                                           "at ~170 Mreads/s a smaller file mostly measures the start-up (page-locked staging buffers, device buffers)")
     ap.add_argument("--pcie-steps", type=int, default=3, help="timed bgr_align_batch calls of the PCIe-inclusive leg (0 disables)")
+    ap.add_argument("--sorted-reads", action="store_true", help="diagnostic: every batch ordered by the genome position its reads were drawn from (the upper bound of any "
+                                                                 "locality ordering of the reads; never the reported configuration)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--debug-stop", type=int, default=0, help="diagnostic builds of the library only (-DBGR_PHASE_TIMING, loaded through BGR_LIB_PATH): "
                                                               "1 = the mapping kernel stops behind the staging of the reads, 2 = behind the anchor scan")
@@ -124,7 +126,7 @@ def run_pmc_passes(args):
            "--genome", str(args.genome), "--site-spacing", str(args.site_spacing), "--alleles", str(args.alleles), "--lds-mphf", str(args.lds_mphf),
            "--waves", str(args.waves), "--blocks-per-cu", str(args.blocks_per_cu), "--gamma", str(args.gamma), "--cpu-threads", str(args.cpu_threads),
            "--debug-stop", str(args.debug_stop)]
-    for flag in ("exhaustive", "anchors", "general_kernel_only", "exh_first_pass_off", "anc_first_pass_off"):
+    for flag in ("exhaustive", "anchors", "general_kernel_only", "exh_first_pass_off", "anc_first_pass_off", "sorted_reads"):
         if getattr(args, flag):
             fwd.append("--" + flag.replace("_", "-"))
     fwd += ["--exh-search", str(args.exh_search), "--exh-frame-cap", str(args.exh_frame_cap)]
@@ -247,6 +249,9 @@ def main():
     first_host = None
     for s in range(K):
         arr, _ = syn.reads((rank * K + s) * R, R, L, args.mismatch, seed_reads, threads=ncpu)
+        if args.sorted_reads:
+            order = np.argsort(syn.read_starts((rank * K + s) * R, R, L, seed_reads), kind="stable")
+            arr = arr.reshape(R, L)[order].reshape(-1)
         if s == 0 and rank == 0 and not args.pmc_child:
             first_host = arr[: max(args.cpu_sample, args.alg_sample) * L].copy()
         batches.append(torch.from_numpy(arr).to("cuda"))

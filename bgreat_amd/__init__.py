@@ -55,7 +55,7 @@ class Params(C.Structure):
 class RunOptions(C.Structure):
     _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
                 ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("correction", C.c_uint32),
-                ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32), ("route", C.c_uint32)]
+                ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32), ("route", C.c_uint32), ("numa", C.c_uint32), ("split_output", C.c_uint32)]
 
 
 class Ticket(C.Structure):
@@ -468,12 +468,13 @@ class Aligner:
 
 
 def align_all(graph, reads_csv, paths_file, notaligned_file, m=2, effort=2, mode=MODE_GREEDY, partial=False, n_gpus=1, threads=1,
-              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False, correction=False, no_overlap_file=None, first_device=0, route=0):
+              batch_reads=0, chunk_bytes=0, fastq=False, write_exhaustive=False, correction=False, no_overlap_file=None, first_device=0, route=0, numa=0, split_output=False):
     """Aligner::alignAll (aligner.cpp:550-597) as one call -> (counters dict, mapping seconds).  route: 0 = FASTA goes through the device as
-    text when it can (bgr_align_fasta_text), 1 = host parser + host formatter always."""
+    text when it can (bgr_align_fasta_text), 1 = host parser + host formatter always.  split_output: one pipeline per device, device d
+    writing `<paths_file>.<d>` / `<notaligned_file>.<d>` (their concatenation = the single-file bytes)."""
     p = Params(mode, m, effort, int(partial))
     o = RunOptions(n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, int(correction),
-                   no_overlap_file.encode() if no_overlap_file else None, first_device, route)
+                   no_overlap_file.encode() if no_overlap_file else None, first_device, route, numa, int(split_output))
     out = np.zeros(5, dtype=np.uint64)
     secs = C.c_double()
     _check(lib().bgr_align_all(graph.h, C.byref(p), C.byref(o), reads_csv.encode(), paths_file.encode(), notaligned_file.encode(),

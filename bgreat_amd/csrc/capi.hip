@@ -966,6 +966,8 @@ void bgr_text_stage_destroy(bgr_text_stage* s) {
     delete s;
 }
 
+int bgr_text_stage_device(const bgr_text_stage* s) { return s ? s->device : -1; }
+
 int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t bytes) {
     if (!s || (bytes && !text)) return fail(BGR_E_ARG, "bgr_text_stage_upload: null argument");
     if (bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_text_stage_upload: piece of 2 GiB or more; cut it");

@@ -361,28 +361,33 @@ static void parse_fastq_range(const char* data, uint64_t begin, uint64_t size, P
     }
 }
 
-std::vector<uint64_t> split_fasta(const char* data, uint64_t size, uint64_t chunk_bytes) {
-    std::vector<uint64_t> starts(1, 0);
-    if (chunk_bytes == 0) chunk_bytes = 1;
+uint64_t fasta_cut_at(const char* data, uint64_t size, uint64_t from) {
     // Line 0 is a header whatever it starts with, so the line after it is sequence even if it starts with '>':
     // a start point must have a previous line that is neither a '>' line nor line 0.
     const char* nl0 = static_cast<const char*>(memchr(data, '\n', size));
     const uint64_t line1 = nl0 ? (uint64_t)(nl0 - data) + 1 : size;
+    uint64_t p = from;
+    while (p < size) {
+        const char* q = static_cast<const char*>(memchr(data + p, '\n', size - p));
+        if (!q) break;
+        const uint64_t ls = (uint64_t)(q - data) + 1;  // start of the next line
+        if (ls >= size) break;
+        if (data[ls] == '>') {
+            uint64_t ps = (uint64_t)(q - data);  // walk back to the start of the line that ends at q
+            while (ps > 0 && data[ps - 1] != '\n') --ps;
+            if (data[ps] != '>' && ps >= line1) return ls;
+        }
+        p = ls;
+    }
+    return size;
+}
+
+std::vector<uint64_t> split_fasta(const char* data, uint64_t size, uint64_t chunk_bytes) {
+    std::vector<uint64_t> starts(1, 0);
+    if (chunk_bytes == 0) chunk_bytes = 1;
     uint64_t target = chunk_bytes;
     while (target < size) {
-        uint64_t p = target, found = size;
-        for (;;) {
-            const char* q = static_cast<const char*>(memchr(data + p, '\n', size - p));
-            if (!q) break;
-            const uint64_t ls = (uint64_t)(q - data) + 1;  // start of the next line
-            if (ls >= size) break;
-            if (data[ls] == '>') {
-                uint64_t ps = (uint64_t)(q - data);  // walk back to the start of the line that ends at q
-                while (ps > 0 && data[ps - 1] != '\n') --ps;
-                if (data[ps] != '>' && ps >= line1) { found = ls; break; }
-            }
-            p = ls;
-        }
+        const uint64_t found = fasta_cut_at(data, size, target);
         if (found >= size) break;
         starts.push_back(found);
         target = found + chunk_bytes;

@@ -58,6 +58,8 @@ bool parse_reads_file(const std::string& path, bool fastq, uint32_t k, ReadSet& 
 // line 0 of the file, is a point where an independent reader can start.  split_fasta returns chunk start
 // offsets (first = 0) about `chunk_bytes` apart at such positions.
 std::vector<uint64_t> split_fasta(const char* data, uint64_t size, uint64_t chunk_bytes);
+// the first such position at or behind `from` (size: none)
+uint64_t fasta_cut_at(const char* data, uint64_t size, uint64_t from);
 // The reference's FASTA state machine over [begin, end) of the image, `end` acting as end-of-file.
 void parse_fasta_chunk(const char* data, uint64_t begin, uint64_t end, uint32_t k, ParsedChunk& out);
 // Whole-image FASTQ, sequential.

@@ -8,6 +8,8 @@
 //                                                   --write-exhaustive (-b normally writes nothing)
 //                                                   --chunk-bytes N (parser chunk size; tests use tiny chunks)
 //                                                   --no-overlap FILE (reads without any anchor go there instead of notAligned.fa)
+//                                                   --split-output (with --gpus N: one pipeline per device, device d writes <paths>.<d> /
+//                                                                   <notAligned>.<d>; `cat` in device order = the reference's files)
 //                                                   --host-route (parse and format on the host always; default: FASTA goes through the
 //                                                                 device as text when the run writes the reference's two files)
 #include <getopt.h>
@@ -33,10 +35,10 @@ int main(int argc, char** argv) {
     std::string reads, unitigs("unitig.fa"), pathFile("paths"), notAlignedFile("notAligned.fa"), noOverlapFile;
     int errors = 2, threads = 1, ka = 30, effort = 2, gpus = 1;  // bgreat.cpp:56-66 defaults (k is 30, not 31)
     long batch = 0, chunk_bytes = 0;  // batch 0 = the pipeline's default per route
-    bool brute = false, incomplete = false, fastq = false, correction = false, dog = false, write_exh = false, host_route = false;
+    bool brute = false, incomplete = false, fastq = false, correction = false, dog = false, write_exh = false, host_route = false, split_out = false;
     static option longopts[] = {{"gpus", required_argument, nullptr, 1000}, {"batch", required_argument, nullptr, 1001},
                                 {"write-exhaustive", no_argument, nullptr, 1002}, {"chunk-bytes", required_argument, nullptr, 1003},
-                                {"no-overlap", required_argument, nullptr, 1004}, {"host-route", no_argument, nullptr, 1005},
+                                {"no-overlap", required_argument, nullptr, 1004}, {"host-route", no_argument, nullptr, 1005}, {"split-output", no_argument, nullptr, 1006},
                                 {nullptr, 0, nullptr, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "r:k:g:m:t:e:f:o:a:biqpcG", longopts, nullptr)) != -1) {  // bgreat.cpp:67
@@ -60,6 +62,7 @@ int main(int argc, char** argv) {
             case 1003: chunk_bytes = std::stol(optarg); break;
             case 1004: noOverlapFile = optarg; break;
             case 1005: host_route = true; break;
+            case 1006: split_out = true; break;
             default: break;  // -o and -p are accepted and ignored, as in the reference (no `case`)
         }
     }
@@ -96,12 +99,14 @@ int main(int argc, char** argv) {
     opt.correction = correction ? 1 : 0;
     opt.no_overlap_file = noOverlapFile.empty() ? nullptr : noOverlapFile.c_str();
     opt.route = host_route ? 1u : 0u;
+    opt.split_output = split_out ? 1u : 0u;
     auto start = std::chrono::system_clock::now();
     uint64_t tot[5] = {0, 0, 0, 0, 0};
     double map_secs = 0;
     const int arc = bgr_align_all(graph, &prm, &opt, reads.c_str(), pathFile.c_str(), notAlignedFile.c_str(), tot, &map_secs);
     if (arc == BGR_E_COMPACTION) {  // aligner.cpp:280-283: cout<<"bug compaction"<<endl; cout<<path<<" "<<unitig<<endl; exit(0);
         std::cout << bgr_last_error() << std::endl;
+        bgr_host_cache_release();
         return 0;
     }
     if (arc != BGR_OK) die("mapping");
@@ -117,6 +122,7 @@ int main(int argc, char** argv) {
     std::cout << "Reads/seconds : " << rn / (uint64_t)(secs + 1) << std::endl;
     std::cout << "Mapping in seconds : " << secs << std::endl;
     if (getenv("BGREAT_TIMING")) fprintf(stderr, "bgreat: mapping %.3f s, %.3f Mreads/s end to end\n", map_secs, map_secs > 0 ? rn / map_secs / 1e6 : 0.0);
+    bgr_host_cache_release();  // the pipeline's page-locked staging sets (kept for a next run of the process): freed while the HIP runtime is up
     bgr_graph_destroy(graph);
     return 0;
 }

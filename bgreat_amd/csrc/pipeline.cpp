@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -163,8 +164,10 @@ struct Pinned {  // the page-locked buffers of one batch in flight: sources / ta
 
 // Page-locked buffers cost ~0.2 s per GB to allocate: a finished run leaves its sets here for the next bgr_align_all of the
 // process (bgr_host_cache_release frees them).
-std::mutex g_pin_cache_m;
-std::vector<std::unique_ptr<Pinned>> g_pin_cache;
+// (heap objects that are never destroyed: a static destructor would release page-locked memory, streams and HBM buffers after the HIP
+// runtime's own teardown at exit; a process that wants them gone calls bgr_host_cache_release -- the CLI does at the end of main)
+std::mutex& g_pin_cache_m = *new std::mutex;
+std::vector<std::unique_ptr<Pinned>>& g_pin_cache = *new std::vector<std::unique_ptr<Pinned>>;
 
 // Something the reference prints to stdout between two reads of the input order: a file name (aligner.cpp:559,576) or, in
 // exhaustive mode, the block its worker prints after every tenth getReads() call (alignerExhaustive.cpp:306-316).  A
@@ -416,11 +419,56 @@ extern "C" void bgr_host_cache_release(void) {
     g_pin_cache.clear();
 }
 
-extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const char* reads_csv,
-                             const char* paths_file, const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds) {
-    if (!graph || !prm || !opt || !reads_csv || !paths_file || !notaligned_file) return bgr::set_error(BGR_E_ARG, "bgr_align_all: null argument");
+namespace {
+
+// Bytes [begin, end) of one input file (end beyond the file: to its end).  `mf`: the file's image when the caller has opened it already
+// (the lanes of a split run share the images; a FIFO can be opened only once), else the producer opens it when it gets there.
+struct InputSpan {
+    std::string file;
+    std::shared_ptr<MappedFile> mf;
+    uint64_t begin = 0, end = ~0ull;
+};
+
+// One pipeline: the devices first_device .. first_device + n_gpus - 1 of `opt` map `inputs` in order into ONE pair of output files.
+// `cancel` (optional): shared with the other lanes of a split run -- a lane that fails stops them all.
+int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const std::vector<InputSpan>& inputs,
+                   const char* paths_file, const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds, std::atomic<bool>* cancel) {
     const unsigned n_gpus = std::max<uint32_t>(1, opt->n_gpus);
-    const unsigned threads = std::max<uint32_t>(1, opt->threads);
+    unsigned threads = std::max<uint32_t>(1, opt->threads);
+    // The threads of this run (and the page-locked memory they allocate) on the NUMA node of the devices they feed: a copy engine
+    // reading staging buffers across the socket link runs at about half its rate.  Only when all devices of the run share a node;
+    // the calling thread's affinity is restored at the end, and the pool of host threads is clamped to the CPUs of the restricted
+    // set (opt->numa = 1, or BGREAT_NUMA=0, leaves the affinity alone).
+    cpu_set_t old_aff, want_aff;
+    bool aff_changed = false;
+    if (!opt->numa && (!getenv("BGREAT_NUMA") || atoi(getenv("BGREAT_NUMA")) != 0)) {
+        CPU_ZERO(&want_aff);
+        bool same = true;
+        std::string first_list;
+        for (unsigned g = 0; g < n_gpus && same; ++g) {
+            char list[512];
+            if (bgr_device_local_cpus((int)(opt->first_device + g), list, sizeof(list)) != BGR_OK) { same = false; break; }
+            if (g == 0) first_list = list; else if (first_list != list) same = false;
+        }
+        if (same && !first_list.empty() && sched_getaffinity(0, sizeof(old_aff), &old_aff) == 0) {
+            int n_set = 0;
+            const char* c = first_list.c_str();
+            while (*c) {  // "a-b,c,d-e"
+                char* e = nullptr;
+                long a = strtol(c, &e, 10), b = a;
+                if (e == c) break;
+                if (*e == '-') { c = e + 1; b = strtol(c, &e, 10); }
+                for (long i = a; i <= b && i < CPU_SETSIZE; ++i) if (CPU_ISSET(i, &old_aff)) { CPU_SET(i, &want_aff); ++n_set; }
+                c = *e == ',' ? e + 1 : e;
+                if (*e != ',' && *e != 0) break;
+            }
+            if (n_set > 0 && sched_setaffinity(0, sizeof(want_aff), &want_aff) == 0) {
+                aff_changed = true;
+                threads = std::min<unsigned>(threads, (unsigned)n_set);  // (a pool larger than the CPU set it may run on only oversubscribes it)
+            }
+        }
+    }
+    struct RestoreAffinity { bool on; cpu_set_t* old; ~RestoreAffinity() { if (on) sched_setaffinity(0, sizeof(cpu_set_t), old); } } restore_aff{aff_changed, &old_aff};
     // Defaults: 128k reads per batch keeps the page-locked staging small (it costs ~0.2 s per GB to allocate) and the
     // pipeline fine-grained; the parser chunk is a thread's share of a batch.
     // (one launch addresses its path arena with 32 bits: a batch stays below 4 M reads and ~1 G bases)
@@ -434,7 +482,10 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     if (bgr_graph_info(graph, &gi_route) != BGR_OK) return BGR_E_ARG;
     const bool text_route = opt->route == 0 && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
     const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (text_route ? 1ull << 18 : 1ull << 17), 4ull << 20);
-    const uint64_t piece_bytes = std::min<uint64_t>(std::max<uint64_t>(batch_reads * 170, 4096), 1ull << 30);  // text route: bytes of a batch
+    // text route: bytes of a batch.  At most kTextPieceMax: the device addresses the two formatted streams with 32 bits, and a piece of B
+    // bytes gives at most 12 B + (its own bytes) of records (--batch beyond ~1.9 M reads of 150 bp is cut to that)
+    const uint64_t kTextPieceMax = 320ull << 20;
+    const uint64_t piece_bytes = std::min<uint64_t>(std::max<uint64_t>(batch_reads * 170, 4096), kTextPieceMax - (16ull << 20));
     uint64_t batch_bases_cap = 1ull << 30;
     if (const char* e = getenv("BGREAT_TEST_BASES_CAP")) batch_bases_cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // (tests: walk the cut with small inputs)
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes
@@ -481,36 +532,6 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         }
     }
 
-    // The threads of this run (and the page-locked memory they allocate) on the NUMA node of the devices they feed: a copy engine
-    // reading staging buffers across the socket link runs at about half its rate.  Only when all devices of the run share a node;
-    // the caller's affinity is restored at the end (BGREAT_NUMA=0 turns it off).
-    cpu_set_t old_aff, want_aff;
-    bool aff_changed = false;
-    if (!getenv("BGREAT_NUMA") || atoi(getenv("BGREAT_NUMA")) != 0) {
-        CPU_ZERO(&want_aff);
-        bool same = true;
-        std::string first_list;
-        for (unsigned g = 0; g < n_gpus && same; ++g) {
-            char list[512];
-            if (bgr_device_local_cpus((int)(opt->first_device + g), list, sizeof(list)) != BGR_OK) { same = false; break; }
-            if (g == 0) first_list = list; else if (first_list != list) same = false;
-        }
-        if (same && !first_list.empty() && sched_getaffinity(0, sizeof(old_aff), &old_aff) == 0) {
-            int n_set = 0;
-            const char* c = first_list.c_str();
-            while (*c) {  // "a-b,c,d-e"
-                char* e = nullptr;
-                long a = strtol(c, &e, 10), b = a;
-                if (e == c) break;
-                if (*e == '-') { c = e + 1; b = strtol(c, &e, 10); }
-                for (long i = a; i <= b && i < CPU_SETSIZE; ++i) if (CPU_ISSET(i, &old_aff)) { CPU_SET(i, &want_aff); ++n_set; }
-                c = *e == ',' ? e + 1 : e;
-                if (*e != ',' && *e != 0) break;
-            }
-            if (n_set > 0 && sched_setaffinity(0, sizeof(want_aff), &want_aff) == 0) aff_changed = true;
-        }
-    }
-    struct RestoreAffinity { bool on; cpu_set_t* old; ~RestoreAffinity() { if (on) sched_setaffinity(0, sizeof(cpu_set_t), old); } } restore_aff{aff_changed, &old_aff};
     auto t_start = std::chrono::steady_clock::now();
     WorkerPool pool(threads + 2);  // + 2: the stage threads mostly wait inside run()
     // A fixed pool of batch objects circulates producer -> GPU workers -> writer -> producer, so the pinned
@@ -532,13 +553,15 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     pool.timing = timing;
     std::atomic<uint64_t> us_parse{0}, us_gather{0}, us_gpu{0}, us_format{0}, us_write{0}, us_alloc{0};
     auto now_us = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    std::atomic<bool> failed{false};
+    std::atomic<bool> failed_here{false};
+    std::atomic<bool>& failed = cancel ? *cancel : failed_here;  // (a split run: one flag for all lanes)
+    bool failed_first = false;  // this pipeline recorded the failure (first_rc / first_err are its own)
     std::mutex err_m;
     std::string first_err;
     int first_rc = BGR_OK;
     auto fail = [&](int rc, const std::string& msg) {
         std::lock_guard<std::mutex> l(err_m);
-        if (!failed.exchange(true)) { first_rc = rc; first_err = msg; }
+        if (!failed.exchange(true)) { first_rc = rc; first_err = msg; failed_first = true; }
     };
     // The page-locked buffers cost ~0.2 s per GB to allocate, so they are few (one set per batch between gather and
     // format), sized from the input up front, allocated by their own thread while the parsers already run, and reused.
@@ -547,13 +570,14 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     std::thread pin_allocator([&]() {
         const uint64_t ta0 = now_us();
         uint64_t total_in = 0, max_file = 0;
-        std::string list(reads_csv);
-        size_t last = 0;
-        for (size_t i = 0; i <= list.size(); ++i) {
-            if (i != list.size() && list[i] != ',') continue;
+        for (const InputSpan& in : inputs) {
+            uint64_t sz = 0;
             struct stat st;
-            if (stat(list.substr(last, i - last).c_str(), &st) == 0) { total_in += (uint64_t)st.st_size; max_file = std::max<uint64_t>(max_file, (uint64_t)st.st_size); }
-            last = i + 1;
+            if (in.mf) sz = in.mf->size;
+            else if (stat(in.file.c_str(), &st) == 0) sz = (uint64_t)st.st_size;
+            sz = std::min(sz, in.end) - std::min(sz, in.begin);
+            total_in += sz;
+            max_file = std::max(max_file, sz);
         }
         const uint64_t group0 = std::max<uint64_t>(threads, (batch_reads * 170) / chunk_bytes);
         const uint64_t est_bytes = std::min<uint64_t>(max_file, opt->fastq ? batch_reads * 160 : group0 * chunk_bytes);
@@ -582,8 +606,6 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     // ---- stage 1: parse + gather -----------------------------------------------------------------------
     std::thread producer([&]() {
         uint64_t next_index = 0;
-        std::string list(reads_csv);
-        size_t last = 0;
         ProgressMarker marker;
         marker.on = progress_blocks;
         std::vector<Mark> pending;      // marks waiting for the next batch (they go in front of its first read)
@@ -608,14 +630,21 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
             free_batches.push(std::move(b));
         };
         bool ok = true;
-        for (size_t i = 0; i <= list.size() && !failed && ok; ++i) {  // aligner.cpp:552-586: comma-separated list
-            if (i != list.size() && list[i] != ',') continue;
-            std::string file = list.substr(last, i - last);
-            last = i + 1;
+        for (size_t fi = 0; fi < inputs.size() && !failed && ok; ++fi) {  // aligner.cpp:552-586: the files of the comma-separated list, in order
+            const InputSpan& in = inputs[fi];
+            const std::string& file = in.file;
             if (opt->echo_files) pending.push_back({0, 1, file});  // aligner.cpp:559,576  cout<<file<<endl
-            auto mf = std::make_shared<MappedFile>();
-            std::string err;
-            if (!mf->open(file, err)) { fail(BGR_E_IO, "read file: " + err); break; }
+            std::shared_ptr<MappedFile> mf = in.mf;
+            if (!mf) {
+                mf = std::make_shared<MappedFile>();
+                std::string err;
+                if (!mf->open(file, err)) { fail(BGR_E_IO, "read file: " + err); break; }
+            }
+            // the span of the file this pipeline maps: all of it, or -- a lane of a split run -- from one record start to another
+            const uint64_t s_begin = std::min(in.begin, mf->size), s_end = std::max(s_begin, std::min(in.end, mf->size));
+            const char* const sdata = mf->data + s_begin;
+            const uint64_t ssize = s_end - s_begin;
+            if (opt->fastq && (s_begin != 0 || s_end != mf->size)) { fail(BGR_E_ARG, "bgr_align_all: a FASTQ file is mapped whole (its records are counted from its first line)"); break; }
             marker.begin_file();
             uint64_t file_iters = 0;  // getReads() iterations of this file handed on so far
             if (opt->fastq) {
@@ -744,19 +773,19 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 continue;
             }
             if (text_route) {  // pieces of the file as they are: the device finds the records (the worker falls back per piece)
-                std::vector<uint64_t> cuts = bgr::split_fasta(mf->data, mf->size, piece_bytes);
+                std::vector<uint64_t> cuts = bgr::split_fasta(sdata, ssize, piece_bytes);
                 for (size_t c = 0; c < cuts.size() && !failed && ok; ++c) {
                     std::unique_ptr<Batch> b;
                     if (!open_batch(b, mf)) { ok = false; break; }
                     b->text_piece = true;
                     b->dev_text = false;
-                    b->t_begin = cuts[c];
-                    b->t_end = c + 1 < cuts.size() ? cuts[c + 1] : mf->size;
+                    b->t_begin = s_begin + cuts[c];
+                    b->t_end = s_begin + (c + 1 < cuts.size() ? cuts[c + 1] : ssize);
                     ok = emit(std::move(b));
                 }
                 continue;
             }
-            std::vector<uint64_t> starts = bgr::split_fasta(mf->data, mf->size, chunk_bytes);
+            std::vector<uint64_t> starts = bgr::split_fasta(sdata, ssize, chunk_bytes);
             size_t c = 0;
             while (c < starts.size() && !failed && ok) {
                 // as many chunks as it takes to reach ~batch_reads (estimated from bytes), at least `threads`
@@ -769,8 +798,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
                 Batch* bp = b.get();
                 const uint64_t tp0 = now_us();
                 pool.run(c_end - c, [&](size_t j) {
-                    uint64_t e = (c + j + 1 < starts.size()) ? starts[c + j + 1] : mf->size;
-                    bgr::parse_fasta_chunk(mf->data, starts[c + j], e, gi.k, *bp->chunks[j]);
+                    uint64_t e = (c + j + 1 < starts.size()) ? starts[c + j + 1] : ssize;
+                    bgr::parse_fasta_chunk(sdata, starts[c + j], e, gi.k, *bp->chunks[j]);
                 }, 1);
                 size_t total = 0;
                 for (auto& ch : b->chunks) total += ch->recs.size();
@@ -895,6 +924,8 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         // ... and on towards its device at once, on the stage's own copy stream: the worker's call finds it there (or waits on the device)
         if (b.pin->stages.size() < n_gpus) b.pin->stages.resize(n_gpus, nullptr);
         bgr_text_stage*& st = b.pin->stages[b.dev];
+        // (a set cached by an earlier run of the process may carry the stage of another device in this place: the index is relative to the run)
+        if (st && bgr_text_stage_device(st) != (int)(opt->first_device + b.dev)) { bgr_text_stage_destroy(st); st = nullptr; }
         if (!st && bgr_text_stage_create((int)(opt->first_device + b.dev), &st) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
         if (bgr_text_stage_upload(st, static_cast<const char*>(b.pin->text.p), bytes) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
         return true;
@@ -934,7 +965,10 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
         std::unique_ptr<Batch> b;
         while (to_gather.pop(b)) {
             b->dev = (unsigned)(b->index % n_gpus);
-            if (b->text_piece && !b->fastq_piece && b->file->irregular_pieces.load() >= 2) {  // this file is not of the device's shape: host route from here on
+            // this file is not of the device's shape: host route from here on.  So is a piece beyond what one text call takes: a piece is
+            // cut at record starts, so a very long record can carry it past the 2 GiB of a call, or past kTextPieceMax bytes, the bound that
+            // keeps the u32 offsets of the formatted streams exact (a path int is at most 12 characters and consumes at least one base)
+            if (b->text_piece && !b->fastq_piece && (b->file->irregular_pieces.load() >= 2 || b->t_end - b->t_begin > kTextPieceMax)) {
                 host_parse_piece(*b);
                 b->text_piece = false;
             }
@@ -1188,6 +1222,114 @@ extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_
     if (timing)  // thread CPU seconds spent inside the pool's tasks, by stage
         fprintf(stderr, "bgreat: pool CPU time (s): parse %.3f  gather/pack %.3f  format %.3f  write %.3f  other %.3f\n", pool.cpu_us[1] / 1e6,
                 pool.cpu_us[2] / 1e6, pool.cpu_us[3] / 1e6, pool.cpu_us[4] / 1e6, pool.cpu_us[0] / 1e6);
-    if (failed) return bgr::set_error(first_rc, first_err);
+    if (failed_first) return bgr::set_error(first_rc, first_err);
+    if (failed) return bgr::set_error(BGR_E_INTERNAL, "stopped: another lane of the run failed");
     return BGR_OK;
+}
+
+}  // namespace
+
+
+
+// ---- split run: one pipeline per device (bgr_run_options.split_output) ---------------------------------------------------------
+// The reference's N workers share ONE reader and ONE writer under a mutex each (alignerGreedy.cpp:372-377,407-411).  Here every
+// device gets a lane of its own -- producer, gatherer, stream workers, ordered writer, output pair -- over a contiguous share of the
+// input, so nothing is shared between devices but the graph and the page cache; `cat` of the pairs in device order is the -t 1 stream.
+static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const std::vector<std::string>& files,
+                           const char* paths_file, const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds) {
+    const unsigned n = std::max<uint32_t>(1, opt->n_gpus);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::shared_ptr<MappedFile>> imgs;
+    uint64_t total = 0;
+    for (const std::string& f : files) {
+        auto mf = std::make_shared<MappedFile>();
+        std::string err;
+        if (!mf->open(f, err)) return bgr::set_error(BGR_E_IO, "read file: " + err);
+        if (opt->echo_files) std::cout << f << std::endl;  // aligner.cpp:559,576 (nothing else is printed while such a run maps)
+        total += mf->size;
+        imgs.push_back(std::move(mf));
+    }
+    // lane d: the bytes between cut d and cut d + 1 of the files taken together; a cut is the first record start at or behind d / n of
+    // the bytes (fasta_cut_at: where an independent reader is in the sequential reader's state), so every lane parses its share exactly
+    // as the one reader would
+    struct Cut { size_t file; uint64_t off; };
+    std::vector<Cut> cuts(n + 1);
+    cuts[0] = {0, 0};
+    cuts[n] = {files.size(), 0};
+    for (unsigned d = 1; d < n; ++d) {
+        const uint64_t target = (uint64_t)((unsigned __int128)total * d / n);
+        uint64_t base = 0;
+        Cut c = {files.size(), 0};
+        for (size_t f = 0; f < imgs.size(); ++f) {
+            const uint64_t sz = imgs[f]->size;
+            if (target < base + sz) {
+                const uint64_t at = target > base ? bgr::fasta_cut_at(imgs[f]->data, sz, target - base) : 0;
+                c = at < sz ? Cut{f, at} : Cut{f + 1, 0};
+                break;
+            }
+            base += sz;
+        }
+        if (c.file < cuts[d - 1].file || (c.file == cuts[d - 1].file && c.off < cuts[d - 1].off)) c = cuts[d - 1];
+        cuts[d] = c;
+    }
+    std::atomic<bool> cancel{false};
+    std::vector<int> rcs(n, BGR_OK);
+    std::vector<std::string> errs(n);
+    std::vector<std::array<uint64_t, 5>> cnt(n);
+    std::vector<std::thread> lanes;
+    for (unsigned d = 0; d < n; ++d) {
+        lanes.emplace_back([&, d]() {
+            std::vector<InputSpan> in;
+            for (size_t f = cuts[d].file; f < files.size() && (f < cuts[d + 1].file || (f == cuts[d + 1].file && cuts[d + 1].off > 0)); ++f) {
+                InputSpan sp;
+                sp.file = files[f];
+                sp.mf = imgs[f];
+                sp.begin = f == cuts[d].file ? cuts[d].off : 0;
+                sp.end = f == cuts[d + 1].file ? cuts[d + 1].off : ~0ull;
+                if (std::min(sp.end, imgs[f]->size) > sp.begin || imgs[f]->size == 0) in.push_back(std::move(sp));
+            }
+            bgr_run_options o = *opt;
+            o.n_gpus = 1;
+            o.first_device = opt->first_device + d;
+            o.threads = std::max<uint32_t>(1, opt->threads / n);
+            o.echo_files = 0;
+            o.split_output = 0;
+            const std::string pf = std::string(paths_file) + "." + std::to_string(d), nf = std::string(notaligned_file) + "." + std::to_string(d);
+            cnt[d].fill(0);
+            double secs = 0;
+            rcs[d] = align_all_impl(graph, prm, &o, in, pf.c_str(), nf.c_str(), cnt[d].data(), &secs, &cancel);
+            if (rcs[d] != BGR_OK) errs[d] = bgr_last_error();  // (the message is the lane thread's own)
+        });
+    }
+    for (auto& t : lanes) t.join();
+    if (mapping_seconds) *mapping_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int rc = BGR_OK;
+    std::string err;
+    for (unsigned d = 0; d < n; ++d)   // the lane that failed, not the ones it stopped
+        if (rcs[d] != BGR_OK && (rc == BGR_OK || (rc == BGR_E_INTERNAL && err.rfind("stopped:", 0) == 0))) { rc = rcs[d]; err = errs[d]; }
+    if (rc != BGR_OK) return bgr::set_error(rc, err);
+    if (counters_out) for (int j = 0; j < 5; ++j) { counters_out[j] = 0; for (unsigned d = 0; d < n; ++d) counters_out[j] += cnt[d][j]; }
+    return BGR_OK;
+}
+
+extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const char* reads_csv,
+                             const char* paths_file, const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds) {
+    if (!graph || !prm || !opt || !reads_csv || !paths_file || !notaligned_file) return bgr::set_error(BGR_E_ARG, "bgr_align_all: null argument");
+    std::vector<std::string> files;  // aligner.cpp:552-586: comma-separated list
+    {
+        const std::string list(reads_csv);
+        size_t last = 0;
+        for (size_t i = 0; i <= list.size(); ++i) {
+            if (i != list.size() && list[i] != ',') continue;
+            files.push_back(list.substr(last, i - last));
+            last = i + 1;
+        }
+    }
+    const bool progress_blocks = opt->echo_files && prm->mode == BGR_MODE_EXHAUSTIVE;
+    const bool correction = opt->correction && prm->mode != BGR_MODE_EXHAUSTIVE;
+    if (opt->split_output && opt->n_gpus > 1 && !opt->fastq && !progress_blocks && !correction && !opt->no_overlap_file)
+        return align_all_lanes(graph, prm, opt, files, paths_file, notaligned_file, counters_out, mapping_seconds);
+    std::vector<InputSpan> inputs(files.size());
+    for (size_t i = 0; i < files.size(); ++i) inputs[i].file = files[i];
+    return align_all_impl(graph, prm, opt, inputs, paths_file, notaligned_file, counters_out, mapping_seconds, nullptr);
 }

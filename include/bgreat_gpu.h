@@ -222,6 +222,7 @@ typedef struct {
 int bgr_text_stage_create(int device, bgr_text_stage** out);
 void bgr_text_stage_destroy(bgr_text_stage* s);
 int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t text_bytes);
+int bgr_text_stage_device(const bgr_text_stage* s);  /* the device the stage was created on (-1: null) */
 int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b);
 int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b);
 
@@ -328,6 +329,16 @@ typedef struct {
     uint32_t route;            /* 0 = automatic: FASTA input without -c / --no-overlap / -b progress blocks goes through the device as
                                   text (bgr_align_fasta_text: parsing, packing, mapping and record formatting on the GPU; pieces of an
                                   irregular shape fall back to the host parser one by one); 1 = host parser + host formatter always */
+    uint32_t numa;             /* 0 = while the run lasts, its threads (the caller's included) and the page-locked memory they allocate are kept
+                                  on the CPUs next to the run's devices when all of them share one NUMA node, and the pool of host threads is
+                                  clamped to that CPU set; 1 = the caller's affinity is left alone                          */
+    uint32_t split_output;     /* 0 = the reference's two files.  1 = one pipeline PER DEVICE: device d of the run maps the d-th of n_gpus
+                                  contiguous shares of the input (cut at record starts, over the files of the list taken together) and writes
+                                  its own pair `<paths_file>.<d>` / `<notaligned_file>.<d>`; the pairs concatenated in device order are the
+                                  reference's -t 1 bytes.  One ordered stream into ONE file is bound by what a single writer gets out of the
+                                  file system (~6-13 GB/s: 125-250 Mreads/s at ~50 bytes per read) whatever the number of GPUs; this form has
+                                  no stage shared between devices.  FASTA input without -c, --no-overlap and -b progress blocks; any
+                                  other run ignores the flag.                                                                  */
 } bgr_run_options;
 /* bgr_align_all keeps its page-locked staging buffers for the next call of the process (they cost ~0.2 s per GB to allocate);
  * this frees them. */

@@ -19,14 +19,14 @@
 #include "fastx.h"
 
 struct bgr_graph { uint32_t k; };
-struct bgr_aligner { uint64_t counters[5] = {0, 0, 0, 0, 0}; std::string ps, ns; /* text form: the last call's streams, for bgr_aligner_fetch_text */ };
+struct bgr_aligner { int device = 0; uint64_t counters[5] = {0, 0, 0, 0, 0}; std::string ps, ns; /* text form: the last call's streams, for bgr_aligner_fetch_text */ };
 static thread_local std::string tl_err;
 namespace bgr { int set_error(int code, const std::string& msg) { tl_err = msg; return code; } }
 extern "C" {
 const char* bgr_last_error(void) { return tl_err.c_str(); }
 int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* o) { memset(o, 0, sizeof(*o)); o->k = g->k; return BGR_OK; }
 int bgr_graph_unitigs(const bgr_graph*, const char**, const uint64_t**, uint64_t*) { return BGR_E_ARG; }
-int bgr_aligner_create(bgr_graph*, int, bgr_aligner** out) { *out = new bgr_aligner(); return BGR_OK; }
+int bgr_aligner_create(bgr_graph*, int device, bgr_aligner** out) { *out = new bgr_aligner(); (*out)->device = device; return BGR_OK; }
 void bgr_aligner_destroy(bgr_aligner* a) { delete a; }
 int bgr_device_local_cpus(int, char*, uint64_t) { return BGR_E_IO; }
 int bgr_host_alloc(uint64_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? BGR_OK : BGR_E_HIP; }
@@ -67,6 +67,7 @@ int bgr_align_batch_packed(bgr_aligner* a, const bgr_params*, const bgr_packed_r
 struct bgr_text_stage { int device; std::string copy; };
 extern "C" int bgr_text_stage_create(int device, bgr_text_stage** out) { *out = new bgr_text_stage{device, std::string()}; return BGR_OK; }
 extern "C" void bgr_text_stage_destroy(bgr_text_stage* s) { delete s; }
+extern "C" int bgr_text_stage_device(const bgr_text_stage* s) { return s ? s->device : -1; }
 extern "C" int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t n) { s->copy.assign(text, n); return BGR_OK; }
 extern "C" int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
     b->paths_bytes = a->ps.size();
@@ -78,6 +79,7 @@ extern "C" int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
 }
 extern "C" int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_batch* b) {
     b->irregular = 0; b->n_records = b->n_accepted = b->paths_bytes = b->notaligned_bytes = 0;
+    if (b->stage && b->stage->device != a->device) return bgr::set_error(BGR_E_ARG, "stand-in: the stage lives on another device");  // (as the real call)
     if (b->stage && (b->stage->copy.size() != b->text_bytes || (b->text_bytes && memcmp(b->stage->copy.data(), b->text, b->text_bytes) != 0))) return BGR_E_INTERNAL;  // the staged piece is this piece
     const char* t = b->stage ? b->stage->copy.data() : b->text;
     const uint64_t n = b->text_bytes;
@@ -151,6 +153,7 @@ int main(int argc, char** argv) {
                 memset(&opt, 0, sizeof(opt));
                 opt.n_gpus = (batch == 37 && threads == 6) ? 8 : 2;  // (eight stand-in devices = 16 stream workers, per-device queues: order and bytes as with two)
                 opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 700; opt.fastq = c.fastq; opt.route = route == 2 ? 1u : route;
+                opt.first_device = (unsigned)((batch + threads) % 3);  // (the staging sets cached by the previous run carry text stages of ITS devices)
                 uint64_t tot[5]; double secs;
                 const std::string list = in + "," + in;  // two files: the batches of the second must follow the first's
                 { const int rc_ = bgr_align_all(&g, &prm, &opt, list.c_str(), pf.c_str(), nf.c_str(), tot, &secs); if (rc_ != BGR_OK) { printf("FAIL run (%s threads=%u batch=%llu route=%u): rc %d %s\n", c.file, threads, (unsigned long long)batch, route, rc_, bgr_last_error()); return 1; } }
@@ -184,6 +187,66 @@ int main(int argc, char** argv) {
           }
         }
         printf("%s ok\n", c.file);
+    }
+    // ---- split runs (bgr_run_options.split_output): one pipeline per stand-in device over contiguous shares of the input; the pairs
+    // concatenated in device order must be the bytes of the single pipeline, whatever the lane count, route and batch size (the stand-in
+    // numbers reads within a device batch: blanked as above; FASTA only -- other runs ignore the flag and write the single pair)
+    {
+        auto blank = [](const std::string& gp) {
+            std::string out; out.reserve(gp.size());
+            std::istringstream ss(gp); std::string line; bool header = true;
+            while (std::getline(ss, line)) {
+                if (!header) { size_t a = line.find('.'), b = line.find('.', a + 1); if (a != std::string::npos && b != std::string::npos) line = line.substr(0, a + 1) + "#" + line.substr(b); }
+                out += line + "\n"; header = !header;
+            }
+            return out;
+        };
+        const std::string big = tmp + "/lanes.fa";
+        {
+            std::ofstream o(big, std::ios::binary);
+            const char* al = "ACGT";
+            for (int i = 0; i < 40000; ++i) {
+                std::string r;
+                for (int j = 0; j < 7 + (i * 3) % 40; ++j) r += al[(i * 11 + j * 7 + (j * j) % 3) & 3];
+                if (i % 211 == 7) r[2] = 'n';
+                o << ">L" << i << " x\n" << r << "\n";
+            }
+        }
+        for (const std::string& list : {big, gold + "/syn_r150.fa," + big + "," + gold + "/deg_reads.fa", gold + "/edge_reads.fa"}) {
+            for (uint32_t route : {0u, 1u}) {
+                bgr_graph g{5u};
+                bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
+                bgr_run_options opt;
+                memset(&opt, 0, sizeof(opt));
+                opt.n_gpus = 1; opt.threads = 3; opt.batch_reads = 997; opt.chunk_bytes = 900; opt.route = route;
+                uint64_t tot1[5]; double secs;
+                if (bgr_align_all(&g, &prm, &opt, list.c_str(), (tmp + "/p1").c_str(), (tmp + "/n1").c_str(), tot1, &secs) != BGR_OK) { printf("FAIL lanes reference run: %s\n", bgr_last_error()); return 1; }
+                const std::string want_p = blank(slurp(tmp + "/p1")), want_n = slurp(tmp + "/n1");
+                for (unsigned lanes : {2u, 3u, 8u}) {
+                    opt.n_gpus = lanes; opt.split_output = 1; opt.threads = 6; opt.first_device = lanes == 3 ? 2 : 0; opt.batch_reads = lanes == 8 ? 64 : 997;
+                    uint64_t tot[5];
+                    if (bgr_align_all(&g, &prm, &opt, list.c_str(), (tmp + "/ps").c_str(), (tmp + "/ns").c_str(), tot, &secs) != BGR_OK) { printf("FAIL lanes run: %s\n", bgr_last_error()); return 1; }
+                    std::string gp, gn;
+                    for (unsigned d = 0; d < lanes; ++d) { gp += slurp(tmp + "/ps." + std::to_string(d)); gn += slurp(tmp + "/ns." + std::to_string(d)); }
+                    if (blank(gp) != want_p || gn != want_n || tot[0] != tot1[0] || tot[2] != tot1[2] || tot[3] != tot1[3]) {
+                        printf("FAIL lanes=%u route=%u list=%s: paths %zu/%zu notAligned %zu/%zu reads %llu/%llu\n", lanes, route, list.c_str(), gp.size(), want_p.size(), gn.size(), want_n.size(),
+                               (unsigned long long)tot[0], (unsigned long long)tot1[0]);
+                        return 1;
+                    }
+                }
+            }
+        }
+        {   // a lane that fails (unreadable output directory) stops the others and its error is the one reported
+            bgr_graph g{5u};
+            bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
+            bgr_run_options opt;
+            memset(&opt, 0, sizeof(opt));
+            opt.n_gpus = 4; opt.split_output = 1; opt.threads = 4;
+            uint64_t tot[5]; double secs;
+            const int rc = bgr_align_all(&g, &prm, &opt, big.c_str(), (tmp + "/no_such_dir/p").c_str(), (tmp + "/no_such_dir/n").c_str(), tot, &secs);
+            if (rc != BGR_E_IO) { printf("FAIL lanes error path: rc %d %s\n", rc, bgr_last_error()); return 1; }
+        }
+        printf("split runs ok\n");
     }
     // ---- what the reference prints while it maps (file names; in exhaustive mode the block after every tenth getReads()
     // call, alignerExhaustive.cpp:306-316): it must come out of the ordered writer between the right reads, whatever the

@@ -156,6 +156,16 @@ static void make_read(const Synth& s, uint64_t idx, uint32_t L, uint32_t max_sub
     }
 }
 
+// genome start positions of reads [first, first+n) (what make_read draws first): lets a bench order a batch by locus
+void syn_read_starts(void* h, uint64_t first, uint64_t n, uint32_t L, uint64_t seed, uint64_t* out) {
+    const Synth& s = *static_cast<Synth*>(h);
+    const uint64_t G = s.genome.size();
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t st = mix2(seed, first + i);
+        out[i] = splitmix(st) % (G - L + 1);
+    }
+}
+
 // reads [first, first+n) of fixed length L into out (n*L bytes, no separators)
 void syn_reads(void* h, uint64_t first, uint64_t n, uint32_t L, uint32_t max_sub, uint64_t seed, char* out, int threads) {
     const Synth& s = *static_cast<Synth*>(h);

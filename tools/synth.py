@@ -25,6 +25,7 @@ def lib():
         L.syn_unitigs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.syn_write_unitigs.argtypes = [C.c_void_p, C.c_char_p]
         L.syn_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
+        L.syn_read_starts.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
         L.syn_write_reads.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
         L.syn_write_reads_mt.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
         _LIB = L
@@ -61,6 +62,12 @@ class Synth:
         lib().syn_reads(self.h, first, n, L, max_sub, seed, out.ctypes.data, threads)
         offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
         return out, offs
+
+    def read_starts(self, first, n, L, seed):
+        """-> uint64[n]: the genome position each of reads first..first+n was drawn from (diagnostics: locality experiments)"""
+        out = np.empty(n, dtype=np.uint64)
+        lib().syn_read_starts(self.h, first, n, L, seed, out.ctypes.data)
+        return out
 
     def write_reads(self, path, first, n, L, max_sub, seed, fastq=False, threads=1):
         if threads > 1:
