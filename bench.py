@@ -85,6 +85,12 @@ def parse_args():
     ap.add_argument("--pcie-steps", type=int, default=3, help="timed bgr_align_batch calls of the PCIe-inclusive leg (0 disables)")
     ap.add_argument("--sorted-reads", action="store_true", help="diagnostic: every batch ordered by the genome position its reads were drawn from (the upper bound of any "
                                                                  "locality ordering of the reads; never the reported configuration)")
+    ap.add_argument("--sub-record", action="store_true", help="run as one of the default line's sub-records: the device-resident leg, counters and parity sample only "
+                                                               "(exhaustive workloads: + the reference's -b run on a bounded sample)")
+    ap.add_argument("--no-sub", action="store_true", help="skip the sub-records of the other BASELINE configs (default run, N=1, workload ecoli: configs[1], [3], [4])")
+    ap.add_argument("--sub-timeout", type=int, default=170, help="seconds one sub-record child may take")
+    ap.add_argument("--cpu-sample-exh", type=int, default=40_000, help="reads of the exhaustive CPU baseline (reference -b, -t cpu-threads)")
+    ap.add_argument("--cpu-sample-all", type=int, default=2_500_000, help="reads of the all-cores leg of the CPU baseline (-t min(255, visible cores)); 0 disables")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--debug-stop", type=int, default=0, help="diagnostic builds of the library only (-DBGR_PHASE_TIMING, loaded through BGR_LIB_PATH): "
                                                               "1 = the mapping kernel stops behind the staging of the reads, 2 = behind the anchor scan")
@@ -97,6 +103,8 @@ def parse_args():
     for key, val in presets.get(args.workload, {}).items():
         if getattr(args, key) == ap.get_default(key):
             setattr(args, key, val)
+    if args.sub_record:
+        args.e2e_reads, args.pcie_steps = 0, 0
     return args
 
 
@@ -176,6 +184,10 @@ def main():
         pmc = {"error": "already running under a profiler: counter passes skipped"} if under_profiler() else run_pmc_passes(args)
         log("pmc passes:", {k: v for k, v in pmc.items() if not k.startswith("_per")} if pmc else None)
 
+    subs = None
+    if world == 1 and args.workload == "ecoli" and mode == 0 and not (args.pmc_child or args.sub_record or args.no_sub):
+        subs = run_sub_records(args)   # child processes, one after the other; this process has not initialised the GPU yet
+
     import torch
     import bgreat_amd as B
     from tools.synth import Synth
@@ -219,9 +231,19 @@ def main():
         g = B.Graph.build(args.k, seqs, offs, args.gamma, anchors=(mode == 2))
         graph_info = g.info()
         log("index build: %.2fs on the host (%d unitigs)" % (time.time() - tb, graph_info["n_unitigs"]))
+    multi = None
     if world > 1:
         from bgreat_amd import dist as D
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if coll_dev is None else "cuda:%d" % coll_dev)
+        dist.all_reduce(ones)                 # (also brings the communicator up before the broadcast is timed)
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
         g, _blob_keepalive = D.broadcast_graph(g, dist, device=coll_dev)  # C1: the only data-path collective; reads never move
+        torch.cuda.synchronize()
+        bc_ms = (time.perf_counter() - tb0) * 1e3
+        multi = {"backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "ranks_seen": int(ones.item()), "graph_broadcast_bytes": int(g.info()["blob_bytes"]),
+                 "graph_broadcast_ms": round(bc_ms, 2), "graph_broadcast_GB_per_s": round(g.info()["blob_bytes"] / max(bc_ms, 1e-6) / 1e6, 2),
+                 "what": "one process per GPU (torch.distributed): all-reduce of ones = ranks that took part; C1 = rank 0's blob to every rank's HBM, adopted in place"}
     al = B.Aligner(g, dev)
     al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
     if args.general_kernel_only:
@@ -244,7 +266,7 @@ def main():
     ncpu_all = len(os.sched_getaffinity(0))
     ncpu = max(1, min(ncpu_all // max(1, world) if world > 1 else ncpu_all, args.cpu_threads))  # the GPU box gives one GPU a 16-core share
     offs_np = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
-    offs_t = torch.from_numpy(offs_np.view(np.int64)).to("cuda")
+    offs_t = B.DeviceBuffer(dev, offs_np)   # parked in HBM through the C-ABI (bgr_device_alloc / bgr_device_upload): torch only synchronises and reduces
     batches = []
     first_host = None
     for s in range(K):
@@ -254,7 +276,7 @@ def main():
             arr = arr.reshape(R, L)[order].reshape(-1)
         if s == 0 and rank == 0 and not args.pmc_child:
             first_host = arr[: max(args.cpu_sample, args.alg_sample) * L].copy()
-        batches.append(torch.from_numpy(arr).to("cuda"))
+        batches.append(B.DeviceBuffer(dev, arr))
         del arr
     torch.cuda.synchronize()
     if rank == 0:
@@ -295,6 +317,16 @@ def main():
     e2e = None
     if args.e2e_reads > 0 and mode == 0:
         e2e = run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D if dist is not None else None, coll_dev, seed_reads)
+
+    # ---- N > 1: the C-ABI's own multi-GPU form next to the one-process-per-GPU form above -- ONE process, bgr_devices_init (one upload,
+    # then device to device over xGMI: RCCL broadcast or peer copies) and one aligner + one host thread per device; rank 0 runs it
+    # while the other ranks wait (their batches stay parked: the devices are otherwise idle)
+    one_proc = None
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            one_proc = run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, rehearsal)
+        dist.barrier()
 
     if rank != 0:
         if dist is not None:
@@ -417,8 +449,10 @@ def main():
 
     # ---- CPU baseline: the compiled reference (oracle/_ref/bgreat -t cores) on a bounded sample, N=1 only -------
     cpu = None
-    if world == 1 and args.cpu_sample > 0 and mode == 0:
+    if world == 1 and args.cpu_sample > 0 and mode == 0 and not args.sub_record:
         cpu = run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads)
+    if world == 1 and args.cpu_sample_exh > 0 and mode == 1:
+        cpu = run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads)
 
     out = {
         "metric": "Mreads/s aligned (k=%d, %dbp, m=%d)" % (args.k, L, args.mismatch), "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -430,7 +464,11 @@ def main():
                    "reads_per_step_per_gpu": R, "read_len": L, "k": args.k, "m": args.mismatch, "effort": args.effort,
                    "parallelism": "reads sharded over %d GPU(s); graph blob broadcast once" % world, "launch": al.launch_info(),
                    "pass_counts_last_launch": pass_counts},
-        "roofline": roofline, "pcie_inclusive": pcie, "e2e": e2e, "cpu_baseline": cpu,
+        # SURVEY 8d's two metrics beside `value` (the device-resident kernel/roofline anchor): (i) H2D + launch + CSR + D2H from page-locked
+        # host buffers, one blocking caller; (ii) file in -> paths / notAligned.fa out, median of the runs (spread in e2e.runs_mreads_per_s)
+        "value_pcie_inclusive": (pcie or {}).get("value"), "value_e2e": (e2e or {}).get("value"),
+        "roofline": roofline, "pcie_inclusive": pcie, "e2e": e2e, "cpu_baseline": cpu, "multi_gpu": multi, "one_process_all_gpus": one_proc,
+        "other_configs": subs,
         "counters": counters, "parity_sample": {"reads": ns, "gpu_equals_oracle": parity_ok},
         "oracle_work_per_read": {k: round(v / ns, 2) for k, v in work.items() if k not in ("reads",)},
     }
@@ -461,7 +499,7 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
         syn.write_reads(f, (world + rank) * 1_000_000_000, n, L, args.mismatch, seed_reads, threads=ncpu)
         fsize = os.path.getsize(f)
         best = None
-        runs = []
+        runs, walls = [], []
         host_route = None
         for rep in range(4):  # later runs have the page-locked staging buffers warm; the box's host cores are shared: runs vary
             route = 1 if rep == 3 else 0   # the last run: the same file through the host parser + host formatter (the round-2 pipeline)
@@ -485,6 +523,7 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
                               "what": "one run of the same file with route = 1: host parser, host packer, host formatter (bgr_align_batch_packed)"}
                 continue
             cnt = cnt_r
+            walls.append(wall)
             runs.append(round(world * n / wall / 1e6, 1))
             if best is None or wall < best:
                 best = wall
@@ -505,7 +544,16 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
                     cnt1, _ = B.align_all(g, f, os.path.join(d, "paths_1p"), os.path.join(d, "notAligned_1p.fa"), m=args.mismatch, effort=args.effort,
                                           threads=min(len(os.sched_getaffinity(0)), ncpu * n_dev), n_gpus=n_dev, first_device=0)
                     w1 = time.perf_counter() - t1
+                    t1 = time.perf_counter()   # ... and as a split run: a pipeline per device, N output pairs (bgr_run_options.split_output)
+                    cnt2, _ = B.align_all(g, f, os.path.join(d, "paths_sp"), os.path.join(d, "notAligned_sp.fa"), m=args.mismatch, effort=args.effort,
+                                          threads=min(len(os.sched_getaffinity(0)), ncpu * n_dev), n_gpus=n_dev, first_device=0, split_output=True)
+                    w2 = time.perf_counter() - t1
+                    parts_p = [os.path.join(d, "paths_sp.%d" % i) for i in range(n_dev)] if n_dev > 1 else [os.path.join(d, "paths_sp")]
+                    parts_n = [os.path.join(d, "notAligned_sp.fa.%d" % i) for i in range(n_dev)] if n_dev > 1 else [os.path.join(d, "notAligned_sp.fa")]
+                    split = {"value": round(n / w2 / 1e6, 3), "unit": "Mreads/s", "output_pairs": n_dev,
+                             "identical_bytes_concatenated": bool(_same_concat(os.path.join(d, "paths0"), parts_p) and _same_concat(os.path.join(d, "notAligned0.fa"), parts_n))}
                     one_process = {"value": round(n / w1 / 1e6, 3), "unit": "Mreads/s", "n_gpus": n_dev, "reads": n, "host_threads": min(len(os.sched_getaffinity(0)), ncpu * n_dev),
+                                   "split_output": split,
                                    "fanout_method": {0: "none", 1: "rccl broadcast", 2: "peer copies"}.get(how, str(how)),
                                    "identical_bytes_to_one_gpu": bool(_same_file(os.path.join(d, "paths0"), os.path.join(d, "paths_1p")) and
                                                                       _same_file(os.path.join(d, "notAligned0.fa"), os.path.join(d, "notAligned_1p.fa"))),
@@ -514,15 +562,34 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
                     one_process = {"error": "%s: %s" % (type(ex).__name__, ex)}
             if dist is not None:
                 dist.barrier()
-        return {"value": round(world * n / best / 1e6, 3), "unit": "Mreads/s", "reads_per_gpu": n, "n_gpus": world, "host_threads_per_gpu": ncpu, "seconds": round(best, 4),
-                "input": "FASTA, %d bytes per GPU, written just before the run: page cache" % fsize, "input_GB_per_s": round(world * fsize / best / 1e9, 2),
-                "output_bytes_per_gpu": out_bytes, "aligned": cnt["aligned"], "runs_mreads_per_s": runs, "host_route": host_route, "one_process_all_gpus": one_process,
+        med = float(np.median(walls))
+        return {"value": round(world * n / med / 1e6, 3), "unit": "Mreads/s", "reads_per_gpu": n, "n_gpus": world, "host_threads_per_gpu": ncpu, "seconds": round(med, 4),
+                "runs_mreads_per_s": runs, "best": round(world * n / best / 1e6, 3), "worst": round(world * n / max(walls) / 1e6, 3),
+                "input": "FASTA, %d bytes per GPU, written just before the run: page cache" % fsize, "input_GB_per_s": round(world * fsize / med / 1e9, 2),
+                "output_bytes_per_gpu": out_bytes, "aligned": cnt["aligned"], "host_route": host_route, "one_process_all_gpus": one_process,
                 "what": "bgr_align_all (the CLI's mapping phase): file -> paths + notAligned.fa, the device taking the FASTA text and returning the record bytes "
-                        "(bgr_align_fasta_text); best of 3 runs (fresh output files, os.sync() before each, not timed); index build excluded"}
+                        "(bgr_align_fasta_text); value = MEDIAN of 3 runs in this process (fresh output files, os.sync() before each, not timed; the box's host "
+                        "cores are shared, the runs vary); index build excluded"}
     except Exception as ex:
         return {"error": "%s: %s" % (type(ex).__name__, ex)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def _same_concat(a, parts, chunk=1 << 24):
+    """file a == the files `parts` concatenated"""
+    if os.path.getsize(a) != sum(os.path.getsize(x) for x in parts):
+        return False
+    with open(a, "rb") as fa:
+        for x in parts:
+            with open(x, "rb") as fx:
+                while True:
+                    y = fx.read(chunk)
+                    if not y:
+                        break
+                    if fa.read(len(y)) != y:
+                        return False
+    return True
 
 
 def _same_file(a, b, chunk=1 << 24):
@@ -638,6 +705,178 @@ def run_pcie(args, B, g, al, syn, seed_reads, ncpu, dev):
         return {"error": "%s: %s" % (type(ex).__name__, ex)}
 
 
+def run_sub_records(args):
+    """The other BASELINE configs inside the one driver-timed line: configs[1] (`--workload small`), the configs[3] graph (`chr1`, one
+    GPU's share of the reads) and configs[4] (`branchy`, exhaustive) each run as a child `bench.py --workload W --sub-record` -- the same
+    code path as a builder run of that workload (device-resident leg, its own rocprofv3 counter passes, parity sample against the
+    oracle; exhaustive: the reference's -b run on a bounded sample) -- and their lines are cut down to the fields below."""
+    out = {}
+    for w in ("small", "chr1", "branchy"):
+        t0 = time.time()
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--sub-record", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--cpu-threads", str(args.cpu_threads), "--pmc-steps", str(args.pmc_steps)]
+        if args.no_pmc:
+            cmd.append("--no-pmc")
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in PROFILER_ENV and not k.startswith("ROCPROF")} if not under_profiler() else dict(os.environ)
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.sub_timeout)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                out[w] = {"error": "rc %d: %s" % (p.returncode, (p.stderr or "")[-300:])}
+                continue
+            d = json.loads(lines[-1])
+            r = d.get("roofline") or {}
+            rec = {"config": d["config"]["workload"], "metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"],
+                   "reads_per_step": d["config"]["reads_per_step_per_gpu"], "dominant_kernel": r.get("dominant_kernel"), "dominant_kernel_ms": r.get("dominant_kernel_ms"),
+                   "roofline": {"bound": r.get("bound"), "frac": r.get("frac"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit")},
+                   "hbm": {"compulsory_frac": (r.get("hbm") or {}).get("frac"), "traffic_frac": r.get("traffic_frac"), "traffic_over_compulsory": r.get("traffic_over_compulsory"),
+                           "traffic_bytes_per_read": r.get("traffic_bytes_per_read")},
+                   "l2_hit_rate": r.get("l2_hit_rate"), "valu_insts_per_read": (r.get("valu_issue") or {}).get("valu_insts_per_read"),
+                   "parity_sample": d.get("parity_sample"), "counters": d.get("counters"), "launch": d["config"].get("launch"), "seconds": round(time.time() - t0, 1)}
+            if d.get("cpu_baseline"):
+                rec["cpu_baseline"] = d["cpu_baseline"]
+            out[w] = rec
+            log("sub-record %s: %s Mreads/s (%.1fs)" % (w, d["value"], time.time() - t0))
+        except Exception as ex:  # a sub-record never fails the line
+            out[w] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    return out
+
+
+def run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, rehearsal):
+    """ONE process, N devices: bgr_devices_init fans the blob out (one upload, then device to device), one aligner and one host thread
+    per device map device-resident batches through bgr_align_device -- the multi-GPU form a C/C++/cgo host of the C-ABI uses (the CLI's
+    `--gpus N`), measured next to the one-process-per-GPU form of this line."""
+    try:
+        import torch
+        n_dev = max(1, min(world, B.device_count(), torch.cuda.device_count()))
+        K, W, R, L = min(args.steps, 4), 1, args.reads_per_step, args.read_len
+        t0 = time.perf_counter()
+        how = g.devices_init(0, n_dev, 0)
+        fan_ms = (time.perf_counter() - t0) * 1e3
+        offs_np = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+        als, bufs, offs = [], [], []
+        for d in range(n_dev):
+            al = B.Aligner(g, d)
+            al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
+            als.append(al)
+            offs.append(B.DeviceBuffer(d, offs_np))
+            dev_b = []
+            for s in range(2):   # two batches per device, taken in turn
+                arr, _ = syn.reads((2 * world + d) * 1_000_000_000 + s * R, R, L, args.mismatch, seed_reads, threads=ncpu)
+                dev_b.append(B.DeviceBuffer(d, arr))
+                del arr
+            bufs.append(dev_b)
+        start = threading.Barrier(n_dev + 1)
+        done = threading.Barrier(n_dev + 1)
+        errs = []
+
+        def work(d):
+            try:
+                for i in range(W):
+                    als[d].align_device(bufs[d][i % 2].data_ptr(), offs[d].data_ptr(), R, R * L, L, m=args.mismatch, effort=args.effort, mode=mode)
+                als[d].sync()
+                start.wait()
+                for i in range(K):
+                    als[d].align_device(bufs[d][i % 2].data_ptr(), offs[d].data_ptr(), R, R * L, L, m=args.mismatch, effort=args.effort, mode=mode)
+                als[d].sync()
+            except Exception as ex:
+                errs.append("%s: %s" % (type(ex).__name__, ex))
+                try:
+                    start.abort()
+                except Exception:
+                    pass
+            finally:
+                try:
+                    done.wait()
+                except threading.BrokenBarrierError:
+                    pass
+
+        ts = [threading.Thread(target=work, args=(d,)) for d in range(n_dev)]
+        for t in ts:
+            t.start()
+        try:
+            start.wait()
+            t1 = time.perf_counter()
+            done.wait()
+            wall = time.perf_counter() - t1
+        except threading.BrokenBarrierError:
+            wall = None
+        for t in ts:
+            t.join()
+        counters = [als[d].counters() for d in range(n_dev)] if not errs else None
+        for al in als:
+            al.close()
+        for x in offs + [b for db in bufs for b in db]:
+            x.free()
+        if errs or wall is None:
+            return {"error": "; ".join(errs) or "barrier broken"}
+        return {"value": round(n_dev * K * R / wall / 1e6, 3), "unit": "Mreads/s", "n_gpus": n_dev, "steps": K, "reads_per_step_per_gpu": R, "ms_per_step": round(wall / K * 1e3, 4),
+                "fanout_method": {0: "none (one device)", 1: "rccl broadcast (ncclCommInitAll)", 2: "peer copies, doubling schedule"}.get(how, str(how)),
+                "fanout_ms": round(fan_ms, 2), "graph_blob_bytes": int(g.info()["blob_bytes"]), "rehearsal_devices_shared": bool(rehearsal),
+                "reads_mapped_per_device": [c["reads"] for c in counters],
+                "what": "bgr_devices_init + one bgr_aligner and one host thread per device in ONE process, batches resident in each device's HBM (bgr_device_alloc), "
+                        "wall time from a common start barrier to the last device's sync"}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+
+def cpu_quota():
+    """CPUs this process may use at once by the cgroup's quota (cpu.max), or None"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(float(q) / float(per), 2)
+    except Exception:
+        return None
+
+
+def run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads):
+    """Exhaustive mode on the host: the compiled reference with -b (alignerExhaustive.cpp:262-318) on a bounded sample.  It writes
+    nothing in that mode (alignerExhaustive.cpp:285: the fwrite is commented out), so what is compared with the GPU is the count it
+    prints at the end (aligner.cpp:588-596 `Overlap and aligned`)."""
+    R, L = args.reads_per_step, args.read_len
+    nc = min(args.cpu_sample_exh, R)
+    ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
+    exe, kind = (ref, "reference") if os.path.exists(ref) else (os.path.join(ROOT, "oracle", "bgreat_oracle"), "port")
+    d = tempfile.mkdtemp(prefix="bgr_cpux_")
+    try:
+        syn.write_unitigs(os.path.join(d, "u.fa"))
+        syn.write_reads(os.path.join(d, "r.fa"), 0, nc, L, args.mismatch, seed_reads)
+        open(os.path.join(d, "empty.fa"), "w").close()
+        cores = min(ncpu, 255)
+
+        def timed(reads_file, sub):
+            wd = os.path.join(d, sub)
+            os.makedirs(wd)
+            cmd = [exe, "-r", os.path.join(d, reads_file), "-k", str(args.k), "-g", os.path.join(d, "u.fa"), "-m", str(args.mismatch), "-e", str(args.effort), "-t", str(cores), "-b"]
+            t1 = time.perf_counter()
+            out = subprocess.run(cmd, cwd=wd, check=True, stdout=subprocess.PIPE, text=True).stdout
+            return time.perf_counter() - t1, out
+
+        wall, out = timed("r.fa", "tN")
+        wall_idx, _ = timed("empty.fa", "iN")
+        map_s = max(1e-6, wall - wall_idx)
+        ref_aligned = ref_reads = None
+        tail = out[out.rfind("The End"):] if "The End" in out else out
+        for line in tail.splitlines():
+            if line.startswith("Overlap and aligned"):
+                ref_aligned = int(line.split(":")[1].split()[0])
+            elif line.startswith("Reads :"):
+                ref_reads = int(line.split(":")[1].split()[0])
+        c_reads = first_host[: nc * L]
+        c_offs = np.arange(nc + 1, dtype=np.uint64) * np.uint64(L)
+        gp, gpo, gst = al.align(c_reads, c_offs, m=args.mismatch, effort=args.effort, mode=1)
+        gpu_aligned = int((gpo[1:] > gpo[:-1]).sum())
+        return {"value": round(nc / map_s / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "host_cores_visible": len(os.sched_getaffinity(0)),
+                "cpu_quota": cpu_quota(),
+                "sample": "first %d reads of step 0 of this workload, %s -b -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(exe), cores, wall, wall_idx),
+                "reference_reads": ref_reads, "reference_aligned": ref_aligned, "gpu_aligned": gpu_aligned,
+                "gpu_matches_cpu_counters": bool(ref_aligned == gpu_aligned and ref_reads == nc)}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -689,6 +928,18 @@ def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
         wall_idx1, _, _ = timed("empty.fa", 1, "i1")
         map_s = max(1e-6, wall - wall_idx)
         map_s1 = max(1e-6, wall1 - wall_idx1)
+        # ... and with a worker per visible CPU (`-t N`, N = all host cores; coreNumber is an unsigned char, bgreat.cpp:75-77: at
+        # most 255).  A GPU box's container sees all CPUs of the host but may run only its cgroup quota of them at once (cpu_quota).
+        all_cores = None
+        n_all = min(255, len(os.sched_getaffinity(0)))
+        if args.cpu_sample_all > 0 and n_all > cores:
+            na = args.cpu_sample_all
+            syn.write_reads(os.path.join(d, "ra.fa"), 0, na, L, args.mismatch, seed_reads, threads=ncpu)
+            wall_a, own_a, _ = timed("ra.fa", n_all, "tA")
+            wall_ia, _, _ = timed("empty.fa", n_all, "iA")
+            all_cores = {"value": round(na / max(1e-6, wall_a - wall_ia) / 1e6, 4), "unit": "Mreads/s", "cores": n_all, "cpu_quota": cpu_quota(),
+                         "sample": "first %d reads, %s -t %d, wall %.2fs minus %.2fs index-only run" % (na, os.path.basename(exe), n_all, wall_a, wall_ia),
+                         "reference_stdout_reads_per_second": own_a}
         # parity at scale: GPU records == reference records as a multiset (-t N interleaves records)
         ref_paths = open(os.path.join(wd, "paths"), "rb").read().split(b"\n")
         c_reads = first_host[: nc * L]
@@ -709,7 +960,7 @@ def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
                     break
         return {"value": round(nc / map_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "host_cores_visible": len(os.sched_getaffinity(0)),
                 "sample": "first %d reads of step 0 of this workload, %s -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(exe), cores, wall, wall_idx),
-                "reference_stdout_reads_per_second": own_line,
+                "reference_stdout_reads_per_second": own_line, "cpu_quota": cpu_quota(), "all_cores": all_cores,
                 "t1": {"value": round(n1 / map_s1 / 1e6, 4), "unit": "Mreads/s", "cores": 1,
                        "sample": "first %d reads, %s -t 1, wall %.2fs minus %.2fs index-only run" % (n1, os.path.basename(exe), wall1, wall_idx1),
                        "reference_stdout_reads_per_second": own_line1},

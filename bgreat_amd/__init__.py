@@ -33,7 +33,8 @@ SYMBOLS = [
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup", "bgr_graph_key_lookup",
     "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
     "bgr_align_fasta_text", "bgr_aligner_fetch_text", "bgr_host_cache_release", "bgr_device_local_cpus", "bgr_text_stage_create", "bgr_text_stage_destroy", "bgr_text_stage_upload",
-    "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait",
+    "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait", "bgr_text_stage_device",
+    "bgr_device_alloc", "bgr_device_free", "bgr_device_upload", "bgr_device_download",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
@@ -174,6 +175,11 @@ def lib():
     L.bgr_readset_load.argtypes = [C.c_char_p, i32, u32, C.POINTER(vp)]
     L.bgr_readset_load_parallel.argtypes = [C.c_char_p, i32, u32, u32, u64, C.POINTER(vp)]
     L.bgr_align_all.argtypes = [vp, C.POINTER(Params), C.POINTER(RunOptions), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_double)]
+    L.bgr_text_stage_device.argtypes = [vp]
+    L.bgr_device_alloc.argtypes = [i32, u64, C.POINTER(vp)]
+    L.bgr_device_free.argtypes = [i32, vp]
+    L.bgr_device_upload.argtypes = [i32, vp, vp, u64]
+    L.bgr_device_download.argtypes = [i32, vp, vp, u64]
     L.bgr_host_alloc.argtypes = [u64, C.POINTER(vp)]
     L.bgr_host_free.argtypes = [vp]
     L.bgr_readset_count.restype = u64
@@ -193,6 +199,29 @@ def _check(rc):
 
 def device_count():
     return lib().bgr_device_count()
+
+
+class DeviceBuffer:
+    """A numpy array parked in a device's HBM through the C-ABI (bgr_device_alloc / upload): input of bgr_align_device."""
+
+    def __init__(self, device, array):
+        a = np.ascontiguousarray(array)
+        self.device, self.nbytes = device, a.nbytes
+        p = C.c_void_p()
+        _check(lib().bgr_device_alloc(device, a.nbytes, C.byref(p)))
+        self.ptr = p.value
+        _check(lib().bgr_device_upload(device, self.ptr, a.ctypes.data, a.nbytes))
+
+    def data_ptr(self):
+        return self.ptr
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().bgr_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
 
 
 def _as_u8(a):

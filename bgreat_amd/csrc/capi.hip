@@ -1450,6 +1450,31 @@ int bgr_device_local_cpus(int device, char* cpulist_out, uint64_t cap) {
     return BGR_OK;
 }
 
+int bgr_device_alloc(int device, uint64_t bytes, void** out) {
+    if (!out) return fail(BGR_E_ARG, "bgr_device_alloc: null argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return BGR_OK;
+}
+int bgr_device_free(int device, void* p) {
+    if (!p) return BGR_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(p));
+    return BGR_OK;
+}
+int bgr_device_upload(int device, void* dst_device, const void* src_host, uint64_t bytes) {
+    if (bytes && (!dst_device || !src_host)) return fail(BGR_E_ARG, "bgr_device_upload: null argument");
+    HIP_TRY(hipSetDevice(device));
+    if (bytes) HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return BGR_OK;
+}
+int bgr_device_download(int device, void* dst_host, const void* src_device, uint64_t bytes) {
+    if (bytes && (!dst_host || !src_device)) return fail(BGR_E_ARG, "bgr_device_download: null argument");
+    HIP_TRY(hipSetDevice(device));
+    if (bytes) HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return BGR_OK;
+}
+
 // Page-locked host memory.  hipHostMalloc pins 4 KB pages at ~4.4 GB/s on this platform, from any number of threads; an anonymous
 // mapping with transparent huge pages asked for, touched once per 2 MB and then registered pins at ~26 GB/s (tools/ubench/pin_alloc.hip) --
 // bgr_align_all takes ~0.7 GB of staging sets while its pipeline ramps up, 0.17 s of a 0.6 s run of 100 M reads.  Buffers of 2 MB and

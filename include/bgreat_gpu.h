@@ -350,6 +350,13 @@ int bgr_align_all(bgr_graph* g, const bgr_params* p, const bgr_run_options* o, c
  * page-locked memory they allocate belong on its NUMA node.  BGR_E_IO when the platform does not say. */
 int bgr_device_local_cpus(int device, char* cpulist_out, uint64_t cap);
 
+/* Device memory for callers of bgr_align_device that have no HIP runtime of their own (a cgo / ctypes host parks its batches in HBM
+ * through these three); any other device pointer of the same process works as well.  upload / download are blocking copies. */
+int bgr_device_alloc(int device, uint64_t bytes, void** out);
+int bgr_device_free(int device, void* p);
+int bgr_device_upload(int device, void* dst_device, const void* src_host, uint64_t bytes);
+int bgr_device_download(int device, void* dst_host, const void* src_device, uint64_t bytes);
+
 /* Page-locked host memory for batches handed to bgr_align_batch (faster H2D/D2H); plain memory works too. */
 int bgr_host_alloc(uint64_t bytes, void** out);
 int bgr_host_free(void* p);

@@ -810,6 +810,43 @@ def test_full_size_batch_properties():
         assert np.array_equal(p1[int(po1[i]): int(po1[i + 1])], ps[int(pos[j]): int(pos[j + 1])])
 
 
+def test_configs1_at_its_stated_size_equals_the_oracle():
+    """BASELINE configs[1] as stated -- 1 M x 100 bp reads, k=31, m=2, ~10 k-unitig graph (250 kb genome, a 2-allele site every ~75 bp:
+    SURVEY 8d config 2), greedy -- one launch, EVERY row against the oracle (sixteen oracle instances on host threads), plus the counters."""
+    from concurrent.futures import ThreadPoolExecutor
+    s = Synth(250_000, 75, 2, 31, 20261003)
+    seqs, offs = s.unitigs()
+    assert 9_000 < len(offs) - 1 < 12_000
+    n, L = 1_000_000, 100
+    reads, roffs = s.reads(0, n, L, 2, 77, threads=16)
+    g = B.Graph.build(31, seqs, offs)
+    al = B.Aligner(g, 0)
+    al.reset_counters()
+    p1, po1, st1 = al.align(reads, roffs, m=2, effort=2)
+    c1 = al.counters()
+    parts = 16
+    cuts = [n * i // parts for i in range(parts + 1)]
+
+    def part(i):
+        o = oracle_py.Oracle(31, seqs, offs)
+        lo, hi = cuts[i], cuts[i + 1]
+        return o.align(reads[lo * L: hi * L], np.arange(hi - lo + 1, dtype=np.uint64) * L, m=2, effort=2), o.counters()
+
+    with ThreadPoolExecutor(parts) as ex:
+        res = list(ex.map(part, range(parts)))
+    tot = {k: 0 for k in res[0][1]}
+    for i, ((p2, po2, st2), c2) in enumerate(res):
+        lo, hi = cuts[i], cuts[i + 1]
+        assert np.array_equal(st1[lo:hi], st2)
+        assert np.array_equal(po1[lo: hi + 1] - po1[lo], po2)
+        assert np.array_equal(p1[int(po1[lo]): int(po1[hi])], p2)
+        for k in tot:
+            tot[k] += c2[k]
+    for k in ("reads", "no_overlap", "aligned", "not_aligned"):
+        assert c1[k] == tot[k], (k, c1, tot)
+    assert c1["reads"] == n and c1["aligned"] > 0.8 * n
+
+
 def test_oversized_batch_is_mapped_in_pieces():
     """bgr_align_batch splits a batch whose path arena would not fit 32-bit addressing; with the limit lowered the split
     path runs on a small batch and must give the rows of the unsplit call."""
@@ -898,7 +935,7 @@ def test_bench_line_contract():
     import subprocess
     import sys
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads-per-step", "200000", "--e2e-reads", "200000",
-           "--pcie-steps", "1", "--cpu-sample", "20000", "--alg-sample", "4000", "--no-pmc", "--genome", "400000"]
+           "--pcie-steps", "1", "--cpu-sample", "20000", "--cpu-sample-all", "30000", "--alg-sample", "4000", "--no-pmc", "--no-sub", "--genome", "400000"]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -924,3 +961,29 @@ def test_bench_line_contract():
     assert c["t1"]["value"] > 0 and c["t1"]["cores"] == 1 and c["cpu_model"]
     assert d["parity_sample"]["gpu_equals_oracle"] is True
     assert d["pcie_inclusive"]["value"] > 0 and d["e2e"]["value"] > 0
+    # SURVEY 8d's two metrics as first-class values: (i) PCIe inclusive, one blocking caller; (ii) end to end = the MEDIAN of the runs
+    assert d["value_pcie_inclusive"] == d["pcie_inclusive"]["value"] and d["value_e2e"] == d["e2e"]["value"]
+    runs = d["e2e"]["runs_mreads_per_s"]
+    assert len(runs) == 3 and min(runs) - 0.1 <= d["e2e"]["value"] <= max(runs) + 0.1 and d["e2e"]["worst"] <= d["e2e"]["value"] <= d["e2e"]["best"]
+    if c.get("all_cores"):   # (only on hosts with more visible CPUs than --cpu-threads)
+        assert c["all_cores"]["value"] > 0 and c["all_cores"]["cores"] > c["cores"]
+
+
+def test_bench_sub_record_of_the_exhaustive_config():
+    """The default bench line carries configs[1], [3] and [4] as sub-records (children `bench.py --workload W --sub-record`); here the
+    exhaustive one on a small graph: one JSON line, the device-resident leg only, a parity sample, and the reference's -b counters on
+    a bounded sample next to the GPU's."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "branchy", "--sub-record", "--steps", "2", "--warmup", "1", "--reads-per-step", "100000",
+           "--genome", "300000", "--cpu-sample-exh", "5000", "--alg-sample", "2000", "--no-pmc"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["e2e"] is None and d["pcie_inclusive"] is None and d["other_configs"] is None
+    assert "exhaustive" in d["config"]["workload"] and d["parity_sample"]["gpu_equals_oracle"] is True
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["value"] > 0 and c["reference_reads"] == 5000 and c["gpu_matches_cpu_counters"] is True

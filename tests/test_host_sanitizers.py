@@ -31,7 +31,9 @@ def test_host_pipeline_is_sanitizer_clean(flags, tmp_path):
     """bgr_align_all's threads (producer, gatherer, 2 stream workers per device x 2 devices, formatter, writers, worker
     pool, page-locked ring) over golden files with 1..100000-read batches, against a stand-in for the GPU calls
     (tests/sanitize_pipeline.cpp): every record once, in input order, in the right file; and what the reference prints to
-    stdout while it maps (file names, the exhaustive worker's periodic block) between the right reads."""
+    stdout while it maps (file names, the exhaustive worker's periodic block) between the right reads; consecutive runs on different
+    first devices (cached staging sets carry text stages of the earlier run's devices); split runs (one pipeline per device, 2 / 3 / 8
+    lanes, both routes, several input files): the pairs concatenated in device order == the single pipeline's bytes."""
     exe = str(tmp_path / "sanitize_pipeline")
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", flags, "-I" + SRC, "-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "sanitize_pipeline.cpp"), os.path.join(SRC, "pipeline.cpp"), os.path.join(SRC, "fastx.cpp"),
@@ -42,5 +44,5 @@ def test_host_pipeline_is_sanitizer_clean(flags, tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
     p = subprocess.run([exe, GOLD, str(out)], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert p.stdout.count(" ok") == 6 and "FAIL" not in p.stdout
+    assert p.stdout.count(" ok") == 7 and "split runs ok" in p.stdout and "FAIL" not in p.stdout
     assert "ERROR: " not in p.stderr and "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
