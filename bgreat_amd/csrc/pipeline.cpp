@@ -1200,7 +1200,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     {   // the page-locked sets wait for the next run of this process (bgr_host_cache_release)
         std::unique_ptr<Pinned> pn;
         std::lock_guard<std::mutex> l(g_pin_cache_m);
-        while (free_pins.try_pop(pn)) if (g_pin_cache.size() < 8) g_pin_cache.push_back(std::move(pn));
+        while (free_pins.try_pop(pn)) if (g_pin_cache.size() < 96) g_pin_cache.push_back(std::move(pn));  // (the lanes of a split run on eight devices hold 64 sets)
     }
     free_pins.close();
     free_batches.close();
@@ -1276,6 +1276,7 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
     std::vector<int> rcs(n, BGR_OK);
     std::vector<std::string> errs(n);
     std::vector<std::array<uint64_t, 5>> cnt(n);
+    std::vector<double> lane_end(n, 0.0), lane_secs(n, 0.0);
     std::vector<std::thread> lanes;
     for (unsigned d = 0; d < n; ++d) {
         lanes.emplace_back([&, d]() {
@@ -1298,11 +1299,18 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
             cnt[d].fill(0);
             double secs = 0;
             rcs[d] = align_all_impl(graph, prm, &o, in, pf.c_str(), nf.c_str(), cnt[d].data(), &secs, &cancel);
+            lane_end[d] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            lane_secs[d] = secs;
+            if (getenv("BGREAT_TIMING")) fprintf(stderr, "bgreat: lane %u (device %u): %llu reads in %.3f s, done %.3f s after the start of the run\n", d, o.first_device, (unsigned long long)cnt[d][0], secs, lane_end[d]);
             if (rcs[d] != BGR_OK) errs[d] = bgr_last_error();  // (the message is the lane thread's own)
         });
     }
     for (auto& t : lanes) t.join();
-    if (mapping_seconds) *mapping_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (mapping_seconds) {  // as for one pipeline: from the (first) pipeline's start -- output files open, aligners made -- to the (last) one's end
+        double first = 1e300, last = 0;
+        for (unsigned d = 0; d < n; ++d) { first = std::min(first, lane_end[d] - lane_secs[d]); last = std::max(last, lane_end[d]); }
+        *mapping_seconds = std::max(0.0, last - first);
+    }
     int rc = BGR_OK;
     std::string err;
     for (unsigned d = 0; d < n; ++d)   // the lane that failed, not the ones it stopped

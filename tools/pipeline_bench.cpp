@@ -2,7 +2,7 @@
 //
 // What it answers: does the HOST side of `bgreat --gpus N` keep N devices fed?  The GPU side of the C-ABI is replaced by a stand-in
 // that costs the host (almost) nothing -- a text call waits as long as the piece would take to cross PCIe (bytes / 40 GB/s, the
-// measured rate of one device's link) and hands back record streams of the real size (52 bytes per read, cut out of the
+// measured rate of one device's link) and hands back record streams of the real size (51 bytes per read, cut out of the
 // piece) -- so the Mreads/s printed are those of the producer, gatherer (pread into the staging buffers), ordered writer and write()
 // stages alone.  Two forms per device count: ONE ordered pipeline into one pair of files (the reference's format; one producer, one
 // gatherer, one writer per file) and the split run (bgr_run_options.split_output: a pipeline per device, N pairs).  The split run's
@@ -50,20 +50,24 @@ int bgr_text_stage_create(int device, bgr_text_stage** out) { *out = new bgr_tex
 void bgr_text_stage_destroy(bgr_text_stage* s) { delete s; }
 int bgr_text_stage_device(const bgr_text_stage* s) { return s ? s->device : -1; }
 int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t n) { s->text = text; s->bytes = n; return BGR_OK; }  // (the copy engine's work: no host CPU)
-// every record is 165 bytes (fixed-width header): its first 28 bytes go to the paths stream, the next 24 to the other one -- 52 bytes per
-// read as in a real run, and the same bytes wherever the pieces are cut
+// Every record is 165 bytes and its header spells its number in the file, so the streams can be defined per record whatever piece it
+// travels in: records whose number is a multiple of 6 go to the paths stream whole, those with number % 7 == 3 to the other one --
+// 27.5 + 23.6 bytes per read as in a real run, one memcpy per selected record (in the product these bytes arrive by DMA).
+static uint64_t first_number(const char* t) { return strtoull(t + 2, nullptr, 10); }   // ">r00000001234\n..."
+static uint64_t count_res(uint64_t first, uint64_t n, uint64_t mod, uint64_t res) {     // numbers in [first, first + n) that are = res (mod)
+    auto upto = [&](uint64_t x) { return x / mod + (x % mod > res ? 1 : 0); };           // in [0, x)
+    return upto(first + n) - upto(first);
+}
 int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
     b->paths_bytes = a->pb;
     b->notaligned_bytes = a->nb;
     if (a->pb > b->paths_cap || a->nb > b->notaligned_cap) return BGR_E_CAPACITY;
-    const uint64_t recs = a->n / 165;
+    const uint64_t recs = a->n / 165, first = first_number(a->text);
     char* po = b->paths_out;
     char* no = b->notaligned_out;
-    for (uint64_t i = 0; i < recs; ++i) {  // (in the product these bytes arrive by DMA)
-        memcpy(po + 28 * i, a->text + 165 * i, 28);
-        memcpy(no + 24 * i, a->text + 165 * i + 28, 24);
-    }
-    return BGR_OK;
+    for (uint64_t i = (6 - first % 6) % 6; i < recs; i += 6) { memcpy(po, a->text + 165 * i, 165); po += 165; }
+    for (uint64_t i = (3 + 7 - first % 7) % 7; i < recs; i += 7) { memcpy(no, a->text + 165 * i, 165); no += 165; }
+    return (uint64_t)(po - b->paths_out) == a->pb && (uint64_t)(no - b->notaligned_out) == a->nb ? BGR_OK : bgr::set_error(BGR_E_INTERNAL, "stand-in: stream sizes");
 }
 int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_batch* b) {
     b->irregular = 0; b->n_records = b->n_accepted = b->paths_bytes = b->notaligned_bytes = 0;
@@ -74,8 +78,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_batch* b) {
     // the piece crosses the device's link, the kernels run under the next piece's copy
     std::this_thread::sleep_for(std::chrono::nanoseconds((uint64_t)((double)n / g_link_gbs)));
     a->text = b->text; a->n = n;
-    const uint64_t recs = n / 165;
-    a->pb = recs * 28; a->nb = recs * 24;
+    const uint64_t recs = n / 165, first = first_number(b->text);
+    a->pb = 165 * count_res(first, recs, 6, 0); a->nb = 165 * count_res(first, recs, 7, 3);
     b->n_records = b->n_accepted = recs;
     a->counters[0] += recs; a->counters[2] += recs * 9 / 10; a->counters[3] += recs - recs * 9 / 10;
     if (!b->want_output) return BGR_OK;
@@ -148,7 +152,10 @@ int main(int argc, char** argv) {
             opt.n_gpus = n; opt.threads = threads; opt.split_output = (uint32_t)split; opt.numa = 1;
             const std::string pf = dir + "/paths", nf = dir + "/notAligned.fa";
             uint64_t tot[5]; double secs = 0, best = 0;
-            for (int rep = 0; rep < 2; ++rep) {  // (the second run has the staging sets of the first)
+            for (int rep = 0; rep < 3; ++rep) {  // (later runs have the staging sets of the first)
+                unlink(pf.c_str()); unlink(nf.c_str());
+                for (unsigned d = 0; d < n; ++d) { unlink((pf + "." + std::to_string(d)).c_str()); unlink((nf + "." + std::to_string(d)).c_str()); }
+                sync();  // not timed: dirty pages of the input file / the previous run's outputs would throttle this run's writes
                 const int rc = bgr_align_all(&g, &prm, &opt, in.c_str(), pf.c_str(), nf.c_str(), tot, &secs);
                 if (rc != BGR_OK) { fprintf(stderr, "run failed: %s\n", bgr_last_error()); return 1; }
                 best = std::max(best, (double)reads / secs / 1e6);
