@@ -33,7 +33,7 @@ SYMBOLS = [
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup", "bgr_graph_key_lookup",
     "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
     "bgr_align_fasta_text", "bgr_aligner_fetch_text", "bgr_host_cache_release", "bgr_device_local_cpus", "bgr_text_stage_create", "bgr_text_stage_destroy", "bgr_text_stage_upload",
-    "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait", "bgr_text_stage_device",
+    "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait", "bgr_text_stage_device", "bgr_text_stage_upload_parts",
     "bgr_device_alloc", "bgr_device_free", "bgr_device_upload", "bgr_device_download",
 ]
 KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8
@@ -176,6 +176,7 @@ def lib():
     L.bgr_readset_load_parallel.argtypes = [C.c_char_p, i32, u32, u32, u64, C.POINTER(vp)]
     L.bgr_align_all.argtypes = [vp, C.POINTER(Params), C.POINTER(RunOptions), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_double)]
     L.bgr_text_stage_device.argtypes = [vp]
+    L.bgr_text_stage_upload_parts.argtypes = [vp, u32, vp, vp]
     L.bgr_device_alloc.argtypes = [i32, u64, C.POINTER(vp)]
     L.bgr_device_free.argtypes = [i32, vp]
     L.bgr_device_upload.argtypes = [i32, vp, vp, u64]
@@ -405,21 +406,31 @@ class Aligner:
         _check(lib().bgr_align_batch_wait(C.byref(t), paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
         return paths[: int(poffs[n])].copy(), poffs, status[:n]
 
-    def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False, fastq=False):
+    def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False, fastq=False, parts=None):
         """bgr_align_fasta_text: a piece of a FASTA file (bytes) -> (paths bytes, notAligned bytes, info dict); info["irregular"] = the
-        device left the piece to the host parser (nothing mapped).  fastq: the piece is whole four-line FASTQ records instead.  A too small `paths_cap` is grown through bgr_aligner_fetch_text."""
+        device left the piece to the host parser (nothing mapped).  fastq: True / 1 = the piece is whole four-line FASTQ records instead, 2 = their
+        header and read lines only.  A too small `paths_cap` is grown through bgr_aligner_fetch_text.  parts (with staged): byte offsets at which
+        the piece is cut into host ranges sent with bgr_text_stage_upload_parts (the call itself then gets no host pointer)."""
         text = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else _as_u8(text)
         n = len(text)
         pcap = n + 64 if paths_cap is None else paths_cap
         pout = np.empty(max(pcap, 1), dtype=np.uint8)
         nout = np.empty(n + 64, dtype=np.uint8)
         b = TextBatch(text.ctypes.data if n else None, n, int(want_output), 0, pout.ctypes.data, pcap, nout.ctypes.data, n + 64, 0, 0, 0, 0, None)
-        b.fastq = int(bool(fastq))
+        b.fastq = int(fastq)
         p = Params(mode, m, effort, int(partial))
         stage = C.c_void_p()
         if staged:  # the piece sent ahead on a copy stream of its own (bgr_text_stage_upload); the call orders itself behind it
             _check(lib().bgr_text_stage_create(0, C.byref(stage)))
-            _check(lib().bgr_text_stage_upload(stage, text.ctypes.data if n else None, n))
+            if parts is None:
+                _check(lib().bgr_text_stage_upload(stage, text.ctypes.data if n else None, n))
+            else:
+                cuts = [0] + sorted(int(x) for x in parts) + [n]
+                keep = [np.ascontiguousarray(text[cuts[i]: cuts[i + 1]]).copy() for i in range(len(cuts) - 1)]   # separate host ranges
+                ptrs = (C.c_void_p * len(keep))(*[k.ctypes.data if len(k) else None for k in keep])
+                lens = (C.c_uint64 * len(keep))(*[len(k) for k in keep])
+                _check(lib().bgr_text_stage_upload_parts(stage, len(keep), ptrs, lens))
+                b.text = None
             b.stage = stage
         try:
             rc = lib().bgr_align_fasta_text(self.h, C.byref(p), C.byref(b))

@@ -983,6 +983,27 @@ int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t bytes) {
     return BGR_OK;
 }
 
+int bgr_text_stage_upload_parts(bgr_text_stage* s, uint32_t n_parts, const char* const* parts, const uint64_t* part_bytes) {
+    if (!s || (n_parts && (!parts || !part_bytes))) return fail(BGR_E_ARG, "bgr_text_stage_upload_parts: null argument");
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < n_parts; ++i) { if (part_bytes[i] && !parts[i]) return fail(BGR_E_ARG, "bgr_text_stage_upload_parts: null part"); bytes += part_bytes[i]; }
+    if (bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_text_stage_upload_parts: piece of 2 GiB or more; cut it");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));  // (a piece still on its way: the buffer may grow, i.e. move)
+    s->settle();
+    HIP_TRY(s->buf.ensure(bytes + 64));
+    if (s->timing) { HIP_TRY(hipEventRecord(s->ev0, s->stream)); s->pending = true; }
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(s->buf.p) + bytes, 0, 64, s->stream));
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n_parts; ++i) {
+        if (part_bytes[i]) HIP_TRY(hipMemcpyAsync(static_cast<char*>(s->buf.p) + at, parts[i], part_bytes[i], hipMemcpyHostToDevice, s->stream));
+        at += part_bytes[i];
+    }
+    HIP_TRY(hipEventRecord(s->ev, s->stream));
+    s->bytes = bytes;
+    return BGR_OK;
+}
+
 static double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b) {
@@ -991,6 +1012,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     auto lap = [&](int i) { const double t = wall_now(); a->tx_phase_s[i] += t - tw; tw = t; };
     if (b->text_bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_align_fasta_text: piece of 2 GiB or more; cut it");
     if (b->want_output > 2) return fail(BGR_E_ARG, "bgr_align_fasta_text: want_output must be 0, 1 or 2");
+    if (b->fastq > 2) return fail(BGR_E_ARG, "bgr_align_fasta_text: fastq must be 0, 1 (four-line records) or 2 (header and read lines only)");
+    const uint32_t rec_lines = b->fastq == 2 ? 2u : b->fastq ? 4u : 0u;  // lines per record of a FASTQ piece (0: FASTA, records start at '>' lines)
     if (b->fastq && b->text_bytes && b->text && b->text[b->text_bytes - 1] != '\n' && !b->stage)
         return fail(BGR_E_ARG, "bgr_align_fasta_text: a FASTQ piece holds whole four-line records and ends with a newline");
     if (b->want_output == 2 && (a->graph->header.has_exc || p->mode == BGR_MODE_EXHAUSTIVE))
@@ -1029,7 +1052,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     HIP_TRY(a->tx_rec.ensure(((uint64_t)R_cap + 1) * 16));
     HIP_TRY(a->tx_offs.ensure(((uint64_t)R_cap + 2) * 8));
     uint32_t* sums2 = static_cast<uint32_t*>(a->tx_sums.p) + bgr::text_tiles(nbytes);
-    hipError_t e = bgr::launch_text_mark(text, nbytes, b->fastq != 0, static_cast<uint32_t*>(a->tx_sums.p), static_cast<uint32_t*>(a->tx_start.p), R_cap, info + TXT_INFO_N_REC, a->stream);
+    hipError_t e = bgr::launch_text_mark(text, nbytes, rec_lines, static_cast<uint32_t*>(a->tx_sums.p), static_cast<uint32_t*>(a->tx_start.p), R_cap, info + TXT_INFO_N_REC, a->stream);
     if (e == hipSuccess) e = bgr::launch_text_records(text, nbytes, b->fastq != 0, static_cast<const uint32_t*>(a->tx_start.p), info + TXT_INFO_N_REC, R_cap, a->dg.k, static_cast<uint4*>(a->tx_rec.p),
                                                       static_cast<uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_len.p), info, a->stream);
     if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_idx.p), R_cap, sums2, info + TXT_INFO_N_ACC, a->stream);

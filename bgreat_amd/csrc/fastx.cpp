@@ -292,6 +292,33 @@ uint64_t FastqPlan::record_offset(uint64_t rec) const {
     return size_;
 }
 
+void FastqPlan::piece_parts(uint64_t o0, uint64_t o1, uint64_t r0, std::vector<std::pair<uint64_t, uint64_t>>& out) const {
+    out.clear();
+    out.push_back({o0, 4 * r0});
+    for (size_t c = (size_t)(o0 / chunk_bytes_) + 1; c < nc_ && c <= summed_ && c * chunk_bytes_ < o1; ++c)
+        out.push_back({c * chunk_bytes_, nl_[c]});  // nl_[c] = newlines in front of the chunk = number of the line its first byte lies in
+}
+
+uint64_t fastq_gather_lines(const char* data, uint64_t b, uint64_t e, uint64_t line, char* dst) {
+    char* o = dst;
+    uint64_t pos = b;
+    while (pos < e) {
+        const uint64_t phase = line & 3;
+        const bool keep = phase < 2;
+        uint64_t need = keep ? 2 - phase : 4 - phase;  // newlines up to the end of this run of kept / skipped lines
+        const uint64_t start = pos;
+        while (need && pos < e) {
+            const char* q = static_cast<const char*>(memchr(data + pos, '\n', (size_t)(e - pos)));
+            if (!q) { pos = e; break; }
+            pos = (uint64_t)(q - data) + 1;
+            ++line;
+            --need;
+        }
+        if (keep) { memcpy(o, data + start, (size_t)(pos - start)); o += pos - start; }
+    }
+    return (uint64_t)(o - dst);
+}
+
 void parse_fastq_records(const char* data, uint64_t begin, uint64_t end, ParsedChunk& out) {
     std::string none;
     uint64_t pos = begin;

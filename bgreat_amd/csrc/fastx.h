@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace bgr {
@@ -90,6 +91,9 @@ public:
     // record_offset(r), r <= par_records(): the byte where line 4r starts (finish_counts() must have run)
     uint64_t par_records() const { return par_records_; }
     uint64_t record_offset(uint64_t rec) const;
+    // (text route) the piece [o0, o1) of whole records, o0 = record_offset(r0), cut where the plan's chunks begin: {first byte, number of
+    // the line that byte lies in}, ascending -- what fastq_gather_lines needs to work on the parts independently
+    void piece_parts(uint64_t o0, uint64_t o1, uint64_t r0, std::vector<std::pair<uint64_t, uint64_t>>& out) const;
 private:
     const char* data_;
     uint64_t size_, chunk_bytes_;
@@ -97,6 +101,10 @@ private:
     std::vector<uint64_t> nl_, tail_start_;
     uint64_t complete_ = 0, par_records_ = 0;
 };
+// Bytes [b, e) of a FASTQ image, byte b lying in line number `line` of the file (record j = lines 4j .. 4j+3, aligner.cpp:51-68): those
+// that belong to header lines (4j) and read lines (4j+1), newlines included, copied to dst in order -> bytes written (<= e - b).
+// The '+' and quality lines never reach the device this way: a 150 bp record crosses PCIe as ~165 instead of ~317 bytes.
+uint64_t fastq_gather_lines(const char* data, uint64_t b, uint64_t e, uint64_t line, char* dst);
 // Whole four-line records in [begin, end) (end = the start of a record): header line + sequence line, kept iff size > 2 and ACGTN
 // (what every getReads() call but a file's last one does, aligner.cpp:51-68).
 void parse_fastq_records(const char* data, uint64_t begin, uint64_t end, ParsedChunk& out);

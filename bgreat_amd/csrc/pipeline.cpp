@@ -192,6 +192,10 @@ struct Batch {
     // dev_text is set and the record streams sit in pin->ptext / pin->ntext
     bool text_piece = false, dev_text = false, fastq_piece = false;
     uint64_t t_begin = 0, t_end = 0, p_bytes = 0, n_bytes = 0;
+    // a FASTQ piece crosses PCIe without its '+' and quality lines: fq_parts = where the gatherer may cut it into independent parts
+    // ({first byte, number of the line it lies in}, FastqPlan::piece_parts), t_gathered = bytes of header + read lines staged
+    std::vector<std::pair<uint64_t, uint64_t>> fq_parts;
+    uint64_t t_gathered = 0;
     unsigned dev = 0;                                     // which device of the run maps the batch (round robin in input order)
     int rc = BGR_OK;
     std::string err;
@@ -551,6 +555,8 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     };
     const bool timing = getenv("BGREAT_TIMING") != nullptr;
     pool.timing = timing;
+    // FASTQ on the text route: only the header and read lines of a piece go to the device (BGREAT_FASTQ_GATHER=0: the four-line records as they are)
+    const bool fastq_gather = !(getenv("BGREAT_FASTQ_GATHER") && atoi(getenv("BGREAT_FASTQ_GATHER")) == 0);
     std::atomic<uint64_t> us_parse{0}, us_gather{0}, us_gpu{0}, us_format{0}, us_write{0}, us_alloc{0};
     auto now_us = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<bool> failed_here{false};
@@ -615,6 +621,8 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
             b->file = mf;
             b->bases = 0;
             b->text_piece = b->dev_text = b->fastq_piece = false;
+            b->fq_parts.clear();
+            b->t_gathered = 0;
             b->marks.clear();
             for (auto& m : pending) { m.pos = 0; b->marks.push_back(std::move(m)); }
             pending.clear();
@@ -683,6 +691,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                             tb->text_piece = o1 - o0 < (1ull << 31);  // (one record of 2 GiB: the host parser takes it)
                             tb->fastq_piece = true;
                             tb->t_begin = o0; tb->t_end = o1;
+                            if (fastq_gather) plan.piece_parts(o0, o1, r0, tb->fq_parts);
                             if (!tb->text_piece) {
                                 tb->chunks.clear();
                                 tb->chunks.push_back(std::make_unique<ParsedChunk>());
@@ -911,10 +920,33 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
         if (!b.pin->text.ensure(bytes + 64) || !b.pin->ptext.ensure(bytes / 2 + 4096) || !b.pin->ntext.ensure(bytes / 2 + 4096)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
         us_alloc += now_us() - tg0;
         const uint64_t tg1 = now_us();
+        Batch* bp = &b;
+        if (b.pin->stages.size() < n_gpus) b.pin->stages.resize(n_gpus, nullptr);
+        bgr_text_stage*& st = b.pin->stages[b.dev];
+        // (a set cached by an earlier run of the process may carry the stage of another device in this place: the index is relative to the run)
+        if (st && bgr_text_stage_device(st) != (int)(opt->first_device + b.dev)) { bgr_text_stage_destroy(st); st = nullptr; }
+        if (!st && bgr_text_stage_create((int)(opt->first_device + b.dev), &st) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+        if (b.fastq_piece && !b.fq_parts.empty()) {
+            // FASTQ: the header and read lines of every part, gathered where the part's bytes would have gone (never more than they are);
+            // the parts travel one after the other and lie back to back on the device
+            const size_t np = b.fq_parts.size();
+            std::vector<const char*> ptrs(np);
+            std::vector<uint64_t> lens(np);
+            pool.run(np, [&](size_t j) {
+                const uint64_t lo = bp->fq_parts[j].first, hi = j + 1 < np ? bp->fq_parts[j + 1].first : bp->t_end;
+                char* dst = static_cast<char*>(bp->pin->text.p) + (lo - bp->t_begin);
+                ptrs[j] = dst;
+                lens[j] = bgr::fastq_gather_lines(bp->file->data, lo, hi, bp->fq_parts[j].second, dst);
+            }, 2);
+            us_gather += now_us() - tg1;
+            b.t_gathered = 0;
+            for (uint64_t l : lens) b.t_gathered += l;
+            if (bgr_text_stage_upload_parts(st, (uint32_t)np, ptrs.data(), lens.data()) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+            return true;
+        }
         const uint64_t part = 4ull << 20;
         const size_t parts = (size_t)((bytes + part - 1) / part);
         std::atomic<bool> okc{true};
-        Batch* bp = &b;
         pool.run(parts, [&](size_t j) {
             const uint64_t lo = j * part, len = std::min<uint64_t>(part, bytes - lo);
             if (!bp->file->copy_out(static_cast<char*>(bp->pin->text.p) + lo, bp->t_begin + lo, len)) okc = false;
@@ -922,11 +954,6 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
         us_gather += now_us() - tg1;
         if (!okc) { fail(BGR_E_IO, "read error on the read file"); return false; }
         // ... and on towards its device at once, on the stage's own copy stream: the worker's call finds it there (or waits on the device)
-        if (b.pin->stages.size() < n_gpus) b.pin->stages.resize(n_gpus, nullptr);
-        bgr_text_stage*& st = b.pin->stages[b.dev];
-        // (a set cached by an earlier run of the process may carry the stage of another device in this place: the index is relative to the run)
-        if (st && bgr_text_stage_device(st) != (int)(opt->first_device + b.dev)) { bgr_text_stage_destroy(st); st = nullptr; }
-        if (!st && bgr_text_stage_create((int)(opt->first_device + b.dev), &st) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
         if (bgr_text_stage_upload(st, static_cast<const char*>(b.pin->text.p), bytes) != BGR_OK) { fail(BGR_E_HIP, bgr_last_error()); return false; }
         return true;
     };
@@ -996,6 +1023,11 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                     tb.text_bytes = b->t_end - b->t_begin;
                     tb.stage = b->pin->stages.size() > b->dev ? b->pin->stages[b->dev] : nullptr;
                     tb.fastq = b->fastq_piece ? 1u : 0u;
+                    if (b->fastq_piece && !b->fq_parts.empty()) {  // gathered: header and read lines only, held by the stage (parts with gaps on the host)
+                        tb.text = nullptr;
+                        tb.text_bytes = b->t_gathered;
+                        tb.fastq = 2u;
+                    }
                     tb.want_output = writes ? (correction ? 2u : 1u) : 0u;
                     tb.paths_out = static_cast<char*>(b->pin->ptext.p);
                     tb.paths_cap = b->pin->ptext.cap;

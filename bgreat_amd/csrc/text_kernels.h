@@ -25,7 +25,7 @@ hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32
 uint32_t scan_tiles(uint32_t n);
 uint32_t text_tiles(uint32_t bytes);
 // record starts: *n_rec_out and rec_start[0 .. min(*n_rec_out, rec_cap)) (sums: text_tiles(n) words of scratch)
-hipError_t launch_text_mark(const uint8_t* text, uint32_t n, bool fastq, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream);
+hipError_t launch_text_mark(const uint8_t* text, uint32_t n, uint32_t fastq_lines, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream);
 hipError_t launch_text_records(const uint8_t* text, uint32_t n, bool fastq, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t max_rec, uint32_t k, uint4* rec,
                                uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, hipStream_t stream);
 hipError_t launch_text_compact(const uint4* rec, const uint32_t* n_rec_p, uint32_t max_rec, const uint32_t* acc_idx, const uint32_t* base_off, uint32_t* acc_rec,

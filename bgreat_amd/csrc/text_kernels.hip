@@ -92,9 +92,11 @@ __device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t pat) { return 
 // (rec_cap: room in rec_start; a piece with more record starts than that is left to the host, the caller sees it from the count)
 // FASTQ (-q): record j is lines 4j .. 4j+3 whatever they contain (aligner.cpp:51-68), so the marks are the NEWLINES; the byte behind
 // every fourth one starts a record (the piece holds whole records and starts at one: the caller cuts it so)
-template <int PHASE, bool FASTQ>
+// (FASTQ = lines per record: 4, or 2 when the caller has left the '+' and quality lines on the host; 0 = FASTA)
+template <int PHASE, int FASTQ>
 __global__ void __launch_bounds__(kTxtThreads) bgr_text_mark_kernel(const uint8_t* text, uint32_t n, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap) {
     __shared__ uint32_t lw[16];
+    constexpr uint32_t LN = FASTQ ? (uint32_t)FASTQ : 1u;  // lines per FASTQ record (a power of two)
     const uint32_t pos = blockIdx.x * kTxtTile + threadIdx.x * 16;
     uint32_t rs = 0;  // bit i: byte pos + i starts a record (FASTQ: is a newline)
     if (FASTQ) {
@@ -134,13 +136,13 @@ __global__ void __launch_bounds__(kTxtThreads) bgr_text_mark_kernel(const uint8_
             const uint32_t i = (uint32_t)__ffs((int)rs) - 1;
             rs &= rs - 1;
             if (!FASTQ) { if (at < rec_cap) rec_start[at] = pos + i; }
-            else if (((at + 1) & 3u) == 0 && ((at + 1) >> 2) < rec_cap && pos + i + 1 < n) rec_start[(at + 1) >> 2] = pos + i + 1;  // behind the 4th, 8th ... newline
+            else if (((at + 1) & (LN - 1u)) == 0 && ((at + 1) / LN) < rec_cap && pos + i + 1 < n) rec_start[(at + 1) / LN] = pos + i + 1;  // behind the 4th, 8th ... (2nd, 4th ...) newline
             ++at;
         }
     }
 }
 // FASTQ: newlines counted -> records (a piece of whole records ends with a newline: 4 per record)
-__global__ void bgr_text_fastq_count_kernel(uint32_t* n_rec) { *n_rec = *n_rec >> 2; }
+__global__ void bgr_text_fastq_count_kernel(uint32_t* n_rec, uint32_t lines) { *n_rec = *n_rec / lines; }
 
 // ---- records: header / sequence extents, shape check, accept test ------------------------------------------------------------
 // min over the 16 lanes of a row, result in every lane
@@ -479,17 +481,19 @@ hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32
 uint32_t scan_tiles(uint32_t n) { return std::max<uint32_t>(1, (n + kScanTile - 1) / kScanTile); }
 uint32_t text_tiles(uint32_t bytes) { return std::max<uint32_t>(1, (bytes + kTxtTile - 1) / kTxtTile); }
 
-hipError_t launch_text_mark(const uint8_t* text, uint32_t n, bool fastq, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream) {
+hipError_t launch_text_mark(const uint8_t* text, uint32_t n, uint32_t fastq_lines, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream) {
     const uint32_t nb = text_tiles(n);
-    if (fastq) {
-        hipLaunchKernelGGL((bgr_text_mark_kernel<0, true>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+    if (fastq_lines) {
+        if (fastq_lines == 2) hipLaunchKernelGGL((bgr_text_mark_kernel<0, 2>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        else hipLaunchKernelGGL((bgr_text_mark_kernel<0, 4>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
         hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, n_rec_out);
-        hipLaunchKernelGGL((bgr_text_mark_kernel<1, true>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-        hipLaunchKernelGGL(bgr_text_fastq_count_kernel, dim3(1), dim3(1), 0, stream, n_rec_out);
+        if (fastq_lines == 2) hipLaunchKernelGGL((bgr_text_mark_kernel<1, 2>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        else hipLaunchKernelGGL((bgr_text_mark_kernel<1, 4>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        hipLaunchKernelGGL(bgr_text_fastq_count_kernel, dim3(1), dim3(1), 0, stream, n_rec_out, fastq_lines);
     } else {
-        hipLaunchKernelGGL((bgr_text_mark_kernel<0, false>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        hipLaunchKernelGGL((bgr_text_mark_kernel<0, 0>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
         hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, n_rec_out);
-        hipLaunchKernelGGL((bgr_text_mark_kernel<1, false>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
+        hipLaunchKernelGGL((bgr_text_mark_kernel<1, 0>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
     }
     return hipGetLastError();
 }

@@ -212,7 +212,9 @@ typedef struct {
                                      waits for that copy on the device instead of making its own */
     uint32_t fastq;               /* in: 1 = the piece is FASTQ (-q): whole four-line records (record j = lines 4j .. 4j+3 whatever they hold,
                                      aligner.cpp:51-68), ending with a newline; the reference's end-of-file behaviour (its phantom record)
-                                     stays with the caller: bgr_align_all maps the file's last getReads() call through the host parser */
+                                     stays with the caller: bgr_align_all maps the file's last getReads() call through the host parser.
+                                     2 = the same records with their '+' and quality lines left out by the caller: record j = lines 2j, 2j+1
+                                     (header line, read line) -- half the bytes over PCIe, the same records out */
     uint32_t reserved;
 } bgr_text_batch;
 /* A stage = a device buffer for one piece + a copy stream: bgr_text_stage_upload starts the host -> device copy and returns; the
@@ -222,6 +224,9 @@ typedef struct {
 int bgr_text_stage_create(int device, bgr_text_stage** out);
 void bgr_text_stage_destroy(bgr_text_stage* s);
 int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t text_bytes);
+/* ... a piece that lies in several host ranges (the header and read lines gathered out of a FASTQ file part by part): the device receives
+ * them back to back, in order; the piece's size is the sum. */
+int bgr_text_stage_upload_parts(bgr_text_stage* s, uint32_t n_parts, const char* const* parts, const uint64_t* part_bytes);
 int bgr_text_stage_device(const bgr_text_stage* s);  /* the device the stage was created on (-1: null) */
 int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b);
 int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b);

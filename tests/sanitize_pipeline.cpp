@@ -69,6 +69,11 @@ extern "C" int bgr_text_stage_create(int device, bgr_text_stage** out) { *out = 
 extern "C" void bgr_text_stage_destroy(bgr_text_stage* s) { delete s; }
 extern "C" int bgr_text_stage_device(const bgr_text_stage* s) { return s ? s->device : -1; }
 extern "C" int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t n) { s->copy.assign(text, n); return BGR_OK; }
+extern "C" int bgr_text_stage_upload_parts(bgr_text_stage* s, uint32_t n_parts, const char* const* parts, const uint64_t* bytes) {
+    s->copy.clear();
+    for (uint32_t i = 0; i < n_parts; ++i) s->copy.append(parts[i], bytes[i]);
+    return BGR_OK;
+}
 extern "C" int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
     b->paths_bytes = a->ps.size();
     b->notaligned_bytes = a->ns.size();
@@ -80,7 +85,8 @@ extern "C" int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
 extern "C" int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_batch* b) {
     b->irregular = 0; b->n_records = b->n_accepted = b->paths_bytes = b->notaligned_bytes = 0;
     if (b->stage && b->stage->device != a->device) return bgr::set_error(BGR_E_ARG, "stand-in: the stage lives on another device");  // (as the real call)
-    if (b->stage && (b->stage->copy.size() != b->text_bytes || (b->text_bytes && memcmp(b->stage->copy.data(), b->text, b->text_bytes) != 0))) return BGR_E_INTERNAL;  // the staged piece is this piece
+    if (b->stage && (b->stage->copy.size() != b->text_bytes || (b->text && b->text_bytes && memcmp(b->stage->copy.data(), b->text, b->text_bytes) != 0))) return BGR_E_INTERNAL;  // the staged piece is this piece
+    if (!b->stage && !b->text) return BGR_E_ARG;
     const char* t = b->stage ? b->stage->copy.data() : b->text;
     const uint64_t n = b->text_bytes;
     if (n == 0) return BGR_OK;
@@ -92,8 +98,8 @@ extern "C" int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_
         lines.push_back({p, (uint64_t)(q - t)});
         p = (uint64_t)(q - t) + 1;
     }
-    const size_t per = b->fastq ? 4 : 2;  // FASTQ pieces: whole four-line records, whatever the lines hold
-    if (b->fastq && lines.size() % 4) return BGR_E_INTERNAL;  // (the pipeline cuts them at record starts)
+    const size_t per = b->fastq == 1 ? 4 : 2;  // FASTQ pieces: whole four-line records, whatever the lines hold -- or (2) their header and read lines only
+    if (b->fastq && lines.size() % per) return BGR_E_INTERNAL;  // (the pipeline cuts them at record starts)
     if (lines.size() % 2) { b->irregular = 1; return BGR_OK; }
     for (size_t i = 0; i < lines.size() && !b->fastq; ++i) {
         const bool gt = lines[i].second > lines[i].first && t[lines[i].first] == '>';

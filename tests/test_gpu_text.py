@@ -195,6 +195,15 @@ def test_fastq_pieces_equal_the_host_route(seed, n, L, k, mode, tmp_path):
     # a piece that is not whole records is refused (the pipeline cuts at record starts)
     with pytest.raises(B.BgrError):
         al.align_fasta_text(text[:-1], fastq=True)
+    # the same records without their '+' and quality lines (fastq = 2: what bgr_align_all sends -- half the bytes over PCIe): same streams,
+    # as one host range, staged, and staged in host ranges cut at arbitrary bytes (bgr_text_stage_upload_parts)
+    two = b"".join(b"\n".join(r.split(b"\n")[:2]) + b"\n" for r in recs)
+    assert len(two) < 0.62 * len(text)
+    for kw in ({}, {"staged": True}, {"staged": True, "parts": [1, len(two) // 3, len(two) // 3 + 1, len(two) - 7]}):
+        al.reset_counters()
+        got_p3, got_n3, info3 = al.align_fasta_text(two, m=2, mode=mode, fastq=2, **kw)
+        assert not info3["irregular"] and info3["n_records"] == n and info3["n_accepted"] == n_acc
+        assert got_p3 == want_p and got_n3 == want_n and al.counters() == c0
 
 
 @pytest.mark.parametrize("n,batch,extra", [(25003, 0, []), (25003, 7000, ["-c"]), (30000, 4096, []), (10001, 0, ["-G"]), (9999, 0, []),
@@ -214,6 +223,10 @@ def test_cli_fastq_text_route_equals_host_route(n, batch, extra, tmp_path):
     assert pa == pb and na == nb
     assert [l for l in oa.splitlines() if "seconds" not in l] == [l for l in ob.splitlines() if "seconds" not in l]
     assert pa.count(b"\n") > n // 4
+    # (default: only the header and read lines of a piece cross PCIe; BGREAT_FASTQ_GATHER=0: the four-line records as they are)
+    from util import run_cli
+    oc, pc, nc = run_cli(B.CLI_PATH, args, env=dict(os.environ, BGREAT_FASTQ_GATHER="0"))
+    assert pc == pa and nc == na
 
 
 def _cli_pair(args, extra_a, extra_b):

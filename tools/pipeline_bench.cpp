@@ -49,6 +49,7 @@ int bgr_align_batch_packed(bgr_aligner*, const bgr_params*, const bgr_packed_rea
 int bgr_text_stage_create(int device, bgr_text_stage** out) { *out = new bgr_text_stage{device, nullptr, 0}; return BGR_OK; }
 void bgr_text_stage_destroy(bgr_text_stage* s) { delete s; }
 int bgr_text_stage_device(const bgr_text_stage* s) { return s ? s->device : -1; }
+int bgr_text_stage_upload_parts(bgr_text_stage*, uint32_t, const char* const*, const uint64_t*) { return bgr::set_error(BGR_E_INTERNAL, "pipeline_bench: FASTQ is not part of this harness"); }
 int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t n) { s->text = text; s->bytes = n; return BGR_OK; }  // (the copy engine's work: no host CPU)
 // Every record is 165 bytes and its header spells its number in the file, so the streams can be defined per record whatever piece it
 // travels in: records whose number is a multiple of 6 go to the paths stream whole, those with number % 7 == 3 to the other one --

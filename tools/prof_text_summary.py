@@ -39,11 +39,16 @@ for mode in ("fasta", "fastq"):
             dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
             nbytes = int(row.get("Bytes") or row.get("Size") or 0) if (row.get("Bytes") or row.get("Size")) else 0
             c.setdefault(kind, []).append((dur, nbytes))
+    # (this rocprofv3 writes no byte counts into the copy trace: the bytes are the run's own -- the input file up, the two output files down)
+    sizes = {}
+    for l in open(os.path.join(out, mode + ".files")):
+        f = l.split()
+        if len(f) >= 9:
+            sizes[os.path.basename(f[-1])] = int(f[4])
+    up = sizes.get("r.fa" if mode == "fasta" else "r.fq", 0)
+    down = sizes.get("paths", 0) + sizes.get("notAligned.fa", 0)
     for kind, v in sorted(c.items()):
-        big = [(d_, b) for d_, b in v if b >= (1 << 20)]
-        tb, td = sum(b for _, b in v), sum(d_ for d_, _ in v)
-        line = "   copies %-28s %7d  %10.1f MB  busy %9.2f ms" % (kind[:28], len(v), tb / 1e6, td / 1e6)
-        if big:
-            line += "   copies >= 1 MB: %d, %.1f GB/s while running" % (len(big), sum(b for _, b in big) / max(1, sum(d_ for d_, _ in big)))
-        print(line)
+        td = sum(d_ for d_, _ in v)
+        nb = up if "HOST_TO_DEVICE" in kind else down if "DEVICE_TO_HOST" in kind else 0
+        print("   copies %-28s %7d  %10.1f MB  busy %9.2f ms  = %5.1f GB/s while a copy runs, %5.1f bytes per read" % (kind[:28], len(v), nb / 1e6, td / 1e6, nb / max(1, td), nb / n_reads))
     print()
