@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
                     if (!__any(phase != 0)) break;
                     uint32_t miss, ext;
                     int32_t sid;
-                    const uint32_t w1 = g4_step<false, GL>(g, S, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
+                    const uint32_t w1 = g4_step<GL>(g, S, L, K1, phase, rec, canon, pos, budget, lane, &miss, &ext, &sid);
                     if (phase != 0) {
                         if (!(w1 & G4_FOUND)) { wfail = 1; phase = 0; }
                         else if (phase == 1) {

@@ -100,6 +100,8 @@ struct bgr_aligner {
 
     DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, lst, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
     uint64_t last_n = 0;
+    DevBuf wave_times;            // diagnostic builds only (-DBGR_PHASE_TIMING)
+    uint64_t wave_times_n = 0;
     uint64_t ticket_serial = 0;       // bgr_align_batch_begin: tickets handed out; the batch of the last one is in flight until its wait
     bool ticket_open = false;
     std::vector<uint64_t> ticket_offs;  // that batch's offsets made relative (kept alive for the asynchronous copy)
@@ -697,6 +699,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.anc4 = 0;
     io.subset_ctr = 2;
     io.ovf_ctr = 2;
+    io.wave_times = nullptr;
     // the sixteen-reads-per-wave greedy kernel keeps a ring of follow-up items per wave: at most one entry per read of the wave's share
     uint32_t q_cap = 0;
     if (fast_pass) {
@@ -763,6 +766,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         iof.q_cap = q_cap;
         iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
         iof.gen_ctr = 8;
+#ifdef BGR_PHASE_TIMING
+        HIP_TRY(a->wave_times.ensure((uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block * 32));
+        iof.wave_times = static_cast<unsigned long long*>(a->wave_times.p);
+        a->wave_times_n = (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block;
+#endif
         e = bgr::launch_align(dgl, iof, kp, cfg_fast, a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (sixteen-reads-per-wave kernel): ") + hipGetErrorString(e));
         HIP_TRY(mark("bgr_align_greedy_multi_kernel (all reads, retries in the launch)"));
@@ -1446,6 +1454,19 @@ int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]) {
     memcpy(out, a->last_launch, sizeof(a->last_launch));
     return BGR_OK;
 }
+
+#ifdef BGR_PHASE_TIMING
+// diagnostic builds only (not part of include/bgreat_gpu.h): the last launch's per-wave time stamps, four u64 per wave (100 MHz ticks)
+int bgr_debug_wave_times(bgr_aligner* a, uint64_t* out, uint64_t cap_waves, uint64_t* n_waves) {
+    if (!a || !n_waves) return BGR_E_ARG;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    *n_waves = a->wave_times_n;
+    const uint64_t n = std::min(cap_waves, a->wave_times_n);
+    if (n && out) HIP_TRY(hipMemcpy(out, a->wave_times.p, n * 32, hipMemcpyDeviceToHost));
+    return BGR_OK;
+}
+#endif
 
 int bgr_aligner_pass_counts(bgr_aligner* a, uint32_t out[4]) {
     if (!a || !out) return fail(BGR_E_ARG, "bgr_aligner_pass_counts: null argument");

@@ -529,7 +529,7 @@ __device__ __forceinline__ bool greedy_from_anchor(const BgrDeviceGraph& g, cons
 // out, 1 = left step (checkBeginGreedy / mapOnLeftEndGreedy), 2 = first right step (checkEndGreedy: the read slice starts
 // behind the k-1 overlap), 3 = later right step (mapOnRightEndGreedy: the slice includes the overlap).  alignerGreedy.cpp:167-364.
 // Result, uniform within a group: next record | next canonical << 28 | fits << 29 | found << 30; miss; ext; sid.
-template <bool NEAR = false, int GL = 16>
+template <int GL = 16>
 __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* FW, uint32_t L, uint32_t K1, uint32_t phase, uint32_t rec, uint32_t canon,
                                             uint32_t pos, uint32_t budget, int lane, uint32_t* miss, uint32_t* ext_o, int32_t* sid_o) {
     constexpr uint32_t QL = GL / 4;  // lanes per candidate slot: each takes 32 bases per round of the compare
@@ -574,16 +574,13 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
     const uint32_t rstart = left ? rl - n : pos + kk;
     const uint32_t nx = canon ? m0.y : m0.z;  // next half | canonical << 28 (graph_layout.h nx0 / nx1)
     if (c >= n_cand) n = 0;
-    // at most 32 bases next to the overlap: they sit in the slot itself (graph_layout.h `near`), no load from seq.  Not for the
-    // later right steps (they compare the overlap as well, alignerGreedy.cpp:222,243) nor for a unitig that hangs on the overlap both ways
-    const uint32_t both = BGR_SLOT_F0 | BGR_SLOT_F1;
-    // (NEAR: the launches whose graph lives in L2/HBM; with everything in L2 and the key table in LDS the launch is bound by
-    // instruction issue and the second compare path costs more than the loads it saves: 1 206 vs 1 286 Mreads/s)
-    const bool near_ok = NEAR && n <= 32 && phase != 3 && (sl.x & both) != both && !(g.flags & BGR_GF_HAS_EXC);
+    // (a slot also carries the <= 32 bases next to its overlap, graph_layout.h `near`: the exhaustive several-reads-per-wave kernel compares
+    // against those when the graph lives in L2/HBM.  Here, with sixteen walks per wave waiting on memory at once, the launch is bound by
+    // instruction issue and the second compare path cost more than the load it saves -- chr1-scale 1 331 with, 1 359 Mreads/s without;
+    // E. coli scale 1 206 / 1 286 -- so this step always reads the bases from `seq`)
     uint32_t cnt = 0;
-    if (NEAR && near_ok && n && q == 0) cnt = ham_near(FW, bgr_slot_near(sl.w, m0.x, m0.w), left != 0, n, rstart);
-    for (uint32_t b = q * 32; wave_any(b < n && !near_ok); b += 32 * ql)
-        if (b < n && !near_ok) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
+    for (uint32_t b = q * 32; wave_any(b < n); b += 32 * ql)
+        if (b < n) cnt += ham_chunk(g, FW, nullptr, false, fw, fo + ustart + b, rstart + b, n - b);
     if (QL >= 2) cnt += quad_xor1(cnt);
     if (QL == 4) cnt += quad_xor2(cnt);
     if (GL == 4) { const uint32_t o2 = quad_xor2(cnt); if (two) cnt += o2; }  // (the two lanes of a candidate: l and l ^ 2)

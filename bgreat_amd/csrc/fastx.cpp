@@ -218,12 +218,11 @@ FastqPlan::FastqPlan(const char* data, uint64_t size, uint64_t chunk_bytes)
     tail_start_.assign(nc_, UINT64_MAX);
 }
 
+static uint64_t count_newlines(const char* p, const char* end);
+
 void FastqPlan::count_chunk(size_t c) {  // pass 1: newlines in chunk c
-    uint64_t b = c * chunk_bytes_, e = std::min<uint64_t>(size_, b + chunk_bytes_), n = 0;
-    const char* p = data_ + b;
-    const char* end = data_ + e;
-    while (p < end && (p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))))) { ++n; ++p; }
-    nl_[c + 1] = n;
+    const uint64_t b = c * chunk_bytes_, e = std::min<uint64_t>(size_, b + chunk_bytes_);
+    nl_[c + 1] = count_newlines(data_ + b, data_ + e);
 }
 
 void FastqPlan::extend_counts(size_t c_end) {  // chunks [0, c_end) have been counted: their prefix sums
@@ -299,24 +298,67 @@ void FastqPlan::piece_parts(uint64_t o0, uint64_t o1, uint64_t r0, std::vector<s
         out.push_back({c * chunk_bytes_, nl_[c]});  // nl_[c] = newlines in front of the chunk = number of the line its first byte lies in
 }
 
-uint64_t fastq_gather_lines(const char* data, uint64_t b, uint64_t e, uint64_t line, char* dst) {
-    char* o = dst;
-    uint64_t pos = b;
-    while (pos < e) {
-        const uint64_t phase = line & 3;
-        const bool keep = phase < 2;
-        uint64_t need = keep ? 2 - phase : 4 - phase;  // newlines up to the end of this run of kept / skipped lines
-        const uint64_t start = pos;
-        while (need && pos < e) {
-            const char* q = static_cast<const char*>(memchr(data + pos, '\n', (size_t)(e - pos)));
-            if (!q) { pos = e; break; }
-            pos = (uint64_t)(q - data) + 1;
-            ++line;
-            --need;
-        }
-        if (keep) { memcpy(o, data + start, (size_t)(pos - start)); o += pos - start; }
+// the newlines of [p, end), in order: fn(position).  32 bytes per step with AVX2 (a memchr call per ~80-byte line costs more than the line)
+#if defined(__x86_64__)
+template <typename F>
+__attribute__((target("avx2"))) static inline void each_newline_avx2(const char* p, const char* end, F&& fn) {
+    const __m256i vNL = _mm256_set1_epi8('\n');
+    while (p + 32 <= end) {
+        uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p)), vNL));
+        while (m) { fn(p + __builtin_ctz(m)); m &= m - 1; }
+        p += 32;
     }
-    return (uint64_t)(o - dst);
+    for (; p < end; ++p) if (*p == '\n') fn(p);
+}
+__attribute__((target("avx2"))) static uint64_t count_newlines_avx2(const char* p, const char* end) {
+    const __m256i vNL = _mm256_set1_epi8('\n');
+    uint64_t n = 0;
+    while (p + 32 <= end) {
+        n += (uint64_t)__builtin_popcount((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p)), vNL)));
+        p += 32;
+    }
+    for (; p < end; ++p) n += *p == '\n';
+    return n;
+}
+#endif
+template <typename F>
+static inline void each_newline_plain(const char* p, const char* end, F&& fn) {
+    while (p < end && (p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))))) { fn(p); ++p; }
+}
+static uint64_t count_newlines(const char* p, const char* end) {
+#if defined(__x86_64__)
+    if (kHaveAvx2) return count_newlines_avx2(p, end);
+#endif
+    uint64_t n = 0;
+    each_newline_plain(p, end, [&](const char*) { ++n; });
+    return n;
+}
+
+namespace {
+struct GatherState {  // the kept lines (4j, 4j+1) of a FASTQ range, copied run by run: a run = header line + read line = one memcpy
+    const char* run;  // start of the kept run the cursor is in, or null
+    uint64_t line;
+    char* o;
+    inline void newline(const char* q) {
+        const uint64_t ph = line++ & 3;
+        if (ph == 1) { memcpy(o, run, (size_t)(q + 1 - run)); o += q + 1 - run; run = nullptr; }
+        else if (ph == 3) run = q + 1;
+    }
+};
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void gather_avx2(const char* p, const char* end, GatherState& st) { each_newline_avx2(p, end, [&](const char* q) { st.newline(q); }); }
+#endif
+}  // namespace
+
+uint64_t fastq_gather_lines(const char* data, uint64_t b, uint64_t e, uint64_t line, char* dst) {
+    GatherState st{(line & 3) < 2 ? data + b : nullptr, line, dst};
+#if defined(__x86_64__)
+    if (kHaveAvx2) gather_avx2(data + b, data + e, st);
+    else
+#endif
+    each_newline_plain(data + b, data + e, [&](const char* q) { st.newline(q); });
+    if (st.run && st.run < data + e) { memcpy(st.o, st.run, (size_t)(data + e - st.run)); st.o += data + e - st.run; }  // the range ends inside a kept line
+    return (uint64_t)(st.o - dst);
 }
 
 void parse_fastq_records(const char* data, uint64_t begin, uint64_t end, ParsedChunk& out) {

@@ -155,9 +155,6 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #define G4_ST_POS_MASK 0xFFFFFu
 
 // GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight, 4 = sixteen.
-#ifndef BGR_G4_NEAR_UNSTAGED
-#define BGR_G4_NEAR_UNSTAGED 0  /* 1: a graph probed in memory compares against the 32 bases a slot carries instead of loading them from seq.  With sixteen walks per wave waiting on memory at once the launch is bound by instruction issue, not by that load: chr1-scale 1 331 with, 1 359 Mreads/s without; 12 Mb genome 1 402 / 1 455 */
-#endif
 template <bool STAGE, int GL>
 __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     constexpr uint32_t RPW = 64 / GL;  // reads per wave
@@ -172,8 +169,15 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     // global atomic per wave and counter, all on the same four addresses, cost a launch of 131 k reads a third of its time)
     uint32_t* wg_counts = reinterpret_cast<uint32_t*>(lds);
     if (threadIdx.x < 4) wg_counts[threadIdx.x] = 0;
+#ifdef BGR_PHASE_TIMING  /* tools/wave_times.sh: when does a wave start, have its table, finish its share of the batch, finish its queue */
+    const unsigned long long wt0 = wall_clock64();
+    unsigned long long wt2 = 0;
+#endif
     uint32_t ktab_words;
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
+#ifdef BGR_PHASE_TIMING
+    const unsigned long long wt1 = wall_clock64();
+#endif
     u64* RD = lds + 64 + ktab_words + (u64)wave * (RPW * W);
     const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
     const uint32_t m = prm.max_mismatch;
@@ -202,6 +206,9 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
             if (ibase + grp < total) r = ibase + grp;
             ibase += stride;
         } else {              // then its queue
+#ifdef BGR_PHASE_TIMING
+            if (!wt2) wt2 = wall_clock64();
+#endif
             if (q_cnt == 0) break;
             const uint32_t take = q_cnt < RPW ? q_cnt : RPW;
             if (grp < take) {
@@ -318,7 +325,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
             if (!__any(on != 0)) break;
             uint32_t miss, ext;
             int32_t sid;
-            const uint32_t w1 = g4_step<BGR_G4_NEAR_UNSTAGED && !STAGE, GL>(g, F, L, K1, on, rec & G4_REC_MASK, (rec >> 28) & 1u, pos, budget, lane, &miss, &ext, &sid);
+            const uint32_t w1 = g4_step<GL>(g, F, L, K1, on, rec & G4_REC_MASK, (rec >> 28) & 1u, pos, budget, lane, &miss, &ext, &sid);
             if (on != 0) {
                 if (!(w1 & G4_FOUND)) {
                     st += 1u << G4_ST_TRIED_SHIFT;
@@ -401,6 +408,12 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         if (sub == 0 && have && outcome <= 3) atomicAdd(&wg_counts[outcome], 1u);
         wave_sync();
     }
+#ifdef BGR_PHASE_TIMING
+    if (io.wave_times && lane == 0) {
+        unsigned long long* w = io.wave_times + 4ull * (blockIdx.x * waves + wave);
+        w[0] = wt0; w[1] = wt1; w[2] = wt2; w[3] = wall_clock64();
+    }
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {  // aligner.h:68 counters: [0] readNumber [1] noOverlapRead [2] alignedRead [3] notAligned
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(io.cursor + 16);

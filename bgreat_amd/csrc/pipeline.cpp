@@ -555,6 +555,11 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     };
     const bool timing = getenv("BGREAT_TIMING") != nullptr;
     pool.timing = timing;
+    // text route: room for a piece's two record streams.  A mapped 150 bp read leaves ~27 bytes of its 165 in `paths`, an unmapped one all
+    // of them in the other file: a quarter of the piece each to start with (page-locked memory costs ~0.2 s per GB: less of it, and a fresh
+    // process reaches its rate sooner); a stream that does not fit comes back as BGR_E_CAPACITY and the set's buffer grows once (-c, whose
+    // paths stream is header + read, starts at the full size)
+    const uint64_t out_div = correction ? 1 : 4;
     // FASTQ on the text route: only the header and read lines of a piece go to the device (BGREAT_FASTQ_GATHER=0: the four-line records as they are)
     const bool fastq_gather = !(getenv("BGREAT_FASTQ_GATHER") && atoi(getenv("BGREAT_FASTQ_GATHER")) == 0);
     std::atomic<uint64_t> us_parse{0}, us_gather{0}, us_gpu{0}, us_format{0}, us_write{0}, us_alloc{0};
@@ -599,7 +604,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
             }
             if (!pn) pn = std::make_unique<Pinned>();
             if (text_route) {  // best effort: the stages grow what turns out too small
-                if (i < need_text) (void)(pn->text.ensure(est_piece + 64) && pn->ptext.ensure(est_piece / 2 + 4096) && pn->ntext.ensure(est_piece / 2 + 4096));
+                if (i < need_text) (void)(pn->text.ensure(est_piece + 64) && pn->ptext.ensure(est_piece / out_div + 4096) && pn->ntext.ensure(est_piece / out_div + 4096));
             } else if (i < need) {
                 (void)(pn->fw3.ensure(bgr::packed_plane_words(est_n, est_bytes) * 8) && pn->hasn.ensure((est_n / 32 + 2) * 4) && pn->offs.ensure((est_n + 1) * 8) &&
                        pn->paths.ensure((8 * est_n + 4096) * 4) && pn->poffs.ensure((est_n + 1) * 8) && pn->status.ensure(est_n + 1));
@@ -917,7 +922,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
         if (!b.pin && !free_pins.pop(b.pin)) { fail(BGR_E_INTERNAL, "pinned buffer pool closed"); return false; }
         const uint64_t tg0 = now_us();
         const uint64_t bytes = b.t_end - b.t_begin;
-        if (!b.pin->text.ensure(bytes + 64) || !b.pin->ptext.ensure(bytes / 2 + 4096) || !b.pin->ntext.ensure(bytes / 2 + 4096)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
+        if (!b.pin->text.ensure(bytes + 64) || !b.pin->ptext.ensure(bytes / out_div + 4096) || !b.pin->ntext.ensure(bytes / out_div + 4096)) { fail(BGR_E_HIP, bgr_last_error()); return false; }
         us_alloc += now_us() - tg0;
         const uint64_t tg1 = now_us();
         Batch* bp = &b;

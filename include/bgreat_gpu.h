@@ -79,7 +79,12 @@ int bgr_device_count(void); /* number of HIP devices visible, 0 if none / no dri
  * Loading stops at the first sequence shorter than k (aligner.cpp:418-420).  gamma = slots per key of the overlap key
  * table that stands in for leftMPHF/rightMPHF + the key compare (1.03 .. 64; <= 0 selects the default: 1.07 when the table can be
  * staged in LDS, else 1.8).
- * The graph is built on the host; inputs are only read during the call. */
+ * The graph is built on the host; inputs are only read during the call.
+ * Limits (narrower than the reference's int32 unitig ids, utils.h:26; a graph beyond them is refused with BGR_E_ARG and a message that
+ * names the limit, never truncated): k <= 32 (as the reference); fewer than 2^30 unitigs (a slot's id field has 30 bits beside its two
+ * orientation bits); fewer than 2^28 overlap keys and fewer than 2^27 - 8 filled neighbour slots (a handle is 28 bits, one of them the
+ * "query is canonical" flag travelling with it); the packed sequence of both strands below 4 GiB = 2^34 bases (the kernels address it
+ * with 32-bit byte offsets).  The BASELINE configs use 2 % / 0.4 % / 5 % of these (4 M unitigs, 2.6 M keys, 0.8 G bases at chr1 scale). */
 /* Host threads of the index build (the reference: BooPHF's `coreNumber` threads, aligner.cpp:450,458); 0 = default
  * (all cores, at most 16).  The built graph does not depend on it.  Process-wide. */
 void bgr_set_build_threads(uint32_t threads);
