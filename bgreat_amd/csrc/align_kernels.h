@@ -55,6 +55,7 @@ struct BatchIO {
     uint32_t exh4;               // exhaustive mode: launch the several-reads-per-wave kernel (what it does not settle goes on ovf_list);
                                  //   the value = levels per side of its level table (8 or 16)
     uint32_t subset_ctr, ovf_ctr; // which words of `cursor` count the reads of `subset` / collect the reads put on `ovf_list`
+    uint32_t task_ctr;            // which word of `cursor` hands out the tasks of a several-reads-per-wave launch (claim_task, device_common.h)
     unsigned long long* wave_times;  // diagnostic builds (-DBGR_PHASE_TIMING) only, else null: four 100 MHz time stamps per wave of the several-reads-per-wave greedy kernel
 };
 

@@ -311,7 +311,6 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
     constexpr uint32_t RPW = 64 / GL;  // reads per wave
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int waves = blockDim.x >> 6;
     const uint32_t W = io.words_per_read;  // <= 16 (checked by the host)
     const uint32_t K = g.k, K1 = g.k - 1;
     const uint32_t grp = (uint32_t)lane / GL, sub = (uint32_t)lane % GL;
@@ -328,9 +327,13 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
     // behind it: reverse(left) ++ [offset,] unitig ++ right is the slice row[LH - nl, LH + nmid + nr)
     constexpr uint32_t LH = kA4PathInts / 2 - 1;
     unsigned long long* wg_counts = wg_counts_init(lds);
+    task_stock_init(lds);
     __syncthreads();
 
-    for (uint32_t rbase = (blockIdx.x * waves + wave) * RPW; rbase < io.n_reads; rbase += gridDim.x * waves * RPW) {
+    // (a wave claims its next RPW reads at run time -- claim_task, device_common.h -- instead of a share dealt out by wave number)
+    const uint32_t n_tasks = (io.n_reads + RPW - 1) / RPW;
+    for (uint32_t task; (task = claim_task(lds, io.cursor + io.task_ctr, n_tasks, lane)) != BGR_NONE;) {
+        const uint32_t rbase = task * RPW;
         const uint32_t r = rbase + grp;
         const uint32_t have = r < io.n_reads ? 1u : 0u;
         u64 off = 0;

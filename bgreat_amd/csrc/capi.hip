@@ -700,12 +700,14 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.subset_ctr = 2;
     io.ovf_ctr = 2;
     io.wave_times = nullptr;
+    io.task_ctr = 10;  // (cursor[0..15] are zeroed in front of every launch; 10 is used by nothing else)
     // the sixteen-reads-per-wave greedy kernel keeps a ring of follow-up items per wave: at most one entry per read of the wave's share
     uint32_t q_cap = 0;
     if (fast_pass) {
         const uint64_t grid_waves = (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block;
         const uint64_t octets = (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave;
-        q_cap = (uint32_t)((octets + grid_waves - 1) / grid_waves) * bgr::kG4ReadsPerWave;
+        (void)octets;
+        q_cap = 2 * bgr::kG4ReadsPerWave;  // (a wave drains its ring whenever it holds a full group: greedy_kernels.hip)
         HIP_TRY(a->ovf.ensure(grid_waves * q_cap * 8));
         HIP_TRY(a->ovf2.ensure(n_reads * 4));
     }

@@ -655,6 +655,40 @@ __device__ __forceinline__ void wg_counts_flush(const BatchIO& io, unsigned long
     if (threadIdx.x < 5 && c[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long*>(io.cursor + 16) + threadIdx.x, c[threadIdx.x]);
 }
 
+// ---- which reads a wave maps next: claimed at run time, not dealt out beforehand ------------------------------------------------
+// A TASK is one wave-load of reads (64 / lanes-per-read of them, consecutive in the batch).  Dealing the tasks out by wave number
+// leaves a third of the wave slots idle: the waves of a SIMD do not advance at one rate (the issue arbiter prefers the oldest), the
+// first ones end after 55 % of the launch and nothing takes their place (profiles/r04_wave_times_static_split_*.txt: a wave of the
+// E. coli-scale launch lives 0.74 of its duration, 0.64 at configs[1], 0.83 at chr1 scale).  So a wave CLAIMS its next task: from its
+// workgroup's stock in LDS (one 64-bit word {end, next}, one LDS atomic per task), which the wave that finds it used up refills with
+// kTaskRefill tasks from the launch's counter in HBM (one global atomic per kTaskRefill tasks: ~10 k per launch).  The end of a launch
+// is then ragged by one task per wave, not by a third of the batch.
+constexpr uint32_t kTaskRefill = 32;          // tasks a workgroup takes from the launch's counter at a time
+constexpr uint32_t kTaskDone = 0xC0000000u;   // `next` of a stock whose launch has no task left
+constexpr uint32_t kLdsTaskWord = 8;          // the stock: u64 number 8 of the workgroup's reserved LDS header (bytes 64 .. 71)
+__device__ __forceinline__ void task_stock_init(u64* lds) { if (threadIdx.x == 0) lds[kLdsTaskWord] = 0; }  // (before the prologue's barrier)
+// -> the task claimed, or BGR_NONE when the launch has none left; wave-uniform.  `ctr`: the launch's counter (zero at launch).
+__device__ __forceinline__ uint32_t claim_task(u64* lds, uint32_t* ctr, uint32_t n_tasks, int lane) {
+    unsigned long long* stock = reinterpret_cast<unsigned long long*>(lds + kLdsTaskWord);
+    for (;;) {
+        unsigned long long old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(stock, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t next = rl32((uint32_t)old, 0), end = rl32((uint32_t)(old >> 32), 0);
+        if (next < end) return next;
+        if (next >= kTaskDone) return BGR_NONE;
+        if (next == end) {  // exactly one wave sees the stock run out (or finds it empty at the start): it refills, and takes the first task itself
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(ctr, kTaskRefill);
+            g = rl32(g, 0);
+            const bool none = g >= n_tasks;
+            const uint32_t e = n_tasks - g < kTaskRefill ? n_tasks : g + kTaskRefill;
+            if (lane == 0) __hip_atomic_store(stock, none ? (unsigned long long)kTaskDone : ((unsigned long long)e << 32) | (g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return none ? BGR_NONE : g;
+        }
+        __builtin_amdgcn_s_sleep(4);  // next > end: another wave of the workgroup is refilling the stock; it never waits for this one
+    }
+}
+
 // Arena space comes in per-wave chunks: ONE global atomic per ~50 reads instead of one per read (a
 // single-address atomic saturates near 90 M/s chip-wide, MI355X_MICROARCH.md "dequeue").
 __device__ __forceinline__ uint32_t publish_path(const BatchIO& io, const int32_t* PATH, uint32_t p_lo, uint32_t p_n,

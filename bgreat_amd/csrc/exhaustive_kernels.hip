@@ -665,6 +665,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const uint32_t mmx_w = (BGR_EXH_MMX && !STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
     const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
     unsigned long long* wg_counts = wg_counts_init(lds);
+    task_stock_init(lds);
     uint32_t ktab_words;
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
     // per wave: RPW x { read words W | level table XL x X4_LV_WORDS u32 | out ints 2 x (XL + 2) }  (x4_group_words, align_kernels.h)
@@ -682,7 +683,10 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     // (the wave's first arena chunk is its own by number: the host starts the cursor behind them, see bgr_align_greedy_multi_kernel)
     uint32_t chunk_pos = (uint32_t)(blockIdx.x * waves + wave) * io.arena_chunk, chunk_end = chunk_pos + io.arena_chunk;
 
-    for (uint32_t rbase = (blockIdx.x * waves + wave) * RPW; rbase < io.n_reads; rbase += gridDim.x * waves * RPW) {
+    // (a wave claims its next RPW reads at run time -- claim_task, device_common.h -- instead of a share dealt out by wave number)
+    const uint32_t n_tasks = (io.n_reads + RPW - 1) / RPW;
+    for (uint32_t task; (task = claim_task(lds, io.cursor + io.task_ctr, n_tasks, lane)) != BGR_NONE;) {
+        const uint32_t rbase = task * RPW;
         const uint32_t r = rbase + grp;
         const uint32_t have = r < io.n_reads ? 1u : 0u;
         u64 off = 0;

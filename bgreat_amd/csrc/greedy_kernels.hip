@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     // global atomic per wave and counter, all on the same four addresses, cost a launch of 131 k reads a third of its time)
     uint32_t* wg_counts = reinterpret_cast<uint32_t*>(lds);
     if (threadIdx.x < 4) wg_counts[threadIdx.x] = 0;
+    task_stock_init(lds);
 #ifdef BGR_PHASE_TIMING  /* tools/wave_times.sh: when does a wave start, have its table, finish its share of the batch, finish its queue */
     const unsigned long long wt0 = wall_clock64();
     unsigned long long wt2 = 0;
@@ -190,25 +191,32 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     // chunks the cursor serves to the other kernels).  Left int number i (near -> far, offset last) at row[PH - 1 - i], right int number
     // i at row[PH + i], so reverse(left) ++ right is the slice row[PH - nl, PH + nr) -- no allocation, no copy when a walk ends.
     const uint32_t wid = (uint32_t)(blockIdx.x * waves + wave);
-    // this wave's queue of follow-up items {read, state}: a ring of io.q_cap entries.  While the wave takes its share of the batch
-    // it only appends (at most one entry per read of the share: q_cap); afterwards every group taken out makes room for what it
-    // leaves behind, so the ring never overflows.
-    const uint32_t q_base = wid * io.q_cap;  // (the rings of all waves hold n_reads + 8 per wave entries at most: 32-bit indices)
+    // this wave's queue of follow-up items {read, state}: a ring of io.q_cap (>= 2 RPW) entries in HBM, written and read by this wave only.
+    // A wave takes a dense group of RPW items off its queue as soon as it holds that many, else its next task of fresh reads (claim_task:
+    // whichever wave is free takes the next one), and what is left of the queue when the launch has no task left.  An item leaves at most
+    // one follow-up item behind, so the ring never holds more than 2 RPW - 1 entries.
+    const uint32_t q_base = wid * io.q_cap;
     uint32_t q_rd = 0, q_wr = 0, q_cnt = 0;
-    const uint32_t stride = gridDim.x * waves * RPW;
-    uint32_t ibase = wid * RPW;
+    const uint32_t n_tasks = (total + RPW - 1) / RPW;
+    uint32_t pool_open = 1;
 
     // (per-lane flags are kept as 0/1 words in VGPRs on purpose: as `bool`s they become 64-bit lane masks in SGPRs, and this
     // kernel is short of SGPRs, not of VGPRs)
     for (;;) {
         uint32_t r = BGR_NONE, st = 0;  // r == BGR_NONE: the group has no item
-        if (ibase < total) {  // the wave's share of the batch
-            if (ibase + grp < total) r = ibase + grp;
-            ibase += stride;
-        } else {              // then its queue
+        uint32_t task = BGR_NONE;
+        if (q_cnt < RPW && pool_open) {
+            task = claim_task(lds, io.cursor + io.task_ctr, n_tasks, lane);
+            if (task == BGR_NONE) {
+                pool_open = 0;
 #ifdef BGR_PHASE_TIMING
-            if (!wt2) wt2 = wall_clock64();
+                if (!wt2) wt2 = wall_clock64();
 #endif
+            }
+        }
+        if (task != BGR_NONE) {  // fresh reads
+            if (task * RPW + grp < total) r = task * RPW + grp;
+        } else {                 // the queue: a full group, or -- no task left -- what remains
             if (q_cnt == 0) break;
             const uint32_t take = q_cnt < RPW ? q_cnt : RPW;
             if (grp < take) {
