@@ -661,9 +661,10 @@ __device__ __forceinline__ void wg_counts_flush(const BatchIO& io, unsigned long
 // first ones end after 55 % of the launch and nothing takes their place (profiles/r04_wave_times_static_split_*.txt: a wave of the
 // E. coli-scale launch lives 0.74 of its duration, 0.64 at configs[1], 0.83 at chr1 scale).  So a wave CLAIMS its next task: from its
 // workgroup's stock in LDS (one 64-bit word {end, next}, one LDS atomic per task), which the wave that finds it used up refills with
-// kTaskRefill tasks from the launch's counter in HBM (one global atomic per kTaskRefill tasks: ~10 k per launch).  The end of a launch
+// up to kTaskRefill tasks from the launch's counter in HBM (one global atomic per refill: ~10-20 k per launch).  The end of a launch
 // is then ragged by one task per wave, not by a third of the batch.
-constexpr uint32_t kTaskRefill = 32;          // tasks a workgroup takes from the launch's counter at a time
+constexpr uint32_t kTaskRefill = 32;          // tasks a workgroup takes from the launch's counter at a time, at most
+constexpr uint32_t kTaskRefillMin = 4;        // ... and at least
 constexpr uint32_t kTaskDone = 0xC0000000u;   // `next` of a stock whose launch has no task left
 constexpr uint32_t kLdsTaskWord = 8;          // the stock: u64 number 8 of the workgroup's reserved LDS header (bytes 64 .. 71)
 __device__ __forceinline__ void task_stock_init(u64* lds) { if (threadIdx.x == 0) lds[kLdsTaskWord] = 0; }  // (before the prologue's barrier)
@@ -677,11 +678,15 @@ __device__ __forceinline__ uint32_t claim_task(u64* lds, uint32_t* ctr, uint32_t
         if (next < end) return next;
         if (next >= kTaskDone) return BGR_NONE;
         if (next == end) {  // exactly one wave sees the stock run out (or finds it empty at the start): it refills, and takes the first task itself
+            // (guided: what is left of the batch -- judged by where the stock just used up ended -- shared out twice over all workgroups, at most
+            // kTaskRefill and at least kTaskRefillMin tasks: towards the end of a launch the workgroups take small bites)
+            const uint32_t left = n_tasks > end ? n_tasks - end : 0u, share = left / (2u * gridDim.x);
+            const uint32_t want = share > kTaskRefill ? kTaskRefill : share < kTaskRefillMin ? kTaskRefillMin : share;
             uint32_t g = 0;
-            if (lane == 0) g = atomicAdd(ctr, kTaskRefill);
+            if (lane == 0) g = atomicAdd(ctr, want);
             g = rl32(g, 0);
             const bool none = g >= n_tasks;
-            const uint32_t e = n_tasks - g < kTaskRefill ? n_tasks : g + kTaskRefill;
+            const uint32_t e = n_tasks - g < want ? n_tasks : g + want;
             if (lane == 0) __hip_atomic_store(stock, none ? (unsigned long long)kTaskDone : ((unsigned long long)e << 32) | (g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return none ? BGR_NONE : g;
         }
