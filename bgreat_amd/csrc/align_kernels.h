@@ -24,8 +24,10 @@ constexpr uint32_t kG4PathInts = 16;  // path ints of a read's row in the arena:
 #define BGR_X4_GROUP_LANES 8
 #endif
 constexpr uint32_t kX4GroupLanes = BGR_X4_GROUP_LANES, kX4ReadsPerWave = 64 / BGR_X4_GROUP_LANES;
-// u64 words per read besides the read's own: level table (8 or 16 levels of a walk per side, 16 words each) + out ints
-constexpr uint32_t x4_group_words(uint32_t levels) { return (levels * 16 + 2 * (levels + 2) + 1) / 2; }
+// u64 words per read besides the read's own: level table (8 or 16 levels of a walk per side, BGR_X4_LEVEL_WORDS u32 each: exhaustive_kernels.hip) + out ints
+#define BGR_X4_LEVEL_WORDS 9
+constexpr uint32_t kX4MaxMismatch = 254, kX4MaxUnitigLen = (1u << 22) - 1;  // what the level table's packed fields hold
+constexpr uint32_t x4_group_words(uint32_t levels) { return (levels * BGR_X4_LEVEL_WORDS + 2 * (levels + 2) + 1) / 2; }
 
 struct BatchIO {
     const uint64_t* fw3;         // 2-bit plane of the batch (bgr_pack_reads_kernel / host packer): read r at word (read_offs[r] >> 5) + r

@@ -637,7 +637,8 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // Exhaustive mode, first pass: eight reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
     // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
     bgr::LaunchCfg cfg_x4;
-    const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && !a->graph->header.has_exc && p->max_mismatch < 0x7FFF &&
+    const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && !a->graph->header.has_exc && p->max_mismatch <= bgr::kX4MaxMismatch &&
+                         a->graph->header.max_unitig_len <= bgr::kX4MaxUnitigLen &&
                          geometry(bgr::kX4ReadsPerWave * 8 * (wfast + bgr::x4_group_words(x4_levels)), (n_reads + bgr::kX4ReadsPerWave - 1) / bgr::kX4ReadsPerWave, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)),
                                   50);  // (E. coli-scale table, 150 bp: one staged workgroup of 16 waves 1 496 Mreads/s, 28 waves probing the table in L2 1 395)
     // Anchors mode, first pass: four reads per wave (bgr_align_anchors4_kernel); reads with an N and very long paths are listed
@@ -802,6 +803,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         iox.subset = nullptr;
         iox.ovf_list = static_cast<uint32_t*>(a->lst.p);
         iox.ovf_ctr = 5;
+#ifdef BGR_PHASE_TIMING
+        HIP_TRY(a->wave_times.ensure((uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * 32));
+        iox.wave_times = static_cast<unsigned long long*>(a->wave_times.p);
+        a->wave_times_n = (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block;
+#endif
         e = bgr::launch_align(dgl, iox, kp, cfg_x4, a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (exhaustive, four reads per wave): ") + hipGetErrorString(e));
         HIP_TRY(mark("bgr_align_exhaustive4_kernel (all reads)"));

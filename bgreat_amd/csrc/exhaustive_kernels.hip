@@ -458,7 +458,11 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
 #ifndef BGR_X4_OCC
 #define BGR_X4_OCC 6
 #endif
-#define X4_LV_WORDS 16  // per level: [0..3] sid, [4..7] aux (the path int a walk ending there emits), [8..11] miss | fits<<16 | alive<<17, [12] node flags, [13] chosen slot
+// per level of a walk, nine words: [0..3] the slots' path ints (+-id), [4..7] per slot miss (8 bits; the pass takes budgets <= 254, a dearer
+// candidate is dead anyway) | fits << 8 | alive << 9 | aux << 10 (aux: the path int a walk ending in this slot emits, < 2^22: the host keeps
+// graphs with longer unitigs off this pass), [8] node flags | chosen slot << 8.  Round 3 kept 16 words (64 B) per level; at nine a wave's
+// eight reads take 6.4 instead of 9.9 KB with 16 levels per side, and a CU holds 24 instead of 16 waves (the register limit)
+#define X4_LV_WORDS BGR_X4_LEVEL_WORDS
 #define X4_END 1u
 #define X4_INF 0xFFFFu
 
@@ -484,7 +488,7 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         if (fwd && lvl >= XL) { fb = 1; fwd = 0; }
         const uint32_t end_here = (fwd && ((DIR == 0) ? (pos == 0) : (L - pos - K1 == 0))) ? 1u : 0u;
         if (end_here) {  // left: the read's first base is reached; right: nothing is left of the read
-            if (sub == 0) LVT[lvl * X4_LV_WORDS + 12] = X4_END;
+            if (sub == 0) LVT[lvl * X4_LV_WORDS + 8] = X4_END;
             nlev = lvl + 1;
             fwd = 0;
         }
@@ -542,9 +546,8 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         if (fwd && q == 0) {
             uint32_t* R = LVT + lvl * X4_LV_WORDS;
             R[c] = fwdu ? id : 0u - id;
-            R[4 + c] = aux;
-            R[8 + c] = miss | (fits << 16) | (alive << 17);
-            if (c == 0) R[12] = 0;
+            R[4 + c] = (miss > 255u ? 255u : miss) | (fits << 8) | (alive << 9) | (aux << 10);
+            if (c == 0) R[8] = 0;
         }
         // the candidates that go on must all reach the same node
         const u64 nmask = __ballot(need && q == 0 && fwd);
@@ -577,12 +580,12 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         uint32_t key = 0xFFFFFFFFu, flags = 0;
         if (in) {
             const uint32_t* R = LVT + (uint32_t)l * X4_LV_WORDS;
-            flags = R[12];
+            flags = R[8] & 0xFFu;
             if (sub < 4) {
-                const uint32_t pk = R[8 + sub];
+                const uint32_t pk = R[4 + sub];
                 uint32_t total = X4_INF;
-                if (pk & (1u << 17)) {
-                    total = (pk & 0xFFFFu) + ((pk & (1u << 16)) ? 0u : cnext);
+                if (pk & (1u << 9)) {
+                    total = (pk & 0xFFu) + ((pk & (1u << 8)) ? 0u : cnext);
                     if (total > X4_INF) total = X4_INF;
                 }
                 key = total << 2 | sub;
@@ -595,7 +598,7 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         key = lane_get(key, gl0);
         if (in) {
             cnext = (flags & X4_END) ? 0u : (key >> 2);
-            if (sub == 0) LVT[(uint32_t)l * X4_LV_WORDS + 13] = key & 3u;
+            if (sub == 0) LVT[(uint32_t)l * X4_LV_WORDS + 8] = flags | ((key & 3u) << 8);
         }
     }
     wave_sync();
@@ -610,12 +613,12 @@ __device__ __forceinline__ void x4_search(const BgrDeviceGraph& g, const u64* FW
         sidv[h] = 0; auxvv[h] = 0; isendv[h] = 0;
         if (ok && j < nlev) {
             const uint32_t* R = LVT + j * X4_LV_WORDS;
-            const uint32_t a = R[13];
-            isendv[h] = R[12] & X4_END;
-            const uint32_t pk = R[8 + a];
-            endj = (isendv[h] || (pk & (1u << 16))) ? 1u : 0u;
+            const uint32_t fc = R[8], a = fc >> 8;
+            isendv[h] = fc & X4_END;
+            const uint32_t pk = R[4 + a];
+            endj = (isendv[h] || (pk & (1u << 8))) ? 1u : 0u;
             sidv[h] = R[a];
-            auxvv[h] = R[4 + a];
+            auxvv[h] = pk >> 10;
         }
         const u64 emask = __ballot(endj != 0);
         ebits |= ((uint32_t)(emask >> gl0) & GM) << (h * GL);
@@ -666,8 +669,14 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
     unsigned long long* wg_counts = wg_counts_init(lds);
     task_stock_init(lds);
+#ifdef BGR_PHASE_TIMING
+    const unsigned long long wt0 = wall_clock64();
+#endif
     uint32_t ktab_words;
     const uint32_t* ktab = block_prologue<STAGE>(g, lds, &ktab_words);
+#ifdef BGR_PHASE_TIMING
+    const unsigned long long wt1 = wall_clock64();
+#endif
     // per wave: RPW x { read words W | level table XL x X4_LV_WORDS u32 | out ints 2 x (XL + 2) }  (x4_group_words, align_kernels.h)
     const uint32_t out_ints = 2 * (XL + 2);
     const uint32_t grp_words = W + (XL * X4_LV_WORDS + out_ints + 1) / 2;
@@ -788,6 +797,12 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
             if ((fin >> (GL * gq)) & 1) c_ov += rl32(npos_g, (int)(GL * gq));  // overlaps += listOverlap.size() (alignerExhaustive.cpp:38)
         wave_sync();
     }
+#ifdef BGR_PHASE_TIMING
+    if (io.wave_times && lane == 0) {
+        unsigned long long* w = io.wave_times + 4ull * (blockIdx.x * (blockDim.x >> 6) + wave);
+        w[0] = wt0; w[1] = wt1; w[2] = w[3] = wall_clock64();
+    }
+#endif
     wg_counts_flush(io, wg_counts, lane, c_al + c_na, 0, c_al, c_na, c_ov);
 }
 

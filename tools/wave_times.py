@@ -18,17 +18,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="ecoli")
 ap.add_argument("--reads", type=int, default=0)
 args = ap.parse_args()
-G, d, L, R = {"ecoli": (4_600_000, 140, 150, 5_000_000), "small": (250_000, 75, 100, 1_000_000), "chr1": (230_000_000, 175, 150, 5_000_000)}[args.workload]
+G, d, L, R, AL, M, MODE = {"ecoli": (4_600_000, 140, 150, 5_000_000, 2, 2, 0), "small": (250_000, 75, 100, 1_000_000, 2, 2, 0), "chr1": (230_000_000, 175, 150, 5_000_000, 2, 2, 0),
+                          "branchy": (50_000_000, 36, 250, 2_000_000, 4, 5, 1)}[args.workload]
 R = args.reads or R
-s = Synth(G, d, 2, 31, 20261003)
+s = Synth(G, d, AL, 31, 20261003)
 seqs, offs = s.unitigs()
 g = B.Graph.build(31, seqs, offs)
 al = B.Aligner(g, 0)
-reads, _ = s.reads(0, R, L, 2, 77, threads=16)
+reads, _ = s.reads(0, R, L, M, 77, threads=16)
 db = B.DeviceBuffer(0, reads)
 do = B.DeviceBuffer(0, np.arange(R + 1, dtype=np.uint64) * np.uint64(L))
 for _ in range(3):
-    al.align_device(db.data_ptr(), do.data_ptr(), R, R * L, L, m=2, effort=2)
+    al.align_device(db.data_ptr(), do.data_ptr(), R, R * L, L, m=M, effort=2, mode=MODE)
 al.sync()
 lib = B.lib()
 lib.bgr_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
