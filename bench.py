@@ -89,7 +89,7 @@ def parse_args():
                                                                "(exhaustive workloads: + the reference's -b run on a bounded sample)")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records of the other BASELINE configs (default run, N=1, workload ecoli: configs[1], [3], [4])")
     ap.add_argument("--sub-timeout", type=int, default=170, help="seconds one sub-record child may take")
-    ap.add_argument("--cpu-sample-exh", type=int, default=40_000, help="reads of the exhaustive CPU baseline (reference -b, -t cpu-threads)")
+    ap.add_argument("--cpu-sample-exh", type=int, default=200_000, help="reads of the exhaustive CPU baseline (reference -b, -t cpu-threads)")
     ap.add_argument("--cpu-sample-all", type=int, default=2_500_000, help="reads of the all-cores leg of the CPU baseline (-t min(255, visible cores)); 0 disables")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--debug-stop", type=int, default=0, help="diagnostic builds of the library only (-DBGR_PHASE_TIMING, loaded through BGR_LIB_PATH): "

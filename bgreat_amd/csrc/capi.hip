@@ -94,6 +94,8 @@ struct bgr_aligner {
     // the text route (bgr_align_fasta_text): the piece, its records, the formatted streams
     DevBuf tx_in, tx_sums, tx_start, tx_rec, tx_flag, tx_len, tx_idx, tx_boff, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout;
     uint64_t tx_n_acc = 0, tx_pbytes = 0, tx_nbytes = 0;
+    bool blocking_sync = getenv("BGREAT_BLOCKING_SYNC") && atoi(getenv("BGREAT_BLOCKING_SYNC")) != 0;
+    hipEvent_t ev_wait = nullptr;
     const uint8_t* tx_text = nullptr;  // where the last call's piece lies in HBM (tx_in, or the caller's stage)
     uint32_t tx_want = 0;              // its want_output (2 = correction mode: mapped reads as spelled by their paths)
     double tx_phase_s[5] = {0, 0, 0, 0, 0};  // BGREAT_TIMING: host wall seconds to the call's four waits (mark, records, mapping + sizes, streams) + calls
@@ -125,6 +127,15 @@ struct bgr_aligner {
 };
 
 namespace {
+
+// Wait for the aligner's stream.  By default hipStreamSynchronize (the runtime spins: lowest latency, one busy CPU per waiting thread);
+// with BGREAT_BLOCKING_SYNC=1 an event made with hipEventBlockingSync is recorded and waited for instead: the thread sleeps until the
+// interrupt, so more stream workers per device than CPUs to spare can overlap their calls (bgr_align_all's text route).
+hipError_t wait_stream(bgr_aligner* a) {
+    if (!a->blocking_sync) return hipStreamSynchronize(a->stream);
+    hipError_t e = hipEventRecord(a->ev_wait, a->stream);
+    return e == hipSuccess ? hipEventSynchronize(a->ev_wait) : e;
+}
 
 int drain_timers(bgr_aligner* a) {
     if (a->ev_used == 0) return BGR_OK;
@@ -440,6 +451,7 @@ int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out) {
             }
         }
     }
+    if (a->blocking_sync && hipEventCreateWithFlags(&a->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) a->blocking_sync = false;
     bgr::resolve_device_graph(&g->header, g->dev[device].ptr, a->dg);
     e = a->small.ensure(256);
     if (e == hipSuccess) e = hipMemset(a->small.p, 0, 256);
@@ -461,6 +473,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
         for (DevBuf* b : {&a->tx_in, &a->tx_sums, &a->tx_start, &a->tx_rec, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_offs,
                           &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff, &a->tx_pout, &a->tx_nout}) b->release();
         for (int i = 0; i < kTimerRing; ++i) for (int j = 0; j <= kTimerSlots; ++j) (void)hipEventDestroy(a->ev[i][j]);
+        if (a->ev_wait) (void)hipEventDestroy(a->ev_wait);
         if (a->stream) (void)hipStreamDestroy(a->stream);
     }
     delete a;
@@ -946,7 +959,7 @@ static int fetch_text_impl(bgr_aligner* a, bgr_text_batch* b) {
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text write launch: ") + hipGetErrorString(e));
     if (a->tx_pbytes) HIP_TRY(hipMemcpyAsync(b->paths_out, a->tx_pout.p, a->tx_pbytes, hipMemcpyDeviceToHost, a->stream));
     if (a->tx_nbytes) HIP_TRY(hipMemcpyAsync(b->notaligned_out, a->tx_nout.p, a->tx_nbytes, hipMemcpyDeviceToHost, a->stream));
-    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(wait_stream(a));
     return BGR_OK;
 }
 
@@ -1079,7 +1092,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text record launches: ") + hipGetErrorString(e));
     uint32_t h[TXT_INFO_WORDS];
     HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
-    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(wait_stream(a));
     lap(0);
     const uint32_t R = h[TXT_INFO_N_REC];
     b->n_records = R;
@@ -1102,7 +1115,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (rc != BGR_OK) return rc;
     a->last_n = 0;  // (bgr_aligner_fetch has no host read_offsets to pair its rows with: the text form hands out text)
     a->tx_n_acc = n_acc;
-    if (!b->want_output) { HIP_TRY(hipStreamSynchronize(a->stream)); return BGR_OK; }
+    if (!b->want_output) { HIP_TRY(wait_stream(a)); return BGR_OK; }
     // 4. sizes of the records, stream offsets, the bytes
     if (b->want_output == 2) {  // (tx_idx is free again behind the compaction: it takes the corrected reads' lengths)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(info + TXT_INFO_BUG), -1, 1, a->stream));
@@ -1118,7 +1131,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     uint32_t h2[TXT_INFO_WORDS + 2];
     HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(hipMemcpyAsync(h2, a->small.p, 8, hipMemcpyDeviceToHost, a->stream));  // cursor[1]: arena overflow flag
-    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(wait_stream(a));
     lap(2);
     if (h2[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
     if (b->want_output == 2 && h[TXT_INFO_BUG] != 0xFFFFFFFFu) {  // a path that does not spell a walk: the reference prints "bug compaction" and exits
@@ -1153,7 +1166,7 @@ int bgr_aligner_device_results(bgr_aligner* a, void** d_results, void** d_arena,
 // their copies into the caller's memory (fetch_copy: relative path_offsets[0..n], status[0..n), total ints at paths_out)
 static int fetch_total(bgr_aligner* a, uint64_t n, uint64_t* total_out) {
     HIP_TRY(hipSetDevice(a->device));
-    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(wait_stream(a));
     const uint64_t nb = (n + 4095) / 4096;
     HIP_TRY(a->csr_sums.ensure(nb * 4 + 64));
     HIP_TRY(a->csr_poffs.ensure((n + 1) * 8));
@@ -1164,7 +1177,7 @@ static int fetch_total(bgr_aligner* a, uint64_t n, uint64_t* total_out) {
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("csr launch: ") + hipGetErrorString(e));
     uint64_t hs[17];  // cursor[0..1] @0, path-int total @128
     HIP_TRY(hipMemcpyAsync(hs, a->small.p, sizeof(hs), hipMemcpyDeviceToHost, a->stream));
-    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(wait_stream(a));
     const uint32_t* cur = reinterpret_cast<const uint32_t*>(hs);
     if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
     *total_out = hs[16];
@@ -1181,7 +1194,7 @@ static int fetch_copy(bgr_aligner* a, uint64_t n, uint64_t total, int32_t* paths
     HIP_TRY(hipMemcpyAsync(path_offsets, a->csr_poffs.p, (n + (with_end ? 1 : 0)) * 8, hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(hipMemcpyAsync(status, a->csr_status.p, n, hipMemcpyDeviceToHost, a->stream));
     if (total) HIP_TRY(hipMemcpyAsync(paths_out, a->csr_paths.p, total * 4, hipMemcpyDeviceToHost, a->stream));
-    HIP_TRY(hipStreamSynchronize(a->stream));
+    HIP_TRY(wait_stream(a));
     return BGR_OK;
 }
 

@@ -987,3 +987,36 @@ def test_bench_sub_record_of_the_exhaustive_config():
     assert "exhaustive" in d["config"]["workload"] and d["parity_sample"]["gpu_equals_oracle"] is True
     c = d["cpu_baseline"]
     assert c["kind"] == "reference" and c["value"] > 0 and c["reference_reads"] == 5000 and c["gpu_matches_cpu_counters"] is True
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """The N > 1 code path of bench.py as the driver launches it (torch.distributed.run, one rank per GPU), rehearsed with two ranks that
+    share this box's one GPU and the gloo backend (BGR_BENCH_BACKEND=gloo; never a reported number): one JSON line from rank 0 with the
+    whole-job value, the ranks that took part, the graph broadcast's bytes and time, the counters summed over the ranks, the end-to-end leg
+    per rank plus the CLI's own forms in one process (ordered pair and split run: bytes identical), and the C-ABI's one-process form
+    (bgr_devices_init + an aligner and a host thread per device)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BGR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads-per-step", "300000", "--e2e-reads", "400000",
+           "--alg-sample", "3000", "--genome", "400000", "--no-pmc"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["parity_sample"]["gpu_equals_oracle"] is True
+    assert d["counters"]["reads"] == 2 * 2 * 300000
+    m = d["multi_gpu"]
+    assert m["ranks_seen"] == 2 and m["graph_broadcast_bytes"] > 1000 and m["graph_broadcast_ms"] > 0
+    o = d["one_process_all_gpus"]
+    assert "error" not in o, o
+    assert o["value"] > 0 and o["n_gpus"] >= 1 and sum(o["reads_mapped_per_device"]) == o["n_gpus"] * (o["steps"] + 1) * 300000
+    e = d["e2e"]
+    assert e["value"] > 0 and e["n_gpus"] == 2 and e["host_route"]["identical_bytes_to_the_text_route"] is True
+    one = e["one_process_all_gpus"]
+    assert "error" not in one, one
+    assert one["identical_bytes_to_one_gpu"] is True and one["split_output"]["identical_bytes_concatenated"] is True
+    assert d["cpu_baseline"] is None and d["pcie_inclusive"] is None and d["other_configs"] is None   # N = 1 only
