@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(1024, BGR_ANC4_OCC) bgr_align_anchors4_kernel(
     // behind it: reverse(left) ++ [offset,] unitig ++ right is the slice row[LH - nl, LH + nmid + nr)
     constexpr uint32_t LH = kA4PathInts / 2 - 1;
     unsigned long long* wg_counts = wg_counts_init(lds);
-    task_stock_init(lds);
+    task_stock_init(lds, (io.n_reads + RPW - 1) / RPW);
     __syncthreads();
 
     // (a wave claims its next RPW reads at run time -- claim_task, device_common.h -- instead of a share dealt out by wave number)

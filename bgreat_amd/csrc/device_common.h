@@ -667,9 +667,19 @@ constexpr uint32_t kTaskRefill = 32;          // tasks a workgroup takes from th
 constexpr uint32_t kTaskRefillMin = 4;        // ... and at least
 constexpr uint32_t kTaskDone = 0xC0000000u;   // `next` of a stock whose launch has no task left
 constexpr uint32_t kLdsTaskWord = 8;          // the stock: u64 number 8 of the workgroup's reserved LDS header (bytes 64 .. 71)
-__device__ __forceinline__ void task_stock_init(u64* lds) { if (threadIdx.x == 0) lds[kLdsTaskWord] = 0; }  // (before the prologue's barrier)
+// A workgroup starts with one task per wave, its own by number (tasks [b W, (b + 1) W) for workgroup b of W waves): no atomic at the start of a
+// launch, when every workgroup would ask at once (512 of them queue ~6 us on one address: a fifth of a 131 k-read launch, whose tasks are as many
+// as its waves); the launch's counter hands out the tasks behind those, so it counts from gridDim.x * W (task_stock_base).
+__device__ __forceinline__ uint32_t task_stock_base() { return gridDim.x * (blockDim.x >> 6); }
+__device__ __forceinline__ void task_stock_init(u64* lds, uint32_t n_tasks) {  // (before the prologue's barrier)
+    if (threadIdx.x == 0) {
+        const uint32_t w = blockDim.x >> 6, first = blockIdx.x * w, end = n_tasks - first < w ? n_tasks : first + w;
+        lds[kLdsTaskWord] = first < n_tasks ? ((u64)end << 32) | first : 0;  // (an empty stock {0, 0}: the first claim goes to the counter and finds the launch used up)
+    }
+}
 // -> the task claimed, or BGR_NONE when the launch has none left; wave-uniform.  `ctr`: the launch's counter (zero at launch).
 __device__ __forceinline__ uint32_t claim_task(u64* lds, uint32_t* ctr, uint32_t n_tasks, int lane) {
+    const uint32_t base = task_stock_base();
     unsigned long long* stock = reinterpret_cast<unsigned long long*>(lds + kLdsTaskWord);
     for (;;) {
         unsigned long long old = 0;
@@ -680,11 +690,12 @@ __device__ __forceinline__ uint32_t claim_task(u64* lds, uint32_t* ctr, uint32_t
         if (next == end) {  // exactly one wave sees the stock run out (or finds it empty at the start): it refills, and takes the first task itself
             // (guided: what is left of the batch -- judged by where the stock just used up ended -- shared out twice over all workgroups, at most
             // kTaskRefill and at least kTaskRefillMin tasks: towards the end of a launch the workgroups take small bites)
-            const uint32_t left = n_tasks > end ? n_tasks - end : 0u, share = left / (2u * gridDim.x);
+            const uint32_t seen = end > base ? end : base;  // (tasks known to be handed out: the static first ones, and what this workgroup took last)
+            const uint32_t left = n_tasks > seen ? n_tasks - seen : 0u, share = left / (2u * gridDim.x);
             const uint32_t want = share > kTaskRefill ? kTaskRefill : share < kTaskRefillMin ? kTaskRefillMin : share;
             uint32_t g = 0;
             if (lane == 0) g = atomicAdd(ctr, want);
-            g = rl32(g, 0);
+            g = rl32(g, 0) + base;
             const bool none = g >= n_tasks;
             const uint32_t e = n_tasks - g < want ? n_tasks : g + want;
             if (lane == 0) __hip_atomic_store(stock, none ? (unsigned long long)kTaskDone : ((unsigned long long)e << 32) | (g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

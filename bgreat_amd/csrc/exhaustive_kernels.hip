@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
     const uint32_t mmx_w = (BGR_EXH_MMX && !STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
     const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
     unsigned long long* wg_counts = wg_counts_init(lds);
-    task_stock_init(lds);
+    task_stock_init(lds, (io.n_reads + RPW - 1) / RPW);
 #ifdef BGR_PHASE_TIMING
     const unsigned long long wt0 = wall_clock64();
 #endif

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     // global atomic per wave and counter, all on the same four addresses, cost a launch of 131 k reads a third of its time)
     uint32_t* wg_counts = reinterpret_cast<uint32_t*>(lds);
     if (threadIdx.x < 4) wg_counts[threadIdx.x] = 0;
-    task_stock_init(lds);
+    task_stock_init(lds, (total + RPW - 1) / RPW);
 #ifdef BGR_PHASE_TIMING  /* tools/wave_times.sh: when does a wave start, have its table, finish its share of the batch, finish its queue */
     const unsigned long long wt0 = wall_clock64();
     unsigned long long wt2 = 0;
