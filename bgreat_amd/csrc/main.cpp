@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
     bgr_set_build_threads((uint32_t)std::max(1, threads));
     if (bgr_graph_build_from_fasta_ex(unitigs.c_str(), (uint32_t)ka, 0.0, dog ? BGR_BUILD_ANCHORS : 0u, &graph) != BGR_OK) die("index");
     // one host -> device copy, then device to device over xGMI (RCCL broadcast, or peer copies): include/bgreat_gpu.h
-    if (bgr_devices_init(graph, 0, (uint32_t)gpus, BGR_FANOUT_AUTO) != BGR_OK) die("device setup");
+    if (bgr_devices_init(graph, 0, getenv("BGREAT_TEST_LANES_ON_ONE_DEVICE") ? 1u : (uint32_t)gpus, BGR_FANOUT_AUTO) != BGR_OK) die("device setup");
     auto t1 = std::chrono::system_clock::now();
     std::cout << "Indexing in seconds : " << std::chrono::duration_cast<std::chrono::seconds>(t1 - t0).count() << std::endl;  // aligner.cpp:546
 

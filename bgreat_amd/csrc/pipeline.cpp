@@ -1328,7 +1328,8 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
             }
             bgr_run_options o = *opt;
             o.n_gpus = 1;
-            o.first_device = opt->first_device + d;
+            // (BGREAT_TEST_LANES_ON_ONE_DEVICE=1, a test hook: every lane on the first device -- the split run's code path on a one-GPU box)
+            o.first_device = getenv("BGREAT_TEST_LANES_ON_ONE_DEVICE") ? opt->first_device : opt->first_device + d;
             o.threads = std::max<uint32_t>(1, opt->threads / n);
             o.echo_files = 0;
             o.split_output = 0;

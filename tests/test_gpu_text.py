@@ -252,3 +252,41 @@ def test_cli_correction_mode_on_the_device_equals_the_host_formatter(seed, L, k,
     # a corrected read is as long as its read (the walk covers it) and made of ACGT
     lines = pa.split(b"\n")
     assert all(len(x) == L and set(x) <= set(b"ACGT") for x in lines[1:2000:2])
+
+
+@pytest.mark.parametrize("lanes,extra", [(2, []), (3, ["--host-route"]), (4, ["--batch", "3000"])])
+def test_cli_split_output_pairs_concatenate_to_the_single_run(lanes, extra, tmp_path):
+    """--gpus N --split-output: one pipeline per device over contiguous shares of the input, N output pairs; `cat` in device order must be
+    the single pipeline's files.  (BGREAT_TEST_LANES_ON_ONE_DEVICE=1 puts every lane on this box's one GPU: the split run's own code --
+    shares cut at record starts over two input files, concurrent pipelines, the text route's fall-back per piece on the messy file -- on
+    real device calls.)"""
+    import subprocess
+    k, L, n = 31, 110, 30000
+    s = Synth(150000, 90, 2, k, 6100)
+    s.write_unitigs(str(tmp_path / "u.fa"))
+    s.write_reads(str(tmp_path / "a.fa"), 0, n, L, 2, 6101)
+    reads, _ = s.reads(n, 4000, L, 2, 6101)
+    with open(tmp_path / "b.fa", "wb") as f:   # a second file of another shape: multi-line sequences, a lower-case read, a short one
+        for i in range(4000):
+            r = reads[i * L:(i + 1) * L].tobytes()
+            if i % 7 == 0:
+                r = r[:50] + b"\n" + r[50:]
+            if i % 97 == 0:
+                r = r.lower()
+            if i % 131 == 0:
+                r = r[:20]
+            f.write(b">b%d\n" % i + r + b"\n")
+    args = ["-r", "%s,%s" % (tmp_path / "a.fa", tmp_path / "b.fa"), "-k", str(k), "-g", str(tmp_path / "u.fa"), "-m", "2", "-t", "6"] + extra
+    from util import run_cli
+    o1, p1, n1 = run_cli(B.CLI_PATH, args)
+    d = tmp_path / "split"
+    d.mkdir()
+    env = dict(os.environ, BGREAT_TEST_LANES_ON_ONE_DEVICE="1")
+    pr = subprocess.run([B.CLI_PATH] + args + ["--gpus", str(lanes), "--split-output"], cwd=d, capture_output=True, text=True, env=env, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    ps = b"".join(open(d / ("paths.%d" % i), "rb").read() for i in range(lanes))
+    ns = b"".join(open(d / ("notAligned.fa.%d" % i), "rb").read() for i in range(lanes))
+    assert ps == p1 and ns == n1 and len(p1) > 100000
+    assert not (d / "paths").exists()
+    keep = lambda o: [l for l in o.splitlines() if "seconds" not in l]
+    assert keep(pr.stdout) == keep(o1)   # file names, then the reference's closing block with the same counters
