@@ -67,7 +67,7 @@ class TextBatch(C.Structure):
     _fields_ = [("text", C.c_void_p), ("text_bytes", C.c_uint64), ("want_output", C.c_uint32), ("irregular", C.c_uint32), ("paths_out", C.c_void_p),
                 ("paths_cap", C.c_uint64), ("notaligned_out", C.c_void_p), ("notaligned_cap", C.c_uint64), ("n_records", C.c_uint64),
                 ("n_accepted", C.c_uint64), ("paths_bytes", C.c_uint64), ("notaligned_bytes", C.c_uint64), ("stage", C.c_void_p),
-                ("fastq", C.c_uint32), ("reserved", C.c_uint32)]
+                ("fastq", C.c_uint32), ("reserved", C.c_uint32), ("record_info_out", C.c_void_p), ("record_info_cap", C.c_uint64)]
 
 
 class PackedReads(C.Structure):
@@ -406,7 +406,7 @@ class Aligner:
         _check(lib().bgr_align_batch_wait(C.byref(t), paths.ctypes.data, cap, poffs.ctypes.data, status.ctypes.data))
         return paths[: int(poffs[n])].copy(), poffs, status[:n]
 
-    def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False, fastq=False, parts=None):
+    def align_fasta_text(self, text, m=2, effort=2, mode=MODE_GREEDY, partial=False, want_output=True, paths_cap=None, staged=False, fastq=False, parts=None, record_info=False):
         """bgr_align_fasta_text: a piece of a FASTA file (bytes) -> (paths bytes, notAligned bytes, info dict); info["irregular"] = the
         device left the piece to the host parser (nothing mapped).  fastq: True / 1 = the piece is whole four-line FASTQ records instead, 2 = their
         header and read lines only.  A too small `paths_cap` is grown through bgr_aligner_fetch_text.  parts (with staged): byte offsets at which
@@ -418,6 +418,10 @@ class Aligner:
         nout = np.empty(n + 64, dtype=np.uint8)
         b = TextBatch(text.ctypes.data if n else None, n, int(want_output), 0, pout.ctypes.data, pcap, nout.ctypes.data, n + 64, 0, 0, 0, 0, None)
         b.fastq = int(fastq)
+        rinfo = None
+        if record_info:
+            rinfo = np.zeros(n // 24 + 1024, dtype=np.uint32)
+            b.record_info_out, b.record_info_cap = rinfo.ctypes.data, len(rinfo)
         p = Params(mode, m, effort, int(partial))
         stage = C.c_void_p()
         if staged:  # the piece sent ahead on a copy stream of its own (bgr_text_stage_upload); the call orders itself behind it
@@ -443,6 +447,8 @@ class Aligner:
                 lib().bgr_text_stage_destroy(stage)
         _check(rc)
         info = {"irregular": bool(b.irregular), "n_records": int(b.n_records), "n_accepted": int(b.n_accepted)}
+        if rinfo is not None:  # one word per record: kept << 31 | mapped << 30 | read length
+            info["records"] = rinfo[: int(b.n_records)].copy()
         return pout[: int(b.paths_bytes)].tobytes(), nout[: int(b.notaligned_bytes)].tobytes(), info
 
     def align_device(self, d_reads_ptr, d_offsets_ptr, n, total_bases, max_len, m=2, effort=2, mode=MODE_GREEDY, partial=False):

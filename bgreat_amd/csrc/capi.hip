@@ -92,7 +92,7 @@ struct bgr_aligner {
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
     // the text route (bgr_align_fasta_text): the piece, its records, the formatted streams
-    DevBuf tx_in, tx_sums, tx_start, tx_rec, tx_flag, tx_len, tx_idx, tx_boff, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout;
+    DevBuf tx_in, tx_sums, tx_start, tx_rec, tx_flag, tx_len, tx_idx, tx_boff, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout, tx_info;
     uint64_t tx_n_acc = 0, tx_pbytes = 0, tx_nbytes = 0;
     bool blocking_sync = getenv("BGREAT_BLOCKING_SYNC") && atoi(getenv("BGREAT_BLOCKING_SYNC")) != 0;
     hipEvent_t ev_wait = nullptr;
@@ -471,7 +471,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
         a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->lst.release(); a->deep.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
         for (DevBuf* b : {&a->tx_in, &a->tx_sums, &a->tx_start, &a->tx_rec, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_offs,
-                          &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff, &a->tx_pout, &a->tx_nout}) b->release();
+                          &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff, &a->tx_pout, &a->tx_nout, &a->tx_info}) b->release();
         for (int i = 0; i < kTimerRing; ++i) for (int j = 0; j <= kTimerSlots; ++j) (void)hipEventDestroy(a->ev[i][j]);
         if (a->ev_wait) (void)hipEventDestroy(a->ev_wait);
         if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -1047,6 +1047,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         return fail(BGR_E_ARG, "bgr_align_fasta_text: a FASTQ piece holds whole four-line records and ends with a newline");
     if (b->want_output == 2 && (a->graph->header.has_exc || p->mode == BGR_MODE_EXHAUSTIVE))
         return fail(BGR_E_ARG, "bgr_align_fasta_text: correction on the device needs a graph of ACGT-only unitigs and greedy mode (format such a run on the host)");
+    if (b->record_info_out && (b->want_output == 2 || b->record_info_cap < b->text_bytes / 24 + 1024))
+        return fail(BGR_E_ARG, "bgr_align_fasta_text: record_info_out needs room for text_bytes / 24 + 1024 words and is not available in correction mode");
     a->tx_want = b->want_output;
     b->irregular = 0;
     b->n_records = b->n_accepted = b->paths_bytes = b->notaligned_bytes = 0;
@@ -1101,7 +1103,10 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (h[TXT_INFO_IRREGULAR]) { b->irregular = 1; return BGR_OK; }
     const uint32_t n_acc = h[TXT_INFO_N_ACC], bases = h[TXT_INFO_BASES], max_len = h[TXT_INFO_MAX_LEN];
     b->n_accepted = n_acc;
-    if (n_acc == 0) return BGR_OK;
+    if (n_acc == 0) {
+        if (b->record_info_out) memset(b->record_info_out, 0, (size_t)R * 4);  // (nothing kept: every record a dropped one)
+        return BGR_OK;
+    }
     // 3. planes, mapping launch
     const uint64_t plane_words = (bases >> 5) + (uint64_t)n_acc + 4;
     HIP_TRY(a->pk_fw3.ensure(plane_words * 8));
@@ -1115,6 +1120,13 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (rc != BGR_OK) return rc;
     a->last_n = 0;  // (bgr_aligner_fetch has no host read_offsets to pair its rows with: the text form hands out text)
     a->tx_n_acc = n_acc;
+    if (b->record_info_out) {  // what became of every record (the -b progress blocks of the caller), on its way to the host behind the mapping launch
+        HIP_TRY(a->tx_info.ensure((uint64_t)R * 4));
+        e = bgr::launch_text_record_info(static_cast<const uint4*>(a->tx_rec.p), static_cast<const uint32_t*>(a->tx_idx.p), static_cast<const uint2*>(a->results.p), R,
+                                         static_cast<uint32_t*>(a->tx_info.p), a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("record info launch: ") + hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(b->record_info_out, a->tx_info.p, (size_t)R * 4, hipMemcpyDeviceToHost, a->stream));
+    }
     if (!b->want_output) { HIP_TRY(wait_stream(a)); return BGR_OK; }
     // 4. sizes of the records, stream offsets, the bytes
     if (b->want_output == 2) {  // (tx_idx is free again behind the compaction: it takes the corrected reads' lengths)

@@ -156,6 +156,7 @@ struct Pinned {  // the page-locked buffers of one batch in flight: sources / ta
     HostBuf fw3{true}, hasn{true}, nm_idx{true}, nm_val{true}, offs{true}, paths{true}, poffs{true}, status{true};
     // text route (bgr_align_fasta_text): the piece of the file as it is, and the two record streams as they come back
     HostBuf text{true}, ptext{true}, ntext{true};
+    HostBuf info{true};  // text route under -b with progress blocks: one word per record of the piece (bgr_text_batch.record_info_out)
     std::vector<bgr_text_stage*> stages;  // per device of the run: where this set's piece waits in HBM (bgr_text_stage_upload), made on first use
     uint64_t nm_count = 0;
     uint32_t max_len = 0;
@@ -196,6 +197,12 @@ struct Batch {
     // ({first byte, number of the line it lies in}, FastqPlan::piece_parts), t_gathered = bytes of header + read lines staged
     std::vector<std::pair<uint64_t, uint64_t>> fq_parts;
     uint64_t t_gathered = 0;
+    // text route under -b with progress blocks: the batch is a piece [t_begin, t_end) of its file whatever route mapped it in the end; the
+    // writer counts getReads() iterations (record attempts) itself.  n_attempts = iterations of the piece; the device's per-record words sit in
+    // pin->info, a piece that fell back to the host parser lists the iteration of each of its reads in att_of_read
+    bool text_origin = false, first_of_file = false, last_of_file = false;
+    uint64_t n_attempts = 0;
+    std::vector<uint64_t> att_of_read;
     unsigned dev = 0;                                     // which device of the run maps the batch (round robin in input order)
     int rc = BGR_OK;
     std::string err;
@@ -484,7 +491,10 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     // Correction mode too (the device spells the reads from its 2-bit unitig store) unless the graph has non-ACGT unitig characters.
     bgr_graph_info_t gi_route;
     if (bgr_graph_info(graph, &gi_route) != BGR_OK) return BGR_E_ARG;
-    const bool text_route = opt->route == 0 && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !progress_blocks && getenv("BGREAT_HOST_ROUTE") == nullptr;
+    // (round 4: -b WITH its progress blocks too, for FASTA -- the device says what became of every record, bgr_text_batch.record_info_out, and
+    // the ordered writer counts getReads() calls from that; FASTQ with progress blocks stays on the host route)
+    const bool text_route = opt->route == 0 && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !(progress_blocks && opt->fastq) && getenv("BGREAT_HOST_ROUTE") == nullptr;
+    const bool text_progress = text_route && progress_blocks;
     const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (text_route ? 1ull << 18 : 1ull << 17), 4ull << 20);
     // text route: bytes of a batch.  At most kTextPieceMax: the device addresses the two formatted streams with 32 bits, and a piece of B
     // bytes gives at most 12 B + (its own bytes) of records (--batch beyond ~1.9 M reads of 150 bp is cut to that)
@@ -628,6 +638,9 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
             b->text_piece = b->dev_text = b->fastq_piece = false;
             b->fq_parts.clear();
             b->t_gathered = 0;
+            b->text_origin = b->first_of_file = b->last_of_file = false;
+            b->n_attempts = 0;
+            b->att_of_read.clear();
             b->marks.clear();
             for (auto& m : pending) { m.pos = 0; b->marks.push_back(std::move(m)); }
             pending.clear();
@@ -795,6 +808,9 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                     b->dev_text = false;
                     b->t_begin = s_begin + cuts[c];
                     b->t_end = s_begin + (c + 1 < cuts.size() ? cuts[c + 1] : ssize);
+                    b->text_origin = true;
+                    b->first_of_file = c == 0;
+                    b->last_of_file = c + 1 == cuts.size();
                     ok = emit(std::move(b));
                 }
                 continue;
@@ -981,14 +997,20 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
         std::vector<uint64_t> starts = bgr::split_fasta(base, bytes, chunk_bytes);
         b.chunks.clear();
         b.chunks.resize(starts.size());
-        for (auto& ch : b.chunks) ch = std::make_unique<ParsedChunk>();
+        for (auto& ch : b.chunks) { ch = std::make_unique<ParsedChunk>(); ch->track_iters = text_progress; }
         Batch* bp = &b;
         pool.run(starts.size(), [&](size_t j) {
             const uint64_t e = j + 1 < starts.size() ? starts[j + 1] : bytes;
             bgr::parse_fasta_chunk(base, starts[j], e, gi.k, *bp->chunks[j]);
         }, 1);
         b.recs.clear();
-        for (auto& ch : b.chunks) b.recs.insert(b.recs.end(), ch->recs.begin(), ch->recs.end());
+        b.att_of_read.clear();
+        b.n_attempts = 0;
+        for (auto& ch : b.chunks) {
+            b.recs.insert(b.recs.end(), ch->recs.begin(), ch->recs.end());
+            if (text_progress) for (uint32_t it : ch->rec_iter) b.att_of_read.push_back(b.n_attempts + it);  // (iterations of the piece: chunk after chunk)
+            b.n_attempts += ch->iters;
+        }
         b.n = b.recs.size();
         b.dev_text = false;
         us_parse += now_us() - tp0;
@@ -1038,7 +1060,14 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                     tb.paths_cap = b->pin->ptext.cap;
                     tb.notaligned_out = static_cast<char*>(b->pin->ntext.p);
                     tb.notaligned_cap = b->pin->ntext.cap;
-                    int rc = bgr_align_fasta_text(aligners[w], prm, &tb);
+                    int rc = BGR_OK;
+                    if (text_progress) {  // what became of every record: the writer's progress blocks
+                        const uint64_t words = tb.text_bytes / 24 + 1024;
+                        if (!b->pin->info.ensure(words * 4)) rc = BGR_E_HIP;
+                        tb.record_info_out = static_cast<uint32_t*>(b->pin->info.p);
+                        tb.record_info_cap = words;
+                    }
+                    if (rc == BGR_OK) rc = bgr_align_fasta_text(aligners[w], prm, &tb);
                     if (rc == BGR_E_CAPACITY) {  // unusually long records: the same device results into larger buffers
                         if (!b->pin->ptext.ensure(tb.paths_bytes + 64) || !b->pin->ntext.ensure(tb.notaligned_bytes + 64)) rc = BGR_E_HIP;
                         else {
@@ -1056,6 +1085,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                     } else {
                         b->dev_text = true;
                         b->n = tb.n_accepted;
+                        b->n_attempts = tb.n_records;
                         b->p_bytes = tb.paths_bytes;
                         b->n_bytes = tb.notaligned_bytes;
                     }
@@ -1170,6 +1200,45 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
             std::cout << "Overlap per reads : " << (got ? c_overlaps / got : 0u) << std::endl;
             std::cout << std::endl;
         };
+        // text route under -b with progress blocks: the writer counts getReads() iterations itself.  A batch is a piece of its file; the
+        // device reports what became of each of its records (pin->info: kept << 31 | mapped << 30 | length, record = iteration), a piece that
+        // went through the host parser lists the iteration of each of its reads.  Same rule as ProgressMarker::chunk / end_file on the host route.
+        ProgressMarker wmark;
+        wmark.on = text_progress;
+        uint64_t w_file_iters = 0;
+        auto count_attempts = [&](const Batch& bt, uint64_t lo, uint64_t hi, uint64_t& rd) {  // iterations [lo, hi) of the piece; rd: cursor into its reads (fallback form)
+            if (bt.dev_text) {
+                const uint32_t* info = static_cast<const uint32_t*>(bt.pin->info.p);
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const uint32_t v = info[i];
+                    if (!(v >> 31)) continue;
+                    ++c_reads;
+                    if (v & 0x40000000u) ++c_aligned; else ++c_failed;
+                    const uint32_t L = v & 0x3FFFFFFFu;
+                    c_overlaps += L >= K1 ? L - K1 + 1 : 1;
+                }
+            } else {
+                uint64_t r1 = rd;
+                while (r1 < bt.att_of_read.size() && bt.att_of_read[r1] < hi) ++r1;
+                if (r1 > rd) count_reads(bt, rd, r1);
+                rd = r1;
+            }
+        };
+        auto text_progress_batch = [&](const Batch& bt) {
+            if (bt.first_of_file) { wmark.begin_file(); w_file_iters = 0; }
+            uint64_t at = 0, rd = 0;
+            while (wmark.next_fc * kRefBatch < w_file_iters + bt.n_attempts) {  // a block is due in front of iteration `rel` of this piece
+                const uint64_t rel = wmark.next_fc * kRefBatch > w_file_iters ? wmark.next_fc * kRefBatch - w_file_iters : 0;
+                count_attempts(bt, at, rel, rd);
+                at = rel;
+                print_block();
+                wmark.next_fc += 10;
+            }
+            count_attempts(bt, at, bt.n_attempts, rd);
+            w_file_iters += bt.n_attempts;
+            if (bt.last_of_file)
+                for (unsigned d = wmark.end_file(std::max<uint64_t>(1, w_file_iters)); d; --d) print_block();
+        };
         while (to_out.pop(b)) {
             pending[b->index] = std::move(b);
             while (!pending.empty() && pending.begin()->first == want) {
@@ -1182,11 +1251,13 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                 } recycle{recycle_batch, cur};
                 if (!failed) {  // what the reference prints between reads, in input order
                     uint64_t at = 0;
+                    const bool own_count = text_progress && cur->text_origin;  // (its marks are file names only; the iterations are counted below)
                     for (const Mark& mk : cur->marks) {
-                        if (progress_blocks) { count_reads(*cur, at, mk.pos); at = mk.pos; }
+                        if (progress_blocks && !own_count) { count_reads(*cur, at, mk.pos); at = mk.pos; }
                         if (mk.kind == 1) std::cout << mk.text << std::endl; else print_block();
                     }
-                    if (progress_blocks) count_reads(*cur, at, cur->n);
+                    if (progress_blocks && !own_count) count_reads(*cur, at, cur->n);
+                    if (own_count) text_progress_batch(*cur);
                 }
                 if ((failed && !stop_writing_after_this) || !writes || wrote_last || cur->n == 0) continue;
                 if (cur->dev_text) {  // the record streams are ready as they are

@@ -34,6 +34,8 @@ hipError_t launch_text_sizes(const uint2* results, const int32_t* arena, const u
                              hipStream_t stream);
 hipError_t launch_text_write(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc,
                              const uint32_t* poff, const uint32_t* noff, uint8_t* pout, uint8_t* nout, hipStream_t stream);
+// one word per record, record order: kept << 31 | mapped << 30 | read length (bgr_text_batch.record_info_out)
+hipError_t launch_text_record_info(const uint4* rec, const uint32_t* acc_idx, const uint2* results, uint32_t n_rec, uint32_t* out, hipStream_t stream);
 // correction mode (-c): mapped reads are written as header + the read spelled by its path (recoverPath, aligner.cpp:270-290)
 hipError_t launch_text_correct_sizes(const BgrDeviceGraph& g, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* psz,
                                      uint32_t* nsz, uint32_t* clen, uint32_t* bug, hipStream_t stream);

@@ -248,6 +248,19 @@ __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* te
     }
 }
 
+// what became of every record, for a caller that reproduces the reference's -b progress blocks: kept << 31 | mapped << 30 | read length
+__global__ void __launch_bounds__(256) bgr_text_record_info_kernel(const uint4* rec, const uint32_t* acc_idx, const uint2* results, uint32_t n_rec, uint32_t* out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rec) return;
+    const uint32_t w = rec[j].w;
+    uint32_t v = 0;
+    if (w >> 31) {
+        const uint32_t st = results[acc_idx[j]].y >> 24;
+        v = 0x80000000u | ((st & BGR_ST_MASK) == BGR_ST_ALIGNED ? 0x40000000u : 0u) | (w & 0x3FFFFFFFu);
+    }
+    out[j] = v;
+}
+
 // accepted records, compacted in input order: which record, where its sequence starts in the text, base offsets of the batch
 __global__ void __launch_bounds__(256) bgr_text_compact_kernel(const uint4* rec, const uint32_t* n_rec_p, const uint32_t* acc_idx, const uint32_t* base_off,
                                                                uint32_t* acc_rec, uint32_t* acc_src, u64* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p) {
@@ -510,6 +523,12 @@ hipError_t launch_text_compact(const uint4* rec, const uint32_t* n_rec_p, uint32
                                uint32_t* acc_src, uint64_t* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p, hipStream_t stream) {
     hipLaunchKernelGGL(bgr_text_compact_kernel, dim3(std::max<uint32_t>(1, (max_rec + 255) / 256)), dim3(256), 0, stream, rec, n_rec_p, acc_idx, base_off, acc_rec, acc_src,
                        reinterpret_cast<u64*>(read_offs), n_acc_p, bases_p);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_record_info(const uint4* rec, const uint32_t* acc_idx, const uint2* results, uint32_t n_rec, uint32_t* out, hipStream_t stream) {
+    if (n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(bgr_text_record_info_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, stream, rec, acc_idx, results, n_rec, out);
     return hipGetLastError();
 }
 

@@ -221,6 +221,11 @@ typedef struct {
                                      2 = the same records with their '+' and quality lines left out by the caller: record j = lines 2j, 2j+1
                                      (header line, read line) -- half the bytes over PCIe, the same records out */
     uint32_t reserved;
+    uint32_t* record_info_out;    /* in, optional: one word per RECORD of the piece, in the piece's order -- bit 31: getReads keeps it, bit 30: it was mapped,
+                                     bits 0..29: its read's length (0 unless kept) -- what the reference's -b progress blocks count between two getReads()
+                                     calls (alignerExhaustive.cpp:306-316: a record, kept or dropped, is one iteration of the call).  Needs room for
+                                     text_bytes / 24 + 1024 words (record_info_cap); n_records of them are written.  Not with want_output = 2. */
+    uint64_t record_info_cap;
 } bgr_text_batch;
 /* A stage = a device buffer for one piece + a copy stream: bgr_text_stage_upload starts the host -> device copy and returns; the
  * bgr_align_fasta_text call that names the stage orders itself behind it (hipStreamWaitEvent), so the copy of the next piece runs

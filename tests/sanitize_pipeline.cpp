@@ -111,11 +111,13 @@ extern "C" int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_
     ps.clear(); ns.clear();
     uint64_t acc = 0;
     const uint32_t k = 5;  // (the FASTA cases of this harness run with k = 5)
+    if (b->record_info_out && b->record_info_cap < n / 24 + 1024) return BGR_E_ARG;
     for (size_t i = 0; i < lines.size(); i += per) {
         ++b->n_records;
         const std::string h(t + lines[i].first, t + lines[i].second), r(t + lines[i + 1].first, t + lines[i + 1].second);
         bool ok = r.size() > 2 && (b->fastq || r.size() > k);
         for (char c : r) if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') ok = false;
+        if (b->record_info_out) b->record_info_out[i / per] = ok ? 0x80000000u | ((r.size() & 1) ? 0x40000000u : 0u) | (uint32_t)r.size() : 0u;  // kept | mapped | length
         if (!ok) continue;
         if (r.size() & 1) { ps += h + "\n" + std::to_string(r.size()) + ".-" + std::to_string(acc) + ".7.\n"; ++a->counters[2]; }
         else { ns += h + "\n" + r + "\n"; ++a->counters[3]; }
@@ -270,6 +272,7 @@ int main(int argc, char** argv) {
                     for (int j = 0; j < 8 + i % 5; ++j) r += al[(i * 5 + j * 11 + (j * j) % 7) & 3];
                     if (i % 97 == 5) r[3] = 'x';     // dropped: still one getReads() iteration
                     if (fq) o << "@q" << i << "\n" << r << "\n+\n" << std::string(r.size(), 'I') << "\n";
+                    else if (fi == 1 && i % 1009 == 3) o << ">r" << i << "\n" << r.substr(0, 4) << "\n" << r.substr(4) << "\n";  // a sequence over two lines: such a piece goes back to the host parser
                     else o << ">r" << i << "\n" << r << "\n";
                 }
             }

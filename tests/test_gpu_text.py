@@ -290,3 +290,29 @@ def test_cli_split_output_pairs_concatenate_to_the_single_run(lanes, extra, tmp_
     assert not (d / "paths").exists()
     keep = lambda o: [l for l in o.splitlines() if "seconds" not in l]
     assert keep(pr.stdout) == keep(o1)   # file names, then the reference's closing block with the same counters
+
+
+@pytest.mark.parametrize("mode", [B.MODE_GREEDY, B.MODE_EXHAUSTIVE])
+def test_record_info_says_what_became_of_every_record(mode, tmp_path):
+    """bgr_text_batch.record_info_out (what bgr_align_all's writer turns into the reference's -b progress blocks): one word per record of
+    the piece, kept << 31 | mapped << 30 | read length -- against the host parser (which records getReads keeps) and bgr_align_batch
+    (which of those are mapped), with and without the formatted streams."""
+    k = 31
+    s, seqs, offs, text = _mixed_piece(5, 6000, 150, k)
+    al = B.Aligner(B.Graph.build(k, seqs, offs), 0)
+    f = tmp_path / "piece.fa"
+    f.write_bytes(text)
+    reads, roffs, heads, hoffs = B.load_reads(str(f), k)
+    paths, poffs, status = al.align(reads, roffs, m=2, mode=mode)
+    kept = {bytes(heads[hoffs[i]:hoffs[i + 1]]): (int(roffs[i + 1] - roffs[i]), bool(poffs[i + 1] > poffs[i])) for i in range(len(roffs) - 1)}
+    assert len(kept) == len(roffs) - 1   # (headers are unique in this piece)
+    headers = [l for l in text.split(b"\n")[0::2] if l]
+    for want in (True, False):
+        _, _, info = al.align_fasta_text(text, m=2, mode=mode, want_output=want, record_info=True)
+        rec = info["records"]
+        assert not info["irregular"] and len(rec) == info["n_records"] == len(headers) and int((rec >> 31).sum()) == info["n_accepted"] == len(kept)
+        for h, v in zip(headers, rec):
+            if h in kept:
+                assert (int(v) >> 31) == 1 and (int(v) & 0x3FFFFFFF) == kept[h][0] and bool(int(v) & 0x40000000) == kept[h][1]
+            else:
+                assert int(v) == 0
