@@ -219,9 +219,18 @@ FastqPlan::FastqPlan(const char* data, uint64_t size, uint64_t chunk_bytes)
 }
 
 static uint64_t count_newlines(const char* p, const char* end);
+static void collect_newlines(const char* p, const char* end, std::vector<uint32_t>& out);
 
 void FastqPlan::count_chunk(size_t c) {  // pass 1: newlines in chunk c
     const uint64_t b = c * chunk_bytes_, e = std::min<uint64_t>(size_, b + chunk_bytes_);
+    if (keep_nl_ && chunk_bytes_ <= 0xFFFFFFFFull) {  // (one pass: where the newlines are, for the gather behind; their number follows)
+        auto v = std::make_shared<std::vector<uint32_t>>();
+        v->reserve((size_t)((e - b) / 64) + 16);
+        collect_newlines(data_ + b, data_ + e, *v);
+        nl_[c + 1] = v->size();
+        nlpos_[c] = std::move(v);
+        return;
+    }
     nl_[c + 1] = count_newlines(data_ + b, data_ + e);
 }
 
@@ -334,6 +343,20 @@ static uint64_t count_newlines(const char* p, const char* end) {
     return n;
 }
 
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void collect_newlines_avx2(const char* p, const char* end, std::vector<uint32_t>& out) {
+    const char* const p0 = p;
+    each_newline_avx2(p, end, [&](const char* q) { out.push_back((uint32_t)(q - p0)); });
+}
+#endif
+static void collect_newlines(const char* p, const char* end, std::vector<uint32_t>& out) {
+#if defined(__x86_64__)
+    if (kHaveAvx2) { collect_newlines_avx2(p, end, out); return; }
+#endif
+    const char* const p0 = p;
+    each_newline_plain(p, end, [&](const char* q) { out.push_back((uint32_t)(q - p0)); });
+}
+
 namespace {
 struct GatherState {  // the kept lines (4j, 4j+1) of a FASTQ range, copied run by run: a run = header line + read line = one memcpy
     const char* run;  // start of the kept run the cursor is in, or null
@@ -358,6 +381,14 @@ uint64_t fastq_gather_lines(const char* data, uint64_t b, uint64_t e, uint64_t l
 #endif
     each_newline_plain(data + b, data + e, [&](const char* q) { st.newline(q); });
     if (st.run && st.run < data + e) { memcpy(st.o, st.run, (size_t)(data + e - st.run)); st.o += data + e - st.run; }  // the range ends inside a kept line
+    return (uint64_t)(st.o - dst);
+}
+
+uint64_t fastq_gather_lines_at(const char* data, uint64_t b, uint64_t e, uint64_t line, char* dst, const uint32_t* nl, size_t n, uint64_t nl_base) {
+    GatherState st{(line & 3) < 2 ? data + b : nullptr, line, dst};
+    const uint32_t* p = std::lower_bound(nl, nl + n, (uint32_t)(b - nl_base));
+    for (const uint32_t* end = nl + n; p < end && nl_base + *p < e; ++p) st.newline(data + nl_base + *p);
+    if (st.run && st.run < data + e) { memcpy(st.o, st.run, (size_t)(data + e - st.run)); st.o += data + e - st.run; }
     return (uint64_t)(st.o - dst);
 }
 

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -94,17 +95,29 @@ public:
     // (text route) the piece [o0, o1) of whole records, o0 = record_offset(r0), cut where the plan's chunks begin: {first byte, number of
     // the line that byte lies in}, ascending -- what fastq_gather_lines needs to work on the parts independently
     void piece_parts(uint64_t o0, uint64_t o1, uint64_t r0, std::vector<std::pair<uint64_t, uint64_t>>& out) const;
+    // keep_newlines(): count_chunk also KEEPS where the newlines of its chunk are (offsets from the chunk's first byte), so that the gather
+    // behind it copies the kept lines without scanning the text a second time; newlines_of(c) hands the list of chunk c to a batch,
+    // release_newlines(c_end) drops the plan's own hold on the chunks in front of c_end (the batches in flight keep theirs alive)
+    void keep_newlines() { keep_nl_ = true; nlpos_.resize(nc_); }
+    std::shared_ptr<const std::vector<uint32_t>> newlines_of(size_t c) const { return c < nlpos_.size() ? nlpos_[c] : nullptr; }
+    void release_newlines(size_t c_end) { for (; released_ < c_end && released_ < nlpos_.size(); ++released_) nlpos_[released_].reset(); }
+    uint64_t chunk_bytes() const { return chunk_bytes_; }
 private:
     const char* data_;
     uint64_t size_, chunk_bytes_;
     size_t nc_ = 0, summed_ = 0;
     std::vector<uint64_t> nl_, tail_start_;
     uint64_t complete_ = 0, par_records_ = 0;
+    bool keep_nl_ = false;
+    size_t released_ = 0;
+    std::vector<std::shared_ptr<const std::vector<uint32_t>>> nlpos_;
 };
 // Bytes [b, e) of a FASTQ image, byte b lying in line number `line` of the file (record j = lines 4j .. 4j+3, aligner.cpp:51-68): those
 // that belong to header lines (4j) and read lines (4j+1), newlines included, copied to dst in order -> bytes written (<= e - b).
 // The '+' and quality lines never reach the device this way: a 150 bp record crosses PCIe as ~165 instead of ~317 bytes.
 uint64_t fastq_gather_lines(const char* data, uint64_t b, uint64_t e, uint64_t line, char* dst);
+// the same from the newline positions a FastqPlan kept (nl[0 .. n): ascending offsets from `nl_base`, covering at least [b, e)): no second scan
+uint64_t fastq_gather_lines_at(const char* data, uint64_t b, uint64_t e, uint64_t line, char* dst, const uint32_t* nl, size_t n, uint64_t nl_base);
 // Whole four-line records in [begin, end) (end = the start of a record): header line + sequence line, kept iff size > 2 and ACGTN
 // (what every getReads() call but a file's last one does, aligner.cpp:51-68).
 void parse_fastq_records(const char* data, uint64_t begin, uint64_t end, ParsedChunk& out);

@@ -196,6 +196,8 @@ struct Batch {
     // a FASTQ piece crosses PCIe without its '+' and quality lines: fq_parts = where the gatherer may cut it into independent parts
     // ({first byte, number of the line it lies in}, FastqPlan::piece_parts), t_gathered = bytes of header + read lines staged
     std::vector<std::pair<uint64_t, uint64_t>> fq_parts;
+    std::vector<std::shared_ptr<const std::vector<uint32_t>>> fq_nl;  // per part: the newline offsets of the plan's chunk the part lies in (from that chunk's first byte), or null
+    uint64_t fq_chunk_bytes = 0;
     uint64_t t_gathered = 0;
     // text route under -b with progress blocks: the batch is a piece [t_begin, t_end) of its file whatever route mapped it in the end; the
     // writer counts getReads() iterations (record attempts) itself.  n_attempts = iterations of the piece; the device's per-record words sit in
@@ -637,6 +639,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
             b->bases = 0;
             b->text_piece = b->dev_text = b->fastq_piece = false;
             b->fq_parts.clear();
+            b->fq_nl.clear();
             b->t_gathered = 0;
             b->text_origin = b->first_of_file = b->last_of_file = false;
             b->n_attempts = 0;
@@ -677,6 +680,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                 // FASTQ: newline counts first (they fix which line of a record every chunk starts in), then the chunks
                 // group by group, so that the later stages already work on the first batches while the rest is parsed
                 bgr::FastqPlan plan(mf->data, mf->size, chunk_bytes);
+                if (text_route && fastq_gather) plan.keep_newlines();  // (the count pass keeps the newline positions: the gather does not scan again)
                 const size_t nc = plan.chunks();
                 uint64_t tp0 = now_us();
                 std::unique_ptr<Batch> b;
@@ -709,7 +713,12 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                             tb->text_piece = o1 - o0 < (1ull << 31);  // (one record of 2 GiB: the host parser takes it)
                             tb->fastq_piece = true;
                             tb->t_begin = o0; tb->t_end = o1;
-                            if (fastq_gather) plan.piece_parts(o0, o1, r0, tb->fq_parts);
+                            if (fastq_gather) {
+                                plan.piece_parts(o0, o1, r0, tb->fq_parts);
+                                tb->fq_chunk_bytes = plan.chunk_bytes();
+                                for (const auto& pt : tb->fq_parts) tb->fq_nl.push_back(plan.newlines_of((size_t)(pt.first / plan.chunk_bytes())));
+                                plan.release_newlines((size_t)(o1 / plan.chunk_bytes()));  // (chunks wholly in front of the next piece)
+                            }
                             if (!tb->text_piece) {
                                 tb->chunks.clear();
                                 tb->chunks.push_back(std::make_unique<ParsedChunk>());
@@ -957,7 +966,9 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                 const uint64_t lo = bp->fq_parts[j].first, hi = j + 1 < np ? bp->fq_parts[j + 1].first : bp->t_end;
                 char* dst = static_cast<char*>(bp->pin->text.p) + (lo - bp->t_begin);
                 ptrs[j] = dst;
-                lens[j] = bgr::fastq_gather_lines(bp->file->data, lo, hi, bp->fq_parts[j].second, dst);
+                const std::vector<uint32_t>* nl = j < bp->fq_nl.size() ? bp->fq_nl[j].get() : nullptr;
+                lens[j] = nl ? bgr::fastq_gather_lines_at(bp->file->data, lo, hi, bp->fq_parts[j].second, dst, nl->data(), nl->size(), (lo / bp->fq_chunk_bytes) * bp->fq_chunk_bytes)
+                             : bgr::fastq_gather_lines(bp->file->data, lo, hi, bp->fq_parts[j].second, dst);
             }, 2);
             us_gather += now_us() - tg1;
             b.t_gathered = 0;
@@ -1133,7 +1144,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     auto recycle_batch = [&](std::unique_ptr<Batch>& b) {  // hand the batch (and its pinned buffers) back to the producer
         if (!b) return;
         if (b->pin) free_pins.push(std::move(b->pin));
-        b->recs.clear(); b->marks.clear(); b->chunks.clear(); b->shared_chunks.reset(); b->file.reset();
+        b->recs.clear(); b->marks.clear(); b->chunks.clear(); b->shared_chunks.reset(); b->file.reset(); b->fq_nl.clear();
         free_batches.push(std::move(b));
     };
     std::thread io_thread([&]() {
