@@ -13,7 +13,9 @@ run greedy_host --extra=--host-route
 run correction_text --extra=-c
 run correction_host "--extra=-c --host-route"
 run anchors_text --extra=-G
-run exhaustive_counts --extra=-b --check 0
-run exhaustive_write "--extra=-b --write-exhaustive" --check 0
+run exhaustive_counts_text --extra=-b --check 0
+run exhaustive_counts_host "--extra=-b --host-route" --check 0
+run exhaustive_write_text "--extra=-b --write-exhaustive" --check 0
+run exhaustive_write_host "--extra=-b --write-exhaustive --host-route" --check 0
 run fastq_text --fastq
 run fastq_host --fastq --extra=--host-route
