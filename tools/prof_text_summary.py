@@ -45,7 +45,7 @@ for mode in ("fasta", "fastq"):
         f = l.split()
         if len(f) >= 9:
             sizes[os.path.basename(f[-1])] = int(f[4])
-    up = sizes.get("r.fa" if mode == "fasta" else "r.fq", 0)
+    up = sizes.get("r.fa", 0)   # (FASTQ pieces travel without their '+' and quality lines: the bytes of the header and read lines = the FASTA file's)
     down = sizes.get("paths", 0) + sizes.get("notAligned.fa", 0)
     for kind, v in sorted(c.items()):
         td = sum(d_ for d_, _ in v)
