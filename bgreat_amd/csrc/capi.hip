@@ -1247,29 +1247,38 @@ static int batch_piece_launch(bgr_aligner* a, const bgr_params* p, const char* r
     return bgr_align_device(a, p, a->in_reads.p, a->in_offs.p, n, total, max_len);
 }
 
-// A large batch in kOverlapPieces pieces on two streams (this aligner's and its twin's, one host thread each): the copies of
-// one piece run under the kernels of the other.  A piece's place in paths_out is known once the pieces in front of it have
-// counted their path ints (fetch_total); results are those of one launch over the whole batch.
+// A large batch in pieces on several streams (this aligner's and its twins', one host thread each): the copies of one piece run under the
+// kernels of the others, and -- with more streams than two -- the link never waits for a stream that is busy fetching its results (two
+// streams kept it 2/3 busy: 243 Mreads/s per 5 M-read call; kOverlapStreams = 4: see DESIGN 9).  A piece's place in paths_out is known
+// once the pieces in front of it have counted their path ints (fetch_total); results are those of one launch over the whole batch.
 static const uint64_t kOverlapMinReads = 512 * 1024;
-static const unsigned kOverlapPieces = 4;
+static const unsigned kOverlapMaxStreams = 4, kOverlapMaxPieces = 2 * kOverlapMaxStreams;
 static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n,
                                   int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
-    if (!a->twin) {
-        int rc = bgr_aligner_create(a->graph, a->device, &a->twin);
-        if (rc != BGR_OK) return rc;
-        a->twin->is_twin = true;
+    unsigned n_streams = kOverlapMaxStreams;
+    if (const char* e = getenv("BGREAT_OVERLAP_STREAMS")) n_streams = (unsigned)std::min<int>((int)kOverlapMaxStreams, std::max(2, atoi(e)));  // (A/B measurements)
+    const unsigned n_pieces = 2 * n_streams;
+    bgr_aligner* al[kOverlapMaxStreams] = {a, nullptr, nullptr, nullptr};
+    for (unsigned t = 1; t < n_streams; ++t) {  // the twins: a chain a -> twin -> twin's twin ..., created on first use
+        bgr_aligner* prev = al[t - 1];
+        if (!prev->twin) {
+            int rc = bgr_aligner_create(a->graph, a->device, &prev->twin);
+            if (rc != BGR_OK) return rc;
+            prev->twin->is_twin = true;
+        }
+        bgr_aligner* tw = prev->twin;
+        tw->cfg_waves = a->cfg_waves; tw->cfg_blocks_per_cu = a->cfg_blocks_per_cu; tw->cfg_lds_mphf = a->cfg_lds_mphf;
+        tw->knob_frame_cap = a->knob_frame_cap; tw->knob_search = a->knob_search; tw->knob_debug_stop = a->knob_debug_stop;
+        tw->knob_greedy_fast = a->knob_greedy_fast; tw->knob_exh_fast = a->knob_exh_fast; tw->knob_anc_fast = a->knob_anc_fast;
+        al[t] = tw;
     }
-    bgr_aligner* al[2] = {a, a->twin};
-    a->twin->cfg_waves = a->cfg_waves; a->twin->cfg_blocks_per_cu = a->cfg_blocks_per_cu; a->twin->cfg_lds_mphf = a->cfg_lds_mphf;
-    a->twin->knob_frame_cap = a->knob_frame_cap; a->twin->knob_search = a->knob_search; a->twin->knob_debug_stop = a->knob_debug_stop;
-    a->twin->knob_greedy_fast = a->knob_greedy_fast; a->twin->knob_exh_fast = a->knob_exh_fast; a->twin->knob_anc_fast = a->knob_anc_fast;
-    uint64_t cut[kOverlapPieces + 1];
-    for (unsigned k = 0; k <= kOverlapPieces; ++k) cut[k] = n * k / kOverlapPieces;
+    uint64_t cut[kOverlapMaxPieces + 1];
+    for (unsigned k = 0; k <= n_pieces; ++k) cut[k] = n * k / n_pieces;
     std::mutex mu;
     std::condition_variable cv;
-    uint64_t totals[kOverlapPieces];
-    bool known[kOverlapPieces];
-    for (unsigned k = 0; k < kOverlapPieces; ++k) { totals[k] = 0; known[k] = false; }
+    uint64_t totals[kOverlapMaxPieces];
+    bool known[kOverlapMaxPieces];
+    for (unsigned k = 0; k < n_pieces; ++k) { totals[k] = 0; known[k] = false; }
     int first_rc = BGR_OK;
     std::string first_err;
     auto give_up = [&](int rc, const char* msg) {
@@ -1278,7 +1287,7 @@ static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const cha
         cv.notify_all();
     };
     auto work = [&](unsigned t) {
-        for (unsigned k = t; k < kOverlapPieces; k += 2) {
+        for (unsigned k = t; k < n_pieces; k += n_streams) {
             { std::lock_guard<std::mutex> l(mu); if (first_rc != BGR_OK) return; }
             const uint64_t i0 = cut[k], cnt = cut[k + 1] - cut[k];
             uint64_t tot = 0;
@@ -1303,16 +1312,17 @@ static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const cha
             }
         }
     };
-    std::thread helper(work, 1u);
+    std::vector<std::thread> helpers;
     try {
+        for (unsigned t = 1; t < n_streams; ++t) helpers.emplace_back(work, t);
         work(0u);
-    } catch (...) {  // (bad_alloc in a piece: the helper must still be joined)
+    } catch (...) {  // (bad_alloc in a piece, or no thread to be had: the helpers that run must still be joined)
         give_up(BGR_E_INTERNAL, "bgr_align_batch: out of memory");
     }
-    helper.join();
+    for (auto& h : helpers) h.join();
     if (first_rc != BGR_OK) return fail(first_rc, first_err);
     uint64_t all = 0;
-    for (unsigned k = 0; k < kOverlapPieces; ++k) all += totals[k];
+    for (unsigned k = 0; k < n_pieces; ++k) all += totals[k];
     path_offsets[n] = all;
     a->last_n = 0;  // several launches: bgr_aligner_fetch has nothing to re-read
     return BGR_OK;
@@ -1410,10 +1420,10 @@ int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) {
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
     HIP_TRY(hipMemcpy(out, static_cast<char*>(a->small.p) + 64, 40, hipMemcpyDeviceToHost));
-    if (a->twin) {  // the pieces of overlapped batches its second stream mapped
+    for (bgr_aligner* tw = a->twin; tw; tw = tw->twin) {  // the pieces of overlapped batches its other streams mapped
         uint64_t t[5];
-        HIP_TRY(hipStreamSynchronize(a->twin->stream));
-        HIP_TRY(hipMemcpy(t, static_cast<char*>(a->twin->small.p) + 64, 40, hipMemcpyDeviceToHost));
+        HIP_TRY(hipStreamSynchronize(tw->stream));
+        HIP_TRY(hipMemcpy(t, static_cast<char*>(tw->small.p) + 64, 40, hipMemcpyDeviceToHost));
         for (int i = 0; i < 5; ++i) out[i] += t[i];
     }
     return BGR_OK;
@@ -1424,9 +1434,9 @@ int bgr_aligner_reset_counters(bgr_aligner* a) {
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
     HIP_TRY(hipMemset(static_cast<char*>(a->small.p) + 64, 0, 40));
-    if (a->twin) {
-        HIP_TRY(hipStreamSynchronize(a->twin->stream));
-        HIP_TRY(hipMemset(static_cast<char*>(a->twin->small.p) + 64, 0, 40));
+    for (bgr_aligner* tw = a->twin; tw; tw = tw->twin) {
+        HIP_TRY(hipStreamSynchronize(tw->stream));
+        HIP_TRY(hipMemset(static_cast<char*>(tw->small.p) + 64, 0, 40));
     }
     return BGR_OK;
 }
@@ -1438,11 +1448,11 @@ int bgr_aligner_kernel_time(bgr_aligner* a, uint64_t* launches, double* total_ms
     if (rc != BGR_OK) return rc;
     if (launches) *launches = a->t_launches;
     if (total_ms) *total_ms = a->t_ms;
-    if (a->twin) {  // the pieces of overlapped batches its second stream mapped
-        rc = drain_timers(a->twin);
+    for (bgr_aligner* tw = a->twin; tw; tw = tw->twin) {  // the pieces of overlapped batches its other streams mapped
+        rc = drain_timers(tw);
         if (rc != BGR_OK) return rc;
-        if (launches) *launches += a->twin->t_launches;
-        if (total_ms) *total_ms += a->twin->t_ms;
+        if (launches) *launches += tw->t_launches;
+        if (total_ms) *total_ms += tw->t_ms;
     }
     return BGR_OK;
 }
@@ -1453,17 +1463,18 @@ int bgr_aligner_kernel_times(bgr_aligner* a, uint64_t* launches, double slot_ms[
     int rc = drain_timers(a);
     if (rc != BGR_OK) return rc;
     if (launches) *launches = a->t_launches;
-    if (a->twin) {
-        rc = drain_timers(a->twin);
+    for (bgr_aligner* tw = a->twin; tw; tw = tw->twin) {
+        rc = drain_timers(tw);
         if (rc != BGR_OK) return rc;
-        if (launches) *launches += a->twin->t_launches;
+        if (launches) *launches += tw->t_launches;
     }
     for (int j = 0; j < kTimerSlots; ++j) {
         slot_ms[j] = a->t_slot_ms[j];
         const char* name = a->t_slot_name[j];
-        if (a->twin && a->twin->t_slot_ms[j] > 0) {  // (both streams run the same launch sequence: slot j is the same kernel)
-            slot_ms[j] += a->twin->t_slot_ms[j];
-            if (!name) name = a->twin->t_slot_name[j];
+        for (bgr_aligner* tw = a->twin; tw; tw = tw->twin) {  // (all streams run the same launch sequence: slot j is the same kernel)
+            if (tw->t_slot_ms[j] <= 0) continue;
+            slot_ms[j] += tw->t_slot_ms[j];
+            if (!name) name = tw->t_slot_name[j];
         }
         if (slot_names) slot_names[j] = slot_ms[j] > 0 ? name : nullptr;
     }
