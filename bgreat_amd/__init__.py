@@ -222,7 +222,10 @@ class DeviceBuffer:
             self.ptr = None
 
     def __del__(self):
-        self.free()
+        try:
+            self.free()
+        except Exception:   # (interpreter shutdown: the library may be gone already)
+            pass
 
 
 def _as_u8(a):
