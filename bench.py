@@ -323,10 +323,7 @@ def main():
     # while the other ranks wait (their batches stay parked: the devices are otherwise idle)
     one_proc = None
     if world > 1:
-        dist.barrier()
-        if rank == 0:
-            one_proc = run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, rehearsal)
-        dist.barrier()
+        one_proc = rank0_alone(dist, rank, "one_process_threads", lambda: run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, rehearsal))
 
     if rank != 0:
         if dist is not None:
@@ -533,9 +530,7 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
         # ranks waiting.  What a future scaling run reads as "does the CLI scale", next to the per-rank figure above.
         one_process = None
         if world > 1:
-            if dist is not None:
-                dist.barrier()
-            if rank == 0:
+            def cli_forms():
                 try:
                     import torch
                     n_dev = min(world, B.device_count(), max(1, torch.cuda.device_count()))
@@ -552,16 +547,15 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
                     parts_n = [os.path.join(d, "notAligned_sp.fa.%d" % i) for i in range(n_dev)] if n_dev > 1 else [os.path.join(d, "notAligned_sp.fa")]
                     split = {"value": round(n / w2 / 1e6, 3), "unit": "Mreads/s", "output_pairs": n_dev,
                              "identical_bytes_concatenated": bool(_same_concat(os.path.join(d, "paths0"), parts_p) and _same_concat(os.path.join(d, "notAligned0.fa"), parts_n))}
-                    one_process = {"value": round(n / w1 / 1e6, 3), "unit": "Mreads/s", "n_gpus": n_dev, "reads": n, "host_threads": min(len(os.sched_getaffinity(0)), ncpu * n_dev),
-                                   "split_output": split,
-                                   "fanout_method": {0: "none", 1: "rccl broadcast", 2: "peer copies"}.get(how, str(how)),
-                                   "identical_bytes_to_one_gpu": bool(_same_file(os.path.join(d, "paths0"), os.path.join(d, "paths_1p")) and
-                                                                      _same_file(os.path.join(d, "notAligned0.fa"), os.path.join(d, "notAligned_1p.fa"))),
-                                   "what": "bgr_align_all(n_gpus = N) in ONE process on rank 0's file while the other ranks wait"}
+                    return {"value": round(n / w1 / 1e6, 3), "unit": "Mreads/s", "n_gpus": n_dev, "reads": n, "host_threads": min(len(os.sched_getaffinity(0)), ncpu * n_dev),
+                            "split_output": split,
+                            "fanout_method": {0: "none", 1: "rccl broadcast", 2: "peer copies"}.get(how, str(how)),
+                            "identical_bytes_to_one_gpu": bool(_same_file(os.path.join(d, "paths0"), os.path.join(d, "paths_1p")) and
+                                                               _same_file(os.path.join(d, "notAligned0.fa"), os.path.join(d, "notAligned_1p.fa"))),
+                            "what": "bgr_align_all(n_gpus = N) in ONE process on rank 0's file while the other ranks wait (on the host: no collective spins on their GPUs)"}
                 except Exception as ex:
-                    one_process = {"error": "%s: %s" % (type(ex).__name__, ex)}
-            if dist is not None:
-                dist.barrier()
+                    return {"error": "%s: %s" % (type(ex).__name__, ex)}
+            one_process = rank0_alone(dist, rank, "one_process_cli", cli_forms)
         med = float(np.median(walls))
         return {"value": round(world * n / med / 1e6, 3), "unit": "Mreads/s", "reads_per_gpu": n, "n_gpus": world, "host_threads_per_gpu": ncpu, "seconds": round(med, 4),
                 "runs_mreads_per_s": runs, "best": round(world * n / best / 1e6, 3), "worst": round(world * n / max(walls) / 1e6, 3),
@@ -574,6 +568,31 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
         return {"error": "%s: %s" % (type(ex).__name__, ex)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def rank0_alone(dist, rank, tag, fn):
+    """All ranks meet, then rank 0 runs fn() while the others wait ON THE HOST (a key of the process group's store) -- a dist.barrier() there
+    would keep a collective kernel spinning on every other GPU while rank 0 drives those very devices; falls back to a barrier when the
+    store cannot be had.  -> fn()'s result on rank 0, None elsewhere."""
+    dist.barrier()
+    store = None
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        store = c10d._get_default_store()
+    except Exception:
+        store = None
+    out = None
+    if rank == 0:
+        try:
+            out = fn()
+        finally:
+            if store is not None:
+                store.set("bgr_" + tag, "1")
+    elif store is not None:
+        store.wait(["bgr_" + tag])
+    if store is None:
+        dist.barrier()
+    return out
 
 
 def _same_concat(a, parts, chunk=1 << 24):
