@@ -1391,6 +1391,13 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
         if (c.file < cuts[d - 1].file || (c.file == cuts[d - 1].file && c.off < cuts[d - 1].off)) c = cuts[d - 1];
         cuts[d] = c;
     }
+    // the graph on every device of the run before the lanes start: bgr_aligner_create would bring it there too, but the lanes run side by side
+    // and the graph's table of resident copies is not made for concurrent writers (a run behind bgr_devices_init finds every copy in place)
+    const bool one_device = getenv("BGREAT_TEST_LANES_ON_ONE_DEVICE") != nullptr;
+    for (unsigned d = 0; d < (one_device ? 1u : n); ++d) {
+        const int rc = bgr_graph_upload(graph, (int)(opt->first_device + d));
+        if (rc != BGR_OK) return rc;
+    }
     std::atomic<bool> cancel{false};
     std::vector<int> rcs(n, BGR_OK);
     std::vector<std::string> errs(n);
@@ -1411,7 +1418,7 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
             bgr_run_options o = *opt;
             o.n_gpus = 1;
             // (BGREAT_TEST_LANES_ON_ONE_DEVICE=1, a test hook: every lane on the first device -- the split run's code path on a one-GPU box)
-            o.first_device = getenv("BGREAT_TEST_LANES_ON_ONE_DEVICE") ? opt->first_device : opt->first_device + d;
+            o.first_device = one_device ? opt->first_device : opt->first_device + d;
             o.threads = std::max<uint32_t>(1, opt->threads / n);
             o.echo_files = 0;
             o.split_output = 0;

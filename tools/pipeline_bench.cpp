@@ -36,6 +36,7 @@ extern "C" {
 const char* bgr_last_error(void) { return tl_err.c_str(); }
 int bgr_graph_info(const bgr_graph* g, bgr_graph_info_t* o) { memset(o, 0, sizeof(*o)); o->k = g->k; return BGR_OK; }
 int bgr_graph_unitigs(const bgr_graph*, const char**, const uint64_t**, uint64_t*) { return BGR_E_ARG; }
+int bgr_graph_upload(bgr_graph*, int) { return BGR_OK; }
 int bgr_aligner_create(bgr_graph*, int device, bgr_aligner** out) { *out = new bgr_aligner(); (*out)->device = device; return BGR_OK; }
 void bgr_aligner_destroy(bgr_aligner* a) { delete a; }
 int bgr_device_local_cpus(int, char*, uint64_t) { return BGR_E_IO; }
