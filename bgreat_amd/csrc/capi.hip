@@ -469,7 +469,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
         a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->lst.release(); a->deep.release(); a->small.release();
-        a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release();
+        a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release(); a->wave_times.release();
         for (DevBuf* b : {&a->tx_in, &a->tx_sums, &a->tx_start, &a->tx_rec, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_offs,
                           &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff, &a->tx_pout, &a->tx_nout, &a->tx_info}) b->release();
         for (int i = 0; i < kTimerRing; ++i) for (int j = 0; j <= kTimerSlots; ++j) (void)hipEventDestroy(a->ev[i][j]);
