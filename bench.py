@@ -774,17 +774,14 @@ def run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, reh
         fan_ms = (time.perf_counter() - t0) * 1e3
         offs_np = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
         als, bufs, offs = [], [], []
+        host_b = [syn.reads(2 * world * 1_000_000_000 + s * R, R, L, args.mismatch, seed_reads, threads=ncpu)[0] for s in range(2)]   # two batches, the same on every device
         for d in range(n_dev):
             al = B.Aligner(g, d)
             al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
             als.append(al)
             offs.append(B.DeviceBuffer(d, offs_np))
-            dev_b = []
-            for s in range(2):   # two batches per device, taken in turn
-                arr, _ = syn.reads((2 * world + d) * 1_000_000_000 + s * R, R, L, args.mismatch, seed_reads, threads=ncpu)
-                dev_b.append(B.DeviceBuffer(d, arr))
-                del arr
-            bufs.append(dev_b)
+            bufs.append([B.DeviceBuffer(d, arr) for arr in host_b])   # taken in turn
+        del host_b
         start = threading.Barrier(n_dev + 1)
         done = threading.Barrier(n_dev + 1)
         errs = []
