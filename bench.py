@@ -313,9 +313,144 @@ def main():
     if dist is not None:  # C2: sum the aligner.h:68 counters over ranks
         counters = D.reduce_counters(counters, dist, device=coll_dev)
 
+    # ---- rank 0: everything the line needs from the device-resident leg (value, roofline, parity sample) BEFORE the optional legs below, so
+    # that a leg that never returns (a collective between real devices that this container has never run, a wedged file system) costs
+    # the line its optional fields, not the line: LineGuard prints what is known when the deadline passes
+    guard = LineGuard(rank, float(os.environ.get("BGR_BENCH_DEADLINE", "480")))
+    line = None
+    if rank == 0:
+        total_reads = world * K * R
+        value = total_reads / elapsed / 1e6
+        avg_launch_ms = kernel_ms / max(1, launches)
+
+        # ---- ALGORITHMIC bytes per read: SURVEY.md 8d formula, counted by the oracle on a sample of this workload ----
+        import oracle_py
+        seqs, offs = syn.unitigs()
+        orc = oracle_py.Oracle(args.k, seqs, offs, anchors=(mode == 2))
+        ns = min(args.alg_sample, R)
+        s_reads = first_host[: ns * L]
+        s_offs = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
+        p2, po2, st2 = orc.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
+        alg_bytes_per_read = orc.alg_bytes() / ns
+        work = orc.work()
+        # parity of the same sample through the GPU path (outside the timed region)
+        p1, po1, st1 = al.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
+        parity_ok = bool(np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2))
+        kernels_ms = [{"kernel": nm, "avg_ms": round(ms / max(1, launches), 4)} for nm, ms in slots]
+        dominant, dom_total_ms = max(slots, key=lambda x: x[1]) if slots else (None, 0.0)
+        dom_ms = dom_total_ms / max(1, launches)            # the dominant kernel's average duration (HIP events on the aligner's stream)
+        dom_short = dominant.split(" ")[0] if dominant else None
+        # ---- this implementation's OWN compulsory HBM bytes per read: what one launch must move through HBM if every
+        # re-used structure (key table, records, unitig bases: the graph blob) is read from HBM once per launch -- counted from the
+        # launch's own numbers: read lengths, path ints written (paths of this run), follow-up items queued (pass_counts)
+        blob_bytes = float(graph_info["blob_bytes"])
+        path_ints = float(len(p1)) / ns                     # per read, from the parity sample's paths
+        items = float(pass_counts[0]) / R if mode == 0 else 0.0
+        words = (L + 31) // 32
+        own = {
+            "bgr_pack_reads_kernel": {"ascii_in": L, "offsets_in": 8, "planes_out": 8 * words, "hasn_out": 0.125},
+            "mapping": {"planes_in": 8 * words * (1.0 + items), "offsets_in": 8 * (1.0 + items), "hasn_in": 0.125, "results_out": 8, "path_ints_out": 4 * path_ints,
+                        "retry_queue_rw": 16 * items, "graph_blob_once_per_launch": blob_bytes / R},
+        }
+        own_pack = sum(own["bgr_pack_reads_kernel"].values())
+        own_map = sum(own["mapping"].values())
+        dom_own = own_pack if (dom_short or "").startswith("bgr_pack") else own_map
+        hbm = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+               "compulsory_bytes_per_read": {"bgr_pack_reads_kernel": round(own_pack, 1), "mapping_kernels": round(own_map, 1), "split_mapping": {k: round(v, 2) for k, v in own["mapping"].items()}},
+               "achieved": round(dom_own * R / (dom_ms / 1e3) / 1e9, 2), "frac": round(dom_own * R / (dom_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+               "whole_launch": {"bytes_per_read": round(own_pack + own_map, 1), "achieved": round((own_pack + own_map) * R / (avg_launch_ms / 1e3) / 1e9, 2),
+                                "frac": round((own_pack + own_map) * R / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)},
+               "definition": "this implementation's compulsory HBM bytes per read of the dominant kernel (planes, offsets, results, path ints, retry queue, the graph blob once per launch) "
+                             "x reads per launch / that kernel's mean duration; `traffic` next to it is what the memory side saw (rocprofv3 PMC)"}
+        roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
+                    "dominant_kernel": dominant, "dominant_kernel_ms": round(dom_ms, 4), "hbm": hbm,
+                    "launch": "pre-pass + mapping kernels of one batch, enqueued back to back on one stream (HIP events around every kernel, on the aligner's stream)",
+                    "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "kernels_ms": kernels_ms, "reads_per_launch": R,
+                    # SURVEY 8d's figure describes the REFERENCE's control flow (gamma-10 BooPHF probes, rank words, 24-B records): kept for the
+                    # record under its own keys, never as a fraction of this implementation's roofline
+                    "reference_alg_bytes_per_read": round(alg_bytes_per_read, 1),
+                    "reference_alg_gbps": round(alg_bytes_per_read * R / (avg_launch_ms / 1e3) / 1e9, 1),
+                    "reference_alg_note": "SURVEY 8d formula counted by the oracle on %d reads of this workload: bytes the REFERENCE's algorithm would move uncached; this "
+                                          "implementation does not perform those probes (its key table is two LDS dwords per position), so this is NOT a fraction of any peak" % ns}
+        if pmc and "error" not in pmc:
+            pk = pmc.get("_per_kernel", {})
+            dom_key = next((k for k in pk if dom_short and k.split("<")[0] == dom_short), None)  # (PMC rows carry the template arguments)
+            dom_pmc = pk.get(dom_key, {}) if dom_key else {}
+            fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
+            if fetch_kb is not None and write_kb is not None:
+                raw = (fetch_kb + write_kb) * 1024.0
+                corrected = (2.0 * fetch_kb + write_kb) * 1024.0  # gfx950: FETCH_SIZE tallies 128-B requests of wide reads at 64 B (upper bound for small gathers)
+                roofline["traffic"] = round(corrected, 1)
+                roofline["traffic_raw"] = round(raw, 1)
+                roofline["traffic_note"] = ("HBM-side bytes per launch (all kernels) = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc in separate passes over a %d-launch child run of "
+                                            "this script in this run; raw = without the gfx950 x2 on FETCH_SIZE (the x2 is exact for wide streaming reads, an upper bound for gathers)" % args.pmc_steps)
+                roofline["traffic_frac"] = round(corrected / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+                roofline["traffic_bytes_per_read"] = round(corrected / R, 1)
+                roofline["traffic_over_compulsory"] = round(corrected / ((own_pack + own_map) * R), 3)
+                if dom_pmc.get("FETCH_SIZE") is not None and dom_pmc.get("WRITE_SIZE") is not None:
+                    dt = (2.0 * dom_pmc["FETCH_SIZE"] + dom_pmc["WRITE_SIZE"]) * 1024.0
+                    hbm["dominant_kernel_traffic"] = round(dt, 1)
+                    hbm["dominant_kernel_traffic_frac"] = round(dt / (dom_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+            if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
+                roofline["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
+            if pmc.get("TCC_REQ_sum") is not None:
+                roofline["l2_requests_per_read"] = round(pmc["TCC_REQ_sum"] / R, 2)
+            if dom_pmc.get("SQ_ACTIVE_INST_VALU") is not None and dom_pmc.get("SQ_ACTIVE_INST_VALU2") is not None:
+                # MEASURED vector-issue occupancy of the dominant kernel.  gfx950 issues one vector instruction per SIMD and 4-cycle slot, or TWO
+                # (from two waves) when both are of the plain VOP1/VOP2 class (add/sub/and/or/xor/mov/not/right shifts: the "2-cycle"
+                # class of profiles/r02_valu_rates.txt); SQ_ACTIVE_INST_VALU counts every instruction, SQ_ACTIVE_INST_VALU2 the ones that
+                # went out as the second of a pair, so (A - A2) is the number of BUSY issue slots -- calibrated on 50 single-opcode
+                # streams, profiles/r03_valu2_pmc_calibration.txt: 4 x (1 - A2/A) reproduces every stream's measured cycles per instruction.
+                busy_slots = dom_pmc["SQ_ACTIVE_INST_VALU"] - dom_pmc["SQ_ACTIVE_INST_VALU2"]        # per launch, summed over all SIMDs
+                busy_cycles_per_s = 4.0 * busy_slots / (dom_ms / 1e3)
+                peak_cycles_per_s = N_SIMD * CLOCK_GHZ * 1e9
+                valu = {"bound": "valu_issue", "unit": "G SIMD-cycles/s", "achieved": round(busy_cycles_per_s / 1e9, 2), "peak": round(peak_cycles_per_s / 1e9, 2),
+                        "frac": round(busy_cycles_per_s / peak_cycles_per_s, 4),
+                        "valu_insts_per_read": round(dom_pmc.get("SQ_INSTS_VALU", 0.0) / R, 1), "paired_share": round(dom_pmc["SQ_ACTIVE_INST_VALU2"] / max(1.0, dom_pmc["SQ_ACTIVE_INST_VALU"]), 4),
+                        "cycles_per_valu_inst": round(4.0 * busy_slots / max(1.0, dom_pmc["SQ_ACTIVE_INST_VALU"]), 3),
+                        "salu_insts_per_read": round(dom_pmc.get("SQ_INSTS_SALU", 0.0) / R, 1),
+                        "salu_issue_frac": round(dom_pmc.get("SQ_INSTS_SALU", 0.0) / (N_SIMD / 4 * (dom_ms / 1e3) * CLOCK_GHZ * 1e9), 4),
+                        "definition": "busy vector issue slots of the dominant kernel = SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 per launch (rocprofv3 PMC, child run of this "
+                                      "script), x 4 cycles / (the kernel's mean duration in the timed region) against %d SIMDs x %.1f GHz" % (N_SIMD, CLOCK_GHZ)}
+                if dom_pmc.get("SQ_BUSY_CU_CYCLES"):
+                    cu_cyc = dom_pmc["SQ_BUSY_CU_CYCLES"]
+                    valu["frac_of_cu_busy_cycles"] = round(busy_slots / cu_cyc, 4)   # (4 x slots) / (4 SIMDs x CU-busy cycles): needs no clock and no timer
+                roofline["valu_issue"] = valu
+                # what bounds the dominant kernel: the larger of the measured vector-issue fraction and the HBM-side fraction
+                hf = max(hbm["frac"], hbm.get("dominant_kernel_traffic_frac") or 0.0)
+                if valu["frac"] >= hf:
+                    roofline.update({"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]})
+                roofline["bound_note"] = ("`bound` names the larger of the dominant kernel's measured vector-issue fraction (roofline.valu_issue) and its HBM fraction "
+                                          "(roofline.hbm: compulsory bytes, and measured traffic); integer hash + byte compare: no MFMA on this path")
+            roofline["pmc_seconds"] = pmc.get("_seconds")
+            roofline["pmc_per_kernel"] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in pk.items()}
+        elif pmc:
+            roofline["traffic_note"] = "not measured in this run: " + pmc["error"]
+
+        line = {
+            "metric": "Mreads/s aligned (k=%d, %dbp, m=%d)" % (args.k, L, args.mismatch), "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %.1fM x %d bp reads per GPU (%d steps x %d), k=%d, m=%d, effort=%d, %s, graph of %d unitigs (genome %d bp, %d alleles every ~%d bp); "
+                                   "reads resident in HBM as ASCII before the timed region, results left in HBM"
+                       % ({"ecoli": "BASELINE configs[2]", "small": "BASELINE configs[1]", "chr1": "BASELINE configs[3] graph scale, one GPU's share", "branchy": "BASELINE configs[4] graph, one GPU's share"}[args.workload],
+                          K * R / 1e6, L, K, R, args.k, args.mismatch, args.effort, ("greedy", "exhaustive", "greedy from k-mer anchors (-G)")[mode], graph_info["n_unitigs"], args.genome, args.alleles, args.site_spacing),
+                       "reads_per_step_per_gpu": R, "read_len": L, "k": args.k, "m": args.mismatch, "effort": args.effort,
+                       "parallelism": "reads sharded over %d GPU(s); graph blob broadcast once" % world, "launch": al.launch_info(),
+                       "pass_counts_last_launch": pass_counts},
+            # SURVEY 8d's two metrics beside `value` (the device-resident kernel/roofline anchor): (i) H2D + launch + CSR + D2H from page-locked
+            # host buffers, one blocking caller; (ii) file in -> paths / notAligned.fa out, median of the runs (spread in e2e.runs_mreads_per_s)
+            "value_pcie_inclusive": None, "value_e2e": None,
+            "roofline": roofline, "pcie_inclusive": None, "e2e": None, "cpu_baseline": None, "multi_gpu": multi, "one_process_all_gpus": None,
+            "other_configs": subs,
+            "counters": counters, "parity_sample": {"reads": ns, "gpu_equals_oracle": parity_ok},
+            "oracle_work_per_read": {k: round(v / ns, 2) for k, v in work.items() if k not in ("reads",)},
+        }
+    guard.arm(line)
+
     # ---- end to end: file in -> paths / notAligned.fa out (every rank its own shard file and GPU) ---------------
     e2e = None
     if args.e2e_reads > 0 and mode == 0:
+        guard.stage("e2e")
         e2e = run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D if dist is not None else None, coll_dev, seed_reads)
 
     # ---- N > 1: the C-ABI's own multi-GPU form next to the one-process-per-GPU form above -- ONE process, bgr_devices_init (one upload,
@@ -323,121 +458,12 @@ def main():
     # while the other ranks wait (their batches stay parked: the devices are otherwise idle)
     one_proc = None
     if world > 1:
+        guard.stage("one_process_all_gpus")
         one_proc = rank0_alone(dist, rank, "one_process_threads", lambda: run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, rehearsal))
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        guard.leave(dist)
         return
-
-    total_reads = world * K * R
-    value = total_reads / elapsed / 1e6
-    avg_launch_ms = kernel_ms / max(1, launches)
-
-    # ---- ALGORITHMIC bytes per read: SURVEY.md 8d formula, counted by the oracle on a sample of this workload ----
-    import oracle_py
-    seqs, offs = syn.unitigs()
-    orc = oracle_py.Oracle(args.k, seqs, offs, anchors=(mode == 2))
-    ns = min(args.alg_sample, R)
-    s_reads = first_host[: ns * L]
-    s_offs = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
-    p2, po2, st2 = orc.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
-    alg_bytes_per_read = orc.alg_bytes() / ns
-    work = orc.work()
-    # parity of the same sample through the GPU path (outside the timed region)
-    p1, po1, st1 = al.align(s_reads, s_offs, m=args.mismatch, effort=args.effort, mode=mode)
-    parity_ok = bool(np.array_equal(p1, p2) and np.array_equal(po1, po2) and np.array_equal(st1, st2))
-    kernels_ms = [{"kernel": nm, "avg_ms": round(ms / max(1, launches), 4)} for nm, ms in slots]
-    dominant, dom_total_ms = max(slots, key=lambda x: x[1]) if slots else (None, 0.0)
-    dom_ms = dom_total_ms / max(1, launches)            # the dominant kernel's average duration (HIP events on the aligner's stream)
-    dom_short = dominant.split(" ")[0] if dominant else None
-    # ---- this implementation's OWN compulsory HBM bytes per read: what one launch must move through HBM if every
-    # re-used structure (key table, records, unitig bases: the graph blob) is read from HBM once per launch -- counted from the
-    # launch's own numbers: read lengths, path ints written (paths of this run), follow-up items queued (pass_counts)
-    blob_bytes = float(graph_info["blob_bytes"])
-    path_ints = float(len(p1)) / ns                     # per read, from the parity sample's paths
-    items = float(pass_counts[0]) / R if mode == 0 else 0.0
-    words = (L + 31) // 32
-    own = {
-        "bgr_pack_reads_kernel": {"ascii_in": L, "offsets_in": 8, "planes_out": 8 * words, "hasn_out": 0.125},
-        "mapping": {"planes_in": 8 * words * (1.0 + items), "offsets_in": 8 * (1.0 + items), "hasn_in": 0.125, "results_out": 8, "path_ints_out": 4 * path_ints,
-                    "retry_queue_rw": 16 * items, "graph_blob_once_per_launch": blob_bytes / R},
-    }
-    own_pack = sum(own["bgr_pack_reads_kernel"].values())
-    own_map = sum(own["mapping"].values())
-    dom_own = own_pack if (dom_short or "").startswith("bgr_pack") else own_map
-    hbm = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-           "compulsory_bytes_per_read": {"bgr_pack_reads_kernel": round(own_pack, 1), "mapping_kernels": round(own_map, 1), "split_mapping": {k: round(v, 2) for k, v in own["mapping"].items()}},
-           "achieved": round(dom_own * R / (dom_ms / 1e3) / 1e9, 2), "frac": round(dom_own * R / (dom_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
-           "whole_launch": {"bytes_per_read": round(own_pack + own_map, 1), "achieved": round((own_pack + own_map) * R / (avg_launch_ms / 1e3) / 1e9, 2),
-                            "frac": round((own_pack + own_map) * R / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)},
-           "definition": "this implementation's compulsory HBM bytes per read of the dominant kernel (planes, offsets, results, path ints, retry queue, the graph blob once per launch) "
-                         "x reads per launch / that kernel's mean duration; `traffic` next to it is what the memory side saw (rocprofv3 PMC)"}
-    roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
-                "dominant_kernel": dominant, "dominant_kernel_ms": round(dom_ms, 4), "hbm": hbm,
-                "launch": "pre-pass + mapping kernels of one batch, enqueued back to back on one stream (HIP events around every kernel, on the aligner's stream)",
-                "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "kernels_ms": kernels_ms, "reads_per_launch": R,
-                # SURVEY 8d's figure describes the REFERENCE's control flow (gamma-10 BooPHF probes, rank words, 24-B records): kept for the
-                # record under its own keys, never as a fraction of this implementation's roofline
-                "reference_alg_bytes_per_read": round(alg_bytes_per_read, 1),
-                "reference_alg_gbps": round(alg_bytes_per_read * R / (avg_launch_ms / 1e3) / 1e9, 1),
-                "reference_alg_note": "SURVEY 8d formula counted by the oracle on %d reads of this workload: bytes the REFERENCE's algorithm would move uncached; this "
-                                      "implementation does not perform those probes (its key table is two LDS dwords per position), so this is NOT a fraction of any peak" % ns}
-    if pmc and "error" not in pmc:
-        pk = pmc.get("_per_kernel", {})
-        dom_key = next((k for k in pk if dom_short and k.split("<")[0] == dom_short), None)  # (PMC rows carry the template arguments)
-        dom_pmc = pk.get(dom_key, {}) if dom_key else {}
-        fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
-        if fetch_kb is not None and write_kb is not None:
-            raw = (fetch_kb + write_kb) * 1024.0
-            corrected = (2.0 * fetch_kb + write_kb) * 1024.0  # gfx950: FETCH_SIZE tallies 128-B requests of wide reads at 64 B (upper bound for small gathers)
-            roofline["traffic"] = round(corrected, 1)
-            roofline["traffic_raw"] = round(raw, 1)
-            roofline["traffic_note"] = ("HBM-side bytes per launch (all kernels) = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc in separate passes over a %d-launch child run of "
-                                        "this script in this run; raw = without the gfx950 x2 on FETCH_SIZE (the x2 is exact for wide streaming reads, an upper bound for gathers)" % args.pmc_steps)
-            roofline["traffic_frac"] = round(corrected / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
-            roofline["traffic_bytes_per_read"] = round(corrected / R, 1)
-            roofline["traffic_over_compulsory"] = round(corrected / ((own_pack + own_map) * R), 3)
-            if dom_pmc.get("FETCH_SIZE") is not None and dom_pmc.get("WRITE_SIZE") is not None:
-                dt = (2.0 * dom_pmc["FETCH_SIZE"] + dom_pmc["WRITE_SIZE"]) * 1024.0
-                hbm["dominant_kernel_traffic"] = round(dt, 1)
-                hbm["dominant_kernel_traffic_frac"] = round(dt / (dom_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
-        if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
-            roofline["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
-        if pmc.get("TCC_REQ_sum") is not None:
-            roofline["l2_requests_per_read"] = round(pmc["TCC_REQ_sum"] / R, 2)
-        if dom_pmc.get("SQ_ACTIVE_INST_VALU") is not None and dom_pmc.get("SQ_ACTIVE_INST_VALU2") is not None:
-            # MEASURED vector-issue occupancy of the dominant kernel.  gfx950 issues one vector instruction per SIMD and 4-cycle slot, or TWO
-            # (from two waves) when both are of the plain VOP1/VOP2 class (add/sub/and/or/xor/mov/not/right shifts: the "2-cycle"
-            # class of profiles/r02_valu_rates.txt); SQ_ACTIVE_INST_VALU counts every instruction, SQ_ACTIVE_INST_VALU2 the ones that
-            # went out as the second of a pair, so (A - A2) is the number of BUSY issue slots -- calibrated on 50 single-opcode
-            # streams, profiles/r03_valu2_pmc_calibration.txt: 4 x (1 - A2/A) reproduces every stream's measured cycles per instruction.
-            busy_slots = dom_pmc["SQ_ACTIVE_INST_VALU"] - dom_pmc["SQ_ACTIVE_INST_VALU2"]        # per launch, summed over all SIMDs
-            busy_cycles_per_s = 4.0 * busy_slots / (dom_ms / 1e3)
-            peak_cycles_per_s = N_SIMD * CLOCK_GHZ * 1e9
-            valu = {"bound": "valu_issue", "unit": "G SIMD-cycles/s", "achieved": round(busy_cycles_per_s / 1e9, 2), "peak": round(peak_cycles_per_s / 1e9, 2),
-                    "frac": round(busy_cycles_per_s / peak_cycles_per_s, 4),
-                    "valu_insts_per_read": round(dom_pmc.get("SQ_INSTS_VALU", 0.0) / R, 1), "paired_share": round(dom_pmc["SQ_ACTIVE_INST_VALU2"] / max(1.0, dom_pmc["SQ_ACTIVE_INST_VALU"]), 4),
-                    "cycles_per_valu_inst": round(4.0 * busy_slots / max(1.0, dom_pmc["SQ_ACTIVE_INST_VALU"]), 3),
-                    "salu_insts_per_read": round(dom_pmc.get("SQ_INSTS_SALU", 0.0) / R, 1),
-                    "salu_issue_frac": round(dom_pmc.get("SQ_INSTS_SALU", 0.0) / (N_SIMD / 4 * (dom_ms / 1e3) * CLOCK_GHZ * 1e9), 4),
-                    "definition": "busy vector issue slots of the dominant kernel = SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 per launch (rocprofv3 PMC, child run of this "
-                                  "script), x 4 cycles / (the kernel's mean duration in the timed region) against %d SIMDs x %.1f GHz" % (N_SIMD, CLOCK_GHZ)}
-            if dom_pmc.get("SQ_BUSY_CU_CYCLES"):
-                cu_cyc = dom_pmc["SQ_BUSY_CU_CYCLES"]
-                valu["frac_of_cu_busy_cycles"] = round(busy_slots / cu_cyc, 4)   # (4 x slots) / (4 SIMDs x CU-busy cycles): needs no clock and no timer
-            roofline["valu_issue"] = valu
-            # what bounds the dominant kernel: the larger of the measured vector-issue fraction and the HBM-side fraction
-            hf = max(hbm["frac"], hbm.get("dominant_kernel_traffic_frac") or 0.0)
-            if valu["frac"] >= hf:
-                roofline.update({"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]})
-            roofline["bound_note"] = ("`bound` names the larger of the dominant kernel's measured vector-issue fraction (roofline.valu_issue) and its HBM fraction "
-                                      "(roofline.hbm: compulsory bytes, and measured traffic); integer hash + byte compare: no MFMA on this path")
-        roofline["pmc_seconds"] = pmc.get("_seconds")
-        roofline["pmc_per_kernel"] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in pk.items()}
-    elif pmc:
-        roofline["traffic_note"] = "not measured in this run: " + pmc["error"]
 
     # ---- PCIe inclusive: pinned host buffers through bgr_align_batch (H2D + launch + CSR + D2H), N=1 only ---------
     pcie = None
@@ -451,28 +477,89 @@ def main():
     if world == 1 and args.cpu_sample_exh > 0 and mode == 1:
         cpu = run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads)
 
-    out = {
-        "metric": "Mreads/s aligned (k=%d, %dbp, m=%d)" % (args.k, L, args.mismatch), "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%s: synthetic %.1fM x %d bp reads per GPU (%d steps x %d), k=%d, m=%d, effort=%d, %s, graph of %d unitigs (genome %d bp, %d alleles every ~%d bp); "
-                               "reads resident in HBM as ASCII before the timed region, results left in HBM"
-                   % ({"ecoli": "BASELINE configs[2]", "small": "BASELINE configs[1]", "chr1": "BASELINE configs[3] graph scale, one GPU's share", "branchy": "BASELINE configs[4] graph, one GPU's share"}[args.workload],
-                      K * R / 1e6, L, K, R, args.k, args.mismatch, args.effort, ("greedy", "exhaustive", "greedy from k-mer anchors (-G)")[mode], graph_info["n_unitigs"], args.genome, args.alleles, args.site_spacing),
-                   "reads_per_step_per_gpu": R, "read_len": L, "k": args.k, "m": args.mismatch, "effort": args.effort,
-                   "parallelism": "reads sharded over %d GPU(s); graph blob broadcast once" % world, "launch": al.launch_info(),
-                   "pass_counts_last_launch": pass_counts},
-        # SURVEY 8d's two metrics beside `value` (the device-resident kernel/roofline anchor): (i) H2D + launch + CSR + D2H from page-locked
-        # host buffers, one blocking caller; (ii) file in -> paths / notAligned.fa out, median of the runs (spread in e2e.runs_mreads_per_s)
-        "value_pcie_inclusive": (pcie or {}).get("value"), "value_e2e": (e2e or {}).get("value"),
-        "roofline": roofline, "pcie_inclusive": pcie, "e2e": e2e, "cpu_baseline": cpu, "multi_gpu": multi, "one_process_all_gpus": one_proc,
-        "other_configs": subs,
-        "counters": counters, "parity_sample": {"reads": ns, "gpu_equals_oracle": parity_ok},
-        "oracle_work_per_read": {k: round(v / ns, 2) for k, v in work.items() if k not in ("reads",)},
-    }
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    line.update({"value_pcie_inclusive": (pcie or {}).get("value"), "value_e2e": (e2e or {}).get("value"), "pcie_inclusive": pcie, "e2e": e2e, "cpu_baseline": cpu,
+                 "one_process_all_gpus": one_proc})
+    guard.finish(line, dist)
+
+
+class LineGuard:
+    """The ONE JSON line of rank 0 must come out even when an optional leg behind the timed region never returns (the N > 1 legs drive
+    collectives between real devices, which this repository has only ever rehearsed on one GPU).  arm(line): rank 0 hands over the line as
+    far as it stands behind the device-resident leg; a timer thread prints it -- marked `incomplete`, naming the leg that was running --
+    when the deadline passes, and ends the process with exit code 0.  The other ranks arm without a line: they just leave at the
+    deadline (a little later than rank 0, so that its line is out first).  finish()/leave(): the normal way out -- rank 0 tells the other
+    ranks through the process group's store whether the closing barrier is still safe to enter."""
+
+    def __init__(self, rank, seconds):
+        self.rank, self.seconds = rank, seconds
+        self.lock = threading.Lock()
+        self.printed = False
+        self.line = None
+        self.what = "?"
+        self.timer = None
+
+    def stage(self, what):
+        self.what = what
+
+    def arm(self, line):
+        self.line = line
+        if self.seconds <= 0:
+            return
+        self.timer = threading.Timer(self.seconds + (0.0 if self.rank == 0 else 20.0), self._expired)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _expired(self):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.rank == 0 and self.line is not None:
+                d = dict(self.line)
+                d["incomplete"] = "the optional legs behind the timed region did not finish within %.0f s (running: %s); value, roofline and parity sample are complete" % (self.seconds, self.what)
+                print(json.dumps(d), flush=True)
+            log("bench.py rank %d: deadline of %.0f s passed in leg '%s': leaving" % (self.rank, self.seconds, self.what))
+            sys.stderr.flush()
+            os._exit(0)
+
+    @staticmethod
+    def _store():
+        try:
+            from torch.distributed import distributed_c10d as c10d
+            return c10d._get_default_store()
+        except Exception:
+            return None
+
+    def finish(self, line, dist):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            print(json.dumps(line), flush=True)
+        if self.timer is not None:
+            self.timer.cancel()
+        if dist is not None:
+            st = self._store()
+            if st is not None:
+                st.set("bgr_line_out", "1")
+            dist.barrier()
+            dist.destroy_process_group()
+
+    def leave(self, dist):
+        """ranks other than 0: wait (on the host) until rank 0 has printed its line, then the closing barrier"""
+        if dist is not None:
+            st = self._store()
+            if st is not None:
+                try:
+                    st.wait(["bgr_line_out"])
+                except Exception as ex:
+                    bail_out(self.rank, "waiting for rank 0's line: %s" % type(ex).__name__)
+            with self.lock:
+                self.printed = True
+            if self.timer is not None:
+                self.timer.cancel()
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_reads):
@@ -570,6 +657,13 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
         shutil.rmtree(d, ignore_errors=True)
 
 
+def bail_out(rank, why):
+    """a rank other than 0 that can no longer reach rank 0 (which prints the line) leaves quietly: exit code 0, no collective"""
+    log("bench.py rank %d: leaving (%s)" % (rank, why))
+    sys.stderr.flush()
+    os._exit(0)
+
+
 def rank0_alone(dist, rank, tag, fn):
     """All ranks meet, then rank 0 runs fn() while the others wait ON THE HOST (a key of the process group's store) -- a dist.barrier() there
     would keep a collective kernel spinning on every other GPU while rank 0 drives those very devices; falls back to a barrier when the
@@ -589,7 +683,10 @@ def rank0_alone(dist, rank, tag, fn):
             if store is not None:
                 store.set("bgr_" + tag, "1")
     elif store is not None:
-        store.wait(["bgr_" + tag])
+        try:
+            store.wait(["bgr_" + tag])
+        except Exception as ex:   # the store went away or the wait timed out: rank 0 has left (its LineGuard deadline) or is about to be reaped
+            bail_out(rank, "waiting for rank 0's leg '%s': %s" % (tag, type(ex).__name__))
     if store is None:
         dist.barrier()
     return out
@@ -767,6 +864,8 @@ def run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, reh
     `--gpus N`), measured next to the one-process-per-GPU form of this line."""
     try:
         import torch
+        if os.environ.get("BGR_BENCH_TEST_HANG") == "one_process_all_gpus":   # test hook (tests/test_gpu_parity.py): this leg never returns
+            time.sleep(1e6)
         n_dev = max(1, min(world, B.device_count(), torch.cuda.device_count()))
         K, W, R, L = min(args.steps, 4), 1, args.reads_per_step, args.read_len
         t0 = time.perf_counter()

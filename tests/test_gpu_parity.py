@@ -1020,3 +1020,24 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert "error" not in one, one
     assert one["identical_bytes_to_one_gpu"] is True and one["split_output"]["identical_bytes_concatenated"] is True
     assert d["cpu_baseline"] is None and d["pcie_inclusive"] is None and d["other_configs"] is None   # N = 1 only
+
+
+def test_bench_line_comes_out_when_an_optional_leg_hangs():
+    """bench.py's LineGuard: the N > 1 legs behind the timed region drive collectives between real devices that have only ever been
+    rehearsed on one GPU; a leg that never returns (test hook: the one-process form sleeps for ever) must cost the line its optional
+    fields, not the line -- rank 0 prints what it holds when the deadline passes (marked `incomplete`), every rank leaves with exit
+    code 0 and torch.distributed.run reports success."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BGR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", BGR_BENCH_TEST_HANG="one_process_all_gpus", BGR_BENCH_DEADLINE="25")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads-per-step", "200000", "--e2e-reads", "0",
+           "--alg-sample", "2000", "--genome", "400000", "--no-pmc"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_sample"]["gpu_equals_oracle"] is True and d["counters"]["reads"] == 2 * 2 * 200000
+    assert "one_process_all_gpus" in d["incomplete"] and d["one_process_all_gpus"] is None and d["roofline"]["dominant_kernel"].startswith("bgr_")
