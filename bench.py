@@ -566,6 +566,10 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
     """bgr_align_all on a FASTA file written just before (so it is read from the page cache): mmap + chunk-parallel parse +
     gather into pinned batches + H2D + launch + CSR + D2H + format + write, `ncpu` host threads per GPU.  Index build excluded."""
     n, L = args.e2e_reads, args.read_len
+    if world > 1:
+        # N ranks write and sync N input files at once on one node: keep the job's total near one rank's default (every os.sync() below
+        # waits for ALL dirty pages of the node), but no rank below 25 M reads (a shorter run measures the pipeline's ramp)
+        n = max(n // world, min(n, 25_000_000))
     # every rank writes its own input (L + 14 bytes per read) and keeps up to three output pairs (~55 bytes per read each) in the node's
     # temporary directory: with N ranks that is N x ~33 GB at the default size.  Cut the per-rank read count to what half of the free
     # space admits -- the same number on every rank (minimum over the ranks), so that all ranks pass the same barriers

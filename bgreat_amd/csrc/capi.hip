@@ -573,7 +573,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
             while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
             while (waves > 1 && !fits(bpc, waves, stage)) --waves;
-            if (!fits(bpc, waves, stage)) { if (stage && a->cfg_lds_mphf != 2) { stage = false; } }
+            if (!fits(bpc, waves, stage) && stage) stage = false;  // (also when staging was asked for: a table beyond the LDS is probed in L2)
         } else {
             uint32_t best_res = 0;
             if (allow_stage && a->cfg_lds_mphf != 1 && p->mode != BGR_MODE_ANCHORS && a->graph->header.n_buckets * 4 < 0xFFFFFFFFull) {
@@ -602,7 +602,9 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             // one wave per SIMD and workgroup schedules best (8-wave workgroups measured 87 vs 123 Mreads/s at 24 vs 20
             // resident waves): take that grouping unless it gives up more than a fifth of the resident waves
             if (w4 == 4 && b4 * w4 * 5 >= res_n * 4) { res_n = b4 * w4; wn = w4; bn = b4; }
-            if (!allow_stage || a->cfg_lds_mphf == 1 || (a->cfg_lds_mphf == 0 && res_n * stage_pct > best_res * 100)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
+            // (lds_mphf = 2 asks for staging: where there is nothing to stage -- anchors mode probes its own index -- or the table does not fit a CU's
+            // LDS next to one wave, the launch runs without; launch_info says which it was)
+            if (!allow_stage || a->cfg_lds_mphf == 1 || best_res == 0 || (a->cfg_lds_mphf == 0 && res_n * stage_pct > best_res * 100)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
             if (best_res == 0) waves = 0;
         }
         if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return false;

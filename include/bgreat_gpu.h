@@ -280,7 +280,8 @@ int bgr_aligner_launch_info(bgr_aligner* a, uint32_t out[4]);
  * / depth-first search, out[0] = reads that search listed for its second pass, out[1] = for its third.  Synchronises the stream. */
 int bgr_aligner_pass_counts(bgr_aligner* a, uint32_t out[4]);
 /* Tuning knobs (0 keeps the default): waves per workgroup, workgroups per CU, LDS staging of the overlap
- * key table (0 auto, 1 off: probed in L2, 2 on). */
+ * key table (0 auto, 1 off: probed in L2, 2 on -- where it can be had: anchors mode stages nothing, a table beyond a CU's LDS is probed in L2;
+ * bgr_aligner_launch_info says what the launch did). */
 int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blocks_per_cu, uint32_t lds_mphf);
 
 /* Test / diagnostic hooks, set once per aligner (they used to be environment variables read on every launch):

@@ -1041,3 +1041,31 @@ def test_bench_line_comes_out_when_an_optional_leg_hangs():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_sample"]["gpu_equals_oracle"] is True and d["counters"]["reads"] == 2 * 2 * 200000
     assert "one_process_all_gpus" in d["incomplete"] and d["one_process_all_gpus"] is None and d["roofline"]["dominant_kernel"].startswith("bgr_")
+
+
+@pytest.mark.parametrize("mode", ["anchors", "large_table"])
+def test_forced_staging_that_cannot_be_had_runs_without(mode):
+    """bgr_aligner_configure(lds_mphf = 2) asks for the key table in LDS.  Anchors mode has no key table to stage (it probes its own
+    index), and a table beyond a CU's LDS cannot be staged: such launches run unstaged (launch_info says so) instead of failing with
+    "read too long" (found by tools/fuzz_big_batches.py, anchors seed 13)."""
+    if mode == "anchors":
+        s = Synth(139510, 47, 3, 21, 3222)
+        seqs, offs = s.unitigs()
+        reads, roffs = s.reads(0, 20000, 100, 5, 7001)
+        g = B.Graph.build(21, seqs, offs, 1.07, anchors=True)
+        o = oracle_py.Oracle(21, seqs, offs, anchors=True)
+        gm, om, m = B.MODE_ANCHORS, 2, 4
+    else:
+        s = Synth(14_000_000, 75, 2, 31, 77)      # ~200 k overlap keys: a table of more than 160 KB
+        seqs, offs = s.unitigs()
+        reads, roffs = s.reads(0, 20000, 150, 3, 78)
+        g = B.Graph.build(31, seqs, offs, 1.07)
+        assert g.info()["mphf_bytes"] > 170_000
+        o = oracle_py.Oracle(31, seqs, offs)
+        gm, om, m = B.MODE_GREEDY, 0, 2
+    al = B.Aligner(g, 0)
+    al.configure(lds_mphf=2)
+    p1, po1, st1 = al.align(reads, roffs, m=m, effort=2, mode=gm)
+    assert al.launch_info()["mphf_in_lds"] is False
+    p2, po2, st2 = o.align(reads, roffs, m=m, effort=2, mode=om)
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)

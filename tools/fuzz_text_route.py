@@ -1,0 +1,142 @@
+"""Randomised campaign over the text route (bgr_align_fasta_text: the device finds the records of a FASTA / FASTQ piece, applies getReads'
+accept rules, maps and formats) against the host route (the exact iostream state machine of fastx.cpp + host formatter) and -- where the
+compiled reference finishes in seconds and its mode writes files -- against oracle/_ref/bgreat at -t 1: random graphs, record counts
+of 5 000 .. 250 000, fixed and mixed read lengths, header styles, batch / chunk sizes, thread counts, modes (greedy, -c, -G, -b with
+--write-exhaustive), and irregular records injected at a random rate (lower case, N, CR, empty sequence lines, multi-line sequences,
+blank lines, '>' inside headers and at the start of sequence lines, reads of at most k bases, a last record without its newline,
+text in front of the first header; FASTQ: '@' / '+' look-alikes in quality lines, truncated tails).  Bytes of both output files and
+the counters must agree.  Run on a GPU box: python tools/fuzz_text_route.py [seed] [configs].  (Test infrastructure.)"""
+import os, shutil, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import bgreat_amd as B
+from synth import Synth
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+NCFG = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+rng = np.random.default_rng(seed)
+REF = os.path.join(ROOT, "oracle", "_ref", "bgreat")
+
+
+def make_file(path, s, k, n, fastq, irr, mixed, hdr_style):
+    """n records drawn from the genome; returns nothing (the file is the test case)"""
+    L = int(rng.choice([k + 3, 60, 100, 150, 150, 250, 400]))
+    if L <= k:
+        L = k + 3
+    reads, roffs = s.reads(int(rng.integers(0, 1 << 30)), n, L, 3, int(rng.integers(1, 1 << 30)))
+    reads = reads.reshape(n, L)
+    lens = np.full(n, L) if not mixed else rng.integers(max(1, k - 4), L + 1, size=n)
+    kinds = rng.random(n) < irr
+    out = []
+    if not fastq and irr and rng.random() < 0.15:
+        out.append(b"text in front of the first header\nACGT\n")
+    for i in range(n):
+        seq = reads[i, : lens[i]].tobytes()
+        if hdr_style == 0:
+            h = b"r%d" % i
+        elif hdr_style == 1:
+            h = b"read_%d length=%d some description with spaces" % (i, lens[i])
+        else:
+            h = b"" if i % 97 == 0 else b"x%d" % i
+        qual = b"I" * len(seq)
+        if kinds[i]:
+            kind = int(rng.integers(0, 12))
+            if kind == 0: seq = seq.lower()
+            elif kind == 1: seq = seq[: len(seq) // 2] + b"N" + seq[len(seq) // 2 + 1:]
+            elif kind == 2: seq = seq + b"\r"
+            elif kind == 3: seq = b""
+            elif kind == 4 and not fastq: seq = seq[: len(seq) // 2] + b"\n" + seq[len(seq) // 2:]     # multi-line sequence
+            elif kind == 5 and not fastq: seq = seq + b"\n"                                           # blank line behind the record
+            elif kind == 6: h = h + b" >inside>"
+            elif kind == 7 and not fastq: seq = b">" + seq[1:]                                          # a sequence line that starts like a header
+            elif kind == 8: seq = seq[: max(1, min(len(seq), k - int(rng.integers(0, 3))))]            # at most k bases
+            elif kind == 9: seq = seq[: len(seq) // 3] + b"X" + seq[len(seq) // 3 + 1:]
+            elif kind == 10 and fastq: qual = b"@" + qual[1:]
+            elif kind == 11 and fastq: qual = b"+" + qual[1:]
+        if fastq:
+            plus = b"+" + (h if i % 5 == 0 else b"")
+            out.append(b"@" + h + b"\n" + seq + b"\n" + plus + b"\n" + qual[: len(seq)] + b"\n")
+        else:
+            out.append(b">" + h + b"\n" + seq + b"\n")
+    data = b"".join(out)
+    tail = int(rng.integers(0, 6)) if irr else 0
+    if tail == 1 and data.endswith(b"\n"):
+        data = data[:-1]                     # the last record without its newline
+    elif tail == 2 and fastq:
+        data = data[: len(data) - int(rng.integers(1, 40))]   # truncated tail
+    elif tail == 3 and not fastq:
+        data += b">dangling header"
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def same(a, b):
+    return os.path.getsize(a) == os.path.getsize(b) and open(a, "rb").read() == open(b, "rb").read()
+
+
+bad = 0
+t0 = time.time()
+for it in range(NCFG):
+    k = int(rng.choice([15, 21, 25, 31, 31, 32]))
+    s = Synth(int(rng.integers(60_000, 1_500_000)), int(rng.integers(k + 2, 5 * k)), int(rng.integers(2, 5)), k, 900 + 31 * seed + it)
+    mode = str(rng.choice(["greedy", "greedy", "greedy", "correct", "anchors", "exhaustive"]))
+    fastq = bool(rng.random() < 0.35)
+    n = int(rng.choice([5_000, 20_000, 29_999, 60_000, 250_000]))
+    irr = float(rng.choice([0.0, 0.0, 1e-4, 2e-3, 0.05]))
+    mixed = bool(rng.random() < 0.4)
+    hdr = int(rng.integers(0, 3))
+    m = int(rng.integers(0, 5)); effort = int(rng.choice([1, 2, 2, 3]))
+    batch = int(rng.choice([0, 0, 5_000, 33_333, 100_000])); chunk = int(rng.choice([0, 0, 1 << 16, 1 << 20])); threads = int(rng.choice([1, 4, 8]))
+    nfiles = int(rng.choice([1, 1, 2]))
+    d = tempfile.mkdtemp(prefix="bgr_fzt_")
+    cfg = dict(k=k, mode=mode, fastq=fastq, n=n, irr=irr, mixed=mixed, hdr=hdr, m=m, effort=effort, batch=batch, chunk=chunk, threads=threads, files=nfiles)
+    try:
+        files = []
+        for j in range(nfiles):
+            f = os.path.join(d, "r%d.%s" % (j, "fq" if fastq else "fa"))
+            make_file(f, s, k, n if j == 0 else max(1, n // 3), fastq, irr, mixed, hdr)
+            files.append(f)
+        seqs, offs = s.unitigs()
+        g = B.Graph.build(k, seqs, offs, 0.0, anchors=(mode == "anchors"))
+        kw = dict(m=m, effort=effort, threads=threads, batch_reads=batch, chunk_bytes=chunk, fastq=fastq, correction=(mode == "correct"),
+                  mode={"greedy": B.MODE_GREEDY, "correct": B.MODE_GREEDY, "anchors": B.MODE_ANCHORS, "exhaustive": B.MODE_EXHAUSTIVE}[mode],
+                  write_exhaustive=(mode == "exhaustive"))
+        res = {}
+        for route in (0, 1):
+            try:
+                c, _ = B.align_all(g, ",".join(files), os.path.join(d, "p%d" % route), os.path.join(d, "n%d" % route), route=route, **kw)
+                res[route] = ("ok", c)
+            except B.BgrError as ex:    # (-c: the reference's "bug compaction" exit is an error of the run on both routes)
+                res[route] = ("err", str(ex)[:80])
+        ok = res[0][0] == res[1][0] and (res[0][0] == "err" or (res[0][1] == res[1][1] and same(os.path.join(d, "p0"), os.path.join(d, "p1")) and same(os.path.join(d, "n0"), os.path.join(d, "n1"))))
+        ref = "-"
+        if ok and res[0][0] == "ok" and os.path.exists(REF) and mode != "exhaustive" and n <= 60_000 and not (fastq and (mixed or irr)):
+            # the compiled reference at -t 1 (FASTQ reads shorter than k-1 make it throw: regular FASTQ only)
+            s.write_unitigs(os.path.join(d, "u.fa"))
+            cmd = [REF, "-r", ",".join(files), "-k", str(k), "-g", os.path.join(d, "u.fa"), "-m", str(m), "-e", str(effort), "-t", "1", "-f", os.path.join(d, "pr"), "-a", os.path.join(d, "nr")]
+            cmd += ["-q"] if fastq else []
+            cmd += ["-c"] if mode == "correct" else []
+            cmd += ["-G"] if mode == "anchors" else []
+            try:
+                p = subprocess.run(cmd, cwd=d, capture_output=True, timeout=120)
+                if p.returncode == 0:
+                    rs = same(os.path.join(d, "p0"), os.path.join(d, "pr")) and same(os.path.join(d, "n0"), os.path.join(d, "nr"))
+                    ref = "same" if rs else "DIFFERENT"
+                    ok = ok and rs
+                else:
+                    ref = "ref rc %d" % p.returncode
+            except subprocess.TimeoutExpired:
+                ref = "ref timeout"
+        print("%s %s routes %s/%s reads %s reference %s" % ("ok      " if ok else "MISMATCH", cfg, res[0][0], res[1][0], res[0][1]["reads"] if res[0][0] == "ok" else res[0][1], ref), flush=True)
+        if not ok:
+            bad += 1
+            keep = os.path.join(ROOT, "gpurun_out", "fuzztext_bad_%d_%d" % (seed, it))
+            os.makedirs(keep, exist_ok=True)
+            for f in files[:1]:
+                if os.path.getsize(f) < (8 << 20):
+                    shutil.copy(f, keep)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+print("configs %d bad %d  %.1fs" % (NCFG, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
