@@ -189,9 +189,10 @@ template <bool FASTQ>
 __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* text, uint32_t n, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t k,
                                                                uint4* rec, uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, uint32_t rec_cap) {
     const uint32_t R = *n_rec_p;
-    if (R > rec_cap) return;  // (the caller hands the piece to the host)
     const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-    if (j >= R) {  // (the scans behind this kernel run over all rec_cap entries)
+    // (more record starts than rec_start holds: the caller hands the piece to the host once it has read the count -- but the scans and the
+    // compaction behind this kernel are already enqueued and run over all rec_cap entries: they must find zeroes, not whatever the buffers held)
+    if (j >= R || R > rec_cap) {
         if (sub == 0 && j < rec_cap) { acc_flag[j] = 0; acc_len[j] = 0; }
         return;
     }
@@ -263,9 +264,10 @@ __global__ void __launch_bounds__(256) bgr_text_record_info_kernel(const uint4* 
 
 // accepted records, compacted in input order: which record, where its sequence starts in the text, base offsets of the batch
 __global__ void __launch_bounds__(256) bgr_text_compact_kernel(const uint4* rec, const uint32_t* n_rec_p, const uint32_t* acc_idx, const uint32_t* base_off,
-                                                               uint32_t* acc_rec, uint32_t* acc_src, u64* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p) {
+                                                               uint32_t* acc_rec, uint32_t* acc_src, u64* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p, uint32_t rec_cap) {
     const uint32_t R = *n_rec_p;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R > rec_cap) return;  // (rec[] was not written: the piece goes to the host parser)
     if (j == 0) read_offs[*n_acc_p] = *bases_p;
     if (j >= R) return;
     const uint4 r = rec[j];
@@ -522,7 +524,7 @@ hipError_t launch_text_records(const uint8_t* text, uint32_t n, bool fastq, cons
 hipError_t launch_text_compact(const uint4* rec, const uint32_t* n_rec_p, uint32_t max_rec, const uint32_t* acc_idx, const uint32_t* base_off, uint32_t* acc_rec,
                                uint32_t* acc_src, uint64_t* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p, hipStream_t stream) {
     hipLaunchKernelGGL(bgr_text_compact_kernel, dim3(std::max<uint32_t>(1, (max_rec + 255) / 256)), dim3(256), 0, stream, rec, n_rec_p, acc_idx, base_off, acc_rec, acc_src,
-                       reinterpret_cast<u64*>(read_offs), n_acc_p, bases_p);
+                       reinterpret_cast<u64*>(read_offs), n_acc_p, bases_p, max_rec);
     return hipGetLastError();
 }
 

@@ -316,3 +316,42 @@ def test_record_info_says_what_became_of_every_record(mode, tmp_path):
                 assert (int(v) >> 31) == 1 and (int(v) & 0x3FFFFFFF) == kept[h][0] and bool(int(v) & 0x40000000) == kept[h][1]
             else:
                 assert int(v) == 0
+
+
+@pytest.mark.parametrize("fastq", [0, 1, 2])
+def test_pieces_of_tiny_records_beyond_the_record_table_go_to_the_host(fastq, tmp_path):
+    """The device keeps room for one record per 24 bytes of a piece; a piece with more record starts (reads of a dozen bases: a k-mer list,
+    adapter fragments) must come back flagged, nothing mapped.  The kernels behind the record count are enqueued before the host has read
+    it: they must run on zeroes, not on what the (here: poisoned) buffers held -- found by tools/fuzz_text_route.py as a GPU memory fault
+    in a long-lived process (FASTQ, k = 15, reads of 11 .. 18 bases).  The aligner goes on mapping regular pieces afterwards, and the CLI
+    writes the same bytes on both routes."""
+    s = Synth(120000, 60, 2, 15, 41)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(15, seqs, offs)
+    # device memory full of ones, handed back to the allocator: what the aligner's fresh buffers are likely to be carved from
+    poison = [B.DeviceBuffer(0, np.full(8 << 20, 0xFF, dtype=np.uint8)) for _ in range(6)]
+    for pb in poison:
+        pb.free()
+    al = B.Aligner(g, 0)
+    reads, _ = s.reads(0, 60000, 12, 1, 42)
+    reads = reads.reshape(60000, 12)
+    if fastq == 0:
+        text = b"".join(b">%d\n%s\n" % (i % 10, reads[i].tobytes()) for i in range(60000))               # 16 bytes per record
+    elif fastq == 1:
+        text = b"".join(b"@\n%s\n+\n%s\n" % (reads[i, :4].tobytes(), b"IIII") for i in range(60000))      # 14 bytes per four-line record
+    else:
+        text = b"".join(b"@%d\n%s\n" % (i % 10, reads[i].tobytes()) for i in range(60000))               # header and read lines only
+    p, n, info = al.align_fasta_text(text, fastq=fastq)
+    assert info["irregular"] and info["n_records"] > len(text) // 24 + 1024 and (p, n) == (b"", b"")
+    # the same aligner, a regular piece behind it
+    r2, o2 = s.reads(0, 3000, 60, 2, 43)
+    text2 = b"".join(b">r%d\n%s\n" % (i, r2[60 * i: 60 * i + 60].tobytes()) for i in range(3000))
+    p2, n2, info2 = al.align_fasta_text(text2)
+    assert not info2["irregular"] and info2["n_accepted"] == 3000 and p2.count(b">") + n2.count(b">") == 3000
+    if fastq != 2:   # whole files through the CLI: the text route (pieces handed back to the host parser) == the host route
+        f = tmp_path / ("tiny.fq" if fastq else "tiny.fa")
+        f.write_bytes(text)
+        u = tmp_path / "u.fa"
+        s.write_unitigs(str(u))
+        a = _cli_pair(["-r", str(f), "-k", "15", "-g", str(u), "-t", "4"] + (["-q"] if fastq else []), [], ["--host-route"])
+        assert a[0][1:] == a[1][1:]

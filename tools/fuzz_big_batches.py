@@ -38,8 +38,8 @@ for it in range(NCFG):
     if nfrac:
         reads = reads.copy(); idx = rng.choice(len(reads), size=max(1, int(len(reads) * nfrac)), replace=False); reads[idx] = ord("N")
     ragged = bool(rng.random() < 0.3)
-    if ragged:   # a batch of mixed lengths: every read cut to a random length 0 .. L (empty reads, reads shorter than k, a few of full length)
-        lens = rng.integers(0, L + 1, size=n).astype(np.uint64)
+    if ragged:   # a batch of mixed lengths: every read cut to a random length k-1 .. L (no anchor position, one, a few ... and some of full length)
+        lens = rng.integers(k - 1, L + 1, size=n).astype(np.uint64)   # (shorter than k-1: the reference's substr throws, and so does the oracle)
         lens[rng.random(n) < 0.05] = L
         keep = (np.arange(L, dtype=np.uint64)[None, :] < lens[:, None]).reshape(-1)
         reads = reads[keep]
