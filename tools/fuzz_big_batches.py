@@ -27,7 +27,9 @@ for it in range(NCFG):
     m = int(rng.integers(0, 6))
     nfrac = float(rng.choice([0, 0, 0.0005, 0.005]))
     effort = int(rng.choice([0, 1, 2, 2, 3, 8]))
-    n = int(rng.choice([40_000, 70_001, 131_072, 200_003, 400_000]))
+    n = int(rng.choice([40_000, 70_001, 131_072, 200_003, 400_000, 600_001, 1_100_000]))   # (from 512 k reads on bgr_align_batch runs in pieces on four streams)
+    if n > 400_000 and (L > 150 or MODE != "greedy"):
+        n = 400_000
     if MODE == "exhaustive":
         n = min(n, 131_072); m = min(m, 3)       # (the oracle's recursion on branchy graphs: keep a configuration in seconds)
     if L >= 250:

@@ -1,8 +1,8 @@
 """Randomised campaign over the text route (bgr_align_fasta_text: the device finds the records of a FASTA / FASTQ piece, applies getReads'
 accept rules, maps and formats) against the host route (the exact iostream state machine of fastx.cpp + host formatter) and -- where the
 compiled reference finishes in seconds and its mode writes files -- against oracle/_ref/bgreat at -t 1: random graphs, record counts
-of 5 000 .. 250 000, fixed and mixed read lengths, header styles, batch / chunk sizes, thread counts, modes (greedy, -c, -G, -b with
---write-exhaustive), and irregular records injected at a random rate (lower case, N, CR, empty sequence lines, multi-line sequences,
+of 5 000 .. 600 000, fixed and mixed read lengths (down to 8 bases: more records than the device's table holds), header styles, batch / chunk sizes, thread counts, modes (greedy, -c, -G, -b with
+and without --write-exhaustive, --no-overlap), and irregular records injected at a random rate (lower case, N, CR, empty sequence lines, multi-line sequences,
 blank lines, '>' inside headers and at the start of sequence lines, reads of at most k bases, a last record without its newline,
 text in front of the first header; FASTQ: '@' / '+' look-alikes in quality lines, truncated tails).  Bytes of both output files and
 the counters must agree.  Run on a GPU box: python tools/fuzz_text_route.py [seed] [configs].  (Test infrastructure.)"""
@@ -20,13 +20,13 @@ REF = os.path.join(ROOT, "oracle", "_ref", "bgreat")
 
 
 def make_file(path, s, k, n, fastq, irr, mixed, hdr_style):
-    """n records drawn from the genome; returns nothing (the file is the test case)"""
-    L = int(rng.choice([k + 3, 60, 100, 150, 150, 250, 400]))
-    if L <= k:
+    """n records drawn from the genome into `path` (the file is the test case) -> the longest read length drawn"""
+    L = int(rng.choice([8, 12, k + 3, 60, 100, 150, 150, 250, 400]))   # (8, 12: more than one record per 24 bytes -- pieces beyond the device's record table)
+    if L <= k and not (fastq or rng.random() < 0.3):
         L = k + 3
     reads, roffs = s.reads(int(rng.integers(0, 1 << 30)), n, L, 3, int(rng.integers(1, 1 << 30)))
     reads = reads.reshape(n, L)
-    lens = np.full(n, L) if not mixed else rng.integers(max(1, k - 4), L + 1, size=n)
+    lens = np.full(n, L) if not mixed else rng.integers(min(L, max(1, k - 4)), L + 1, size=n)
     kinds = rng.random(n) < irr
     out = []
     if not fastq and irr and rng.random() < 0.15:
@@ -69,9 +69,13 @@ def make_file(path, s, k, n, fastq, irr, mixed, hdr_style):
         data += b">dangling header"
     with open(path, "wb") as f:
         f.write(data)
+    return L
 
 
 def same(a, b):
+    ea, eb = os.path.exists(a), os.path.exists(b)
+    if not ea or not eb:
+        return ea == eb     # (-b without --write-exhaustive writes nothing)
     return os.path.getsize(a) == os.path.getsize(b) and open(a, "rb").read() == open(b, "rb").read()
 
 
@@ -82,36 +86,42 @@ for it in range(NCFG):
     s = Synth(int(rng.integers(60_000, 1_500_000)), int(rng.integers(k + 2, 5 * k)), int(rng.integers(2, 5)), k, 900 + 31 * seed + it)
     mode = str(rng.choice(["greedy", "greedy", "greedy", "correct", "anchors", "exhaustive"]))
     fastq = bool(rng.random() < 0.35)
-    n = int(rng.choice([5_000, 20_000, 29_999, 60_000, 250_000]))
+    n = int(rng.choice([5_000, 20_000, 29_999, 60_000, 250_000, 600_000]))
     irr = float(rng.choice([0.0, 0.0, 1e-4, 2e-3, 0.05]))
     mixed = bool(rng.random() < 0.4)
     hdr = int(rng.integers(0, 3))
     m = int(rng.integers(0, 5)); effort = int(rng.choice([1, 2, 2, 3]))
     batch = int(rng.choice([0, 0, 5_000, 33_333, 100_000])); chunk = int(rng.choice([0, 0, 1 << 16, 1 << 20])); threads = int(rng.choice([1, 4, 8]))
     nfiles = int(rng.choice([1, 1, 2]))
+    wex = bool(rng.random() < 0.7)            # -b: with --write-exhaustive, or counts only (the reference's behaviour: record info from the device, progress blocks)
+    novl = bool(mode == "greedy" and rng.random() < 0.15)   # --no-overlap FILE (host route by design: both runs take it)
     d = tempfile.mkdtemp(prefix="bgr_fzt_")
-    cfg = dict(k=k, mode=mode, fastq=fastq, n=n, irr=irr, mixed=mixed, hdr=hdr, m=m, effort=effort, batch=batch, chunk=chunk, threads=threads, files=nfiles)
+    cfg = dict(k=k, mode=mode, fastq=fastq, n=n, irr=irr, mixed=mixed, hdr=hdr, m=m, effort=effort, batch=batch, chunk=chunk, threads=threads, files=nfiles, wex=wex, novl=novl)
     try:
         files = []
         for j in range(nfiles):
             f = os.path.join(d, "r%d.%s" % (j, "fq" if fastq else "fa"))
-            make_file(f, s, k, n if j == 0 else max(1, n // 3), fastq, irr, mixed, hdr)
+            L = make_file(f, s, k, n if j == 0 else max(1, n // 3), fastq, irr, mixed, hdr)
             files.append(f)
         seqs, offs = s.unitigs()
         g = B.Graph.build(k, seqs, offs, 0.0, anchors=(mode == "anchors"))
         kw = dict(m=m, effort=effort, threads=threads, batch_reads=batch, chunk_bytes=chunk, fastq=fastq, correction=(mode == "correct"),
                   mode={"greedy": B.MODE_GREEDY, "correct": B.MODE_GREEDY, "anchors": B.MODE_ANCHORS, "exhaustive": B.MODE_EXHAUSTIVE}[mode],
-                  write_exhaustive=(mode == "exhaustive"))
+                  write_exhaustive=(mode == "exhaustive" and wex), no_overlap_file=(os.path.join(d, "o%d") if novl else None))
         res = {}
         for route in (0, 1):
             try:
-                c, _ = B.align_all(g, ",".join(files), os.path.join(d, "p%d" % route), os.path.join(d, "n%d" % route), route=route, **kw)
+                kwr = dict(kw)
+                if kwr.get("no_overlap_file"):
+                    kwr["no_overlap_file"] = kwr["no_overlap_file"] % route
+                c, _ = B.align_all(g, ",".join(files), os.path.join(d, "p%d" % route), os.path.join(d, "n%d" % route), route=route, **kwr)
                 res[route] = ("ok", c)
             except B.BgrError as ex:    # (-c: the reference's "bug compaction" exit is an error of the run on both routes)
                 res[route] = ("err", str(ex)[:80])
-        ok = res[0][0] == res[1][0] and (res[0][0] == "err" or (res[0][1] == res[1][1] and same(os.path.join(d, "p0"), os.path.join(d, "p1")) and same(os.path.join(d, "n0"), os.path.join(d, "n1"))))
+        ok = res[0][0] == res[1][0] and (res[0][0] == "err" or (res[0][1] == res[1][1] and same(os.path.join(d, "p0"), os.path.join(d, "p1")) and same(os.path.join(d, "n0"), os.path.join(d, "n1"))
+                                                                   and (not novl or same(os.path.join(d, "o0"), os.path.join(d, "o1")))))
         ref = "-"
-        if ok and res[0][0] == "ok" and os.path.exists(REF) and mode != "exhaustive" and n <= 60_000 and not (fastq and (mixed or irr)):
+        if ok and res[0][0] == "ok" and os.path.exists(REF) and mode != "exhaustive" and not novl and n <= 60_000 and not (fastq and (mixed or irr or L < k)):
             # the compiled reference at -t 1 (FASTQ reads shorter than k-1 make it throw: regular FASTQ only)
             s.write_unitigs(os.path.join(d, "u.fa"))
             cmd = [REF, "-r", ",".join(files), "-k", str(k), "-g", os.path.join(d, "u.fa"), "-m", str(m), "-e", str(effort), "-t", "1", "-f", os.path.join(d, "pr"), "-a", os.path.join(d, "nr")]
