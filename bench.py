@@ -991,6 +991,7 @@ def run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads):
                 "reference_reads": ref_reads, "reference_aligned": ref_aligned, "gpu_aligned": gpu_aligned,
                 "gpu_matches_cpu_counters": bool(ref_aligned == gpu_aligned and ref_reads == nc)}
     except Exception as ex:
+        log("cpu_baseline (exhaustive) failed: %s: %s" % (type(ex).__name__, ex))
         return {"error": "%s: %s" % (type(ex).__name__, ex)}
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -65,6 +65,10 @@ struct DevBuf {
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
+        // diagnostic (BGREAT_POISON_DEVICE_BUFFERS=1; tools/fuzz_*.py, the GPU suite): fresh device memory usually reads as zeroes, recycled memory of
+        // a long-lived process does not -- fill every new buffer with a pattern so that a kernel that reads what nothing has written shows in ANY run
+        static const bool poison = getenv("BGREAT_POISON_DEVICE_BUFFERS") != nullptr;
+        if (e == hipSuccess && poison) { e = hipMemset(p, 0xA5, want); if (e == hipSuccess) e = hipDeviceSynchronize(); }  // (the fill runs on the null stream: the aligner's streams do not wait for it)
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -454,7 +458,8 @@ int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out) {
     if (a->blocking_sync && hipEventCreateWithFlags(&a->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) a->blocking_sync = false;
     bgr::resolve_device_graph(&g->header, g->dev[device].ptr, a->dg);
     e = a->small.ensure(256);
-    if (e == hipSuccess) e = hipMemset(a->small.p, 0, 256);
+    if (e == hipSuccess) e = hipMemset(a->small.p, 0, a->small.cap);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // (the fill runs on the null stream, which the aligner's non-blocking stream does not wait for)
     if (e != hipSuccess) { delete a; return fail(BGR_E_HIP, hipGetErrorString(e)); }
     *out = a;
     return BGR_OK;
@@ -1434,11 +1439,12 @@ int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) {
 int bgr_aligner_reset_counters(bgr_aligner* a) {
     if (!a) return fail(BGR_E_ARG, "bgr_aligner_reset_counters: null aligner");
     HIP_TRY(hipSetDevice(a->device));
+    // (on the aligner's own stream: a fill on the null stream is not ordered with a non-blocking stream's kernels)
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(a->small.p) + 64, 0, 40, a->stream));
     HIP_TRY(hipStreamSynchronize(a->stream));
-    HIP_TRY(hipMemset(static_cast<char*>(a->small.p) + 64, 0, 40));
     for (bgr_aligner* tw = a->twin; tw; tw = tw->twin) {
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(tw->small.p) + 64, 0, 40, tw->stream));
         HIP_TRY(hipStreamSynchronize(tw->stream));
-        HIP_TRY(hipMemset(static_cast<char*>(tw->small.p) + 64, 0, 40));
     }
     return BGR_OK;
 }

@@ -65,6 +65,7 @@ int bgr_align_batch_packed(bgr_aligner* a, const bgr_params*, const bgr_packed_r
 // Stand-in for the text form (bgr_align_fasta_text): the same contract on the CPU -- a piece of the regular shape (header line,
 // one sequence line, ... , ends with a newline) is "mapped" with the rule above and comes back as record bytes; any other piece is
 // handed back as irregular, untouched.
+static uint32_t g_standin_k = 5;
 struct bgr_text_stage { int device; std::string copy; };
 extern "C" int bgr_text_stage_create(int device, bgr_text_stage** out) { *out = new bgr_text_stage{device, std::string()}; return BGR_OK; }
 extern "C" void bgr_text_stage_destroy(bgr_text_stage* s) { delete s; }
@@ -106,12 +107,13 @@ extern "C" int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_
         const bool gt = lines[i].second > lines[i].first && t[lines[i].first] == '>';
         if ((i % 2 == 0) != gt) { b->irregular = 1; return BGR_OK; }  // headers start with '>', sequence lines do not
     }
+    if (lines.size() / per > n / 24 + 1024) { b->n_records = lines.size() / per; b->irregular = 1; return BGR_OK; }  // (more records than the device's table holds: as the real call)
     std::this_thread::sleep_for(std::chrono::microseconds(200 + (n * 31) % 900));
     std::string& ps = a->ps;
     std::string& ns = a->ns;
     ps.clear(); ns.clear();
     uint64_t acc = 0;
-    const uint32_t k = 5;  // (the FASTA cases of this harness run with k = 5)
+    const uint32_t k = g_standin_k;  // (the FASTA cases of this harness run with k = 5; --files: the k given)
     if (b->record_info_out && b->record_info_cap < n / 24 + 1024) return BGR_E_ARG;
     for (size_t i = 0; i < lines.size(); i += per) {
         ++b->n_records;
@@ -134,7 +136,62 @@ extern "C" int bgr_align_fasta_text(bgr_aligner* a, const bgr_params*, bgr_text_
 
 static std::string slurp(const std::string& p) { std::ifstream in(p, std::ios::binary); std::stringstream ss; ss << in.rdbuf(); return ss.str(); }
 
+// --files <tmp> <k> <fastq 0|1> file [file ...]: the given files (tools/fuzz_host_sanitizers.py: random files with irregular records) through
+// bgr_align_all on both routes, several thread counts, batch sizes and device counts; expected bytes straight from the sequential parser
+static int check_files(const std::string& tmp, uint32_t k, bool fastq, const std::vector<std::string>& files) {
+    g_standin_k = k;
+    std::string list, ep, en;
+    uint64_t n_reads = 0, aligned = 0;
+    for (size_t i = 0; i < files.size(); ++i) {
+        list += (i ? "," : "") + files[i];
+        const std::string d = slurp(files[i]);
+        bgr::ReadSet rs; bgr::parse_reads(d.data(), d.size(), fastq, k, rs);
+        n_reads += rs.count();
+        for (uint64_t j = 0; j < rs.count(); ++j) {
+            const std::string h(rs.headers.data() + rs.header_offs[j], rs.headers.data() + rs.header_offs[j + 1]);
+            const std::string r(rs.reads.data() + rs.read_offs[j], rs.reads.data() + rs.read_offs[j + 1]);
+            if (r.size() & 1) { ep += h + "\n" + std::to_string(r.size()) + ".#.7.\n"; ++aligned; }
+            else en += h + "\n" + r + "\n";
+        }
+    }
+    const std::string pf = tmp + "/p", nf = tmp + "/n";
+    for (unsigned threads : {1u, 6u}) {
+        for (uint32_t route : {0u, 1u}) {
+            for (uint64_t batch : {37ull, 5000ull, 0ull}) {
+                if (batch == 37 && n_reads > 30000) continue;   // (thousands of tiny batches: slow under TSan, nothing new)
+                bgr_graph g{k};
+                bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
+                bgr_run_options opt;
+                memset(&opt, 0, sizeof(opt));
+                opt.n_gpus = (batch == 5000 && threads == 6) ? 8 : 2;
+                opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = batch == 0 ? 0 : 4096; opt.fastq = fastq; opt.route = route;
+                uint64_t tot[5]; double secs;
+                const int rc = bgr_align_all(&g, &prm, &opt, list.c_str(), pf.c_str(), nf.c_str(), tot, &secs);
+                if (rc != BGR_OK) { printf("FAIL run threads=%u batch=%llu route=%u: rc %d %s\n", threads, (unsigned long long)batch, route, rc, bgr_last_error()); return 1; }
+                const std::string gp = slurp(pf), gn = slurp(nf);
+                std::string gp2; gp2.reserve(gp.size());
+                { std::istringstream ss(gp); std::string line; bool header = true;
+                  while (std::getline(ss, line)) {
+                      if (!header) { size_t a = line.find('.'), b = line.find('.', a + 1); if (a == std::string::npos || b == std::string::npos) { printf("FAIL path line\n"); return 1; } line = line.substr(0, a + 1) + "#" + line.substr(b); }
+                      gp2 += line + "\n"; header = !header; } }
+                if (gp2 != ep || gn != en || tot[0] != n_reads || tot[2] != aligned) {
+                    printf("FAIL threads=%u batch=%llu route=%u: paths %zu/%zu notAligned %zu/%zu reads %llu/%llu\n", threads, (unsigned long long)batch, route, gp2.size(), ep.size(), gn.size(), en.size(),
+                           (unsigned long long)tot[0], (unsigned long long)n_reads);
+                    return 1;
+                }
+            }
+        }
+    }
+    printf("files ok (%llu reads)\n", (unsigned long long)n_reads);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 6 && std::string(argv[1]) == "--files") {
+        std::vector<std::string> files;
+        for (int i = 5; i < argc; ++i) files.push_back(argv[i]);
+        return check_files(argv[2], (uint32_t)atoi(argv[3]), atoi(argv[4]) != 0, files);
+    }
     if (argc < 3) return 2;
     const std::string gold = argv[1], tmp = argv[2];
     struct Case { const char* file; bool fastq; };

@@ -986,6 +986,7 @@ def test_bench_sub_record_of_the_exhaustive_config():
     assert d["value"] > 0 and d["e2e"] is None and d["pcie_inclusive"] is None and d["other_configs"] is None
     assert "exhaustive" in d["config"]["workload"] and d["parity_sample"]["gpu_equals_oracle"] is True
     c = d["cpu_baseline"]
+    assert "error" not in c, c
     assert c["kind"] == "reference" and c["value"] > 0 and c["reference_reads"] == 5000 and c["gpu_matches_cpu_counters"] is True
 
 

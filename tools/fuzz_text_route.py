@@ -12,64 +12,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.p
 import numpy as np
 import bgreat_amd as B
 from synth import Synth
+from irregular_files import make_file
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 NCFG = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rng = np.random.default_rng(seed)
 REF = os.path.join(ROOT, "oracle", "_ref", "bgreat")
-
-
-def make_file(path, s, k, n, fastq, irr, mixed, hdr_style):
-    """n records drawn from the genome into `path` (the file is the test case) -> the longest read length drawn"""
-    L = int(rng.choice([8, 12, k + 3, 60, 100, 150, 150, 250, 400]))   # (8, 12: more than one record per 24 bytes -- pieces beyond the device's record table)
-    if L <= k and not (fastq or rng.random() < 0.3):
-        L = k + 3
-    reads, roffs = s.reads(int(rng.integers(0, 1 << 30)), n, L, 3, int(rng.integers(1, 1 << 30)))
-    reads = reads.reshape(n, L)
-    lens = np.full(n, L) if not mixed else rng.integers(min(L, max(1, k - 4)), L + 1, size=n)
-    kinds = rng.random(n) < irr
-    out = []
-    if not fastq and irr and rng.random() < 0.15:
-        out.append(b"text in front of the first header\nACGT\n")
-    for i in range(n):
-        seq = reads[i, : lens[i]].tobytes()
-        if hdr_style == 0:
-            h = b"r%d" % i
-        elif hdr_style == 1:
-            h = b"read_%d length=%d some description with spaces" % (i, lens[i])
-        else:
-            h = b"" if i % 97 == 0 else b"x%d" % i
-        qual = b"I" * len(seq)
-        if kinds[i]:
-            kind = int(rng.integers(0, 12))
-            if kind == 0: seq = seq.lower()
-            elif kind == 1: seq = seq[: len(seq) // 2] + b"N" + seq[len(seq) // 2 + 1:]
-            elif kind == 2: seq = seq + b"\r"
-            elif kind == 3: seq = b""
-            elif kind == 4 and not fastq: seq = seq[: len(seq) // 2] + b"\n" + seq[len(seq) // 2:]     # multi-line sequence
-            elif kind == 5 and not fastq: seq = seq + b"\n"                                           # blank line behind the record
-            elif kind == 6: h = h + b" >inside>"
-            elif kind == 7 and not fastq: seq = b">" + seq[1:]                                          # a sequence line that starts like a header
-            elif kind == 8: seq = seq[: max(1, min(len(seq), k - int(rng.integers(0, 3))))]            # at most k bases
-            elif kind == 9: seq = seq[: len(seq) // 3] + b"X" + seq[len(seq) // 3 + 1:]
-            elif kind == 10 and fastq: qual = b"@" + qual[1:]
-            elif kind == 11 and fastq: qual = b"+" + qual[1:]
-        if fastq:
-            plus = b"+" + (h if i % 5 == 0 else b"")
-            out.append(b"@" + h + b"\n" + seq + b"\n" + plus + b"\n" + qual[: len(seq)] + b"\n")
-        else:
-            out.append(b">" + h + b"\n" + seq + b"\n")
-    data = b"".join(out)
-    tail = int(rng.integers(0, 6)) if irr else 0
-    if tail == 1 and data.endswith(b"\n"):
-        data = data[:-1]                     # the last record without its newline
-    elif tail == 2 and fastq:
-        data = data[: len(data) - int(rng.integers(1, 40))]   # truncated tail
-    elif tail == 3 and not fastq:
-        data += b">dangling header"
-    with open(path, "wb") as f:
-        f.write(data)
-    return L
 
 
 def same(a, b):
@@ -101,7 +49,7 @@ for it in range(NCFG):
         files = []
         for j in range(nfiles):
             f = os.path.join(d, "r%d.%s" % (j, "fq" if fastq else "fa"))
-            L = make_file(f, s, k, n if j == 0 else max(1, n // 3), fastq, irr, mixed, hdr)
+            L = make_file(rng, f, s, k, n if j == 0 else max(1, n // 3), fastq, irr, mixed, hdr)
             files.append(f)
         seqs, offs = s.unitigs()
         g = B.Graph.build(k, seqs, offs, 0.0, anchors=(mode == "anchors"))
