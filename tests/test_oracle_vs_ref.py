@@ -44,3 +44,17 @@ def test_exhaustive_random(oracle_bins, seed, m, partial):
         o2, p2, n2 = run_cli(oracle_bins["cli"], args, env={"ORACLE_EXH_WRITES": "1"})
         assert parse_counters(o1) == parse_counters(o2)
         assert p1 == p2 and n1 == n2
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_degenerate_graphs(oracle_bins, seed):
+    """tools/fuzz_soup.py cpu: unitig soups with fans of more than four unitigs per overlap, palindromic overlaps, self-loops, hairpins,
+    duplicates, homopolymers, N, k from 4 to 32, all modes -- the oracle's bytes and counters against the compiled reference's (the
+    campaign of profiles/r04_fuzz_campaign.txt ran 1 800 of them; here 20 per seed)."""
+    if not oracle_bins["ref"] or not oracle_bins["ref_exh"]:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    import subprocess
+    import sys
+    from util import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_soup.py"), "cpu", str(seed), "20"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "bad 0" in p.stdout and p.stdout.count("\nok ") + p.stdout.startswith("ok ") >= 15, p.stdout[-2000:] + p.stderr[-2000:]
