@@ -68,6 +68,24 @@ for it in range(NCFG):
                 res[route] = ("err", str(ex)[:80])
         ok = res[0][0] == res[1][0] and (res[0][0] == "err" or (res[0][1] == res[1][1] and same(os.path.join(d, "p0"), os.path.join(d, "p1")) and same(os.path.join(d, "n0"), os.path.join(d, "n1"))
                                                                    and (not novl or same(os.path.join(d, "o0"), os.path.join(d, "o1")))))
+        # a split run (one pipeline per lane over contiguous shares of the input, N output pairs; BGREAT_TEST_LANES_ON_ONE_DEVICE: every lane on this
+        # box's one device): the pairs concatenated in lane order must be the single pipeline's bytes
+        split = "-"
+        if ok and res[0][0] == "ok" and not fastq and mode in ("greedy", "anchors") and not novl and rng.random() < 0.5:
+            lanes = int(rng.choice([2, 3, 5]))
+            os.environ["BGREAT_TEST_LANES_ON_ONE_DEVICE"] = "1"
+            try:
+                kws = dict(kw); kws["threads"] = max(threads, lanes)
+                cs, _ = B.align_all(g, ",".join(files), os.path.join(d, "ps"), os.path.join(d, "ns"), route=int(rng.integers(0, 2)), n_gpus=lanes, split_output=True, **kws)
+                cat = lambda stem: b"".join(open(os.path.join(d, "%s.%d" % (stem, i)), "rb").read() for i in range(lanes))
+                sok = cs == res[0][1] and cat("ps") == open(os.path.join(d, "p0"), "rb").read() and cat("ns") == open(os.path.join(d, "n0"), "rb").read()
+                split = "%d lanes %s" % (lanes, "same" if sok else "DIFFERENT")
+                ok = ok and sok
+            except B.BgrError as ex:
+                split = "error %s" % str(ex)[:80]
+                ok = False
+            finally:
+                del os.environ["BGREAT_TEST_LANES_ON_ONE_DEVICE"]
         ref = "-"
         if ok and res[0][0] == "ok" and os.path.exists(REF) and mode != "exhaustive" and not novl and n <= 60_000 and not (fastq and (mixed or irr or L < k)):
             # the compiled reference at -t 1 (FASTQ reads shorter than k-1 make it throw: regular FASTQ only)
@@ -86,7 +104,7 @@ for it in range(NCFG):
                     ref = "ref rc %d" % p.returncode
             except subprocess.TimeoutExpired:
                 ref = "ref timeout"
-        print("%s %s routes %s/%s reads %s reference %s" % ("ok      " if ok else "MISMATCH", cfg, res[0][0], res[1][0], res[0][1]["reads"] if res[0][0] == "ok" else res[0][1], ref), flush=True)
+        print("%s %s routes %s/%s reads %s reference %s split %s" % ("ok      " if ok else "MISMATCH", cfg, res[0][0], res[1][0], res[0][1]["reads"] if res[0][0] == "ok" else res[0][1], ref, split), flush=True)
         if not ok:
             bad += 1
             keep = os.path.join(ROOT, "gpurun_out", "fuzztext_bad_%d_%d" % (seed, it))
