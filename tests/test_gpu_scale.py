@@ -95,3 +95,39 @@ def test_branchy_graph_exhaustive_level_search_without_staging():
     assert np.array_equal(p3, p1[:int(po1[h])]) and np.array_equal(po3, po1[:h + 1]) and np.array_equal(st3, st1[:h])
     idx = np.sort(np.random.default_rng(4).choice(n, size=3000, replace=False))
     _check_sample_against_oracle(k, seqs, offs, reads, roffs, L, p1, po1, st1, idx, m=5, mode=1)
+
+
+def test_largest_single_launch():
+    """One launch addresses its path arena and its planes with 32 bits: 2 x (bases + 16 x reads) < 2^32 - 2^28.  A batch just below that -- 12 M x 150 bp,
+    read rows, arena offsets and plane words near the top of their range -- through bgr_align_device + bgr_aligner_fetch: every row equal to what two
+    launches of half the batch give, a sample of rows at both ends and in the middle equal to the oracle, counters consistent; one read more than the
+    limit admits is refused."""
+    k, L, n = 31, 150, 12_000_000
+    assert 2 * (n * L + 16 * n) < 2**32 - 2**28 <= 2 * ((n + 800_000) * L + 16 * (n + 800_000))
+    s = Synth(4_600_000, 140, 2, k, 20261003)
+    seqs, offs = s.unitigs()
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    reads, roffs = s.reads(0, n, L, 2, 4711, threads=16)
+    dr, do = B.DeviceBuffer(0, reads), B.DeviceBuffer(0, roffs)
+    al.align_device(dr.data_ptr(), do.data_ptr(), n, n * L, L, m=2, effort=2)
+    p1, po1, st1 = al.fetch(n, 4 * n + 1024)
+    c1 = al.counters()
+    assert c1["reads"] == n and c1["aligned"] + c1["no_overlap"] + c1["not_aligned"] == n and c1["aligned"] > 0.8 * n
+    assert int(((st1 & 3) == 2).sum()) == c1["aligned"] and po1[n] == len(p1)
+    # the same reads in two launches
+    h = n // 2
+    parts = []
+    for a, b in ((0, h), (h, n)):
+        sub_offs = B.DeviceBuffer(0, roffs[a:b + 1] - roffs[a])
+        al.align_device(dr.data_ptr() + a * L, sub_offs.data_ptr(), b - a, (b - a) * L, L, m=2, effort=2)
+        parts.append(al.fetch(b - a, 4 * (b - a) + 1024))
+        sub_offs.free()
+    assert np.array_equal(np.concatenate([parts[0][0], parts[1][0]]), p1) and np.array_equal(np.concatenate([parts[0][2], parts[1][2]]), st1)
+    assert np.array_equal(np.concatenate([np.diff(parts[0][1].astype(np.int64)), np.diff(parts[1][1].astype(np.int64))]), np.diff(po1.astype(np.int64)))
+    idx = np.concatenate([np.arange(0, 2000), np.arange(h - 1000, h + 1000), np.arange(n - 2000, n)])
+    _check_sample_against_oracle(k, seqs, offs, reads, roffs, L, p1, po1, st1, idx, m=2, effort=2)
+    # beyond the limit of one launch: refused (bgr_align_batch would cut such a batch; the device-resident form says so)
+    with pytest.raises(B.BgrError):
+        al.align_device(dr.data_ptr(), do.data_ptr(), n, 2**31 + 2**28, L, m=2, effort=2)
+    dr.free(); do.free()
