@@ -281,6 +281,7 @@ int bgr_graph_upload(bgr_graph* g, int device) {
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, g->header.blob_bytes));
     hipError_t e = hipMemcpy(p, g->host.blob.data(), g->header.blob_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // (from pageable memory on the null stream; the aligners' streams are non-blocking: the blob is there before any of them starts)
     if (e != hipSuccess) { (void)hipFree(p); return fail(BGR_E_HIP, std::string("blob H2D: ") + hipGetErrorString(e)); }
     g->dev[device] = {p, true};
     return BGR_OK;
@@ -1561,7 +1562,7 @@ int bgr_device_free(int device, void* p) {
 int bgr_device_upload(int device, void* dst_device, const void* src_host, uint64_t bytes) {
     if (bytes && (!dst_device || !src_host)) return fail(BGR_E_ARG, "bgr_device_upload: null argument");
     HIP_TRY(hipSetDevice(device));
-    if (bytes) HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    if (bytes) { HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice)); HIP_TRY(hipStreamSynchronize(nullptr)); }  // (the callers' kernels run on non-blocking streams)
     return BGR_OK;
 }
 int bgr_device_download(int device, void* dst_host, const void* src_device, uint64_t bytes) {
