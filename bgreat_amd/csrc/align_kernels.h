@@ -48,6 +48,9 @@ struct BatchIO {
     uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
+    uint32_t search_iters;       // exhaustive, depth-first passes with their stack in LDS: loop iterations one search may take before its read is handed to the
+                                 //   last pass (0 = no bound): the recursion is exponential where unitigs duplicate each other's k-mers
+    uint32_t deep_levels;        // exhaustive, last pass: levels of the level search it tries first, tables in deep_scratch (a walk has at most |read| - (k-1) of them)
     uint32_t greedy_multi;       // greedy mode: launch the sixteen-reads-per-wave kernel; reads it does not take go on gen_list (for the general kernel)
     uint2* queue;                // its per-wave rings of follow-up items {read, state}: q_cap entries per wave of the grid
     uint32_t q_cap;
@@ -90,7 +93,9 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
         fr = (max_len >= k - 1 ? max_len - (k - 1) : 0) + 3;
         if (frame_cap && fr > frame_cap) fr = frame_cap;
         bytes = 4 * 8 * w + 3 * 4 * pc + fr * 20 * 4;  // ... OUT | CUR | BEST | frames
-        if (scratch_words) *scratch_words = 3ull * pc + (uint64_t)fr * 20;
+        // (the last pass keeps OUT | CUR | BEST and, in one region, either the depth-first frames (20 words each) or the level search's tables:
+        // 32 + levels x 53 words, levels = fr)
+        if (scratch_words) *scratch_words = 3ull * pc + ((32ull + (uint64_t)fr * 53 + 3) & ~3ull);
     }
     if (mode == 2) {  // exhaustive pass 1 with the level-by-level search: FW3 | FWQ | RCW | NM | OUT | BEST | tables
         fr = (max_len >= k - 1 ? max_len - (k - 1) : 0) + 3;

@@ -556,7 +556,9 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     const uint32_t level_cap = fc_set ? kExhFrameCap : std::max<uint32_t>(16, (max_read_len / 64) * 4);
     const uint32_t per_wave = bgr::lds_bytes_per_wave(level_search ? 2u : lmode, a->dg.k, max_read_len, &words, &path_cap, &frames,
                                                       level_search ? level_cap : kExhFrameCap);
-    bool two_pass = exhaustive && (frames < frames_deep || level_search);  // the level search can also overflow on a wide level
+    // (every exhaustive launch has its last pass behind it: the depth-first passes with their stack in LDS bound their work per search -- io.search_iters --
+    // and hand on what exceeds it, besides what outgrows their frames; the level search can also overflow on a wide level)
+    bool two_pass = exhaustive;
     const size_t lds_cu = a->lds_per_cu;
     const uint32_t mphf_bytes = a->dg.table_bytes;
     // Resident waves per CU are bounded by registers (bgr::resident_waves_per_cu); LDS decides how they are grouped:
@@ -712,6 +714,10 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.deep_scratch = nullptr;
     io.deep_stride = (uint32_t)deep_stride;
     io.level_search = level_search ? 1u : 0u;
+    // a depth-first search in LDS takes ~2 iterations per read base on a branching graph (500 for 250 bp, 4 alleles every 36 bp, m = 5); beyond 64 x that
+    // its read goes to the last pass (level search over HBM tables first) -- never reached on a graph of unique k-mers
+    io.search_iters = (exhaustive && two_pass && !deep_only) ? 128u * (max_read_len + 64u) : 0u;
+    io.deep_levels = frames_deep;
     io.greedy_multi = 0;
     io.queue = nullptr;
     io.q_cap = 0;

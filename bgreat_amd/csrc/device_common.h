@@ -614,7 +614,7 @@ __device__ __forceinline__ uint32_t g4_step(const BgrDeviceGraph& g, const u64* 
 #define BGR_EXH_OCC 6 /* waves per SIMD the exhaustive kernel is compiled for */
 #endif
 #ifndef BGR_EXH_DEEP_OCC
-#define BGR_EXH_DEEP_OCC BGR_EXH_OCC /* ... its variant with the search state in HBM */
+#define BGR_EXH_DEEP_OCC 4 /* ... its variant with the search state in HBM: it carries the level search as well (128 VGPRs: the last pass sees few reads, its occupancy matters little) */
 #endif
 
 // ================================================ kernels ===============================================

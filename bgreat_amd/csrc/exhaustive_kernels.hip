@@ -27,18 +27,22 @@ namespace {
 template <int DIR>
 __device__ __forceinline__ uint32_t exh_search(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
                                                uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t budget, bool partial,
-                                               uint32_t* FR, uint32_t max_frames, int32_t* CUR, int32_t* BEST, uint32_t* best_n, int lane) {
-    // returns the best total (budget+1 if none; EXH_OVERFLOW if the search needs more than max_frames frames);
+                                               uint32_t* FR, uint32_t max_frames, int32_t* CUR, int32_t* BEST, uint32_t* best_n, int lane, uint32_t max_iters = 0) {
+    // returns the best total (budget+1 if none; EXH_OVERFLOW if the search needs more than max_frames frames -- or, max_iters != 0, more
+    // than that many loop iterations: on unitig sets that duplicate each other's k-mers the recursion enumerates exponentially many walks
+    // (DESIGN 8 item 6); the read then goes to the last pass, whose level search over tables in HBM is polynomial);
     // the best walk's ints are BEST[0..*best_n) in output order
     uint32_t best = budget + 1;
     *best_n = 0;
     int depth = 0;
+    uint32_t iters = 0;
     {   // (a frame names the HALF its candidates come from -- a handle, graph_layout.h; the anchor is a key entry)
         const uint32_t h0 = half_handle(g, a_rec, a_canon, DIR == 0);
         if (lane == 0) { FR[0] = h0; FR[1] = a_pos; FR[2] = 0; FR[3] = a_canon ? (1u << 17) : 0u; }
     }
     wave_sync();
     while (depth >= 0) {
+        if (max_iters && ++iters > max_iters) { wave_sync(); return EXH_OVERFLOW; }
         uint32_t* F = FR + (uint32_t)depth * FR_WORDS;
         const uint32_t rec = F[0], pos = F[1], cost = F[2];
         uint32_t ctl = F[3];
@@ -403,7 +407,9 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
                     if (lane == 0) OUT[0] = 0;
                     nl = 1;
                 } else {
-                    eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane);
+                    // (last pass: the level search first, its tables where the frames would lie -- polynomial; the recursion only for a level wider than four nodes)
+                    eb = DEEP ? exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.deep_levels, BEST, &nl, lane) : EXH_OVERFLOW;
+                    if (eb == EXH_OVERFLOW) eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane, DEEP ? 0u : io.search_iters);
                     if (eb == EXH_OVERFLOW) { overflow = true; break; }
                     if (eb > m) continue;
                     for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
@@ -412,7 +418,8 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
                 // position 0 is tried whatever its (k-1)-mer: when that is no overlap of the graph getBegin() is empty, and only an
                 // empty right side or -i can make the anchor succeed (alignerExhaustive.cpp:206-221): no search either
                 if (a_rec == BGR_NONE && !prm.partial && L - a_pos - K1 != 0) continue;
-                const uint32_t ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane);
+                uint32_t ee = DEEP ? exh_dp<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.deep_levels, BEST, &nr, lane) : EXH_OVERFLOW;
+                if (ee == EXH_OVERFLOW) ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane, DEEP ? 0u : io.search_iters);
                 if (ee == EXH_OVERFLOW) { overflow = true; break; }
                 if (ee > m - eb) continue;
                 for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];

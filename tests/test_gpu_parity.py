@@ -1070,3 +1070,40 @@ def test_forced_staging_that_cannot_be_had_runs_without(mode):
     assert al.launch_info()["mphf_in_lds"] is False
     p2, po2, st2 = o.align(reads, roffs, m=m, effort=2, mode=om)
     assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+
+
+def test_exhaustive_on_duplicated_kmers_comes_back_and_equals_the_reference(tmp_path):
+    """A unitig set that duplicates its own k-mers (a homopolymer on both strands next to chains, fans, self-loops: tests/make_golden_soup.py) makes the
+    reference's exhaustive recursion enumerate exponentially many identical walks -- 150 s for one 79-base read.  The device's depth-first passes bound
+    their work per search and hand such a read to the last pass, whose level search over tables in HBM is polynomial: the run is back in seconds (it did
+    not come back at all before), with the reference's bytes (found by tools/fuzz_soup.py)."""
+    import time
+    from util import run_cli
+    args = ["-r", os.path.join(GOLD, "soup_polyA_reads.fa"), "-k", "31", "-g", os.path.join(GOLD, "soup_polyA_unitig.fa"), "-m", "1", "-e", "2", "-t", "4", "-b", "--write-exhaustive"]
+    t0 = time.time()
+    out, paths, na = run_cli(B.CLI_PATH, args, timeout=120)
+    assert time.time() - t0 < 60
+    assert paths == open(os.path.join(GOLD, "soup_polyA_expected_paths"), "rb").read()
+    assert na == open(os.path.join(GOLD, "soup_polyA_expected_notAligned.fa"), "rb").read()
+    from util import parse_counters
+    assert parse_counters(out)["aligned"] == 141 and parse_counters(out)["reads"] == 400
+    # the batch form, tiny search caps: the same rows through every pass
+    us = [l.strip() for l in open(os.path.join(GOLD, "soup_polyA_unitig.fa")) if not l.startswith(">")]
+    rd = [l.strip() for l in open(os.path.join(GOLD, "soup_polyA_reads.fa")) if not l.startswith(">")]
+    seqs = np.frombuffer("".join(us).encode(), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(u) for u in us])]).astype(np.uint64)
+    rb = np.frombuffer("".join(rd).encode(), dtype=np.uint8)
+    roffs = np.concatenate([[0], np.cumsum([len(r) for r in rd])]).astype(np.uint64)
+    g = B.Graph.build(31, seqs, offs, 1.8)
+    rows = None
+    for knobs in ({}, {B.KNOB_EXH_FRAME_CAP: 3}, {B.KNOB_EXH_FAST: 1}, {B.KNOB_EXH_FAST: 1, B.KNOB_EXH_SEARCH: 1}, {B.KNOB_EXH_FAST: 1, B.KNOB_EXH_SEARCH: 2, B.KNOB_EXH_FRAME_CAP: 3}):
+        al = B.Aligner(g, 0)
+        for kk, v in knobs.items():
+            al.set_knob(kk, v)
+        p, po, st = al.align(rb, roffs, m=1, effort=2, mode=B.MODE_EXHAUSTIVE)
+        assert int(((st & 3) == 2).sum()) == 141, knobs
+        if rows is None:
+            rows = (p, po, st)
+        else:
+            assert np.array_equal(p, rows[0]) and np.array_equal(po, rows[1]) and np.array_equal(st, rows[2]), knobs
+        al.close()
