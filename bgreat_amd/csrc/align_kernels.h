@@ -50,7 +50,8 @@ struct BatchIO {
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
     uint32_t search_iters;       // exhaustive, depth-first passes with their stack in LDS: loop iterations one search may take before its read is handed to the
                                  //   last pass (0 = no bound): the recursion is exponential where unitigs duplicate each other's k-mers
-    uint32_t deep_levels;        // exhaustive, last pass: levels of the level search it tries first, tables in deep_scratch (a walk has at most |read| - (k-1) of them)
+    uint32_t deep_levels;        // exhaustive, last pass: levels of the level search it tries first, tables in deep_scratch (a walk has at most |read| - (k-1) of them; 0: not tried)
+    uint32_t deep_iters;         // exhaustive, last pass: loop iterations its recursion may take before the launch reports an error (cursor[1] = 2)
     uint32_t greedy_multi;       // greedy mode: launch the sixteen-reads-per-wave kernel; reads it does not take go on gen_list (for the general kernel)
     uint2* queue;                // its per-wave rings of follow-up items {read, state}: q_cap entries per wave of the grid
     uint32_t q_cap;

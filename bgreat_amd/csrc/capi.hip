@@ -30,6 +30,8 @@ namespace {
 
 thread_local std::string tl_err;
 int fail(int code, const std::string& msg) { tl_err = msg; return code; }
+const char* const kSearchGaveUp = "exhaustive search gave up on a read after 2^26 steps of the recursion in the last pass: the unitig set duplicates its own k-mers and spreads the walks of a "
+                                  "level over more than four nodes (no compacted de Bruijn graph does; the reference's recursion is exponential there too)";
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
@@ -718,6 +720,12 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // its read goes to the last pass (level search over HBM tables first) -- never reached on a graph of unique k-mers
     io.search_iters = (exhaustive && two_pass && !deep_only) ? 128u * (max_read_len + 64u) : 0u;
     io.deep_levels = frames_deep;
+    io.deep_iters = 1u << 26;
+    // (test hooks, tests/test_gpu_parity.py: the error path of the last pass needs a unitig set that is hard to build and minutes of device time otherwise)
+    if (exhaustive) {
+        if (const char* e = getenv("BGREAT_TEST_DEEP_ITERS")) io.deep_iters = (uint32_t)std::max(1, atoi(e));
+        if (getenv("BGREAT_TEST_DEEP_NO_LEVELS")) io.deep_levels = 0;
+    }
     io.greedy_multi = 0;
     io.queue = nullptr;
     io.q_cap = 0;
@@ -1159,7 +1167,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     HIP_TRY(hipMemcpyAsync(h2, a->small.p, 8, hipMemcpyDeviceToHost, a->stream));  // cursor[1]: arena overflow flag
     HIP_TRY(wait_stream(a));
     lap(2);
-    if (h2[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+    if (h2[1]) return fail(BGR_E_INTERNAL, h2[1] == 2 ? kSearchGaveUp : "path arena overflow (internal sizing error)");
     if (b->want_output == 2 && h[TXT_INFO_BUG] != 0xFFFFFFFFu) {  // a path that does not spell a walk: the reference prints "bug compaction" and exits
         b->irregular = 2;                                          // (aligner.cpp:280-283); the caller reproduces that on the host
         a->tx_n_acc = 0;
@@ -1205,7 +1213,7 @@ static int fetch_total(bgr_aligner* a, uint64_t n, uint64_t* total_out) {
     HIP_TRY(hipMemcpyAsync(hs, a->small.p, sizeof(hs), hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(wait_stream(a));
     const uint32_t* cur = reinterpret_cast<const uint32_t*>(hs);
-    if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+    if (cur[1]) return fail(BGR_E_INTERNAL, cur[1] == 2 ? kSearchGaveUp : "path arena overflow (internal sizing error)");
     *total_out = hs[16];
     return BGR_OK;
 }

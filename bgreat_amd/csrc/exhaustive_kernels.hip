@@ -408,8 +408,8 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
                     nl = 1;
                 } else {
                     // (last pass: the level search first, its tables where the frames would lie -- polynomial; the recursion only for a level wider than four nodes)
-                    eb = DEEP ? exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.deep_levels, BEST, &nl, lane) : EXH_OVERFLOW;
-                    if (eb == EXH_OVERFLOW) eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane, DEEP ? 0u : io.search_iters);
+                    eb = (DEEP && io.deep_levels) ? exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.deep_levels, BEST, &nl, lane) : EXH_OVERFLOW;
+                    if (eb == EXH_OVERFLOW) eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane, DEEP ? io.deep_iters : io.search_iters);
                     if (eb == EXH_OVERFLOW) { overflow = true; break; }
                     if (eb > m) continue;
                     for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
@@ -418,8 +418,8 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
                 // position 0 is tried whatever its (k-1)-mer: when that is no overlap of the graph getBegin() is empty, and only an
                 // empty right side or -i can make the anchor succeed (alignerExhaustive.cpp:206-221): no search either
                 if (a_rec == BGR_NONE && !prm.partial && L - a_pos - K1 != 0) continue;
-                uint32_t ee = DEEP ? exh_dp<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.deep_levels, BEST, &nr, lane) : EXH_OVERFLOW;
-                if (ee == EXH_OVERFLOW) ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane, DEEP ? 0u : io.search_iters);
+                uint32_t ee = (DEEP && io.deep_levels) ? exh_dp<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.deep_levels, BEST, &nr, lane) : EXH_OVERFLOW;
+                if (ee == EXH_OVERFLOW) ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane, DEEP ? io.deep_iters : io.search_iters);
                 if (ee == EXH_OVERFLOW) { overflow = true; break; }
                 if (ee > m - eb) continue;
                 for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];
@@ -430,8 +430,15 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
         }
         wave_sync();
         if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
-            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
-            continue;
+            if (!DEEP) {
+                if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+                continue;
+            }
+            // the last pass: a level wider than four nodes sent the read into the recursion, and that took io.deep_iters iterations (2^26: minutes of one wavefront, about a second of the reference's recursion on a CPU core) without an end --
+            // duplicated k-mers AND wide levels.  The launch reports an error (cursor[1] = 2) instead of running for hours; the read
+            // is written as not aligned so that the rows stay well formed.
+            if (lane == 0) io.cursor[1] = 2;
+            done = false;
         }
         c_ov += npos;
         uint32_t abase = 0;

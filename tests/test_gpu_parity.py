@@ -1107,3 +1107,33 @@ def test_exhaustive_on_duplicated_kmers_comes_back_and_equals_the_reference(tmp_
         else:
             assert np.array_equal(p, rows[0]) and np.array_equal(po, rows[1]) and np.array_equal(st, rows[2]), knobs
         al.close()
+
+
+def test_exhaustive_last_pass_gives_up_loudly(monkeypatch):
+    """The recursion of the last exhaustive pass (behind a level wider than four nodes) is bounded: beyond 2^26 loop iterations the launch returns an error
+    instead of holding the device for hours.  Test hooks shrink the bound to 40 iterations and switch the level search of that pass off; tiny search caps push
+    the reads of a 4-allele graph there."""
+    s = Synth(60000, 40, 4, 31, 88)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 3000, 250, 4, 89)
+    g = B.Graph.build(31, seqs, offs)
+    o = oracle_py.Oracle(31, seqs, offs)
+    p2, po2, st2 = o.align(reads, roffs, m=4, mode=1)
+
+    def run():
+        al = B.Aligner(g, 0)
+        al.set_knob(B.KNOB_EXH_FAST, 1)
+        al.set_knob(B.KNOB_EXH_FRAME_CAP, 3)
+        try:
+            return al.align(reads, roffs, m=4, mode=B.MODE_EXHAUSTIVE), al.pass_counts()
+        finally:
+            al.close()
+    (p1, po1, st1), passes = run()           # the bound as shipped: every read through the last pass, rows equal to the oracle's
+    assert passes[1] > 1000 or passes[0] > 1000, passes
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    monkeypatch.setenv("BGREAT_TEST_DEEP_NO_LEVELS", "1")
+    (p1, po1, st1), _ = run()                # the recursion alone in the last pass (as before this round): the same rows
+    assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
+    monkeypatch.setenv("BGREAT_TEST_DEEP_ITERS", "40")
+    with pytest.raises(B.BgrError, match="gave up"):
+        run()
