@@ -31,12 +31,12 @@ SYMBOLS = [
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup", "bgr_graph_key_lookup",
-    "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
+    "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_last_pass_runs", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
     "bgr_align_fasta_text", "bgr_aligner_fetch_text", "bgr_host_cache_release", "bgr_device_local_cpus", "bgr_text_stage_create", "bgr_text_stage_destroy", "bgr_text_stage_upload",
     "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait", "bgr_text_stage_device", "bgr_text_stage_upload_parts",
     "bgr_device_alloc", "bgr_device_free", "bgr_device_upload", "bgr_device_download",
 ]
-KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8
+KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP, KNOB_EXH_MEMO_CAP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
 
 
@@ -172,6 +172,7 @@ def lib():
     L.bgr_aligner_configure.argtypes = [vp, u32, u32, u32]
     L.bgr_aligner_set_knob.argtypes = [vp, u32, u64]
     L.bgr_aligner_pass_counts.argtypes = [vp, vp]
+    L.bgr_aligner_last_pass_runs.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.bgr_readset_load.argtypes = [C.c_char_p, i32, u32, C.POINTER(vp)]
     L.bgr_readset_load_parallel.argtypes = [C.c_char_p, i32, u32, u32, u64, C.POINTER(vp)]
     L.bgr_align_all.argtypes = [vp, C.POINTER(Params), C.POINTER(RunOptions), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_double)]
@@ -503,6 +504,12 @@ class Aligner:
         out = np.zeros(4, dtype=np.uint32)
         _check(lib().bgr_aligner_pass_counts(self.h, out.ctypes.data))
         return tuple(int(x) for x in out)
+
+    def last_pass_runs(self):
+        """Exhaustive mode: (runs of the last pass for the launch last settled, entries per wave of its table of remembered calls in the final run)."""
+        r, c = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().bgr_aligner_last_pass_runs(self.h, C.byref(r), C.byref(c)))
+        return int(r.value), int(c.value)
 
     def close(self):
         if self.h:

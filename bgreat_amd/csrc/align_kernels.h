@@ -45,13 +45,13 @@ struct BatchIO {
     uint32_t frames_per_wave;    // exhaustive mode: DFS frames (20 u32 each) in the per-wave LDS region
     uint32_t* ovf_list;          // exhaustive pass 1: reads whose search outgrew frames_per_wave are listed here (count at cursor[2])
     const uint32_t* subset;      // exhaustive pass 2: map reads subset[0 .. cursor[2]) instead of 0 .. n_reads
-    uint32_t* deep_scratch;      // exhaustive pass 2: per-wave search state in HBM (OUT | CUR | BEST | frames), else nullptr
+    uint32_t* deep_scratch;      // exhaustive, last pass: per-wave search state in HBM (OUT | CUR | BEST | frames | table), else nullptr
     uint32_t deep_stride;        // u32 words of one wave's region in deep_scratch
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
     uint32_t search_iters;       // exhaustive, depth-first passes with their stack in LDS: loop iterations one search may take before its read is handed to the
                                  //   last pass (0 = no bound): the recursion is exponential where unitigs duplicate each other's k-mers
-    uint32_t deep_levels;        // exhaustive, last pass: levels of the level search it tries first, tables in deep_scratch (a walk has at most |read| - (k-1) of them; 0: not tried)
-    uint32_t deep_iters;         // exhaustive, last pass: loop iterations its recursion may take before the launch reports an error (cursor[1] = 2)
+    uint32_t deep_memo_cap;      // exhaustive, last pass: entries (a power of two) of a wave's table of remembered calls in deep_scratch (exh_memo); a read that
+                                 //   fills it is put on ovf_list and run again by the host with a larger table
     uint32_t greedy_multi;       // greedy mode: launch the sixteen-reads-per-wave kernel; reads it does not take go on gen_list (for the general kernel)
     uint2* queue;                // its per-wave rings of follow-up items {read, state}: q_cap entries per wave of the grid
     uint32_t q_cap;
@@ -77,13 +77,17 @@ struct LaunchCfg {
     uint32_t stage_mphf;       // 1: copy the MPHF cascade into LDS at block start
 };
 
+// the last exhaustive pass (exh_memo, exhaustive_kernels.hip): u32 words of a frame of its explicit stack / of an entry of its table, both in HBM;
+// runs of that pass one launch's arena has room for (the first one and its repeats with larger tables: 16 x per repeat, capi.hip settle_launch)
+#define BGR_MEMO_FRAME_WORDS 32
+#define BGR_MEMO_ENTRY_WORDS 8
+constexpr uint32_t kDeepRuns = 8;
+
 // Per-wave LDS bytes for a batch whose longest read has max_len bases (mode 0 greedy, 1 exhaustive).
-// frame_cap > 0 limits the exhaustive DFS stack (a second pass with the full stack maps the few reads that need more).
-// scratch_words (may be null): u32 words of the search state (OUT | CUR | BEST | frames), which that second pass keeps
-// in HBM; its LDS need is then deep_lds_bytes_per_wave().
+// frame_cap > 0 limits the exhaustive DFS stack (the last pass, with the full stack in HBM, maps the few reads that need more; its LDS need is
+// deep_lds_bytes_per_wave(), its HBM need deep_scratch_words(), launch_plan.h).
 inline uint32_t deep_lds_bytes_per_wave(uint32_t max_len) { return 4 * 8 * (max_len / 32 + 2); }
-inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, uint32_t* words, uint32_t* path_cap, uint32_t* frames, uint32_t frame_cap = 0,
-                                   uint64_t* scratch_words = nullptr) {
+inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, uint32_t* words, uint32_t* path_cap, uint32_t* frames, uint32_t frame_cap = 0) {
     uint32_t w = max_len / 32 + 2;
     uint32_t pc = max_len + 8;
     pc = (pc + 3) & ~3u;  // multiple of 4 ints: what lies behind the path buffers stays 16-byte aligned
@@ -94,9 +98,6 @@ inline uint32_t lds_bytes_per_wave(uint32_t mode, uint32_t k, uint32_t max_len, 
         fr = (max_len >= k - 1 ? max_len - (k - 1) : 0) + 3;
         if (frame_cap && fr > frame_cap) fr = frame_cap;
         bytes = 4 * 8 * w + 3 * 4 * pc + fr * 20 * 4;  // ... OUT | CUR | BEST | frames
-        // (the last pass keeps OUT | CUR | BEST and, in one region, either the depth-first frames (20 words each) or the level search's tables:
-        // 32 + levels x 53 words, levels = fr)
-        if (scratch_words) *scratch_words = 3ull * pc + ((32ull + (uint64_t)fr * 53 + 3) & ~3ull);
     }
     if (mode == 2) {  // exhaustive pass 1 with the level-by-level search: FW3 | FWQ | RCW | NM | OUT | BEST | tables
         fr = (max_len >= k - 1 ? max_len - (k - 1) : 0) + 3;

@@ -23,6 +23,7 @@
 #include "fastx.h"
 #include "anchor_index.h"
 #include "graph_build.h"
+#include "launch_plan.h"
 #include "read_pack.h"
 #include "text_kernels.h"
 
@@ -30,15 +31,13 @@ namespace {
 
 thread_local std::string tl_err;
 int fail(int code, const std::string& msg) { tl_err = msg; return code; }
-const char* const kSearchGaveUp = "exhaustive search gave up on a read after 2^26 steps of the recursion in the last pass: the unitig set duplicates its own k-mers and spreads the walks of a "
-                                  "level over more than four nodes (no compacted de Bruijn graph does; the reference's recursion is exponential there too)";
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess) return fail(BGR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-const uint32_t kLdsFixed = 512;  // level descriptors at the start of the dynamic LDS
+const uint32_t kRetryCtr = 6, kRetrySubsetCtr = 7;  // words of `cursor`: reads the last exhaustive pass hands back / reads of the list it maps when it runs again
 const int kTimerRing = 64;   // launches between two drains of the timers
 const int kTimerSlots = 8;   // kernels of one launch timed separately (pre-pass, passes)
 
@@ -106,7 +105,17 @@ struct bgr_aligner {
     uint32_t tx_want = 0;              // its want_output (2 = correction mode: mapped reads as spelled by their paths)
     double tx_phase_s[5] = {0, 0, 0, 0, 0};  // BGREAT_TIMING: host wall seconds to the call's four waits (mark, records, mapping + sizes, streams) + calls
 
-    DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, lst, deep, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[2] u32 @0, counters[5] u64 @64
+    DevBuf in_reads, in_offs, pk_fw3, pk_nm, pk_hasn, results, arena, ovf, ovf2, lst, deepbuf, retry, retry2, small, csr_sums, csr_poffs, csr_status, csr_paths;  // small: cursor[16] u32 @0, counters[5] u64 @64
+    struct DeepRun {  // the last pass of the exhaustive launch in flight, as enqueued: settle_launch runs it again for reads whose table filled up
+        bool open = false;
+        bgr::BatchIO io;
+        bgr::KernelParams kp;
+        BgrDeviceGraph dg;
+        bgr::LaunchCfg cfg;
+        uint32_t per_wave_lds = 0, path_cap = 0, frames = 0, memo_cap = 0, runs = 0;
+    } deep;
+    bgr::PlanDevice plan_dev;     // CUs, LDS, resident waves per kernel: asked once
+    bool plan_dev_known = false;
     uint64_t last_n = 0;
     DevBuf wave_times;            // diagnostic builds only (-DBGR_PHASE_TIMING)
     uint64_t wave_times_n = 0;
@@ -117,7 +126,7 @@ struct bgr_aligner {
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
     bool exh_filter = !(getenv("BGREAT_EXH_FILTER") && atoi(getenv("BGREAT_EXH_FILTER")) == 0);  // exhaustive mode through the minimizer filter too (BGREAT_EXH_FILTER=0: without)
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
-    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0;
+    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0, knob_memo_cap = 0;
     uint64_t knob_split_limit = 0;
     uint32_t knob_overlap = 0;      // BGR_KNOB_BATCH_OVERLAP
     bgr_aligner* twin = nullptr;    // second stream + buffers for the overlapped form of bgr_align_batch (created on first use)
@@ -476,7 +485,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
     if (a->twin) { bgr_aligner_destroy(a->twin); a->twin = nullptr; }
     if (hipSetDevice(a->device) == hipSuccess) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
-        a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->lst.release(); a->deep.release(); a->small.release();
+        a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->lst.release(); a->deepbuf.release(); a->retry.release(); a->retry2.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release(); a->wave_times.release();
         for (DevBuf* b : {&a->tx_in, &a->tx_sums, &a->tx_start, &a->tx_rec, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_offs,
                           &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff, &a->tx_pout, &a->tx_nout, &a->tx_info}) b->release();
@@ -506,12 +515,30 @@ int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
         case BGR_KNOB_GREEDY_FAST: if (value > 1) break; a->knob_greedy_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_EXH_FAST: if (value > 1) break; a->knob_exh_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_ANCHORS_FAST: if (value > 1) break; a->knob_anc_fast = (uint32_t)value; return BGR_OK;
+        case BGR_KNOB_EXH_MEMO_CAP: a->knob_memo_cap = (uint32_t)std::min<uint64_t>(value, 1u << 24); return BGR_OK;
         default: break;
     }
     return fail(BGR_E_ARG, "bgr_aligner_set_knob: unknown knob or value out of range");
 }
 
-// The mapping launch of one batch.  planes_ready: the aligner's 2-bit planes (pk_fw3 / pk_nm / pk_hasn) already hold the batch
+// What the planner needs of the graph / device / caller's tuning (launch_plan.h)
+static bgr::PlanGraph plan_graph_of(const BgrBlobHeader& h) {
+    bgr::PlanGraph g;
+    g.k = h.k; g.slot_fill_x100 = h.slot_fill_x100; g.table_bytes = (uint32_t)std::min<uint64_t>((uint64_t)h.n_buckets * 4, 0xFFFFFFFFull);
+    g.total_bases = h.total_bases; g.n_unitigs = h.n_unitigs; g.n_buckets = h.n_buckets; g.max_unitig_len = h.max_unitig_len;
+    g.anc_n = h.anc_n; g.anc_active_levels = h.anc_active_levels; g.has_exc = h.has_exc != 0;
+    return g;
+}
+static bgr::PlanTuning plan_tuning_of(const bgr_aligner* a) {
+    bgr::PlanTuning t;
+    t.cfg_waves = a->cfg_waves; t.cfg_blocks_per_cu = a->cfg_blocks_per_cu; t.cfg_lds_mphf = a->cfg_lds_mphf;
+    t.frame_cap = a->knob_frame_cap; t.search = a->knob_search; t.memo_cap = a->knob_memo_cap;
+    t.no_greedy_fast = a->knob_greedy_fast != 0; t.no_exh_fast = a->knob_exh_fast != 0; t.no_anc_fast = a->knob_anc_fast != 0;
+    return t;
+}
+
+// The mapping launch of one batch: the geometry comes from plan_launch (launch_plan.h, a pure function of numbers), this function sizes the
+// buffers and enqueues.  planes_ready: the aligner's 2-bit planes (pk_fw3 / pk_nm / pk_hasn) already hold the batch
 // (bgr_align_batch_packed copied them in); else they are made from the ASCII reads at d_reads by the pre-pass.
 static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
                              uint64_t total_bases, uint32_t max_read_len, bool planes_ready) {
@@ -520,6 +547,8 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (p->mode == BGR_MODE_ANCHORS && !a->graph->header.anc_n)
         return fail(BGR_E_ARG, "bgr_align_device: BGR_MODE_ANCHORS needs a graph built with BGR_BUILD_ANCHORS");
     a->last_n = n_reads;
+    a->deep.open = false;
+    a->deep.runs = 0; a->deep.memo_cap = 0;
     if (n_reads == 0) return BGR_OK;
     if ((!d_reads && !planes_ready) || !d_read_offsets) return fail(BGR_E_ARG, "bgr_align_device: null device buffer");
     if (n_reads >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: more than 2^32-2 reads in one batch");
@@ -527,178 +556,32 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (a->ev_used == kTimerRing) { int rc = drain_timers(a); if (rc != BGR_OK) return rc; }
     HIP_TRY(a->results.ensure(n_reads * 8));
 
-    // ---- launch geometry -----------------------------------------------------------------------
-    // Exhaustive mode runs in two passes: pass 1 gives every wave a SHALLOW search stack (kExhFrameCap frames) in LDS
-    // so that many waves fit a CU; the rare read whose search goes deeper is listed and mapped by pass 2, which
-    // keeps the worst-case search state in HBM.  Reads too long for pass 1's LDS layout all go through pass 2's
-    // kernel directly.  Greedy mode is one pass.
-    const bool fc_set = a->knob_frame_cap != 0;  // BGR_KNOB_EXH_FRAME_CAP: tests shrink it to push most reads through pass 2
-    const uint32_t kExhFrameCap = fc_set ? std::max<uint32_t>(2, a->knob_frame_cap) : 24;
-    uint32_t words = 0, path_cap = 0, frames = 0, frames_deep = 0;
-    uint64_t deep_stride = 0;
-    const uint32_t lmode = p->mode == BGR_MODE_EXHAUSTIVE ? 1u : 0u;  // anchors mode uses the greedy per-wave layout
-    bgr::lds_bytes_per_wave(lmode, a->dg.k, max_read_len, &words, &path_cap, &frames_deep, 0, &deep_stride);
-    const uint32_t per_wave_deep = bgr::deep_lds_bytes_per_wave(max_read_len);
+    // ---- launch geometry (launch_plan.h) ------------------------------------------------------------
+    if (!a->plan_dev_known) {
+        a->plan_dev.num_cus = (uint32_t)a->num_cus;
+        a->plan_dev.lds_per_cu = a->lds_per_cu;
+        for (uint32_t m = 0; m < 7; ++m) a->plan_dev.resident[m] = bgr::resident_waves_per_cu(m);
+        a->plan_dev_known = true;
+    }
+    bgr::PlanBatch pb;
+    pb.mode = p->mode; pb.max_mismatch = p->max_mismatch; pb.partial = p->partial; pb.max_read_len = max_read_len;
+    pb.n_reads = n_reads; pb.total_bases = total_bases;
+    const bgr::LaunchPlan P = bgr::plan_launch(plan_graph_of(a->graph->header), a->plan_dev, plan_tuning_of(a), pb);
+    if (P.error) return fail(BGR_E_ARG, P.error);
     const bool exhaustive = p->mode == BGR_MODE_EXHAUSTIVE;
-    // pass 1 of exhaustive mode runs the level-by-level search (exh_dp) or the depth-first one (BGR_KNOB_EXH_SEARCH forces either).
-    // Which one is faster depends on how much the walks branch within the mismatch budget: the depth-first search wins
-    // on a graph with an occasional 2-way bubble (about 1.2x), the level search where a read crosses many multi-way
-    // sites (3.6x at 4 alleles every ~36 bp, m=5).  Estimate: (extra candidates per record) x (m+1) x (unitigs per read).
-    bool level_search = false;
-    uint32_t x4_levels = 16;  // levels (unitigs) per side of a walk the several-reads-per-wave pass keeps in LDS
-    if (exhaustive) {
-        const BgrBlobHeader& gh = a->graph->header;
-        const double mean_ext = std::max(1.0, (double)gh.total_bases / (2.0 * (double)std::max<uint64_t>(1, gh.n_unitigs)) - (double)(gh.k - 1));
-        const double branching = (gh.slot_fill_x100 / 100.0 - 1.0) * (double)(p->max_mismatch + 1) * ((double)max_read_len / mean_ext);
-        level_search = a->knob_search ? a->knob_search == 2 : branching >= 15.0;
-        // short walks (E. coli-scale graph, 150 bp: 2-3 unitigs per side): half the table, twice the waves per CU (1 200 vs 1 440 Mreads/s)
-        if (2.0 * (double)max_read_len / mean_ext <= 8.0) x4_levels = 8;
-    }
-    // level search: a level is one unitig of the walk; 16 levels cover 250 bp reads on a graph that branches every ~36 bp
-    const uint32_t level_cap = fc_set ? kExhFrameCap : std::max<uint32_t>(16, (max_read_len / 64) * 4);
-    const uint32_t per_wave = bgr::lds_bytes_per_wave(level_search ? 2u : lmode, a->dg.k, max_read_len, &words, &path_cap, &frames,
-                                                      level_search ? level_cap : kExhFrameCap);
-    // (every exhaustive launch has its last pass behind it: the depth-first passes with their stack in LDS bound their work per search -- io.search_iters --
-    // and hand on what exceeds it, besides what outgrows their frames; the level search can also overflow on a wide level)
-    bool two_pass = exhaustive;
-    const size_t lds_cu = a->lds_per_cu;
-    const uint32_t mphf_bytes = a->dg.table_bytes;
-    // Resident waves per CU are bounded by registers (bgr::resident_waves_per_cu); LDS decides how they are grouped:
-    // `b` workgroups per CU of `w` waves each, every staged workgroup holding its own copy of the MPHF cascade.
-    // More resident waves hide more of the walk's dependent-load latency (measured 16 -> 24 waves/CU: +18 %), and a
-    // grid of exactly CUs x b workgroups avoids a partial last round.
-    const uint32_t cap_default = std::max<uint32_t>(4, bgr::resident_waves_per_cu(level_search ? 3u : p->mode));  // 3: the level-search kernel
-    const uint64_t lds_fit = lds_cu - 64;  // keep a little slack for alignment
-    // (stage_pct: the staged grouping is taken when it keeps at least this share of the resident waves of the best grouping without staging)
-    auto geometry = [&](uint32_t pw, uint64_t n_items, bool allow_tuning, bool allow_stage, bgr::LaunchCfg& cfg, uint32_t cap_override = 0, uint32_t stage_pct = 100) -> bool {
-        const uint32_t cap = cap_override ? cap_override : cap_default;
-        uint32_t waves = 0, bpc = 0;
-        bool stage = false;
-        auto fits = [&](uint32_t b, uint32_t w, bool st) {
-            return (uint64_t)b * (kLdsFixed + (st ? ((mphf_bytes + 15) / 16) * 16 : 0) + (uint64_t)w * pw) <= lds_fit;
-        };
-        if (allow_tuning && (a->cfg_waves || a->cfg_blocks_per_cu)) {  // explicit tuning through bgr_aligner_configure
-            stage = allow_stage && p->mode != BGR_MODE_ANCHORS && (a->cfg_lds_mphf == 2 || (a->cfg_lds_mphf == 0 && fits(1, 1, true)));
-            waves = a->cfg_waves ? a->cfg_waves : (stage ? 12 : 4);
-            bpc = a->cfg_blocks_per_cu ? a->cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
-            while (bpc > 1 && !fits(bpc, waves, stage)) --bpc;
-            while (waves > 1 && !fits(bpc, waves, stage)) --waves;
-            if (!fits(bpc, waves, stage) && stage) stage = false;  // (also when staging was asked for: a table beyond the LDS is probed in L2)
-        } else {
-            uint32_t best_res = 0;
-            if (allow_stage && a->cfg_lds_mphf != 1 && p->mode != BGR_MODE_ANCHORS && a->graph->header.n_buckets * 4 < 0xFFFFFFFFull) {
-                const uint32_t bs[] = {1, 2, 3, 4, 6};
-                for (uint32_t b : bs) {
-                    uint32_t w = std::min<uint32_t>(16, cap / b);
-                    while (w > 0 && !fits(b, w, true)) --w;
-                    if (w > 4) w -= w % 4;  // whole waves per SIMD: 5-, 7-wave workgroups measured up to 40 % slower
-                    if (w && b * w > best_res) { best_res = b * w; waves = w; bpc = b; stage = true; }
-                }
-            }
-            // without staging: as many small workgroups as the registers admit; when the per-wave LDS region is large
-            // (long reads, exhaustive frame stacks) fewer, larger workgroups keep more waves resident
-            uint32_t wn = 0, bn = 0, res_n = 0;
-            // (4-wave workgroups first: a workgroup whose wave count is not a multiple of the 4 SIMDs measured far slower)
-            const uint32_t bs2[] = {6, 5, 4, 3, 2, 1};
-            uint32_t w4 = 0, b4 = 0;  // the best grouping made of 4-wave workgroups
-            for (uint32_t b : bs2) {
-                uint32_t w = std::min<uint32_t>(b >= 5 ? 4 : 16, std::max<uint32_t>(1, cap / b));
-                while (w > 0 && !fits(b, w, false)) --w;
-                if (w > 4) w -= w % 4;
-                if (w && b * w > res_n) { res_n = b * w; wn = w; bn = b; }
-                const uint32_t wq = std::min<uint32_t>(w, 4);
-                if (wq && b * wq > b4 * w4) { w4 = wq; b4 = b; }
-            }
-            // one wave per SIMD and workgroup schedules best (8-wave workgroups measured 87 vs 123 Mreads/s at 24 vs 20
-            // resident waves): take that grouping unless it gives up more than a fifth of the resident waves
-            if (w4 == 4 && b4 * w4 * 5 >= res_n * 4) { res_n = b4 * w4; wn = w4; bn = b4; }
-            // (lds_mphf = 2 asks for staging: where there is nothing to stage -- anchors mode probes its own index -- or the table does not fit a CU's
-            // LDS next to one wave, the launch runs without; launch_info says which it was)
-            if (!allow_stage || a->cfg_lds_mphf == 1 || best_res == 0 || (a->cfg_lds_mphf == 0 && res_n * stage_pct > best_res * 100)) { stage = false; waves = wn; bpc = bn; best_res = res_n; }
-            if (best_res == 0) waves = 0;
-        }
-        if (waves == 0 || !fits(bpc ? bpc : 1, waves, stage)) return false;
-        cfg.lds_bytes = kLdsFixed + (stage ? ((mphf_bytes + 15) / 16) * 16 : 0) + waves * pw;
-        cfg.blocks = (uint32_t)std::min<uint64_t>((n_items + waves - 1) / waves, (uint64_t)a->num_cus * bpc);
-        cfg.waves_per_block = waves;
-        cfg.stage_mphf = stage ? 1 : 0;
-        return true;
-    };
-    bgr::LaunchCfg cfg, cfg_deep, cfg_mid;
-    bool deep_only = false;  // pass 1 does not fit LDS: every read goes through the deep kernel
-    // level search: what it cannot hold (a level wider than 4 nodes, too many levels) goes to the depth-first kernel with
-    // its LDS stack first, and only what overflows that one to the HBM-stack pass
-    uint32_t frames_mid = 0;
-    const uint32_t per_wave_mid = bgr::lds_bytes_per_wave(1u, a->dg.k, max_read_len, nullptr, nullptr, &frames_mid, kExhFrameCap);
-    bool mid_pass = false;
-    if (!geometry(per_wave, n_reads, true, true, cfg)) {
-        if (!exhaustive) return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~30 kb)");
-        deep_only = two_pass = true;
-    }
-    if (two_pass) {
-        if (!geometry(per_wave_deep, n_reads, false, false, cfg_deep))  // the HBM-stack kernel never stages the cascade
-            return fail(BGR_E_ARG, "bgr_align_device: read too long for the per-wave LDS staging (limit ~160 kb)");
-        // the HBM search state is sized for the worst case per wave: bound the grid by a 2 GiB scratch budget
-        const uint64_t wave_bytes = deep_stride * 4;
-        const uint64_t max_waves = std::max<uint64_t>(1, (2ull << 30) / wave_bytes);
-        if ((uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block > max_waves) {
-            cfg_deep.waves_per_block = (uint32_t)std::min<uint64_t>(cfg_deep.waves_per_block, max_waves);
-            cfg_deep.blocks = (uint32_t)std::max<uint64_t>(1, max_waves / cfg_deep.waves_per_block);
-            cfg_deep.lds_bytes = kLdsFixed + cfg_deep.waves_per_block * per_wave_deep;
-        }
-        if (deep_stride > 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: read too long");
-        HIP_TRY(a->deep.ensure((uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * wave_bytes));
-        if (deep_only) cfg = cfg_deep;
-        mid_pass = level_search && !deep_only && frames_mid < frames_deep && geometry(per_wave_mid, n_reads, false, true, cfg_mid);
-    }
-    // Greedy mode, first pass: sixteen reads per wave (bgr_align_greedy_multi_kernel, the reference's retry ladder inside the launch)
-    // when a read fits one lane per word and the graph has no exception planes; what it does not take (N reads, very long paths)
-    // is listed and mapped by the general kernel (cfg) right behind.
-    bgr::LaunchCfg cfg_fast;
-    const uint32_t wfast = std::min<uint32_t>(words, 16);  // the many-reads-per-wave kernels take reads of < 16 words; longer ones of a mixed batch are listed
-    bool fast_pass = p->mode == BGR_MODE_GREEDY && !a->knob_greedy_fast && !a->graph->header.has_exc &&
-                           geometry(bgr::kG4ReadsPerWave * 8 * wfast, (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave, true, true, cfg_fast, std::max<uint32_t>(4, bgr::resident_waves_per_cu(4)),
-                                    50);  // sixteen reads per wave, E. coli-scale table (72 KB): 2 x 12 waves with the table in LDS 1 877 Mreads/s, 1 x 16: 1 543, 32 waves probing it in L2: 1 381
-    // Exhaustive mode, first pass: eight reads per wave (bgr_align_exhaustive4_kernel) for the shape nearly every read has (one
-    // node per level of the walk); what it does not settle is listed and goes through the passes above from scratch.
-    bgr::LaunchCfg cfg_x4;
-    const bool x4_pass = exhaustive && !deep_only && !a->knob_exh_fast && !p->partial && !a->graph->header.has_exc && p->max_mismatch <= bgr::kX4MaxMismatch &&
-                         a->graph->header.max_unitig_len <= bgr::kX4MaxUnitigLen &&
-                         geometry(bgr::kX4ReadsPerWave * 8 * (wfast + bgr::x4_group_words(x4_levels)), (n_reads + bgr::kX4ReadsPerWave - 1) / bgr::kX4ReadsPerWave, true, true, cfg_x4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(5)),
-                                  50);  // (E. coli-scale table, 150 bp: one staged workgroup of 16 waves 1 496 Mreads/s, 28 waves probing the table in L2 1 395)
-    // Anchors mode, first pass: four reads per wave (bgr_align_anchors4_kernel); reads with an N and very long paths are listed
-    // for the one-read-per-wave kernel.
-    bgr::LaunchCfg cfg_a4;
-    // lanes per read: a lookup spreads BooPHF's active levels over the lanes of the read's group (8 when they fit, else 16)
-    const uint32_t a4_lanes = a->graph->header.anc_active_levels <= 8 ? 8u : 16u, a4_rpw = 64 / a4_lanes;
-    const bool a4_pass = p->mode == BGR_MODE_ANCHORS && !a->knob_anc_fast && !a->graph->header.has_exc && a->graph->header.anc_active_levels <= 16 &&
-                         geometry(a4_rpw * 16 * wfast, (n_reads + a4_rpw - 1) / a4_rpw, true, false, cfg_a4, std::max<uint32_t>(4, bgr::resident_waves_per_cu(6)));
-    const uint32_t waves = cfg.waves_per_block;
-    // Path arena: every path int consumes at least one read base (+8 per read for offsets / short reads), plus
-    // the unused tail of the per-wave chunks the kernel reserves with one atomic each.
-    // A chunk is at least twice the longest possible path, so an abandoned chunk is more than half used.
-    const uint32_t arena_chunk = std::max<uint32_t>(256, 2 * path_cap);
-    // the several-reads-per-wave greedy kernel writes a read's path ints where they are found, into the read's own row of kG4PathInts ints
-    // at the start of the arena (no per-wave chunks, no copy at the end of a walk); the cursor-served chunks of the other kernels follow
-    const uint64_t fast_rows = fast_pass ? n_reads * bgr::kG4PathInts : 0;
-    const uint64_t arena_cap = 2 * (total_bases + 8 * n_reads) + (uint64_t)cfg.blocks * waves * arena_chunk +
-                               (two_pass && !deep_only ? (uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * arena_chunk : 0) +
-                               (mid_pass ? (uint64_t)cfg_mid.blocks * cfg_mid.waves_per_block * arena_chunk : 0) +
-                               fast_rows +
-                               (x4_pass ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk : 0) +
-                               (a4_pass ? n_reads * bgr::kA4PathInts : 0);  // (per-read rows, as for the greedy kernel)
-    if (arena_cap >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large (2*(bases + 16*reads) must stay below 2^32); split it");
-    HIP_TRY(a->arena.ensure(arena_cap * 4));
+    const bgr::LaunchCfg &cfg = P.cfg, &cfg_deep = P.cfg_deep, &cfg_mid = P.cfg_mid, &cfg_fast = P.cfg_fast, &cfg_x4 = P.cfg_x4, &cfg_a4 = P.cfg_a4;
+    const bool level_search = P.level_search, two_pass = P.two_pass, deep_only = P.deep_only, mid_pass = P.mid_pass, fast_pass = P.fast_pass, x4_pass = P.x4_pass, a4_pass = P.a4_pass;
+    const uint32_t waves = cfg.waves_per_block, wfast = P.wfast;
+    if (two_pass) HIP_TRY(a->deepbuf.ensure((uint64_t)cfg_deep.blocks * cfg_deep.waves_per_block * P.deep_stride * 4));
+    HIP_TRY(a->arena.ensure(P.arena_cap * 4));
     a->last_launch[0] = cfg.blocks; a->last_launch[1] = waves * 64; a->last_launch[2] = cfg.lds_bytes; a->last_launch[3] = cfg.stage_mphf | (level_search && !deep_only ? 2u : 0u) | (fast_pass ? 4u : 0u);
     if (a4_pass) { a->last_launch[0] = cfg_a4.blocks; a->last_launch[1] = cfg_a4.waves_per_block * 64; a->last_launch[2] = cfg_a4.lds_bytes; a->last_launch[3] = 4u; }
     if (x4_pass) { a->last_launch[0] = cfg_x4.blocks; a->last_launch[1] = cfg_x4.waves_per_block * 64; a->last_launch[2] = cfg_x4.lds_bytes; a->last_launch[3] = cfg_x4.stage_mphf | (level_search ? 2u : 0u) | 4u; }
     if (fast_pass) { a->last_launch[0] = cfg_fast.blocks; a->last_launch[1] = cfg_fast.waves_per_block * 64; a->last_launch[2] = cfg_fast.lds_bytes; a->last_launch[3] = cfg_fast.stage_mphf | 4u; }
 
     // the reads as 2-bit planes (streaming pre-pass over the ASCII bytes; the mapping kernels only see the planes)
-    const uint64_t plane_words = (total_bases >> 5) + n_reads + 4;
-    if (plane_words >= 0xFFFFFFFFull) return fail(BGR_E_ARG, "bgr_align_device: batch too large; split it");
-    HIP_TRY(a->pk_fw3.ensure(plane_words * 8));
-    HIP_TRY(a->pk_nm.ensure(plane_words * 8));
+    HIP_TRY(a->pk_fw3.ensure(P.plane_words * 8));
+    HIP_TRY(a->pk_nm.ensure(P.plane_words * 8));
     HIP_TRY(a->pk_hasn.ensure((n_reads + 31) / 32 * 4 + 4));
     bgr::BatchIO io;
     io.fw3 = static_cast<const uint64_t*>(a->pk_fw3.p);
@@ -706,26 +589,18 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.hasn = static_cast<const uint32_t*>(a->pk_hasn.p);
     io.read_offs = static_cast<const uint64_t*>(d_read_offsets);
     io.n_reads = (uint32_t)n_reads;
-    io.words_per_read = words;
-    io.path_cap = path_cap;
-    io.arena_cap = (uint32_t)arena_cap;
-    io.arena_chunk = arena_chunk;
-    io.frames_per_wave = frames;
+    io.words_per_read = P.words;
+    io.path_cap = P.path_cap;
+    io.arena_cap = (uint32_t)P.arena_cap;
+    io.arena_chunk = P.arena_chunk;
+    io.frames_per_wave = P.frames;
     io.ovf_list = nullptr;
     io.subset = nullptr;
     io.deep_scratch = nullptr;
-    io.deep_stride = (uint32_t)deep_stride;
+    io.deep_stride = (uint32_t)P.deep_stride;
     io.level_search = level_search ? 1u : 0u;
-    // a depth-first search in LDS takes ~2 iterations per read base on a branching graph (500 for 250 bp, 4 alleles every 36 bp, m = 5); beyond 64 x that
-    // its read goes to the last pass (level search over HBM tables first) -- never reached on a graph of unique k-mers
-    io.search_iters = (exhaustive && two_pass && !deep_only) ? 128u * (max_read_len + 64u) : 0u;
-    io.deep_levels = frames_deep;
-    io.deep_iters = 1u << 26;
-    // (test hooks, tests/test_gpu_parity.py: the error path of the last pass needs a unitig set that is hard to build and minutes of device time otherwise)
-    if (exhaustive) {
-        if (const char* e = getenv("BGREAT_TEST_DEEP_ITERS")) io.deep_iters = (uint32_t)std::max(1, atoi(e));
-        if (getenv("BGREAT_TEST_DEEP_NO_LEVELS")) io.deep_levels = 0;
-    }
+    io.search_iters = P.search_iters;
+    io.deep_memo_cap = P.memo_cap;
     io.greedy_multi = 0;
     io.queue = nullptr;
     io.q_cap = 0;
@@ -737,25 +612,25 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.ovf_ctr = 2;
     io.wave_times = nullptr;
     io.task_ctr = 10;  // (cursor[0..15] are zeroed in front of every launch; 10 is used by nothing else)
-    // the sixteen-reads-per-wave greedy kernel keeps a ring of follow-up items per wave: at most one entry per read of the wave's share
-    uint32_t q_cap = 0;
     if (fast_pass) {
         const uint64_t grid_waves = (uint64_t)cfg_fast.blocks * cfg_fast.waves_per_block;
-        const uint64_t octets = (n_reads + bgr::kG4ReadsPerWave - 1) / bgr::kG4ReadsPerWave;
-        (void)octets;
-        q_cap = 2 * bgr::kG4ReadsPerWave;  // (a wave drains its ring whenever it holds a full group: greedy_kernels.hip)
-        HIP_TRY(a->ovf.ensure(grid_waves * q_cap * 8));
+        HIP_TRY(a->ovf.ensure(grid_waves * P.q_cap * 8));
         HIP_TRY(a->ovf2.ensure(n_reads * 4));
     }
-    if (two_pass && !deep_only) {
-        HIP_TRY(a->ovf.ensure(n_reads * 4));
-        io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
-        if (mid_pass) HIP_TRY(a->ovf2.ensure(n_reads * 4));
+    if (two_pass) {
+        HIP_TRY(a->retry.ensure(n_reads * 4));  // what the last pass hands back for another run (a table that filled up)
+        if (!deep_only) {
+            HIP_TRY(a->ovf.ensure(n_reads * 4));
+            io.ovf_list = static_cast<uint32_t*>(a->ovf.p);
+            if (mid_pass) HIP_TRY(a->ovf2.ensure(n_reads * 4));
+        }
     }
     if (deep_only) {
         io.level_search = 0;
-        io.frames_per_wave = frames_deep;
-        io.deep_scratch = static_cast<uint32_t*>(a->deep.p);
+        io.frames_per_wave = P.frames_deep;
+        io.deep_scratch = static_cast<uint32_t*>(a->deepbuf.p);
+        io.ovf_list = static_cast<uint32_t*>(a->retry.p);
+        io.ovf_ctr = kRetryCtr;
     }
     io.results = static_cast<uint2*>(a->results.p);
     io.arena = static_cast<int32_t*>(a->arena.p);
@@ -765,14 +640,14 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // 1 020 -> 1 184 Mreads/s, L2 requests per read 135 -> 28).  The exhaustive scan meets its first hit within a few positions; with
     // fingerprints behind it the filter cost it more than it saved (4-allele graph: 697 without, 664 with), with the bucket's keys compared
     // directly behind it, it pays there too (4-allele graph 702 -> 720, chr1-scale graph 1 111 -> 1 231): on by default for the minimizer
-    // kind (BGREAT_EXH_FILTER=0: without); the one-hash kind of short k stays off in exhaustive mode
+    // kind (BGR_KNOB_EXH_FILTER 0: without); the one-hash kind of short k stays off in exhaustive mode
     BgrDeviceGraph dgl = a->dg;
     if (p->mode == BGR_MODE_EXHAUSTIVE && !(dgl.filter_kind == BGR_FILTER_MINIMIZER && a->exh_filter)) dgl.bloom = nullptr;
 
     HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters
     {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: the cursor starts behind
-        const uint64_t own = fast_pass ? fast_rows
-                           : x4_pass   ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * arena_chunk
+        const uint64_t own = fast_pass ? P.fast_rows
+                           : x4_pass   ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * P.arena_chunk
                            : a4_pass   ? n_reads * bgr::kA4PathInts : 0;
         if (own) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->small.p), (int)own, 1, a->stream));
     }
@@ -801,7 +676,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         iof.greedy_multi = 1;
         iof.words_per_read = wfast;
         iof.queue = static_cast<uint2*>(a->ovf.p);
-        iof.q_cap = q_cap;
+        iof.q_cap = P.q_cap;
         iof.gen_list = static_cast<uint32_t*>(a->ovf2.p);
         iof.gen_ctr = 8;
 #ifdef BGR_PHASE_TIMING
@@ -818,7 +693,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (a4_pass) {
         HIP_TRY(a->lst.ensure(n_reads * 4));
         bgr::BatchIO ioa = io;
-        ioa.anc4 = a4_lanes;
+        ioa.anc4 = P.a4_lanes;
         ioa.words_per_read = wfast;
         ioa.subset = nullptr;
         ioa.ovf_list = static_cast<uint32_t*>(a->lst.p);
@@ -832,7 +707,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (x4_pass) {
         HIP_TRY(a->lst.ensure(n_reads * 4));
         bgr::BatchIO iox = io;
-        iox.exh4 = x4_levels;
+        iox.exh4 = P.x4_levels;
         iox.words_per_read = wfast;
         iox.level_search = 0;
         iox.subset = nullptr;
@@ -853,14 +728,15 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(mark(p->mode == BGR_MODE_GREEDY ? (fast_pass ? "bgr_align_greedy_kernel (listed reads)" : "bgr_align_greedy_kernel")
                  : p->mode == BGR_MODE_ANCHORS ? (a4_pass ? "bgr_align_anchors_kernel (listed reads)" : "bgr_align_anchors_kernel")
-                 : deep_only ? "bgr_align_exhaustive_kernel (HBM stack)" : level_search ? "bgr_align_exhaustive_dp_kernel" : "bgr_align_exhaustive_kernel"));
+                 : deep_only ? "bgr_align_exhaustive_kernel (HBM state, remembered calls)" : level_search ? "bgr_align_exhaustive_dp_kernel" : "bgr_align_exhaustive_kernel"));
+    bgr::BatchIO io2 = io;  // the last pass as enqueued (deep_only: the launch above)
     if (two_pass && !deep_only) {  // always enqueued: with an empty list its waves exit at once (no host round trip in between)
         const uint32_t* pending = io.ovf_list;
         uint32_t pending_ctr = 2;
         if (mid_pass) {  // depth-first search, LDS stack, over what the level search listed; its own overflow goes to list 2
             bgr::BatchIO iom = io;
             iom.level_search = 0;
-            iom.frames_per_wave = frames_mid;
+            iom.frames_per_wave = P.frames_mid;
             iom.subset = io.ovf_list;
             iom.subset_ctr = 2;
             iom.ovf_list = static_cast<uint32_t*>(a->ovf2.p);
@@ -871,20 +747,88 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
             pending = iom.ovf_list;
             pending_ctr = 3;
         }
-        bgr::BatchIO io2 = io;
-        io2.frames_per_wave = frames_deep;
+        io2.frames_per_wave = P.frames_deep;
         io2.subset = pending;
         io2.subset_ctr = pending_ctr;
-        io2.ovf_list = nullptr;
-        io2.deep_scratch = static_cast<uint32_t*>(a->deep.p);
+        io2.ovf_list = static_cast<uint32_t*>(a->retry.p);
+        io2.ovf_ctr = kRetryCtr;
+        io2.deep_scratch = static_cast<uint32_t*>(a->deepbuf.p);
         io2.level_search = 0;
         e = bgr::launch_align(dgl, io2, kp, cfg_deep, a->stream);
-        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (deep pass): ") + hipGetErrorString(e));
-        HIP_TRY(mark("bgr_align_exhaustive_kernel (HBM stack, listed reads)"));
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (last pass): ") + hipGetErrorString(e));
+        HIP_TRY(mark("bgr_align_exhaustive_kernel (HBM state, remembered calls; listed reads)"));
+    }
+    if (two_pass) {  // what settle_launch needs to run the last pass again for the reads it handed back
+        a->deep.open = true;
+        a->deep.io = io2; a->deep.kp = kp; a->deep.dg = dgl; a->deep.cfg = cfg_deep;
+        a->deep.per_wave_lds = bgr::deep_lds_bytes_per_wave(max_read_len);
+        a->deep.path_cap = P.path_cap; a->deep.frames = P.frames_deep; a->deep.memo_cap = P.memo_cap;
+        a->deep.runs = 1;
     }
     a->ev_marks[a->ev_used] = marks;
     ++a->ev_used;
     return BGR_OK;
+}
+
+// Behind a mapping launch, with its stream waited for and cursor[0 .. 15] on the host (`cur`): the arena must not have overflowed, and in
+// exhaustive mode the last pass may have handed reads back whose table of remembered calls filled up (exh_memo, exhaustive_kernels.hip):
+// those run again -- the last pass only, over that list -- with a table sixteen times as large and as few waves as the list has reads, until
+// none is left.  A search visits at most positions x halves x 2 nodes, so this ends; what can end it early is the device's memory.
+static int settle_launch(bgr_aligner* a, uint32_t* cur) {
+    if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+    if (!a->deep.open) return BGR_OK;
+    while (cur[kRetryCtr]) {
+        const uint32_t n_retry = cur[kRetryCtr];
+        auto& D = a->deep;
+        if (D.runs >= bgr::kDeepRuns || D.memo_cap >= (1u << 28))
+            return fail(BGR_E_NOMEM, "exhaustive search: a read's table of remembered calls outgrew 2^28 entries per wave (8 GiB)");
+        D.memo_cap *= 16;
+        const uint64_t stride = bgr::deep_scratch_words(D.path_cap, D.frames, D.memo_cap);
+        if (stride > 0xFFFFFFFFull) return fail(BGR_E_NOMEM, "exhaustive search: a read's table of remembered calls outgrew the 16 GiB a wave can address");
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t room = (uint64_t)free_b + a->deepbuf.cap;
+        uint64_t waves = std::min<uint64_t>(n_retry, (uint64_t)D.cfg.blocks * D.cfg.waves_per_block);
+        waves = std::min<uint64_t>(waves, std::max<uint64_t>(1, room / 2 / (stride * 4)));
+        if (stride * 4 > room - room / 8) return fail(BGR_E_NOMEM, "exhaustive search: not enough device memory for a read's table of remembered calls");
+        HIP_TRY(a->deepbuf.ensure(waves * stride * 4));
+        // the list handed back becomes the list to map; the kernel appends to the other one
+        DevBuf& other = a->retry2;
+        HIP_TRY(other.ensure((uint64_t)n_retry * 4));
+        bgr::BatchIO io = D.io;
+        io.subset = io.ovf_list;
+        io.subset_ctr = kRetrySubsetCtr;
+        io.ovf_list = static_cast<uint32_t*>(other.p);
+        io.ovf_ctr = kRetryCtr;
+        io.deep_scratch = static_cast<uint32_t*>(a->deepbuf.p);
+        io.deep_stride = (uint32_t)stride;
+        io.deep_memo_cap = D.memo_cap;
+        uint32_t ctr[2] = {0, n_retry};  // cursor[kRetryCtr] = 0, cursor[kRetrySubsetCtr] = n
+        static_assert(kRetrySubsetCtr == kRetryCtr + 1, "the two counters are written with one copy");
+        HIP_TRY(hipMemcpyAsync(static_cast<uint32_t*>(a->small.p) + kRetryCtr, ctr, 8, hipMemcpyHostToDevice, a->stream));
+        bgr::LaunchCfg cfg = D.cfg;
+        cfg.waves_per_block = (uint32_t)std::min<uint64_t>(cfg.waves_per_block, waves);
+        cfg.blocks = (uint32_t)std::max<uint64_t>(1, waves / cfg.waves_per_block);
+        cfg.lds_bytes = bgr::kLdsFixed + cfg.waves_per_block * D.per_wave_lds;
+        hipError_t e = bgr::launch_align(D.dg, io, D.kp, cfg, a->stream);
+        if (e != hipSuccess) return fail(BGR_E_HIP, std::string("kernel launch (last pass, run again): ") + hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(cur, a->small.p, 64, hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(wait_stream(a));
+        if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+        std::swap(a->retry, a->retry2);  // (D.io.ovf_list names the list the next round maps)
+        D.io.ovf_list = io.ovf_list;
+        ++D.runs;
+    }
+    a->deep.open = false;
+    return BGR_OK;
+}
+// ... for callers that have not looked at the cursor yet (exhaustive launches only: nothing to settle otherwise but the arena flag, which every fetch checks)
+static int settle_launch_sync(bgr_aligner* a) {
+    if (!a->deep.open) return BGR_OK;
+    uint32_t cur[16];
+    HIP_TRY(hipMemcpyAsync(cur, a->small.p, sizeof(cur), hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(wait_stream(a));
+    return settle_launch(a, cur);
 }
 
 int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
@@ -1140,6 +1084,10 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text pack launch: ") + hipGetErrorString(e));
     int rc = align_device_impl(a, p, nullptr, a->tx_offs.p, n_acc, bases, max_len, true);
     if (rc != BGR_OK) return rc;
+    if (a->deep.open) {  // exhaustive mode: what is enqueued below reads the FINAL results (reads the last pass handed back are mapped first)
+        rc = settle_launch_sync(a);
+        if (rc != BGR_OK) return rc;
+    }
     a->last_n = 0;  // (bgr_aligner_fetch has no host read_offsets to pair its rows with: the text form hands out text)
     a->tx_n_acc = n_acc;
     if (b->record_info_out) {  // what became of every record (the -b progress blocks of the caller), on its way to the host behind the mapping launch
@@ -1149,7 +1097,12 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("record info launch: ") + hipGetErrorString(e));
         HIP_TRY(hipMemcpyAsync(b->record_info_out, a->tx_info.p, (size_t)R * 4, hipMemcpyDeviceToHost, a->stream));
     }
-    if (!b->want_output) { HIP_TRY(wait_stream(a)); return BGR_OK; }
+    if (!b->want_output) {  // counters only: the launch still has to be settled (arena flag; exhaustive mode: reads the last pass handed back)
+        uint32_t cur[16];
+        HIP_TRY(hipMemcpyAsync(cur, a->small.p, sizeof(cur), hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(wait_stream(a));
+        return settle_launch(a, cur);
+    }
     // 4. sizes of the records, stream offsets, the bytes
     if (b->want_output == 2) {  // (tx_idx is free again behind the compaction: it takes the corrected reads' lengths)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(info + TXT_INFO_BUG), -1, 1, a->stream));
@@ -1162,12 +1115,12 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_poff.p), n_acc, sums2, info + TXT_INFO_PBYTES, a->stream);
     if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_noff.p), n_acc, sums2, info + TXT_INFO_NBYTES, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text size launches: ") + hipGetErrorString(e));
-    uint32_t h2[TXT_INFO_WORDS + 2];
+    uint32_t h2[16];
     HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
-    HIP_TRY(hipMemcpyAsync(h2, a->small.p, 8, hipMemcpyDeviceToHost, a->stream));  // cursor[1]: arena overflow flag
+    HIP_TRY(hipMemcpyAsync(h2, a->small.p, sizeof(h2), hipMemcpyDeviceToHost, a->stream));  // cursor[1]: arena overflow flag
     HIP_TRY(wait_stream(a));
     lap(2);
-    if (h2[1]) return fail(BGR_E_INTERNAL, h2[1] == 2 ? kSearchGaveUp : "path arena overflow (internal sizing error)");
+    if (h2[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
     if (b->want_output == 2 && h[TXT_INFO_BUG] != 0xFFFFFFFFu) {  // a path that does not spell a walk: the reference prints "bug compaction" and exits
         b->irregular = 2;                                          // (aligner.cpp:280-283); the caller reproduces that on the host
         a->tx_n_acc = 0;
@@ -1185,7 +1138,7 @@ int bgr_aligner_sync(bgr_aligner* a) {
     if (!a) return fail(BGR_E_ARG, "bgr_aligner_sync: null aligner");
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
-    return BGR_OK;
+    return settle_launch_sync(a);  // (exhaustive mode: reads the last pass handed back are mapped before the results count as final)
 }
 
 int bgr_aligner_device_results(bgr_aligner* a, void** d_results, void** d_arena, void** d_cursor) {
@@ -1200,7 +1153,8 @@ int bgr_aligner_device_results(bgr_aligner* a, void** d_results, void** d_arena,
 // their copies into the caller's memory (fetch_copy: relative path_offsets[0..n], status[0..n), total ints at paths_out)
 static int fetch_total(bgr_aligner* a, uint64_t n, uint64_t* total_out) {
     HIP_TRY(hipSetDevice(a->device));
-    HIP_TRY(wait_stream(a));
+    if (a->deep.open) { const int src = settle_launch_sync(a); if (src != BGR_OK) return src; }
+    else HIP_TRY(wait_stream(a));
     const uint64_t nb = (n + 4095) / 4096;
     HIP_TRY(a->csr_sums.ensure(nb * 4 + 64));
     HIP_TRY(a->csr_poffs.ensure((n + 1) * 8));
@@ -1213,7 +1167,7 @@ static int fetch_total(bgr_aligner* a, uint64_t n, uint64_t* total_out) {
     HIP_TRY(hipMemcpyAsync(hs, a->small.p, sizeof(hs), hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(wait_stream(a));
     const uint32_t* cur = reinterpret_cast<const uint32_t*>(hs);
-    if (cur[1]) return fail(BGR_E_INTERNAL, cur[1] == 2 ? kSearchGaveUp : "path arena overflow (internal sizing error)");
+    if (cur[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
     *total_out = hs[16];
     return BGR_OK;
 }
@@ -1534,6 +1488,13 @@ int bgr_debug_wave_times(bgr_aligner* a, uint64_t* out, uint64_t cap_waves, uint
     return BGR_OK;
 }
 #endif
+
+int bgr_aligner_last_pass_runs(const bgr_aligner* a, uint32_t* runs, uint32_t* memo_cap) {
+    if (!a) return fail(BGR_E_ARG, "bgr_aligner_last_pass_runs: null aligner");
+    if (runs) *runs = a->deep.runs;
+    if (memo_cap) *memo_cap = a->deep.memo_cap;
+    return BGR_OK;
+}
 
 int bgr_aligner_pass_counts(bgr_aligner* a, uint32_t out[4]) {
     if (!a || !out) return fail(BGR_E_ARG, "bgr_aligner_pass_counts: null argument");

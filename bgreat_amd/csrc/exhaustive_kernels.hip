@@ -1,7 +1,8 @@
 // exhaustive_kernels.hip -- exhaustive mode (-b: alignReadExhaustive, alignerExhaustive.cpp:35-259) on gfx950.
 //   bgr_align_exhaustive4_kernel    eight reads per wavefront (8 lanes per read), one node per level of the walk (x4_search)
 //   bgr_align_exhaustive_dp_kernel  the level search (exh_dp): all nodes of a level at once, backward cost pass
-//   bgr_align_exhaustive_kernel     depth-first search in slot order (exh_search); DEEP: search state in HBM
+//   bgr_align_exhaustive_kernel     depth-first search in slot order (exh_search); DEEP (the last pass): the same recursion memoised on the
+//                                   node (exh_memo), search state in HBM -- polynomial whatever the unitig set looks like
 #include "device_common.h"
 #ifndef BGR_EXH_MMX
 #define BGR_EXH_MMX 1
@@ -336,13 +337,198 @@ __device__ __forceinline__ uint32_t exh_dp(const BgrDeviceGraph& g, const u64* C
     return s;
 }
 
+// ---- the same search, memoised on the node (the last pass) ----------------------------------------------------
+// The reference's recursion (alignerExhaustive.cpp:61-259) re-explores a node -- (overlap k-mer, read position) = (half, strand, position) here --
+// once per way of getting there.  On a compacted de Bruijn graph that is harmless; on a unitig set that duplicates its own k-mers (a homopolymer
+// on both strands, copied unitigs) the ways multiply and the recursion is exponential (150 s for one 79-base read in the compiled reference).
+// What a call returns depends on the node and its budget only:
+//   f(node) = min over the candidates c in slot order, first minimum kept (strict `<`), of miss_c [+ f(child_c) when the walk goes on]
+//   call(node, b) = f(node) if f(node) <= b, else "none" (b + 1 in the reference) -- a candidate is explored only if miss_c < best so far
+//                   (<= b at first), its child is called with b - miss_c (:85,:134,:185,:243), and which candidate wins does not depend on b.
+// So every call is remembered per read: {node -> exact f} or {node -> "none within bmax"}; a later call with b <= bmax is answered from the table,
+// one with a larger budget computes again (at most budget + 1 times per node).  Nodes <= positions x halves x 2: polynomial.  A position strictly
+// advances with every unitig taken (a unitig has at least k bases), so the recursion never meets a node that is still being computed.
+// The walk is read off afterwards from the winners kept in the table.  Table: open addressing in the wave's HBM scratch, entries of one read
+// carry its generation number; a table that fills up returns EXH_OVERFLOW and the host runs the read again with a larger one (capi.hip).
+// Frame (32 u32, HBM): [0] half  [1] pos  [2] budget of this call  [3] cursor | ncand<<8 | scored<<16 | canon<<17  [4] best total so far
+//                      [5] its slot  [6] table slot  [8+5c..] candidate c: sid, next half, ext, miss, fits | next canon<<1
+// Entry (8 u32): [0] half | canon<<28 | DIR<<29 | 1<<31  [1] pos  [2] generation  [3] 1 = exact  [4] f  [5] bmax  [6] winning slot
+#define MF_WORDS BGR_MEMO_FRAME_WORDS
+#define MM_WORDS BGR_MEMO_ENTRY_WORDS
+#define EXH_NONE 0xFFFFFFFEu
+struct MemoTab {
+    uint32_t* E;
+    uint32_t mask, gen, used, limit;
+};
+__device__ __forceinline__ uint32_t memo_find(const MemoTab& t, uint32_t k0, uint32_t pos, bool* found) {
+    uint32_t h = (k0 * 0x9E3779B1u) ^ (pos * 0x85EBCA6Bu);
+    h = (h ^ (h >> 15)) & t.mask;
+    for (;;) {  // (the table is never full: `limit` < its size)
+        const uint32_t* e = t.E + (size_t)h * MM_WORDS;
+        if (e[2] != t.gen) { *found = false; return h; }
+        if (e[0] == k0 && e[1] == pos) { *found = true; return h; }
+        h = (h + 1) & t.mask;
+    }
+}
+
+template <int DIR>
+__device__ __forceinline__ uint32_t exh_memo(const BgrDeviceGraph& g, const u64* CMP, const u64* NM, bool useN, uint32_t L, uint32_t K1,
+                                             uint32_t a_rec, bool a_canon, uint32_t a_pos, uint32_t budget, bool partial,
+                                             uint32_t* FR, uint32_t max_frames, MemoTab& mt, int32_t* CUR, int32_t* BEST, uint32_t* best_n, int lane) {
+    // returns the best total (budget + 1 if none; EXH_OVERFLOW: the table is full); the best walk's ints are BEST[0..*best_n) in output order
+    *best_n = 0;
+    const uint32_t h0 = half_handle(g, a_rec, a_canon, DIR == 0);
+    const uint32_t kdir = ((uint32_t)DIR << 29) | (1u << 31);
+    int depth = 0;
+    uint32_t ret = EXH_NONE;
+    bool have_ret = false;
+    if (lane == 0) { FR[0] = h0; FR[1] = a_pos; FR[2] = budget; FR[3] = a_canon ? (1u << 17) : 0u; }
+    wave_sync();
+    while (depth >= 0) {
+        uint32_t* F = FR + (size_t)depth * MF_WORDS;
+        const uint32_t hnd = F[0], pos = F[1], b = F[2];
+        uint32_t ctl = F[3];
+        if (!((ctl >> 16) & 1u)) {
+            // ---- first visit: base cases, the table, then score the candidates once -----------------------------
+            const bool end_here = (DIR == 0) ? (pos == 0) : (L - pos - K1 == 0);
+            if (end_here) { ret = 0; have_ret = true; --depth; continue; }  // (:64,:112,:159,:210: nothing left to pay)
+            if (hnd == BGR_HNONE) {  // getBegin / getEnd return an empty list
+                if (DIR == 1 && depth == 0 && partial) return 0;  // alignerExhaustive.cpp:217-221 (-i)
+                ret = EXH_NONE; have_ret = true; --depth;
+                continue;
+            }
+            const bool canon = (ctl >> 17) & 1u;
+            const uint32_t k0 = hnd | (canon ? 1u << 28 : 0u) | kdir;
+            bool found;
+            const uint32_t slot = memo_find(mt, k0, pos, &found);
+            uint32_t* E = mt.E + (size_t)slot * MM_WORDS;
+            if (found) {
+                const uint32_t exact = E[3], val = E[4], bmax = E[5];
+                if (exact) { ret = val <= b ? val : EXH_NONE; have_ret = true; --depth; continue; }
+                if (b <= bmax) { ret = EXH_NONE; have_ret = true; --depth; continue; }
+            } else {
+                if (mt.used >= mt.limit) { wave_sync(); return EXH_OVERFLOW; }
+                ++mt.used;
+                if (lane == 0) { E[0] = k0; E[1] = pos; E[2] = mt.gen; E[3] = 0; E[4] = 0; E[5] = 0; E[6] = 0; }
+            }
+            const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, hnd, canon, pos, lane);
+            const uint32_t ncand = (uint32_t)sc.first_zero;
+            if ((lane & 15) == 0 && (lane >> 4) < sc.first_zero) {
+                uint32_t* C = F + 8 + 5 * (lane >> 4);
+                C[0] = (uint32_t)sc.sid; C[1] = sc.nrec; C[2] = sc.ext; C[3] = sc.cnt; C[4] = sc.info;
+            }
+            if (DIR == 1 && depth == 0 && partial && ncand == 0) { wave_sync(); return 0; }
+            ctl = (ctl & (1u << 17)) | (1u << 16) | (ncand << 8);
+            if (lane == 0) { F[3] = ctl; F[4] = EXH_NONE; F[5] = 0; F[6] = slot; }
+            wave_sync();
+        }
+        uint32_t best = F[4], bslot = F[5];
+        uint32_t cur = ctl & 0xFFu;
+        const uint32_t ncand = (ctl >> 8) & 0xFFu;
+        if (have_ret) {  // the child of candidate cur - 1 has come back
+            have_ret = false;
+            if (ret != EXH_NONE) {
+                const uint32_t total = F[8 + 5 * (cur - 1) + 3] + ret;
+                if (total < best) { best = total; bslot = cur - 1; }
+            }
+        }
+        bool descended = false;
+        while (cur < ncand) {
+            const uint32_t* C = F + 8 + 5 * cur;
+            const uint32_t c = cur++;
+            const uint32_t miss = C[3], info = C[4];
+            if (miss > b || miss >= best) continue;  // the reference explores a candidate only if miss < minMiss (errors + 1 at first)
+            if (info & 1u) { best = miss; bslot = c; continue; }  // the walk ends inside this unitig
+            if ((uint32_t)depth + 1 >= max_frames) { wave_sync(); return EXH_OVERFLOW; }  // (cannot happen: the frames are sized for |read| - (k-1) + 3 levels)
+            const uint32_t ext = C[2], nrec = C[1];
+            wave_sync();
+            if (lane == 0) {
+                F[3] = (ctl & ~0xFFu) | cur; F[4] = best; F[5] = bslot;
+                uint32_t* N = F + MF_WORDS;
+                N[0] = nrec;
+                N[1] = (DIR == 0) ? pos - ext : pos + ext;
+                N[2] = b - miss;
+                N[3] = (info & 2u) ? (1u << 17) : 0u;
+            }
+            wave_sync();
+            ++depth;
+            descended = true;
+            break;
+        }
+        if (descended) continue;
+        // ---- every candidate seen: remember the answer ------------------------------------------------------------
+        const uint32_t slot = F[6];
+        wave_sync();
+        if (lane == 0) {
+            uint32_t* E = mt.E + (size_t)slot * MM_WORDS;
+            if (best <= b) { E[3] = 1; E[4] = best; E[6] = bslot; }
+            else E[5] = b;
+        }
+        wave_sync();
+        ret = best <= b ? best : EXH_NONE;
+        have_ret = true;
+        --depth;
+    }
+    if (ret == EXH_NONE || ret > budget) return budget + 1;
+    // ---- read the walk off: every node on it has its exact entry (its call's budget covered its f) -----------------
+    {
+        uint32_t hnd = h0, pos = a_pos, d = 0;
+        bool canon = a_canon;
+        for (;;) {
+            const bool end_here = (DIR == 0) ? (pos == 0) : (L - pos - K1 == 0);
+            if (end_here) {
+                wave_sync();
+                // left: checkBeginExhaustive pushes 0 only at the top (:159 vs :112); right: every depth pushes 0 (:64,:210)
+                if (DIR == 0) {
+                    for (uint32_t j = lane; j < d; j += 64) BEST[j] = CUR[d - 1 - j];  // far -> near
+                    *best_n = d;
+                    if (d == 0) { if (lane == 0) BEST[0] = 0; *best_n = 1; }
+                } else {
+                    for (uint32_t j = lane; j < d; j += 64) BEST[j] = CUR[j];          // near -> far
+                    if (lane == 0) BEST[d] = 0;
+                    *best_n = d + 1;
+                }
+                break;
+            }
+            bool found;
+            const uint32_t slot = memo_find(mt, hnd | (canon ? 1u << 28 : 0u) | kdir, pos, &found);
+            const uint32_t bs = mt.E[(size_t)slot * MM_WORDS + 6];
+            const Scored sc = score_candidates<DIR>(g, CMP, NM, useN, L, K1, hnd, canon, pos, lane);
+            const int bl = (int)bs * 16;
+            const int32_t sid = (int32_t)rl32((uint32_t)sc.sid, bl);
+            const uint32_t ext = rl32(sc.ext, bl), nrec = rl32(sc.nrec, bl), info = rl32(sc.info, bl);
+            if (info & 1u) {
+                wave_sync();
+                // fitting: left emits the offset in the last unitig (ext-pos, :126,:175), right |readLeft|+k-1 (:99,:231)
+                if (DIR == 0) {  // [offset, this (farthest) unitig, ..., nearest unitig]
+                    for (uint32_t j = lane; j < d; j += 64) BEST[2 + j] = CUR[d - 1 - j];
+                    if (lane == 0) { BEST[0] = (int32_t)(ext - pos); BEST[1] = sid; }
+                } else {         // [nearest ... this (farthest) unitig, end offset]
+                    for (uint32_t j = lane; j < d; j += 64) BEST[j] = CUR[j];
+                    if (lane == 0) { BEST[d] = sid; BEST[d + 1] = (int32_t)(L - pos); }
+                }
+                *best_n = d + 2;
+                break;
+            }
+            if (lane == 0) CUR[d] = sid;
+            ++d;
+            pos = (DIR == 0) ? pos - ext : pos + ext;
+            hnd = nrec;
+            canon = (info & 2u) != 0;
+        }
+        wave_sync();
+    }
+    return ret;
+}
+
 // alignReadExhaustive (alignerExhaustive.cpp:35-58): every read position is an anchor candidate
 // (getListOverlap, aligner.cpp:318-342, keeps them all); per anchor the best left walk with budget m, then
 // the best right walk with what is left; no reverse-complement retry.  Only position 0 and positions whose
 // (k-1)-mer is an overlap of the graph can succeed (anywhere else getEnd() is empty), so the position scan
 // is the same lane-parallel membership test as in the greedy kernel.
-// DEEP (pass 2): the search state (OUT | CUR | BEST | frames) of every wave lives in HBM (io.deep_scratch) instead
-// of LDS, sized for the worst case, so neither the depth of the search nor the read length is bounded by LDS.
+// DEEP (the last pass): the search state (OUT | CUR | BEST | frames | table of remembered calls) of every wave lives in HBM (io.deep_scratch)
+// instead of LDS, frames sized for the worst case, so neither the depth of the search nor the read length is bounded by LDS, and the search is
+// exh_memo: polynomial on any unitig set.  A read whose table fills up is listed (io.ovf_list, count at cursor[io.ovf_ctr]) for a run with a larger one.
 template <bool STAGE, bool DEEP>
 __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) bgr_align_exhaustive_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     extern __shared__ u64 lds[];
@@ -363,6 +549,15 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
     int32_t* CUR = OUT + io.path_cap;
     int32_t* BEST = CUR + io.path_cap;
     uint32_t* FR = reinterpret_cast<uint32_t*>(BEST + io.path_cap);
+    MemoTab mt;
+    mt.E = nullptr; mt.mask = 0; mt.gen = 0; mt.used = 0; mt.limit = 0;
+    if (DEEP) {  // (deep_scratch_words, align_kernels.h)
+        mt.E = FR + (size_t)io.frames_per_wave * MF_WORDS;
+        mt.mask = io.deep_memo_cap - 1;
+        mt.limit = io.deep_memo_cap - (io.deep_memo_cap >> 2);
+        for (uint32_t j = lane; j < io.deep_memo_cap; j += 64) mt.E[(size_t)j * MM_WORDS + 2] = 0;  // no entry carries generation 0
+        wave_sync();
+    }
 
     uint32_t c_reads = 0, c_al = 0, c_na = 0;
     unsigned long long c_ov = 0;
@@ -372,6 +567,8 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
     // pass 2 maps only the reads that pass 1 listed as needing a deeper stack (count left in cursor[subset_ctr] by the pass before)
     const uint32_t total = io.subset ? io.cursor[io.subset_ctr] : io.n_reads;
     for (uint32_t it = blockIdx.x * waves + wave; it < total; it += gridDim.x * waves) {
+        ++mt.gen;      // (what the searches of one read remember holds for all of its anchors: f depends on the node and the read only)
+        mt.used = 0;
         const uint32_t r = io.subset ? io.subset[it] : it;
         const u64 off = io.read_offs[r];
         const uint32_t L = (uint32_t)(io.read_offs[r + 1] - off);
@@ -407,9 +604,8 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
                     if (lane == 0) OUT[0] = 0;
                     nl = 1;
                 } else {
-                    // (last pass: the level search first, its tables where the frames would lie -- polynomial; the recursion only for a level wider than four nodes)
-                    eb = (DEEP && io.deep_levels) ? exh_dp<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.deep_levels, BEST, &nl, lane) : EXH_OVERFLOW;
-                    if (eb == EXH_OVERFLOW) eb = exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane, DEEP ? io.deep_iters : io.search_iters);
+                    eb = DEEP ? exh_memo<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, mt, CUR, BEST, &nl, lane)
+                              : exh_search<0>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m, false, FR, io.frames_per_wave, CUR, BEST, &nl, lane, io.search_iters);
                     if (eb == EXH_OVERFLOW) { overflow = true; break; }
                     if (eb > m) continue;
                     for (uint32_t j = lane; j < nl; j += 64) OUT[j] = BEST[j];
@@ -418,8 +614,8 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
                 // position 0 is tried whatever its (k-1)-mer: when that is no overlap of the graph getBegin() is empty, and only an
                 // empty right side or -i can make the anchor succeed (alignerExhaustive.cpp:206-221): no search either
                 if (a_rec == BGR_NONE && !prm.partial && L - a_pos - K1 != 0) continue;
-                uint32_t ee = (DEEP && io.deep_levels) ? exh_dp<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.deep_levels, BEST, &nr, lane) : EXH_OVERFLOW;
-                if (ee == EXH_OVERFLOW) ee = exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane, DEEP ? io.deep_iters : io.search_iters);
+                const uint32_t ee = DEEP ? exh_memo<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, mt, CUR, BEST, &nr, lane)
+                                         : exh_search<1>(g, FW3, NM, hasN, L, K1, a_rec, a_canon, a_pos, m - eb, prm.partial != 0, FR, io.frames_per_wave, CUR, BEST, &nr, lane, io.search_iters);
                 if (ee == EXH_OVERFLOW) { overflow = true; break; }
                 if (ee > m - eb) continue;
                 for (uint32_t j = lane; j < nr; j += 64) OUT[nl + j] = BEST[j];
@@ -429,16 +625,9 @@ __global__ void __launch_bounds__(1024, DEEP ? BGR_EXH_DEEP_OCC : BGR_EXH_OCC) b
             }
         }
         wave_sync();
-        if (overflow) {  // leave this read to pass 2 (full-depth stack); nothing is written or counted for it here
-            if (!DEEP) {
-                if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
-                continue;
-            }
-            // the last pass: a level wider than four nodes sent the read into the recursion, and that took io.deep_iters iterations (2^26: minutes of one wavefront, about a second of the reference's recursion on a CPU core) without an end --
-            // duplicated k-mers AND wide levels.  The launch reports an error (cursor[1] = 2) instead of running for hours; the read
-            // is written as not aligned so that the rows stay well formed.
-            if (lane == 0) io.cursor[1] = 2;
-            done = false;
+        if (overflow) {  // leave this read to the next pass (the last one: to its next run with a larger table); nothing is written or counted for it here
+            if (lane == 0) io.ovf_list[atomicAdd(io.cursor + io.ovf_ctr, 1u)] = r;
+            continue;
         }
         c_ov += npos;
         uint32_t abase = 0;

@@ -34,6 +34,8 @@ extern "C" {
 #define BGR_E_IO (-3)       /* file could not be opened / read */
 #define BGR_E_CAPACITY (-4) /* caller-provided output buffer too small */
 #define BGR_E_INTERNAL (-5)
+#define BGR_E_NOMEM (-7)    /* device memory exhausted (exhaustive mode on a unitig set that duplicates its own k-mers: the table of remembered
+                               calls of one read's search outgrew what the device can hold -- see BGR_KNOB_EXH_MEMO_CAP) */
 #define BGR_E_COMPACTION (-6) /* correction mode: a path does not spell a walk -- the reference's "bug compaction" exit
                                 (aligner.cpp:280-283); bgr_last_error() = "bug compaction\n<walk> <unitig>", outputs hold the
                                 records before the offending read, as the reference leaves them */
@@ -297,8 +299,14 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
 #define BGR_KNOB_BATCH_OVERLAP 8u /* bgr_align_batch of >= 512 k reads: 0 = in four pieces on two streams, copies under kernels (default), 1 = one launch */
 #define BGR_KNOB_ANCHORS_FAST 7u /* anchors mode: 0 = four-reads-per-wave first pass + the one-read-per-wave kernel for the rest (default), 1 = without it */
 #define BGR_KNOB_EXH_FAST 6u    /* exhaustive mode: 0 = four-reads-per-wave first pass + the level / depth-first passes for the rest (default), 1 = without it */
+#define BGR_KNOB_EXH_MEMO_CAP 9u /* exhaustive mode, last pass (the reference's recursion memoised on (overlap, position): polynomial on any unitig set): entries per wave of
+                                   its table of remembered calls in the FIRST run, 0 = from the read length (>= 1024).  A read whose search fills the table is run again with a table
+                                   16 times as large, until it fits (bgr_aligner_last_pass_runs); tests set 8 to walk that path with small inputs */
 #define BGR_KNOB_GREEDY_FAST 5u /* greedy mode: 0 = sixteen-reads-per-wave pass + general kernel for the rest (default), 1 = general kernel only */
 int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value);
+/* Exhaustive mode: how often the last pass ran for the launch last settled (1 = once, as enqueued; more: reads whose table of remembered calls filled
+ * up were run again) and the table size (entries per wave) of its final run.  0 / 0 when the last launch had no last pass (greedy, anchors mode). */
+int bgr_aligner_last_pass_runs(const bgr_aligner* a, uint32_t* runs, uint32_t* memo_cap);
 
 /* ---- read files (host) ----------------------------------------------------------------------------
  * Replaces Aligner::getReads (aligner.cpp:46-117) for a whole file: the accepted (header, read) records

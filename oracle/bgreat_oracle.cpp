@@ -26,6 +26,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -722,7 +723,52 @@ struct Oracle {
     // ---- exhaustive -------------------------------------------------------- alignerExhaustive.cpp
     // alignerExhaustive.cpp:61-106 mapOnRightEndExhaustive / :206-259 checkEndExhaustive.  Same shape at
     // every depth; `top` adds only the partial (-i) early return of :217-221.
+    // (exh_memo, off by default: the literal recursion above is what pins this file to the reference.  On unitig sets that duplicate their own k-mers
+    // the literal recursion is exponential -- 150 s for one 79-base read, in the reference too -- and cannot serve as a checker; with exh_memo every
+    // non-top call (ov, pos, errors) is remembered per read: an answer within the budget is exact whatever the budget was (the children get
+    // errors - miss, :85,:134, and the winner is the first strict minimum), a failure holds for every budget up to the one it was found with.  The
+    // memoised form must return what the literal form returns: tools/fuzz_soup.py cpu compares the two, and both with the compiled reference, on
+    // every soup the reference finishes.)
+    struct MemoVal { bool exact = false; unsigned val = 0, bmax = 0; vector<unum_t> path; };
+    struct MemoKey {
+        kmer_t ov; unsigned pos; bool right;
+        bool operator<(const MemoKey& o) const { return ov != o.ov ? ov < o.ov : pos != o.pos ? pos < o.pos : right < o.right; }
+    };
+    bool exh_memo = false;
+    static std::map<MemoKey, MemoVal>& memo() { static thread_local std::map<MemoKey, MemoVal> m; return m; }
+    // -> true: answered from the table (*out = what the call returns, path appended)
+    bool memo_lookup(bool right, kmer_t ov, unsigned pos, unsigned errors, vector<unum_t>& path, unsigned* out) const {
+        auto it = memo().find(MemoKey{ov, pos, right});
+        if (it == memo().end()) return false;
+        const MemoVal& v = it->second;
+        if (v.exact) {
+            if (v.val <= errors) { path.insert(path.end(), v.path.begin(), v.path.end()); *out = v.val; }
+            else *out = errors + 1;
+            return true;
+        }
+        if (errors <= v.bmax) { *out = errors + 1; return true; }
+        return false;
+    }
+    void memo_store(bool right, kmer_t ov, unsigned pos, unsigned errors, unsigned minMiss, const vector<unum_t>& path, size_t path_from) const {
+        MemoVal& v = memo()[MemoKey{ov, pos, right}];
+        if (minMiss <= errors) { v.exact = true; v.val = minMiss; v.path.assign(path.begin() + (long)path_from, path.end()); }
+        else if (!v.exact) v.bmax = std::max(v.bmax, errors);
+    }
     unsigned right_exh(const string& read, vector<unum_t>& path, kmer_t ov, unsigned pos, unsigned errors, bool top) const {
+        const size_t path_from = path.size();
+        if (exh_memo && !top) { unsigned r; if (memo_lookup(true, ov, pos, errors, path, &r)) return r; }
+        const unsigned r = right_exh_body(read, path, ov, pos, errors, top);
+        if (exh_memo && !top) memo_store(true, ov, pos, errors, r, path, path_from);
+        return r;
+    }
+    unsigned left_exh(const string& read, vector<unum_t>& path, kmer_t ov, unsigned pos, unsigned errors, bool top) const {
+        const size_t path_from = path.size();
+        if (exh_memo && !top) { unsigned r; if (memo_lookup(false, ov, pos, errors, path, &r)) return r; }
+        const unsigned r = left_exh_body(read, path, ov, pos, errors, top);
+        if (exh_memo && !top) memo_store(false, ov, pos, errors, r, path, path_from);
+        return r;
+    }
+    unsigned right_exh_body(const string& read, vector<unum_t>& path, kmer_t ov, unsigned pos, unsigned errors, bool top) const {
         string readLeft(read.substr(pos + k - 1));
         vector<unum_t> path2keep;
         if (readLeft.empty()) { path.push_back(0); return 0; }
@@ -752,7 +798,7 @@ struct Oracle {
         return minMiss;
     }
     // alignerExhaustive.cpp:109-155 mapOnLeftEndExhaustive / :158-203 checkBeginExhaustive.
-    unsigned left_exh(const string& read, vector<unum_t>& path, kmer_t ov, unsigned pos, unsigned errors, bool top) const {
+    unsigned left_exh_body(const string& read, vector<unum_t>& path, kmer_t ov, unsigned pos, unsigned errors, bool top) const {
         if (pos == 0) { if (top) path.push_back(0); return 0; }  // :159 pushes 0, :112 does not
         string readLeft(read.substr(0, pos));
         vector<unum_t> path2keep;
@@ -784,6 +830,7 @@ struct Oracle {
     // alignerExhaustive.cpp:35-58 alignReadExhaustive (readNumber is counted in here, not by the worker)
     vector<unum_t> align_read_exhaustive(const string& read, bool& overlapFound, unsigned errors) {
         auto list = get_list_overlap(read);
+        if (exh_memo) memo().clear();  // (what is remembered holds for one read)
         if (list.empty()) { ++noOverlapRead; ++readNumber; return {}; }
         overlaps += list.size();
         overlapFound = true;
@@ -1016,6 +1063,8 @@ int64_t orc_align(void* h, int mode, int m, int effort, int partial, const char*
     o->errorsMax = (unsigned)m;
     o->tryNumber = (unsigned)effort;
     o->partial = partial != 0;
+    o->exh_memo = mode == 3;  // mode 3: exhaustive with remembered calls (the checker for unitig sets on which the literal recursion is exponential)
+    if (mode == 3) mode = 1;
     uint64_t w = 0;
     for (uint64_t i = 0; i < n; ++i) {
         string r(reads + offs[i], reads + offs[i + 1]);
@@ -1152,6 +1201,7 @@ int orc_main(int argc, char** argv, int exh_writes) {
     o.tryNumber = (unsigned)effort;
     o.partial = incomplete;
     o.dogMode = dog;
+    o.exh_memo = getenv("ORACLE_EXH_MEMO") != nullptr;  // (-b: remembered calls, see Oracle::exh_memo)
     Runner run(o);
     run.fastq = fastq;
     run.correction = correction;

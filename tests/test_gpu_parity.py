@@ -1109,10 +1109,10 @@ def test_exhaustive_on_duplicated_kmers_comes_back_and_equals_the_reference(tmp_
         al.close()
 
 
-def test_exhaustive_last_pass_gives_up_loudly(monkeypatch):
-    """The recursion of the last exhaustive pass (behind a level wider than four nodes) is bounded: beyond 2^26 loop iterations the launch returns an error
-    instead of holding the device for hours.  Test hooks shrink the bound to 40 iterations and switch the level search of that pass off; tiny search caps push
-    the reads of a 4-allele graph there."""
+def test_exhaustive_last_pass_runs_again_with_a_larger_table():
+    """The last exhaustive pass is the reference's recursion memoised on (overlap, position) (exh_memo): a read whose table of remembered calls fills up is
+    handed back and run again by the host with a table sixteen times as large, until it fits -- never an error, never a row that differs.  Tiny search caps
+    push every read of a 4-allele graph into that pass, a table of 8 entries per wave makes its first run hand most of them back."""
     s = Synth(60000, 40, 4, 31, 88)
     seqs, offs = s.unitigs()
     reads, roffs = s.reads(0, 3000, 250, 4, 89)
@@ -1120,20 +1120,53 @@ def test_exhaustive_last_pass_gives_up_loudly(monkeypatch):
     o = oracle_py.Oracle(31, seqs, offs)
     p2, po2, st2 = o.align(reads, roffs, m=4, mode=1)
 
-    def run():
+    def run(memo_cap, partial=False):
         al = B.Aligner(g, 0)
         al.set_knob(B.KNOB_EXH_FAST, 1)
         al.set_knob(B.KNOB_EXH_FRAME_CAP, 3)
+        al.set_knob(B.KNOB_EXH_MEMO_CAP, memo_cap)
         try:
-            return al.align(reads, roffs, m=4, mode=B.MODE_EXHAUSTIVE), al.pass_counts()
+            return al.align(reads, roffs, m=4, mode=B.MODE_EXHAUSTIVE, partial=partial), al.pass_counts(), al.last_pass_runs(), al.counters()
         finally:
             al.close()
-    (p1, po1, st1), passes = run()           # the bound as shipped: every read through the last pass, rows equal to the oracle's
+    (p1, po1, st1), passes, (runs, cap), c = run(0)     # the table as shipped: every read through the last pass, once
     assert passes[1] > 1000 or passes[0] > 1000, passes
+    assert runs == 1 and cap >= 1024
     assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
-    monkeypatch.setenv("BGREAT_TEST_DEEP_NO_LEVELS", "1")
-    (p1, po1, st1), _ = run()                # the recursion alone in the last pass (as before this round): the same rows
+    assert c["reads"] == 3000 and c["aligned"] == int(((st2 & 3) == 2).sum())
+    (p1, po1, st1), _, (runs, cap), c = run(8)         # 8 entries: most reads come back for a second (128 entries) and third run
+    assert runs >= 2 and cap >= 128, (runs, cap)
     assert np.array_equal(st1, st2) and np.array_equal(po1, po2) and np.array_equal(p1, p2)
-    monkeypatch.setenv("BGREAT_TEST_DEEP_ITERS", "40")
-    with pytest.raises(B.BgrError, match="gave up"):
-        run()
+    assert c["reads"] == 3000 and c["aligned"] == int(((st2 & 3) == 2).sum())   # (a read handed back is counted once, by the run that maps it)
+    p3, po3, st3 = o.align(reads, roffs, m=4, mode=1, partial=True)             # -i
+    (p1, po1, st1), _, (runs, cap), _ = run(8, partial=True)
+    assert runs >= 2
+    assert np.array_equal(st1, st3) and np.array_equal(po1, po3) and np.array_equal(p1, p3)
+
+
+@pytest.mark.parametrize("m", [0, 2, 5])
+def test_exhaustive_where_the_reference_is_exponential(m):
+    """The hole round 4 left: on such unitig sets the device's last pass ran the reference's recursion and gave up with an error after 2^26 steps.  It now
+    remembers its calls (exh_memo): every read comes back in milliseconds with the rows of the recursion -- checked against the oracle's literal form on
+    the reads that one finishes (<= 32 bases) and against its remembered-calls form (pinned to the literal one and to the compiled reference by
+    tools/fuzz_soup.py cpu and tests/test_oracle_golden.py) on reads of up to 250 bases, through every route into the last pass and with tables that
+    start at 8 entries."""
+    import time
+    from util import homopolymer_soup
+    k, (seqs, offs), (sr, so), (lr, lo) = homopolymer_soup()
+    g = B.Graph.build(k, seqs, offs)
+    o = oracle_py.Oracle(k, seqs, offs)
+    exp_short = o.align(sr, so, m=m, mode=1)
+    assert all(np.array_equal(a, b) for a, b in zip(exp_short, o.align(sr, so, m=m, mode=3)))
+    exp_long = o.align(lr, lo, m=m, mode=3)
+    for knobs in ({}, {B.KNOB_EXH_MEMO_CAP: 8}, {B.KNOB_EXH_FAST: 1, B.KNOB_EXH_SEARCH: 1}, {B.KNOB_EXH_FAST: 1, B.KNOB_EXH_SEARCH: 2, B.KNOB_EXH_FRAME_CAP: 3, B.KNOB_EXH_MEMO_CAP: 64}):
+        al = B.Aligner(g, 0)
+        for kk, v in knobs.items():
+            al.set_knob(kk, v)
+        t0 = time.time()
+        got_s = al.align(sr, so, m=m, mode=B.MODE_EXHAUSTIVE)
+        got_l = al.align(lr, lo, m=m, mode=B.MODE_EXHAUSTIVE)
+        assert time.time() - t0 < 30, knobs
+        assert all(np.array_equal(a, b) for a, b in zip(got_s, exp_short)), knobs
+        assert all(np.array_equal(a, b) for a, b in zip(got_l, exp_long)), knobs
+        al.close()

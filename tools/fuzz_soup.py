@@ -7,7 +7,12 @@ shared by dozens of unitigs) to 32.  Reads: walks through the chains with substi
 
   python tools/fuzz_soup.py cpu [seed] [configs]   oracle CLI (oracle/bgreat_oracle) against the compiled reference (oracle/_ref/bgreat, -t 1): bytes
                                                    of paths / notAligned.fa and the counters -- runs anywhere /root/reference was compiled (no GPU)
-  python tools/fuzz_soup.py gpu [seed] [configs]   the C-ABI on a GPU box against the oracle, row for row, greedy / exhaustive / anchors
+                                                   exhaustive soups also through the oracle's remembered-calls form (ORACLE_EXH_MEMO): same bytes as the literal one
+  python tools/fuzz_soup.py gpu [seed] [configs]   the C-ABI on a GPU box against the oracle, row for row, greedy / exhaustive / anchors; exhaustive mode WITH the
+                                                   ingredients that duplicate k-mers (the last pass is polynomial since round 5), checked by the oracle's
+                                                   remembered-calls form (the literal recursion is exponential there -- `cpu` pins the one to the other)
+  python tools/fuzz_soup.py gpuref [seed] [configs] exhaustive soups through bin/bgreat -b --write-exhaustive on a GPU box against the compiled reference
+                                                   (oracle/_ref/bgreat_exh, -t 1, 120 s): bytes and counters wherever the reference finishes
 (Test infrastructure.)"""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,8 +37,9 @@ def rc(s):
 def soup(k, no_dup_kmers=False):
     """no_dup_kmers: leave out what duplicates k-mers between unitigs on a grand scale (a homopolymer on both strands, copied unitigs).  On such a
     graph -- no compacted de Bruijn graph has it -- the reference's exhaustive recursion is exponential: every base of a poly-A read is a
-    choice between slots that name the same move, 150 s for ONE 79-base read in the compiled reference and in the oracle; the device's
-    depth-first pass is the same recursion run by one wavefront, a thousand times slower per step than a CPU core: it does not come back."""
+    choice between slots that name the same move, 150 s for ONE 79-base read in the compiled reference and in the oracle's literal form.
+    (Round 4 left these out of the device's exhaustive soups: its last pass was that recursion.  Since round 5 it remembers its calls and
+    every campaign runs with them.)"""
     K1 = k - 1
     us = []
     chains = []
@@ -119,8 +125,10 @@ if what == "cpu":
     for it in range(NCFG):
         k = int(rng.choice([4, 5, 6, 7, 8, 10, 12, 15, 21, 31, 32]))
         us, reads = soup(k)
-        mode = str(rng.choice(["greedy", "greedy", "correct", "anchors", "exhaustive", "exhaustive_i"]))
+        mode = str(rng.choice(os.environ["FUZZ_MODES"].split(",") if os.environ.get("FUZZ_MODES") else ["greedy", "greedy", "correct", "anchors", "exhaustive", "exhaustive_i"]))
         m = int(rng.integers(0, 6)); e = int(rng.choice([0, 1, 2, 2, 3, 8]))
+        if mode.startswith("exhaustive"):
+            reads = reads[:400]   # (the literal recursion is exponential on the duplicated k-mers: keep the checkers in seconds)
         with tempfile.TemporaryDirectory() as d:
             write_inputs(d, us, reads)
             args = ["-r", os.path.join(d, "r.fa"), "-k", str(k), "-g", os.path.join(d, "u.fa"), "-m", str(m), "-e", str(e), "-t", "1"]
@@ -134,6 +142,9 @@ if what == "cpu":
             try:
                 o2, p2, n2 = run_cli(ORC, args, env={"ORACLE_EXH_WRITES": "1"} if exh else None, timeout=300)
                 ok = parse_counters(o1) == parse_counters(o2) and p1 == p2 and n1 == n2
+                if exh:   # the remembered-calls form of the oracle: what checks the device where the literal recursion does not come back
+                    o3, p3, n3 = run_cli(ORC, args, env={"ORACLE_EXH_WRITES": "1", "ORACLE_EXH_MEMO": "1"}, timeout=300)
+                    ok = ok and parse_counters(o1) == parse_counters(o3) and p1 == p3 and n1 == n3
             except Exception as ex:
                 ok = False
                 print("oracle failed:", str(ex)[:200])
@@ -144,12 +155,45 @@ if what == "cpu":
                 os.makedirs(keep, exist_ok=True)
                 write_inputs(keep, us, reads)
                 open(os.path.join(keep, "args.txt"), "w").write(" ".join(args))
+elif what == "gpuref":
+    import bgreat_amd as B
+    from util import parse_counters, run_cli
+    REFX = os.path.join(ROOT, "oracle", "_ref", "bgreat_exh")
+    skipped = 0
+    for it in range(NCFG):
+        k = int(rng.choice([4, 5, 6, 7, 8, 10, 12, 15, 21, 31, 32]))
+        us, reads = soup(k)
+        reads = reads[:400]
+        m = int(rng.integers(0, 6)); mode = str(rng.choice(["exhaustive", "exhaustive_i"]))
+        with tempfile.TemporaryDirectory() as d:
+            write_inputs(d, us, reads)
+            args = ["-r", os.path.join(d, "r.fa"), "-k", str(k), "-g", os.path.join(d, "u.fa"), "-m", str(m), "-t", "1", "-b"] + (["-i"] if mode == "exhaustive_i" else [])
+            tg = time.time()
+            o2, p2, n2 = run_cli(B.CLI_PATH, args + ["--write-exhaustive"], timeout=600)
+            tg = time.time() - tg
+            try:
+                tr = time.time()
+                o1, p1, n1 = run_cli(REFX, args, timeout=120)
+                tr = time.time() - tr
+            except Exception as ex:
+                skipped += 1
+                print("skipped  %s reference: %s (device %.1fs)" % (dict(k=k, mode=mode, m=m, unitigs=len(us), reads=len(reads)), str(ex)[:60].replace("\n", " "), tg), flush=True)
+                continue
+            ok = parse_counters(o1) == parse_counters(o2) and p1 == p2 and n1 == n2
+            print("%s %s aligned %s device %.1fs reference %.1fs" % ("ok      " if ok else "MISMATCH", dict(k=k, mode=mode, m=m, unitigs=len(us), reads=len(reads)), parse_counters(o1).get("aligned"), tg, tr), flush=True)
+            if not ok:
+                bad += 1
+                keep = os.path.join(ROOT, "gpurun_out", "soup_bad_%d_%d" % (seed, it))
+                os.makedirs(keep, exist_ok=True)
+                write_inputs(keep, us, reads)
+                open(os.path.join(keep, "args.txt"), "w").write(" ".join(args))
+    print("reference did not finish within 120 s:", skipped)
 else:
     import bgreat_amd as B, oracle_py
     for it in range(NCFG):
         k = int(rng.choice([4, 5, 6, 7, 8, 10, 12, 15, 21, 31, 32]))
-        mode = str(rng.choice(["greedy", "greedy", "anchors", "exhaustive", "exhaustive_i"]))
-        us, reads = soup(k, no_dup_kmers=mode.startswith("exhaustive"))
+        mode = str(rng.choice(os.environ["FUZZ_MODES"].split(",") if os.environ.get("FUZZ_MODES") else ["greedy", "greedy", "anchors", "exhaustive", "exhaustive_i"]))
+        us, reads = soup(k)
         m = int(rng.integers(0, 6)); e = int(rng.choice([0, 1, 2, 2, 3, 8]))
         seqs = np.frombuffer("".join(us).encode(), dtype=np.uint8)
         offs = np.concatenate([[0], np.cumsum([len(u) for u in us])]).astype(np.uint64)
@@ -160,10 +204,12 @@ else:
         al.configure(0, 0, int(rng.choice([0, 1, 2])))
         if rng.random() < 0.3:
             al.set_knob(B.KNOB_EXH_FRAME_CAP, int(rng.choice([3, 6, 16])))
-        gm, om = {"greedy": (B.MODE_GREEDY, 0), "anchors": (B.MODE_ANCHORS, 2), "exhaustive": (B.MODE_EXHAUSTIVE, 1), "exhaustive_i": (B.MODE_EXHAUSTIVE, 1)}[mode]
+        gm, om = {"greedy": (B.MODE_GREEDY, 0), "anchors": (B.MODE_ANCHORS, 2), "exhaustive": (B.MODE_EXHAUSTIVE, 3), "exhaustive_i": (B.MODE_EXHAUSTIVE, 3)}[mode]   # (3: remembered calls)
+        if gm == B.MODE_EXHAUSTIVE and rng.random() < 0.3:
+            al.set_knob(B.KNOB_EXH_MEMO_CAP, int(rng.choice([8, 64])))   # (the last pass's table: reads handed back and run again)
         partial = mode == "exhaustive_i"
-        if gm == B.MODE_EXHAUSTIVE and len(reads) > 400:   # the reference's recursion is exponential on self-overlapping unitigs (a homopolymer: 227 s for 2 929 reads
-            roffs = roffs[:401]; rb = rb[: int(roffs[400])]   # in the compiled reference, 210 s in the oracle): keep the CHECKER in seconds
+        if gm == B.MODE_EXHAUSTIVE and len(reads) > 1000:
+            roffs = roffs[:1001]; rb = rb[: int(roffs[1000])]
         tg = time.time()
         p1, po1, st1 = al.align(rb, roffs, m=m, effort=e, mode=gm, partial=partial)
         tg = time.time() - tg
