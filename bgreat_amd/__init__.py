@@ -31,7 +31,7 @@ SYMBOLS = [
     "bgr_aligner_configure", "bgr_readset_load", "bgr_readset_count", "bgr_readset_view", "bgr_readset_destroy",
     "bgr_write_records", "bgr_graph_unitigs", "bgr_readset_load_parallel", "bgr_align_all", "bgr_host_alloc", "bgr_host_free",
     "bgr_set_build_threads", "bgr_graph_build_ex", "bgr_graph_build_from_fasta_ex", "bgr_graph_anchor_lookup", "bgr_graph_key_lookup",
-    "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_last_pass_runs", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
+    "bgr_aligner_set_knob", "bgr_aligner_pass_counts", "bgr_aligner_last_pass_runs", "bgr_set_option", "bgr_get_option", "bgr_option_name", "bgr_plan_launch", "bgr_aligner_kernel_times", "bgr_devices_init", "bgr_devices_method", "bgr_packed_plane_words", "bgr_pack_reads", "bgr_align_batch_packed",
     "bgr_align_fasta_text", "bgr_aligner_fetch_text", "bgr_host_cache_release", "bgr_device_local_cpus", "bgr_text_stage_create", "bgr_text_stage_destroy", "bgr_text_stage_upload",
     "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait", "bgr_text_stage_device", "bgr_text_stage_upload_parts",
     "bgr_device_alloc", "bgr_device_free", "bgr_device_upload", "bgr_device_download",
@@ -43,6 +43,24 @@ SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
 class _Borrowed(np.ndarray):
     """ndarray view of library-owned memory; `_owner` pins the handle that owns it."""
     _owner = None
+
+
+class PlanInput(C.Structure):  # bgr_plan_input
+    _fields_ = [("k", C.c_uint32), ("slot_fill_x100", C.c_uint32), ("table_bytes", C.c_uint32), ("has_exceptions", C.c_uint32), ("anchors", C.c_uint32), ("anchor_levels", C.c_uint32),
+                ("graph_bases", C.c_uint64), ("n_unitigs", C.c_uint64), ("max_unitig_len", C.c_uint64),
+                ("num_cus", C.c_uint32), ("resident_waves", C.c_uint32 * 7), ("lds_per_cu", C.c_uint64),
+                ("cfg_waves", C.c_uint32), ("cfg_blocks_per_cu", C.c_uint32), ("cfg_lds_mphf", C.c_uint32),
+                ("mode", C.c_uint32), ("max_mismatch", C.c_uint32), ("partial", C.c_uint32), ("max_read_len", C.c_uint32),
+                ("n_reads", C.c_uint64), ("total_bases", C.c_uint64)]
+
+
+class PlanPass(C.Structure):
+    _fields_ = [("used", C.c_uint32), ("blocks", C.c_uint32), ("waves_per_block", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_staged", C.c_uint32)]
+
+
+class PlanOutput(C.Structure):  # bgr_plan_output
+    _fields_ = [("pass_", PlanPass * 6), ("level_search", C.c_uint32), ("deep_only", C.c_uint32), ("x4_levels", C.c_uint32), ("memo_cap", C.c_uint32),
+                ("deep_scratch_bytes", C.c_uint64), ("arena_ints", C.c_uint64)]
 
 
 class BgrError(RuntimeError):
@@ -173,6 +191,11 @@ def lib():
     L.bgr_aligner_set_knob.argtypes = [vp, u32, u64]
     L.bgr_aligner_pass_counts.argtypes = [vp, vp]
     L.bgr_aligner_last_pass_runs.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.bgr_set_option.argtypes = [C.c_char_p, C.c_int64]
+    L.bgr_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
+    L.bgr_option_name.restype = C.c_char_p
+    L.bgr_option_name.argtypes = [u32, C.POINTER(C.c_char_p)]
+    L.bgr_plan_launch.argtypes = [C.POINTER(PlanInput), C.POINTER(PlanOutput)]
     L.bgr_readset_load.argtypes = [C.c_char_p, i32, u32, C.POINTER(vp)]
     L.bgr_readset_load_parallel.argtypes = [C.c_char_p, i32, u32, u32, u64, C.POINTER(vp)]
     L.bgr_align_all.argtypes = [vp, C.POINTER(Params), C.POINTER(RunOptions), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_double)]
@@ -201,6 +224,69 @@ def _check(rc):
 
 def device_count():
     return lib().bgr_device_count()
+
+
+def set_option(name, value):
+    """Process-wide library option (bgr_set_option): the library reads no environment variables."""
+    _check(lib().bgr_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int64(0)
+    _check(lib().bgr_get_option(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+def option_names():
+    out, i = [], 0
+    while True:
+        what = C.c_char_p()
+        n = lib().bgr_option_name(i, C.byref(what))
+        if n is None:
+            return out
+        out.append((n.decode(), what.value.decode()))
+        i += 1
+
+
+def set_options_from_string(spec):
+    """"name=value,name=value" -> bgr_set_option (tools: their BGR_FUZZ_OPTIONS / --options; the LIBRARY reads no environment)."""
+    for kv in filter(None, (spec or "").split(",")):
+        k, v = kv.split("=")
+        set_option(k.strip(), int(v))
+
+
+class options:
+    """with B.options(build_filter=2, **{"test.bases_cap": 5000}): ...  -- set, and put back on exit (tests)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
+def plan_launch(**kw):
+    """bgr_plan_launch: the launch geometry for a graph header / device / batch given as numbers (no device needed).  -> dict, or raises BgrError."""
+    i, o = PlanInput(), PlanOutput()
+    for k, v in kw.items():
+        if k == "resident_waves":
+            for j, w in enumerate(v):
+                i.resident_waves[j] = int(w)
+        else:
+            setattr(i, k, int(v))
+    _check(lib().bgr_plan_launch(C.byref(i), C.byref(o)))
+    names = ["general", "greedy16", "exhaustive8", "anchors4", "depth_first_mid", "last"]
+    d = {n: dict(used=bool(p.used), blocks=p.blocks, waves_per_block=p.waves_per_block, lds_bytes=p.lds_bytes, table_staged=bool(p.table_staged)) for n, p in zip(names, o.pass_)}
+    d.update(level_search=bool(o.level_search), deep_only=bool(o.deep_only), x4_levels=o.x4_levels, memo_cap=o.memo_cap, deep_scratch_bytes=o.deep_scratch_bytes, arena_ints=o.arena_ints)
+    return d
 
 
 class DeviceBuffer:

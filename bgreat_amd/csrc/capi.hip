@@ -26,6 +26,7 @@
 #include "launch_plan.h"
 #include "read_pack.h"
 #include "text_kernels.h"
+#include "options.h"
 
 namespace {
 
@@ -66,9 +67,9 @@ struct DevBuf {
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
-        // diagnostic (BGREAT_POISON_DEVICE_BUFFERS=1; tools/fuzz_*.py, the GPU suite): fresh device memory usually reads as zeroes, recycled memory of
+        // diagnostic (bgr_set_option("poison_device_buffers", 1); tools/fuzz_*.py, the GPU suite): fresh device memory usually reads as zeroes, recycled memory of
         // a long-lived process does not -- fill every new buffer with a pattern so that a kernel that reads what nothing has written shows in ANY run
-        static const bool poison = getenv("BGREAT_POISON_DEVICE_BUFFERS") != nullptr;
+        const bool poison = bgr::opt("poison_device_buffers") != 0;
         if (e == hipSuccess && poison) { e = hipMemset(p, 0xA5, want); if (e == hipSuccess) e = hipDeviceSynchronize(); }  // (the fill runs on the null stream: the aligner's streams do not wait for it)
         return e;
     }
@@ -99,7 +100,7 @@ struct bgr_aligner {
     // the text route (bgr_align_fasta_text): the piece, its records, the formatted streams
     DevBuf tx_in, tx_sums, tx_start, tx_rec, tx_flag, tx_len, tx_idx, tx_boff, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout, tx_info;
     uint64_t tx_n_acc = 0, tx_pbytes = 0, tx_nbytes = 0;
-    bool blocking_sync = getenv("BGREAT_BLOCKING_SYNC") && atoi(getenv("BGREAT_BLOCKING_SYNC")) != 0;
+    bool blocking_sync = bgr::opt("blocking_sync") != 0;
     hipEvent_t ev_wait = nullptr;
     const uint8_t* tx_text = nullptr;  // where the last call's piece lies in HBM (tx_in, or the caller's stage)
     uint32_t tx_want = 0;              // its want_output (2 = correction mode: mapped reads as spelled by their paths)
@@ -124,7 +125,7 @@ struct bgr_aligner {
     std::vector<uint64_t> ticket_offs;  // that batch's offsets made relative (kept alive for the asynchronous copy)
     uint32_t last_launch[4] = {0, 0, 0, 0};
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
-    bool exh_filter = !(getenv("BGREAT_EXH_FILTER") && atoi(getenv("BGREAT_EXH_FILTER")) == 0);  // exhaustive mode through the minimizer filter too (BGREAT_EXH_FILTER=0: without)
+    bool exh_filter = bgr::opt("exh_filter") != 0;  // exhaustive mode through the minimizer filter too (option exh_filter = 0: without)
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
     uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0, knob_memo_cap = 0;
     uint64_t knob_split_limit = 0;
@@ -174,6 +175,27 @@ int drain_timers(bgr_aligner* a) {
 extern "C" {
 
 const char* bgr_last_error(void) { return tl_err.c_str(); }
+
+int bgr_set_option(const char* name, int64_t value) {
+    bgr::Option* o = name ? bgr::find_option(name) : nullptr;
+    if (!o) return fail(BGR_E_ARG, std::string("bgr_set_option: unknown option '") + (name ? name : "") + "'");
+    if (value < o->lo || value > o->hi) return fail(BGR_E_ARG, std::string("bgr_set_option: value out of range for '") + name + "'");
+    o->value.store(value, std::memory_order_relaxed);
+    return BGR_OK;
+}
+int bgr_get_option(const char* name, int64_t* value) {
+    bgr::Option* o = name ? bgr::find_option(name) : nullptr;
+    if (!o || !value) return fail(BGR_E_ARG, std::string("bgr_get_option: unknown option '") + (name ? name : "") + "'");
+    *value = o->value.load(std::memory_order_relaxed);
+    return BGR_OK;
+}
+const char* bgr_option_name(uint32_t index, const char** what) {
+    size_t n;
+    bgr::Option* t = bgr::option_table(&n);
+    if (index >= n) return nullptr;
+    if (what) *what = t[index].what;
+    return t[index].name;
+}
 void bgr_set_build_threads(uint32_t threads) { bgr::set_build_threads(threads); }
 
 int bgr_device_count(void) {
@@ -479,7 +501,7 @@ int bgr_aligner_create(bgr_graph* g, int device, bgr_aligner** out) {
 
 void bgr_aligner_destroy(bgr_aligner* a) {
     if (!a) return;
-    if (a->tx_phase_s[4] > 0 && getenv("BGREAT_TIMING"))
+    if (a->tx_phase_s[4] > 0 && bgr::opt("timing"))
         fprintf(stderr, "bgreat: text calls %.0f on device %d: to record count %.3f s, records %.3f s, mapping + sizes %.3f s, streams out %.3f s\n", a->tx_phase_s[4], a->device,
                 a->tx_phase_s[0], a->tx_phase_s[1], a->tx_phase_s[2], a->tx_phase_s[3]);
     if (a->twin) { bgr_aligner_destroy(a->twin); a->twin = nullptr; }
@@ -537,6 +559,36 @@ static bgr::PlanTuning plan_tuning_of(const bgr_aligner* a) {
     return t;
 }
 
+// The planner by itself, on numbers (no device, no graph object): what tests/test_launch_plan.py sweeps on the CPU.
+extern "C" int bgr_plan_launch(const bgr_plan_input* in, bgr_plan_output* out) {
+    if (!in || !out) return fail(BGR_E_ARG, "bgr_plan_launch: null argument");
+    bgr::PlanGraph g;
+    g.k = in->k; g.slot_fill_x100 = in->slot_fill_x100; g.table_bytes = in->table_bytes; g.total_bases = in->graph_bases; g.n_unitigs = in->n_unitigs;
+    g.n_buckets = in->table_bytes / 4; g.max_unitig_len = in->max_unitig_len; g.anc_n = in->anchors ? 1 : 0; g.anc_active_levels = in->anchor_levels; g.has_exc = in->has_exceptions != 0;
+    bgr::PlanDevice d;
+    if (in->num_cus) d.num_cus = in->num_cus;
+    if (in->lds_per_cu) d.lds_per_cu = in->lds_per_cu;
+    for (int i = 0; i < 7; ++i) if (in->resident_waves[i]) d.resident[i] = in->resident_waves[i];
+    bgr::PlanTuning t;
+    t.cfg_waves = in->cfg_waves; t.cfg_blocks_per_cu = in->cfg_blocks_per_cu; t.cfg_lds_mphf = in->cfg_lds_mphf;
+    bgr::PlanBatch b;
+    b.mode = in->mode; b.max_mismatch = in->max_mismatch; b.partial = in->partial; b.max_read_len = in->max_read_len; b.n_reads = in->n_reads; b.total_bases = in->total_bases;
+    const bgr::LaunchPlan P = bgr::plan_launch(g, d, t, b);
+    memset(out, 0, sizeof(*out));
+    if (P.error) return fail(BGR_E_ARG, P.error);
+    const bgr::LaunchCfg* cf[6] = {&P.cfg, &P.cfg_fast, &P.cfg_x4, &P.cfg_a4, &P.cfg_mid, &P.cfg_deep};
+    const bool used[6] = {true, P.fast_pass, P.x4_pass, P.a4_pass, P.mid_pass, P.two_pass};
+    for (int i = 0; i < 6; ++i) {
+        if (!used[i]) continue;
+        out->pass[i].used = 1; out->pass[i].blocks = cf[i]->blocks; out->pass[i].waves_per_block = cf[i]->waves_per_block;
+        out->pass[i].lds_bytes = cf[i]->lds_bytes; out->pass[i].table_staged = cf[i]->stage_mphf;
+    }
+    out->level_search = P.level_search; out->deep_only = P.deep_only; out->x4_levels = P.x4_levels; out->memo_cap = P.memo_cap;
+    out->deep_scratch_bytes = P.two_pass ? (uint64_t)P.cfg_deep.blocks * P.cfg_deep.waves_per_block * P.deep_stride * 4 : 0;
+    out->arena_ints = P.arena_cap;
+    return BGR_OK;
+}
+
 // The mapping launch of one batch: the geometry comes from plan_launch (launch_plan.h, a pure function of numbers), this function sizes the
 // buffers and enqueues.  planes_ready: the aligner's 2-bit planes (pk_fw3 / pk_nm / pk_hasn) already hold the batch
 // (bgr_align_batch_packed copied them in); else they are made from the ASCII reads at d_reads by the pre-pass.
@@ -568,7 +620,6 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     pb.n_reads = n_reads; pb.total_bases = total_bases;
     const bgr::LaunchPlan P = bgr::plan_launch(plan_graph_of(a->graph->header), a->plan_dev, plan_tuning_of(a), pb);
     if (P.error) return fail(BGR_E_ARG, P.error);
-    const bool exhaustive = p->mode == BGR_MODE_EXHAUSTIVE;
     const bgr::LaunchCfg &cfg = P.cfg, &cfg_deep = P.cfg_deep, &cfg_mid = P.cfg_mid, &cfg_fast = P.cfg_fast, &cfg_x4 = P.cfg_x4, &cfg_a4 = P.cfg_a4;
     const bool level_search = P.level_search, two_pass = P.two_pass, deep_only = P.deep_only, mid_pass = P.mid_pass, fast_pass = P.fast_pass, x4_pass = P.x4_pass, a4_pass = P.a4_pass;
     const uint32_t waves = cfg.waves_per_block, wfast = P.wfast;
@@ -640,7 +691,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // 1 020 -> 1 184 Mreads/s, L2 requests per read 135 -> 28).  The exhaustive scan meets its first hit within a few positions; with
     // fingerprints behind it the filter cost it more than it saved (4-allele graph: 697 without, 664 with), with the bucket's keys compared
     // directly behind it, it pays there too (4-allele graph 702 -> 720, chr1-scale graph 1 111 -> 1 231): on by default for the minimizer
-    // kind (BGR_KNOB_EXH_FILTER 0: without); the one-hash kind of short k stays off in exhaustive mode
+    // kind (option exh_filter = 0: without); the one-hash kind of short k stays off in exhaustive mode
     BgrDeviceGraph dgl = a->dg;
     if (p->mode == BGR_MODE_EXHAUSTIVE && !(dgl.filter_kind == BGR_FILTER_MINIMIZER && a->exh_filter)) dgl.bloom = nullptr;
 
@@ -941,7 +992,7 @@ int bgr_text_stage_create(int device, bgr_text_stage** out) {
     bgr_text_stage* s = new bgr_text_stage();
     s->device = device;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    s->timing = getenv("BGREAT_TIMING") != nullptr;
+    s->timing = bgr::opt("timing") != 0;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev, s->timing ? hipEventDefault : hipEventDisableTiming);
     if (e == hipSuccess && s->timing) e = hipEventCreate(&s->ev0);
     if (e != hipSuccess) { bgr_text_stage_destroy(s); return fail(BGR_E_HIP, std::string("bgr_text_stage_create: ") + hipGetErrorString(e)); }
@@ -1232,7 +1283,7 @@ static const unsigned kOverlapMaxStreams = 4, kOverlapMaxPieces = 2 * kOverlapMa
 static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const char* reads, const uint64_t* read_offsets, uint64_t n,
                                   int32_t* paths_out, uint64_t paths_cap, uint64_t* path_offsets, uint8_t* status) {
     unsigned n_streams = kOverlapMaxStreams;
-    if (const char* e = getenv("BGREAT_OVERLAP_STREAMS")) n_streams = (unsigned)std::min<int>((int)kOverlapMaxStreams, std::max(2, atoi(e)));  // (A/B measurements)
+    n_streams = (unsigned)std::min<int64_t>((int64_t)kOverlapMaxStreams, std::max<int64_t>(2, bgr::opt("overlap_streams")));  // (option overlap_streams: A/B measurements)
     const unsigned n_pieces = 2 * n_streams;
     bgr_aligner* al[kOverlapMaxStreams] = {a, nullptr, nullptr, nullptr};
     for (unsigned t = 1; t < n_streams; ++t) {  // the twins: a chain a -> twin -> twin's twin ..., created on first use
@@ -1558,7 +1609,7 @@ static std::map<void*, uint64_t>& g_host_mapped = *new std::map<void*, uint64_t>
 int bgr_host_alloc(uint64_t bytes, void** out) {
     if (!out) return fail(BGR_E_ARG, "bgr_host_alloc: null argument");
     void* p = nullptr;
-    if (bytes >= (2ull << 20) && !getenv("BGREAT_NO_HUGE_PINNED")) {
+    if (bytes >= (2ull << 20) && bgr::opt("huge_pinned")) {
         const uint64_t len = (bytes + (2ull << 20) - 1) & ~((2ull << 20) - 1);
         void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m != MAP_FAILED) {

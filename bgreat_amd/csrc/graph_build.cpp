@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include "options.h"
 
 namespace bgr {
 
@@ -439,7 +440,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
     h.off_fallback = off; off = align256(off + h.n_fallback * 8 + 8);
     // a table too large for LDS staging gets a filter in front: minimizer-blocked when k-1 >= 20 (24-48 bits per key), else one hash
     // (4-8 bits per key).  BGREAT_BLOOM=0 builds without, =1 the one-hash kind, =2 the minimizer kind whatever the table size (tests)
-    const int filter_env = getenv("BGREAT_BLOOM") ? atoi(getenv("BGREAT_BLOOM")) : -1;
+    const int filter_env = (int)opt("build_filter");  // (bgr_set_option: tests force a filter kind onto small graphs)
     const bool large_table = (double)tab.buckets.size() * 4.0 > kStageTwice;  // (may be probed in memory: always beyond kStageOnce, below it with long reads)
     if (filter_env != 0 && !keys.empty() && (large_table || filter_env == 2)) {
         const bool minimizer = k - 1 >= BGR_MMX_MIN_K1 && filter_env != 1;
@@ -601,7 +602,7 @@ bool build_graph(uint32_t k, uint64_t n_in, const char* seqs, const uint64_t* of
         for (unsigned t = 0; t < T; ++t) { f += filled[t]; hh += halves[t]; }
         BgrBlobHeader* hw = reinterpret_cast<BgrBlobHeader*>(base);
         hw->slot_fill_x100 = hh ? (uint32_t)(100 * f / hh) : 100;
-        if (getenv("BGREAT_TIMING")) fprintf(stderr, "[build] slot fill %.2f per non-empty half record\n", hw->slot_fill_x100 / 100.0);
+        if (opt("timing")) fprintf(stderr, "[build] slot fill %.2f per non-empty half record\n", hw->slot_fill_x100 / 100.0);
     }
     {   // ---- compaction: the filled slots of every half next to each other, handles in the key entries and in the slots ----
         const uint64_t nh = 2 * nk;

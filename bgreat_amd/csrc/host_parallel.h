@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <thread>
 #include <vector>
+#include "options.h"
 
 namespace bgr {
 
@@ -47,7 +48,7 @@ inline void parallel_sort(std::vector<uint64_t>& v, unsigned T) {
 }
 
 struct PhaseTimer {  // BGREAT_TIMING=1: per-phase wall time of the index build on stderr
-    bool on = getenv("BGREAT_TIMING") != nullptr;
+    bool on = opt("timing") != 0;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char* what) {
         if (!on) return;

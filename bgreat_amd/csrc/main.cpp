@@ -12,6 +12,7 @@
 //                                                                   <notAligned>.<d>; `cat` in device order = the reference's files)
 //                                                   --host-route (parse and format on the host always; default: FASTA goes through the
 //                                                                 device as text when the run writes the reference's two files)
+//                                                   --set name=value (library option, bgr_set_option: INTEGRATION.md 5; e.g. --set timing=1)
 #include <getopt.h>
 
 #include <algorithm>
@@ -39,6 +40,7 @@ int main(int argc, char** argv) {
     static option longopts[] = {{"gpus", required_argument, nullptr, 1000}, {"batch", required_argument, nullptr, 1001},
                                 {"write-exhaustive", no_argument, nullptr, 1002}, {"chunk-bytes", required_argument, nullptr, 1003},
                                 {"no-overlap", required_argument, nullptr, 1004}, {"host-route", no_argument, nullptr, 1005}, {"split-output", no_argument, nullptr, 1006},
+                                {"set", required_argument, nullptr, 1007},
                                 {nullptr, 0, nullptr, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "r:k:g:m:t:e:f:o:a:biqpcG", longopts, nullptr)) != -1) {  // bgreat.cpp:67
@@ -63,6 +65,12 @@ int main(int argc, char** argv) {
             case 1004: noOverlapFile = optarg; break;
             case 1005: host_route = true; break;
             case 1006: split_out = true; break;
+            case 1007: {  // the environment is not read anywhere: options come in here
+                const std::string kv = optarg;
+                const size_t eq = kv.find('=');
+                if (eq == std::string::npos || bgr_set_option(kv.substr(0, eq).c_str(), std::stoll(kv.substr(eq + 1))) != BGR_OK) die("--set name=value");
+                break;
+            }
             default: break;  // -o and -p are accepted and ignored, as in the reference (no `case`)
         }
     }
@@ -81,7 +89,10 @@ int main(int argc, char** argv) {
     bgr_set_build_threads((uint32_t)std::max(1, threads));
     if (bgr_graph_build_from_fasta_ex(unitigs.c_str(), (uint32_t)ka, 0.0, dog ? BGR_BUILD_ANCHORS : 0u, &graph) != BGR_OK) die("index");
     // one host -> device copy, then device to device over xGMI (RCCL broadcast, or peer copies): include/bgreat_gpu.h
-    if (bgr_devices_init(graph, 0, getenv("BGREAT_TEST_LANES_ON_ONE_DEVICE") ? 1u : (uint32_t)gpus, BGR_FANOUT_AUTO) != BGR_OK) die("device setup");
+    int64_t one_device = 0, timing = 0;  // (test hook: every lane on device 0)
+    (void)bgr_get_option("test.lanes_on_one_device", &one_device);
+    (void)bgr_get_option("timing", &timing);
+    if (bgr_devices_init(graph, 0, one_device ? 1u : (uint32_t)gpus, BGR_FANOUT_AUTO) != BGR_OK) die("device setup");
     auto t1 = std::chrono::system_clock::now();
     std::cout << "Indexing in seconds : " << std::chrono::duration_cast<std::chrono::seconds>(t1 - t0).count() << std::endl;  // aligner.cpp:546
 
@@ -121,7 +132,7 @@ int main(int argc, char** argv) {
     auto secs = std::chrono::duration_cast<std::chrono::seconds>(end - start).count();
     std::cout << "Reads/seconds : " << rn / (uint64_t)(secs + 1) << std::endl;
     std::cout << "Mapping in seconds : " << secs << std::endl;
-    if (getenv("BGREAT_TIMING")) fprintf(stderr, "bgreat: mapping %.3f s, %.3f Mreads/s end to end\n", map_secs, map_secs > 0 ? rn / map_secs / 1e6 : 0.0);
+    if (timing) fprintf(stderr, "bgreat: mapping %.3f s, %.3f Mreads/s end to end\n", map_secs, map_secs > 0 ? rn / map_secs / 1e6 : 0.0);
     bgr_host_cache_release();  // the pipeline's page-locked staging sets (kept for a next run of the process): freed while the HIP runtime is up
     bgr_graph_destroy(graph);
     return 0;

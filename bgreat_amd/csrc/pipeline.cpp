@@ -37,6 +37,7 @@
 #include "fastx.h"
 #include "file_image.h"
 #include "read_pack.h"
+#include "options.h"
 
 namespace bgr {
 int set_error(int code, const std::string& msg);  // capi.hip
@@ -451,10 +452,10 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     // The threads of this run (and the page-locked memory they allocate) on the NUMA node of the devices they feed: a copy engine
     // reading staging buffers across the socket link runs at about half its rate.  Only when all devices of the run share a node;
     // the calling thread's affinity is restored at the end, and the pool of host threads is clamped to the CPUs of the restricted
-    // set (opt->numa = 1, or BGREAT_NUMA=0, leaves the affinity alone).
+    // set (opt->numa = 1, or the option numa = 0, leaves the affinity alone).
     cpu_set_t old_aff, want_aff;
     bool aff_changed = false;
-    if (!opt->numa && (!getenv("BGREAT_NUMA") || atoi(getenv("BGREAT_NUMA")) != 0)) {
+    if (!opt->numa && bgr::opt("numa") != 0) {
         CPU_ZERO(&want_aff);
         bool same = true;
         std::string first_list;
@@ -495,7 +496,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     if (bgr_graph_info(graph, &gi_route) != BGR_OK) return BGR_E_ARG;
     // (round 4: -b WITH its progress blocks too, for FASTA -- the device says what became of every record, bgr_text_batch.record_info_out, and
     // the ordered writer counts getReads() calls from that; FASTQ with progress blocks stays on the host route)
-    const bool text_route = opt->route == 0 && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !(progress_blocks && opt->fastq) && getenv("BGREAT_HOST_ROUTE") == nullptr;
+    const bool text_route = opt->route == 0 && !(correction && gi_route.has_exceptions) && !opt->no_overlap_file && !(progress_blocks && opt->fastq);
     const bool text_progress = text_route && progress_blocks;
     const uint64_t batch_reads = std::min<uint64_t>(opt->batch_reads ? opt->batch_reads : (text_route ? 1ull << 18 : 1ull << 17), 4ull << 20);
     // text route: bytes of a batch.  At most kTextPieceMax: the device addresses the two formatted streams with 32 bits, and a piece of B
@@ -503,7 +504,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     const uint64_t kTextPieceMax = 320ull << 20;
     const uint64_t piece_bytes = std::min<uint64_t>(std::max<uint64_t>(batch_reads * 170, 4096), kTextPieceMax - (16ull << 20));
     uint64_t batch_bases_cap = 1ull << 30;
-    if (const char* e = getenv("BGREAT_TEST_BASES_CAP")) batch_bases_cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // (tests: walk the cut with small inputs)
+    if (const int64_t cap = bgr::opt("test.bases_cap")) batch_bases_cap = (uint64_t)cap;  // (test hook: walk the cut with small inputs)
     const uint64_t chunk_bytes = opt->chunk_bytes ? opt->chunk_bytes
                                                   : std::min<uint64_t>(8ull << 20, std::max<uint64_t>(256ull << 10, batch_reads * 170 / threads));
     Unitigs unitigs;
@@ -533,7 +534,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     // two aligners (streams) per device so that consecutive batches overlap copy and compute (text route: the piece is already on its
     // way to the device when a worker takes the batch; measured 185 / 163 / 149 Mreads/s end to end with 2 / 3 / 4 workers per device)
     unsigned per_dev = 2;
-    if (const char* e = getenv("BGREAT_WORKERS_PER_DEVICE")) per_dev = (unsigned)std::min(16, std::max(1, atoi(e)));  // (tuning / experiments)
+    if (const int64_t w = bgr::opt("workers_per_device")) per_dev = (unsigned)w;  // (tuning / experiments)
     std::vector<bgr_aligner*> aligners;
     for (unsigned g = 0; g < n_gpus; ++g) {
         for (unsigned j = 0; j < per_dev; ++j) {
@@ -553,7 +554,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
     // A fixed pool of batch objects circulates producer -> GPU workers -> writer -> producer, so the pinned
     // buffers are allocated once and the number of batches in flight is bounded.
     size_t extra_sets = text_route ? 3 : 0;  // text route: a set is held from the read of its piece until its streams are written
-    if (const char* e = getenv("BGREAT_EXTRA_SETS")) extra_sets = (size_t)std::min(32, std::max(0, atoi(e)));
+    if (bgr::opt("extra_sets") >= 0) extra_sets = (size_t)bgr::opt("extra_sets");
     const size_t max_batches = aligners.size() * 2 + 2 + extra_sets;
     Channel<std::unique_ptr<Batch>> to_gather(max_batches), to_out(max_batches), free_batches(max_batches);
     std::vector<std::unique_ptr<Channel<std::unique_ptr<Batch>>>> to_gpu;  // one queue per device: its workers and its share of the batches
@@ -565,15 +566,15 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
         created.fetch_sub(1);
         return free_batches.pop(b);
     };
-    const bool timing = getenv("BGREAT_TIMING") != nullptr;
+    const bool timing = bgr::opt("timing") != 0;
     pool.timing = timing;
     // text route: room for a piece's two record streams.  A mapped 150 bp read leaves ~27 bytes of its 165 in `paths`, an unmapped one all
     // of them in the other file: a quarter of the piece each to start with (page-locked memory costs ~0.2 s per GB: less of it, and a fresh
     // process reaches its rate sooner); a stream that does not fit comes back as BGR_E_CAPACITY and the set's buffer grows once (-c, whose
     // paths stream is header + read, starts at the full size)
     const uint64_t out_div = correction ? 1 : 4;
-    // FASTQ on the text route: only the header and read lines of a piece go to the device (BGREAT_FASTQ_GATHER=0: the four-line records as they are)
-    const bool fastq_gather = !(getenv("BGREAT_FASTQ_GATHER") && atoi(getenv("BGREAT_FASTQ_GATHER")) == 0);
+    // FASTQ on the text route: only the header and read lines of a piece go to the device (option fastq_gather = 0: the four-line records as they are)
+    const bool fastq_gather = bgr::opt("fastq_gather") != 0;
     std::atomic<uint64_t> us_parse{0}, us_gather{0}, us_gpu{0}, us_format{0}, us_write{0}, us_alloc{0};
     auto now_us = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<bool> failed_here{false};
@@ -1393,7 +1394,7 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
     }
     // the graph on every device of the run before the lanes start: bgr_aligner_create would bring it there too, but the lanes run side by side
     // and the graph's table of resident copies is not made for concurrent writers (a run behind bgr_devices_init finds every copy in place)
-    const bool one_device = getenv("BGREAT_TEST_LANES_ON_ONE_DEVICE") != nullptr;
+    const bool one_device = bgr::opt("test.lanes_on_one_device") != 0;
     for (unsigned d = 0; d < (one_device ? 1u : n); ++d) {
         const int rc = bgr_graph_upload(graph, (int)(opt->first_device + d));
         if (rc != BGR_OK) return rc;
@@ -1428,7 +1429,7 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
             rcs[d] = align_all_impl(graph, prm, &o, in, pf.c_str(), nf.c_str(), cnt[d].data(), &secs, &cancel);
             lane_end[d] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             lane_secs[d] = secs;
-            if (getenv("BGREAT_TIMING")) fprintf(stderr, "bgreat: lane %u (device %u): %llu reads in %.3f s, done %.3f s after the start of the run\n", d, o.first_device, (unsigned long long)cnt[d][0], secs, lane_end[d]);
+            if (bgr::opt("timing")) fprintf(stderr, "bgreat: lane %u (device %u): %llu reads in %.3f s, done %.3f s after the start of the run\n", d, o.first_device, (unsigned long long)cnt[d][0], secs, lane_end[d]);
             if (rcs[d] != BGR_OK) errs[d] = bgr_last_error();  // (the message is the lane thread's own)
         });
     }

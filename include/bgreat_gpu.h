@@ -73,6 +73,14 @@ typedef struct {
 } bgr_graph_info_t;
 
 const char* bgr_last_error(void);
+
+/* Process-wide tuning / diagnostic options.  The library never reads the environment: a host sets what it wants changed here (the CLI:
+ * --set name=value) before it creates the objects that look at it (graph build, aligners, bgr_align_all).  Names, defaults and what they
+ * replace: INTEGRATION.md section 5; bgr_option_name(i, &what) enumerates them (nullptr behind the last).  Unknown name / value out of
+ * range: BGR_E_ARG.  Options named test.* are test hooks. */
+int bgr_set_option(const char* name, int64_t value);
+int bgr_get_option(const char* name, int64_t* value);
+const char* bgr_option_name(uint32_t index, const char** what);
 int bgr_device_count(void); /* number of HIP devices visible, 0 if none / no driver */
 
 /* ---- index ----------------------------------------------------------------------------------------
@@ -304,6 +312,28 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
                                    16 times as large, until it fits (bgr_aligner_last_pass_runs); tests set 8 to walk that path with small inputs */
 #define BGR_KNOB_GREEDY_FAST 5u /* greedy mode: 0 = sixteen-reads-per-wave pass + general kernel for the rest (default), 1 = general kernel only */
 int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value);
+/* The launch geometry by itself (bgreat_amd/csrc/launch_plan.h: a pure function of these numbers; no device, no graph object needed -- CPU tests sweep
+ * it over synthetic graph headers).  Zero fields of the device part mean "an MI355X" (256 CUs, 160 KB of LDS per CU, the shipped kernels' occupancies).
+ * pass[]: 0 the mode's general kernel, 1 greedy sixteen-reads-per-wave, 2 exhaustive eight-reads-per-wave, 3 anchors four-reads-per-wave,
+ * 4 exhaustive depth-first over what the level search listed, 5 exhaustive last pass.  BGR_E_ARG (message: bgr_last_error) when the batch cannot
+ * be mapped in one launch (a read too long for the LDS layouts, a batch beyond the 32-bit path arena). */
+typedef struct bgr_plan_input {
+    uint32_t k, slot_fill_x100, table_bytes, has_exceptions, anchors, anchor_levels;   /* graph header */
+    uint64_t graph_bases, n_unitigs, max_unitig_len;
+    uint32_t num_cus, resident_waves[7];                                                /* device (0: MI355X defaults) */
+    uint64_t lds_per_cu;
+    uint32_t cfg_waves, cfg_blocks_per_cu, cfg_lds_mphf;                                /* bgr_aligner_configure */
+    uint32_t mode, max_mismatch, partial, max_read_len;                                 /* batch */
+    uint64_t n_reads, total_bases;
+} bgr_plan_input;
+typedef struct bgr_plan_pass { uint32_t used, blocks, waves_per_block, lds_bytes, table_staged; } bgr_plan_pass;
+typedef struct bgr_plan_output {
+    bgr_plan_pass pass[6];
+    uint32_t level_search, deep_only, x4_levels, memo_cap;
+    uint64_t deep_scratch_bytes, arena_ints;
+} bgr_plan_output;
+int bgr_plan_launch(const bgr_plan_input* in, bgr_plan_output* out);
+
 /* Exhaustive mode: how often the last pass ran for the launch last settled (1 = once, as enqueued; more: reads whose table of remembered calls filled
  * up were run again) and the table size (entries per wave) of its final run.  0 / 0 when the last launch had no last pass (greedy, anchors mode). */
 int bgr_aligner_last_pass_runs(const bgr_aligner* a, uint32_t* runs, uint32_t* memo_cap);

@@ -17,6 +17,7 @@
 
 #include "../include/bgreat_gpu.h"
 #include "fastx.h"
+#include "options.h"
 
 struct bgr_graph { uint32_t k; };
 struct bgr_aligner { int device = 0; uint64_t counters[5] = {0, 0, 0, 0, 0}; std::string ps, ns; /* text form: the last call's streams, for bgr_aligner_fetch_text */ };
@@ -209,7 +210,8 @@ int main(int argc, char** argv) {
     for (const Case& c : cases) {
         for (unsigned threads : {1u, 6u}) {
           for (uint32_t route : {0u, 1u, 2u}) {   // 2 = the host route with the batches' base cap lowered to 3 000 (a chunk group cut into pieces)
-            if (route == 2) { if (c.fastq) continue; setenv("BGREAT_TEST_BASES_CAP", "3000", 1); } else unsetenv("BGREAT_TEST_BASES_CAP");  // route 0: through the (stand-in) device as text (FASTA: with the fall-back per irregular piece; FASTQ: whole records up to the last getReads() boundary, host tail), 1: the host route
+            if (route == 2 && c.fastq) continue;
+            bgr::find_option("test.bases_cap")->value.store(route == 2 ? 3000 : 0);  // route 0: through the (stand-in) device as text (FASTA: with the fall-back per irregular piece; FASTQ: whole records up to the last getReads() boundary, host tail), 1: the host route
             for (uint64_t batch : {1ull, 37ull, 100000ull}) {
                 if (std::string(c.file) == "big.fq" && batch == 1) continue;  // 50 000 one-read batches: slow under TSan, nothing new
                 const std::string in = (std::string(c.file) == "big.fq" ? tmp : gold) + "/" + c.file, pf = tmp + "/p", nf = tmp + "/n";

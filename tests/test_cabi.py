@@ -227,7 +227,7 @@ def test_large_tables_get_a_filter_that_passes_every_key(k, env, kind, monkeypat
     bits per key in 64-byte blocks chosen by the key's minimizer), one hash (4-8 bits per key) for shorter k; every key passes (a member
     is never turned away), the filter is not saturated, and both strands of a key choose the same block."""
     if env is not None:
-        monkeypatch.setenv("BGREAT_BLOOM", env)
+        B.set_option("build_filter", int(env))   # (put back by conftest.py's fixture)
     small = env == "2"
     s = Synth(60000 if small else 2_600_000, 60, 2, k, 23)
     seqs, offs = s.unitigs()

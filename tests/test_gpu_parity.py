@@ -485,8 +485,8 @@ def test_minimizer_filter_in_front_of_the_key_table(seed, k, L, m, e, nfrac, mon
     """The filter of large graphs (graph_layout.h bgr_mmx_*: block chosen by the (k-1)-mer's minimizer, worked out across the lanes of a scan
     with whole-wave DPP shifts, 65 - (k-16) positions per scan step) forced onto a small graph whose table is probed in memory: eight-reads-
     per-wave kernel and general kernel (N reads: per-key minimizer) against the oracle, and against the same graph without filter."""
-    monkeypatch.setenv("BGREAT_BLOOM", "2")
-    monkeypatch.setenv("BGREAT_EXH_FILTER", "1")   # (the default; spelled out: exhaustive mode goes through the filter as well)
+    B.set_option("build_filter", 2)   # (put back by conftest.py's fixture)
+    B.set_option("exh_filter", 1)     # (the default; spelled out: exhaustive mode goes through the filter as well)
     s = Synth(150000, 3 * k, 3, k, 9100 + seed)
     seqs, offs = s.unitigs()
     n = 20000
@@ -743,8 +743,8 @@ def test_keys_in_the_fallback_list_are_found(mode, stage, monkeypatch):
     bisection path, which ordinary graphs never take.  stage 3 = table in memory behind the (forced) minimizer filter, where the
     lanes the filter lets through compare their bucket's four keys directly."""
     if stage == 3:
-        monkeypatch.setenv("BGREAT_BLOOM", "2")
-        monkeypatch.setenv("BGREAT_EXH_FILTER", "1")
+        B.set_option("build_filter", 2)   # (put back by conftest.py's fixture)
+        B.set_option("exh_filter", 1)
         stage = 1
     s = Synth(120000, 60, 3, 31, 91)
     seqs, offs = s.unitigs()
@@ -905,10 +905,10 @@ def test_tiny_and_very_long_reads_through_the_api():
 @pytest.mark.parametrize("nbytes,env", [(8 << 20, None), (3 << 20, None), (4096, None), (8 << 20, "1")])
 def test_page_locked_host_buffers(nbytes, env, monkeypatch):
     """bgr_host_alloc: buffers of 2 MB and more come from huge-page mappings registered with the runtime, smaller ones (and all of them
-    under BGREAT_NO_HUGE_PINNED=1) from hipHostMalloc; either kind is writable, feeds a batch call and is freed by bgr_host_free."""
+    with the option huge_pinned = 0) from hipHostMalloc; either kind is writable, feeds a batch call and is freed by bgr_host_free."""
     import ctypes
     if env:
-        monkeypatch.setenv("BGREAT_NO_HUGE_PINNED", env)
+        B.set_option("huge_pinned", 0)   # (put back by conftest.py's fixture)
     L = B.lib()
     p = ctypes.c_void_p()
     B._check(L.bgr_host_alloc(nbytes, ctypes.byref(p)))

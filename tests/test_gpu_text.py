@@ -223,9 +223,9 @@ def test_cli_fastq_text_route_equals_host_route(n, batch, extra, tmp_path):
     assert pa == pb and na == nb
     assert [l for l in oa.splitlines() if "seconds" not in l] == [l for l in ob.splitlines() if "seconds" not in l]
     assert pa.count(b"\n") > n // 4
-    # (default: only the header and read lines of a piece cross PCIe; BGREAT_FASTQ_GATHER=0: the four-line records as they are)
+    # (default: only the header and read lines of a piece cross PCIe; --set fastq_gather=0: the four-line records as they are)
     from util import run_cli
-    oc, pc, nc = run_cli(B.CLI_PATH, args, env=dict(os.environ, BGREAT_FASTQ_GATHER="0"))
+    oc, pc, nc = run_cli(B.CLI_PATH, args + ["--set", "fastq_gather=0"])
     assert pc == pa and nc == na
 
 
@@ -257,7 +257,7 @@ def test_cli_correction_mode_on_the_device_equals_the_host_formatter(seed, L, k,
 @pytest.mark.parametrize("lanes,extra", [(2, []), (3, ["--host-route"]), (4, ["--batch", "3000"])])
 def test_cli_split_output_pairs_concatenate_to_the_single_run(lanes, extra, tmp_path):
     """--gpus N --split-output: one pipeline per device over contiguous shares of the input, N output pairs; `cat` in device order must be
-    the single pipeline's files.  (BGREAT_TEST_LANES_ON_ONE_DEVICE=1 puts every lane on this box's one GPU: the split run's own code --
+    the single pipeline's files.  (--set test.lanes_on_one_device=1 puts every lane on this box's one GPU: the split run's own code --
     shares cut at record starts over two input files, concurrent pipelines, the text route's fall-back per piece on the messy file -- on
     real device calls.)"""
     import subprocess
@@ -281,8 +281,7 @@ def test_cli_split_output_pairs_concatenate_to_the_single_run(lanes, extra, tmp_
     o1, p1, n1 = run_cli(B.CLI_PATH, args)
     d = tmp_path / "split"
     d.mkdir()
-    env = dict(os.environ, BGREAT_TEST_LANES_ON_ONE_DEVICE="1")
-    pr = subprocess.run([B.CLI_PATH] + args + ["--gpus", str(lanes), "--split-output"], cwd=d, capture_output=True, text=True, env=env, timeout=600)
+    pr = subprocess.run([B.CLI_PATH] + args + ["--gpus", str(lanes), "--split-output", "--set", "test.lanes_on_one_device=1"], cwd=d, capture_output=True, text=True, timeout=600)
     assert pr.returncode == 0, pr.stderr[-2000:]
     ps = b"".join(open(d / ("paths.%d" % i), "rb").read() for i in range(lanes))
     ns = b"".join(open(d / ("notAligned.fa.%d" % i), "rb").read() for i in range(lanes))

@@ -54,7 +54,8 @@ def main():
         if args.fastq:
             base.append("-q")
         base += args.extra.split()
-        env = dict(os.environ, BGREAT_TIMING="1")
+        base += ["--set", "timing=1"]
+        env = dict(os.environ)
         out = {}
         for rep in range(2):  # second run: page cache warm, device warm
             rd = os.path.join(d, "run%d" % rep)

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import bgreat_amd as B, oracle_py
+B.set_options_from_string(os.environ.get("BGR_FUZZ_OPTIONS"))   # (library options of this campaign: the library itself reads no environment)
 from synth import Synth
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import bgreat_amd as B, oracle_py
+B.set_options_from_string(os.environ.get("BGR_FUZZ_OPTIONS"))   # (library options of this campaign: the library itself reads no environment)
 from synth import Synth
 SEARCH = {"by-level": 2, "depth-first": 1, "auto": 0}[sys.argv[3] if len(sys.argv) > 3 else "by-level"]
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)

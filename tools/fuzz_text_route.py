@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import bgreat_amd as B
+B.set_options_from_string(os.environ.get("BGR_FUZZ_OPTIONS"))
 from synth import Synth
 from irregular_files import make_file
 
@@ -68,12 +69,12 @@ for it in range(NCFG):
                 res[route] = ("err", str(ex)[:80])
         ok = res[0][0] == res[1][0] and (res[0][0] == "err" or (res[0][1] == res[1][1] and same(os.path.join(d, "p0"), os.path.join(d, "p1")) and same(os.path.join(d, "n0"), os.path.join(d, "n1"))
                                                                    and (not novl or same(os.path.join(d, "o0"), os.path.join(d, "o1")))))
-        # a split run (one pipeline per lane over contiguous shares of the input, N output pairs; BGREAT_TEST_LANES_ON_ONE_DEVICE: every lane on this
+        # a split run (one pipeline per lane over contiguous shares of the input, N output pairs; option test.lanes_on_one_device: every lane on this
         # box's one device): the pairs concatenated in lane order must be the single pipeline's bytes
         split = "-"
         if ok and res[0][0] == "ok" and not fastq and mode in ("greedy", "anchors") and not novl and rng.random() < 0.5:
             lanes = int(rng.choice([2, 3, 5]))
-            os.environ["BGREAT_TEST_LANES_ON_ONE_DEVICE"] = "1"
+            B.set_option("test.lanes_on_one_device", 1)
             try:
                 kws = dict(kw); kws["threads"] = max(threads, lanes)
                 cs, _ = B.align_all(g, ",".join(files), os.path.join(d, "ps"), os.path.join(d, "ns"), route=int(rng.integers(0, 2)), n_gpus=lanes, split_output=True, **kws)
@@ -85,7 +86,7 @@ for it in range(NCFG):
                 split = "error %s" % str(ex)[:80]
                 ok = False
             finally:
-                del os.environ["BGREAT_TEST_LANES_ON_ONE_DEVICE"]
+                B.set_option("test.lanes_on_one_device", 0)
         ref = "-"
         if ok and res[0][0] == "ok" and os.path.exists(REF) and mode != "exhaustive" and not novl and n <= 60_000 and not (fastq and (mixed or irr or L < k)):
             # the compiled reference at -t 1 (FASTQ reads shorter than k-1 make it throw: regular FASTQ only)

@@ -22,7 +22,7 @@ PY
 for mode in fasta fastq; do
   if [ $mode = fasta ]; then ARGS="-r $W/r.fa"; else ARGS="-r $W/r.fq -q"; fi
   mkdir -p "$W/run_$mode" && cd "$W/run_$mode"
-  BGREAT_TIMING=1 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d "$OUT/$mode" -- "$ROOT/bgreat_amd/bin/bgreat" $ARGS -k 31 -g "$W/u.fa" -m 2 -t 16 > "$OUT/$mode.stdout" 2> "$OUT/$mode.err" \
+  rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d "$OUT/$mode" -- "$ROOT/bgreat_amd/bin/bgreat" $ARGS --set timing=1 -k 31 -g "$W/u.fa" -m 2 -t 16 > "$OUT/$mode.stdout" 2> "$OUT/$mode.err" \
      || { echo "profiled run ($mode) failed"; tail -5 "$OUT/$mode.err"; rm -rf "$W"; exit 1; }
   ls -l paths notAligned.fa "$W/r.fa" "$W/r.fq" > "$OUT/$mode.files"
 done
