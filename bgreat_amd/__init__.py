@@ -72,7 +72,7 @@ class Params(C.Structure):
 
 
 class RunOptions(C.Structure):
-    _fields_ = [("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint64), ("n_gpus", C.c_uint32), ("threads", C.c_uint32), ("batch_reads", C.c_uint64), ("chunk_bytes", C.c_uint64),
                 ("fastq", C.c_uint32), ("write_exhaustive", C.c_uint32), ("echo_files", C.c_uint32), ("correction", C.c_uint32),
                 ("no_overlap_file", C.c_char_p), ("first_device", C.c_uint32), ("route", C.c_uint32), ("numa", C.c_uint32), ("split_output", C.c_uint32)]
 
@@ -82,7 +82,7 @@ class Ticket(C.Structure):
 
 
 class TextBatch(C.Structure):
-    _fields_ = [("text", C.c_void_p), ("text_bytes", C.c_uint64), ("want_output", C.c_uint32), ("irregular", C.c_uint32), ("paths_out", C.c_void_p),
+    _fields_ = [("struct_size", C.c_uint64), ("text", C.c_void_p), ("text_bytes", C.c_uint64), ("want_output", C.c_uint32), ("irregular", C.c_uint32), ("paths_out", C.c_void_p),
                 ("paths_cap", C.c_uint64), ("notaligned_out", C.c_void_p), ("notaligned_cap", C.c_uint64), ("n_records", C.c_uint64),
                 ("n_accepted", C.c_uint64), ("paths_bytes", C.c_uint64), ("notaligned_bytes", C.c_uint64), ("stage", C.c_void_p),
                 ("fastq", C.c_uint32), ("reserved", C.c_uint32), ("record_info_out", C.c_void_p), ("record_info_cap", C.c_uint64)]
@@ -506,7 +506,7 @@ class Aligner:
         pcap = n + 64 if paths_cap is None else paths_cap
         pout = np.empty(max(pcap, 1), dtype=np.uint8)
         nout = np.empty(n + 64, dtype=np.uint8)
-        b = TextBatch(text.ctypes.data if n else None, n, int(want_output), 0, pout.ctypes.data, pcap, nout.ctypes.data, n + 64, 0, 0, 0, 0, None)
+        b = TextBatch(C.sizeof(TextBatch), text.ctypes.data if n else None, n, int(want_output), 0, pout.ctypes.data, pcap, nout.ctypes.data, n + 64, 0, 0, 0, 0, None)
         b.fastq = int(fastq)
         rinfo = None
         if record_info:
@@ -615,7 +615,7 @@ def align_all(graph, reads_csv, paths_file, notaligned_file, m=2, effort=2, mode
     text when it can (bgr_align_fasta_text), 1 = host parser + host formatter always.  split_output: one pipeline per device, device d
     writing `<paths_file>.<d>` / `<notaligned_file>.<d>` (their concatenation = the single-file bytes)."""
     p = Params(mode, m, effort, int(partial))
-    o = RunOptions(n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, int(correction),
+    o = RunOptions(C.sizeof(RunOptions), n_gpus, threads, batch_reads, chunk_bytes, int(fastq), int(write_exhaustive), 0, int(correction),
                    no_overlap_file.encode() if no_overlap_file else None, first_device, route, numa, int(split_output))
     out = np.zeros(5, dtype=np.uint64)
     secs = C.c_double()

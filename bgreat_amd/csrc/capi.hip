@@ -982,6 +982,7 @@ static int fetch_text_impl(bgr_aligner* a, bgr_text_batch* b) {
 
 int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b) {
     if (!a || !b) return fail(BGR_E_ARG, "bgr_aligner_fetch_text: null argument");
+    if (b->struct_size != sizeof(bgr_text_batch)) return fail(BGR_E_ARG, "bgr_aligner_fetch_text: bgr_text_batch.struct_size is not this library's sizeof(bgr_text_batch)");
     HIP_TRY(hipSetDevice(a->device));
     return fetch_text_impl(a, b);
 }
@@ -1053,7 +1054,10 @@ int bgr_text_stage_upload_parts(bgr_text_stage* s, uint32_t n_parts, const char*
 static double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b) {
-    if (!a || !p || !b || (b->text_bytes && !b->text && !b->stage)) return fail(BGR_E_ARG, "bgr_align_fasta_text: null argument");
+    if (!a || !p || !b) return fail(BGR_E_ARG, "bgr_align_fasta_text: null argument");
+    if (b->struct_size != sizeof(bgr_text_batch)) return fail(BGR_E_ARG, "bgr_align_fasta_text: bgr_text_batch.struct_size is not this library's sizeof(bgr_text_batch): the caller was built against another header (zero the struct, set struct_size)");
+    if (b->text_bytes && !b->text && !b->stage) return fail(BGR_E_ARG, "bgr_align_fasta_text: null argument");
+    if (b->record_info_out && b->text_bytes >= (1ull << 30)) return fail(BGR_E_ARG, "bgr_align_fasta_text: record_info_out holds a read's length in 30 bits: pieces below 2^30 bytes");
     double tw = wall_now();
     auto lap = [&](int i) { const double t = wall_now(); a->tx_phase_s[i] += t - tw; tw = t; };
     if (b->text_bytes >= (1ull << 31)) return fail(BGR_E_ARG, "bgr_align_fasta_text: piece of 2 GiB or more; cut it");

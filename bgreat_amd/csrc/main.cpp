@@ -100,6 +100,7 @@ int main(int argc, char** argv) {
     bgr_params prm = {brute ? (uint32_t)BGR_MODE_EXHAUSTIVE : (dog ? (uint32_t)BGR_MODE_ANCHORS : (uint32_t)BGR_MODE_GREEDY), (uint32_t)errors, (uint32_t)effort, incomplete ? 1u : 0u};
     bgr_run_options opt;
     memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
     opt.n_gpus = (uint32_t)gpus;
     opt.threads = (uint32_t)std::max(1, threads);   // -t: host threads of the pipeline (the reference: worker threads)
     opt.batch_reads = (uint64_t)batch;

@@ -1058,6 +1058,7 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                     const uint64_t tq0 = now_us();
                     bgr_text_batch tb;
                     memset(&tb, 0, sizeof(tb));
+                    tb.struct_size = sizeof(tb);
                     tb.text = static_cast<const char*>(b->pin->text.p);
                     tb.text_bytes = b->t_end - b->t_begin;
                     tb.stage = b->pin->stages.size() > b->dev ? b->pin->stages[b->dev] : nullptr;
@@ -1451,6 +1452,8 @@ static int align_all_lanes(bgr_graph* graph, const bgr_params* prm, const bgr_ru
 extern "C" int bgr_align_all(bgr_graph* graph, const bgr_params* prm, const bgr_run_options* opt, const char* reads_csv,
                              const char* paths_file, const char* notaligned_file, uint64_t counters_out[5], double* mapping_seconds) {
     if (!graph || !prm || !opt || !reads_csv || !paths_file || !notaligned_file) return bgr::set_error(BGR_E_ARG, "bgr_align_all: null argument");
+    if (opt->struct_size != sizeof(bgr_run_options))
+        return bgr::set_error(BGR_E_ARG, "bgr_align_all: bgr_run_options.struct_size is not this library's sizeof(bgr_run_options): the caller was built against another header (zero the struct, set struct_size)");
     std::vector<std::string> files;  // aligner.cpp:552-586: comma-separated list
     {
         const std::string list(reads_csv);

@@ -211,6 +211,9 @@ int bgr_align_batch_wait(const bgr_ticket* ticket, int32_t* paths_out, uint64_t 
  * bgr_aligner_fetch_text delivers the same bytes into larger buffers.  Blocking; page-locked buffers recommended. */
 typedef struct bgr_text_stage bgr_text_stage;
 typedef struct {
+    uint64_t struct_size;         /* in: sizeof(bgr_text_batch) of the header the caller was built with.  The struct has grown over the rounds and will again: a
+                                     caller built against another layout is refused (BGR_E_ARG) instead of having fields read past the end of its struct.
+                                     Zero the whole struct, then set this first. */
     const char* text;             /* in: the piece (may be NULL when `stage` holds it) */
     uint64_t text_bytes;          /*     < 2^31 */
     uint32_t want_output;         /*     0 = map and count only (-b without --write-exhaustive writes nothing), 1 = the reference's records,
@@ -364,6 +367,7 @@ int bgr_write_records(void* paths_file, void* notaligned_file, uint64_t n_reads,
  * returns the bytes to write (`route`), or the host pipeline parses chunk-parallel, packs into pinned batches and formats
  * range-parallel; two streams per device, one ordered writer.  counters_out as bgr_aligner_counters. */
 typedef struct {
+    uint64_t struct_size;      /* sizeof(bgr_run_options) of the header the caller was built with (see bgr_text_batch.struct_size): zero the struct, set this */
     uint32_t n_gpus;           /* devices 0..n_gpus-1 (0 = 1)                                                  */
     uint32_t threads;          /* host threads for parsing / gathering / formatting (-t; 0 = 1)                */
     uint64_t batch_reads;      /* target reads per device batch (0 = default: 128k on the host route, 256k as text)  */

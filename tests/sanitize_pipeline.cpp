@@ -164,6 +164,7 @@ static int check_files(const std::string& tmp, uint32_t k, bool fastq, const std
                 bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
                 bgr_run_options opt;
                 memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
                 opt.n_gpus = (batch == 5000 && threads == 6) ? 8 : 2;
                 opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = batch == 0 ? 0 : 4096; opt.fastq = fastq; opt.route = route;
                 uint64_t tot[5]; double secs;
@@ -219,6 +220,7 @@ int main(int argc, char** argv) {
                 bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
                 bgr_run_options opt;
                 memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
                 opt.n_gpus = (batch == 37 && threads == 6) ? 8 : 2;  // (eight stand-in devices = 16 stream workers, per-device queues: order and bytes as with two)
                 opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 700; opt.fastq = c.fastq; opt.route = route == 2 ? 1u : route;
                 opt.first_device = (unsigned)((batch + threads) % 3);  // (the staging sets cached by the previous run carry text stages of ITS devices)
@@ -286,6 +288,7 @@ int main(int argc, char** argv) {
                 bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
                 bgr_run_options opt;
                 memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
                 opt.n_gpus = 1; opt.threads = 3; opt.batch_reads = 997; opt.chunk_bytes = 900; opt.route = route;
                 uint64_t tot1[5]; double secs;
                 if (bgr_align_all(&g, &prm, &opt, list.c_str(), (tmp + "/p1").c_str(), (tmp + "/n1").c_str(), tot1, &secs) != BGR_OK) { printf("FAIL lanes reference run: %s\n", bgr_last_error()); return 1; }
@@ -309,6 +312,7 @@ int main(int argc, char** argv) {
             bgr_params prm = {BGR_MODE_GREEDY, 2, 2, 0};
             bgr_run_options opt;
             memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
             opt.n_gpus = 4; opt.split_output = 1; opt.threads = 4;
             uint64_t tot[5]; double secs;
             const int rc = bgr_align_all(&g, &prm, &opt, big.c_str(), (tmp + "/no_such_dir/p").c_str(), (tmp + "/no_such_dir/n").c_str(), tot, &secs);
@@ -374,6 +378,7 @@ int main(int argc, char** argv) {
                     bgr_params prm = {BGR_MODE_EXHAUSTIVE, 2, 2, 0};
                     bgr_run_options opt;
                     memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
                     opt.n_gpus = batch == 911ull ? 8 : (threads == 1 ? 1 : 2);  // 16 / 1 / 4 stream workers over the stand-in devices
                     opt.threads = threads; opt.batch_reads = batch; opt.chunk_bytes = 30000; opt.fastq = fq; opt.echo_files = 1;
                     uint64_t tot[5]; double secs;

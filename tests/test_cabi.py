@@ -614,3 +614,40 @@ def test_mapping_fails_loudly_without_gpu():
     g = B.Graph.from_fasta(os.path.join(GOLD, "toy_unitig.fa"), 4)
     with pytest.raises(B.BgrError, match="(?i)no HIP device|hip"):
         B.Aligner(g, 0)
+
+
+def test_structs_of_another_header_version_are_refused(tmp_path):
+    """bgr_run_options / bgr_text_batch carry their own size: a caller built against another layout of the header gets BGR_E_ARG instead of having
+    fields read past the end of its struct (both structs have grown in every round)."""
+    import ctypes as C
+    L = B.lib()
+    o = B.RunOptions(C.sizeof(B.RunOptions) - 8, 1, 1)
+    p = B.Params(0, 2, 2, 0)
+    cnt = (C.c_uint64 * 5)()
+    secs = C.c_double(0)
+    rc = L.bgr_align_all(C.c_void_p(1), C.byref(p), C.byref(o), b"x.fa", str(tmp_path / "p").encode(), str(tmp_path / "n").encode(), cnt, C.byref(secs))
+    assert rc == -1 and b"struct_size" in L.bgr_last_error()
+    o.struct_size = 0
+    assert L.bgr_align_all(C.c_void_p(1), C.byref(p), C.byref(o), b"x.fa", str(tmp_path / "p").encode(), str(tmp_path / "n").encode(), cnt, C.byref(secs)) == -1
+    b = B.TextBatch(0)
+    assert L.bgr_align_fasta_text(C.c_void_p(1), C.byref(p), C.byref(b)) == -1 and b"struct_size" in L.bgr_last_error()
+
+
+def test_options_are_named_bounded_and_put_back():
+    names = dict(B.option_names())
+    assert {"timing", "build_filter", "poison_device_buffers", "test.bases_cap", "test.lanes_on_one_device"} <= set(names)
+    assert B.get_option("build_filter") == -1
+    with B.options(build_filter=2, timing=1):
+        assert B.get_option("build_filter") == 2 and B.get_option("timing") == 1
+    assert B.get_option("build_filter") == -1 and B.get_option("timing") == 0
+    with pytest.raises(B.BgrError, match="unknown option"):
+        B.set_option("no_such_option", 1)
+    with pytest.raises(B.BgrError, match="out of range"):
+        B.set_option("build_filter", 7)
+
+
+def test_the_library_reads_no_environment_variables():
+    """Options come in through bgr_set_option / --set; getenv appears nowhere in the product's sources."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "bgreat_amd", "csrc", "*")):
+        assert "getenv" not in open(f, errors="replace").read(), f

@@ -151,6 +151,7 @@ int main(int argc, char** argv) {
         for (int split = 0; split < 2; ++split) {
             bgr_run_options opt;
             memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
             opt.n_gpus = n; opt.threads = threads; opt.split_output = (uint32_t)split; opt.numa = 1;
             const std::string pf = dir + "/paths", nf = dir + "/notAligned.fa";
             uint64_t tot[5]; double secs = 0, best = 0;

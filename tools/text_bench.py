@@ -35,7 +35,7 @@ hp, tin = pinned(len(text) + 64)
 tin[: len(text)] = text
 ho, pout = pinned(len(text))
 hn, nout = pinned(len(text))
-b = B.TextBatch(tin.ctypes.data, len(text), 1, 0, pout.ctypes.data, len(text), nout.ctypes.data, len(text), 0, 0, 0, 0, None)
+b = B.TextBatch(C.sizeof(B.TextBatch), tin.ctypes.data, len(text), 1, 0, pout.ctypes.data, len(text), nout.ctypes.data, len(text), 0, 0, 0, 0, None)
 p = B.Params(B.MODE_GREEDY, 2, 2, 0)
 for i in range(reps):
     t0 = time.perf_counter()
