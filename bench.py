@@ -91,6 +91,10 @@ def parse_args():
     ap.add_argument("--sub-timeout", type=int, default=170, help="seconds one sub-record child may take")
     ap.add_argument("--cpu-sample-exh", type=int, default=200_000, help="reads of the exhaustive CPU baseline (reference -b, -t cpu-threads)")
     ap.add_argument("--cpu-sample-all", type=int, default=2_500_000, help="reads of the all-cores leg of the CPU baseline (-t min(255, visible cores)); 0 disables")
+    ap.add_argument("--full-parity", action="store_true", help="off by default (+4-6 minutes): tools/full_parity.py -- the WHOLE read sets of configs[1] (10 M) and configs[2] (50 M) "
+                                                                "and 2 M reads of configs[4] through bin/bgreat and through the compiled reference (-t cpu-threads); sorted record "
+                                                                "multisets + counters; the report goes to gpurun_out/full_parity.txt, the verdict into the line (full_parity, config.full_parity_*)")
+    ap.add_argument("--full-parity-scale", type=float, default=1.0, help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--debug-stop", type=int, default=0, help="diagnostic builds of the library only (-DBGR_PHASE_TIMING, loaded through BGR_LIB_PATH): "
                                                               "1 = the mapping kernel stops behind the staging of the reads, 2 = behind the anchor scan")
@@ -316,7 +320,7 @@ def main():
     # ---- rank 0: everything the line needs from the device-resident leg (value, roofline, parity sample) BEFORE the optional legs below, so
     # that a leg that never returns (a collective between real devices that this container has never run, a wedged file system) costs
     # the line its optional fields, not the line: LineGuard prints what is known when the deadline passes
-    guard = LineGuard(rank, float(os.environ.get("BGR_BENCH_DEADLINE", "480")))
+    guard = LineGuard(rank, float(os.environ.get("BGR_BENCH_DEADLINE", "1500" if args.full_parity else "480")))
     line = None
     if rank == 0:
         total_reads = world * K * R
@@ -477,9 +481,93 @@ def main():
     if world == 1 and args.cpu_sample_exh > 0 and mode == 1:
         cpu = run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads)
 
+    if world == 1 and args.full_parity and not args.sub_record:
+        guard.stage("full_parity")
+        try:
+            from tools import full_parity
+            fp = full_parity.run(threads=ncpu, scale=args.full_parity_scale, out=os.path.join(ROOT, "gpurun_out", "full_parity.txt"), log=log)
+            line["full_parity"] = {"equal": fp["equal"], "seconds": fp["seconds"], "against": "oracle/_ref (the reference compiled from its own sources), -t %d" % ncpu,
+                                   **{"c%s_%s" % (c, k): v for c, r in fp["configs"].items() for k, v in (("reads", r["reads"]), ("equal", r["equal"]))},
+                                   "report": "gpurun_out/full_parity.txt"}
+        except Exception as ex:
+            line["full_parity"] = {"equal": False, "error": "%s: %s" % (type(ex).__name__, ex)}
     line.update({"value_pcie_inclusive": (pcie or {}).get("value"), "value_e2e": (e2e or {}).get("value"), "pcie_inclusive": pcie, "e2e": e2e, "cpu_baseline": cpu,
                  "one_process_all_gpus": one_proc})
     guard.finish(line, dist)
+
+
+TEMP_DIRS = set()   # scratch directories of the legs in flight (tens of GB at default sizes): removed on every way out, the deadline's os._exit included
+
+
+def scalar_copies(line):
+    """The driver's record keeps the scalar members of `config`, `roofline` and `cpu_baseline` (nested objects and other top-level keys survive as
+    key names only): every number the line carries elsewhere gets a scalar copy there, so that BENCH_rNN.json proves all five configs, not one."""
+    cfg, roof, cpu = line.get("config"), line.get("roofline"), line.get("cpu_baseline")
+    if isinstance(cfg, dict):
+        cfg["value_e2e"] = line.get("value_e2e")
+        cfg["value_pcie_inclusive"] = line.get("value_pcie_inclusive")
+        e2e = line.get("e2e") or {}
+        if isinstance(e2e.get("host_route"), dict):
+            cfg["e2e_host_route_mreads"] = e2e["host_route"].get("value")
+        cfg["e2e_routes_identical_bytes"] = (e2e.get("host_route") or {}).get("identical_bytes_to_the_text_route") if isinstance(e2e.get("host_route"), dict) else None
+        cfg["parity_sample_ok"] = (line.get("parity_sample") or {}).get("gpu_equals_oracle")
+        for w, sub in (line.get("other_configs") or {}).items():
+            if not isinstance(sub, dict):
+                continue
+            cfg["%s_mreads" % w] = sub.get("value")
+            cfg["%s_ms_per_step" % w] = sub.get("ms_per_step")
+            cfg["%s_parity_ok" % w] = (sub.get("parity_sample") or {}).get("gpu_equals_oracle")
+            if "error" in sub:
+                cfg["%s_error" % w] = str(sub["error"])[:200]
+        fp = line.get("full_parity") or {}
+        for k, v in fp.items():
+            if isinstance(v, (bool, int, float, str)) or v is None:
+                cfg["full_parity_%s" % k] = v
+        one = line.get("one_process_all_gpus") or {}
+        if isinstance(one, dict) and one.get("value") is not None:
+            cfg["one_process_all_gpus_mreads"] = one.get("value")
+            cfg["one_process_fanout_method"] = one.get("fanout_method")
+        mg = line.get("multi_gpu") or {}
+        if isinstance(mg, dict):
+            for k in ("backend", "ranks_seen", "broadcast_bytes", "broadcast_ms", "broadcast_gbps", "rccl_version", "broadcast_form"):
+                if mg.get(k) is not None and isinstance(mg.get(k), (bool, int, float, str)):
+                    cfg["multi_gpu_%s" % k] = mg[k]
+    if isinstance(roof, dict):
+        v = roof.get("valu_issue") or {}
+        roof["valu_insts_per_read"] = v.get("valu_insts_per_read")
+        roof["salu_insts_per_read"] = v.get("salu_insts_per_read")
+        roof["valu_issue_frac"] = v.get("frac")
+        roof["hbm_compulsory_frac"] = (roof.get("hbm") or {}).get("frac")
+        for w, sub in (line.get("other_configs") or {}).items():
+            if not isinstance(sub, dict):
+                continue
+            r = sub.get("roofline") or {}
+            roof["%s_frac" % w] = r.get("frac")
+            roof["%s_bound" % w] = r.get("bound")
+            roof["%s_dominant_kernel_ms" % w] = sub.get("dominant_kernel_ms")
+            roof["%s_valu_insts_per_read" % w] = sub.get("valu_insts_per_read")
+            h = sub.get("hbm") or {}
+            roof["%s_traffic_over_compulsory" % w] = h.get("traffic_over_compulsory")
+            roof["%s_traffic_frac" % w] = h.get("traffic_frac")
+            roof["%s_l2_hit_rate" % w] = sub.get("l2_hit_rate")
+    if isinstance(cpu, dict):
+        if isinstance(cpu.get("all_cores"), dict):
+            cpu["all_cores_value"] = cpu["all_cores"].get("value")
+            cpu["all_cores_threads"] = cpu["all_cores"].get("cores")
+        if isinstance(cpu.get("t1"), dict):
+            cpu["t1_value"] = cpu["t1"].get("value")
+        x = ((line.get("other_configs") or {}).get("branchy") or {}).get("cpu_baseline")
+        if isinstance(x, dict):
+            cpu["exhaustive_value"] = x.get("value")
+            cpu["exhaustive_cores"] = x.get("cores")
+            cpu["exhaustive_sample"] = x.get("sample")
+    return line
+
+
+def drop_temp_dirs():
+    for d in list(TEMP_DIRS):
+        shutil.rmtree(d, ignore_errors=True)
+        TEMP_DIRS.discard(d)
 
 
 class LineGuard:
@@ -517,7 +605,8 @@ class LineGuard:
             if self.rank == 0 and self.line is not None:
                 d = dict(self.line)
                 d["incomplete"] = "the optional legs behind the timed region did not finish within %.0f s (running: %s); value, roofline and parity sample are complete" % (self.seconds, self.what)
-                print(json.dumps(d), flush=True)
+                print(json.dumps(scalar_copies(d)), flush=True)
+            drop_temp_dirs()
             log("bench.py rank %d: deadline of %.0f s passed in leg '%s': leaving" % (self.rank, self.seconds, self.what))
             sys.stderr.flush()
             os._exit(0)
@@ -535,7 +624,7 @@ class LineGuard:
             if self.printed:
                 return
             self.printed = True
-            print(json.dumps(line), flush=True)
+            print(json.dumps(scalar_copies(line)), flush=True)
         if self.timer is not None:
             self.timer.cancel()
         if dist is not None:
@@ -582,6 +671,7 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
     if n < 100_000:
         return {"error": "not enough free space under %s for the end-to-end leg (%d bytes free, %d ranks)" % (tempfile.gettempdir(), free, world)}
     d = tempfile.mkdtemp(prefix="bgr_e2e_r%d_" % rank)
+    TEMP_DIRS.add(d)
     try:
         f = os.path.join(d, "reads.fa")
         syn.write_reads(f, (world + rank) * 1_000_000_000, n, L, args.mismatch, seed_reads, threads=ncpu)
@@ -664,6 +754,7 @@ def run_e2e(args, B, syn, g, rank, world, dev, ncpu, dist, D, coll_dev, seed_rea
 def bail_out(rank, why):
     """a rank other than 0 that can no longer reach rank 0 (which prints the line) leaves quietly: exit code 0, no collective"""
     log("bench.py rank %d: leaving (%s)" % (rank, why))
+    drop_temp_dirs()
     sys.stderr.flush()
     os._exit(0)
 
@@ -957,6 +1048,7 @@ def run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads):
     ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
     exe, kind = (ref, "reference") if os.path.exists(ref) else (os.path.join(ROOT, "oracle", "bgreat_oracle"), "port")
     d = tempfile.mkdtemp(prefix="bgr_cpux_")
+    TEMP_DIRS.add(d)
     try:
         syn.write_unitigs(os.path.join(d, "u.fa"))
         syn.write_reads(os.path.join(d, "r.fa"), 0, nc, L, args.mismatch, seed_reads)
@@ -1016,6 +1108,7 @@ def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
     n1 = max(1, min(nc, args.cpu_sample_t1))
     ref = os.path.join(ROOT, "oracle", "_ref", "bgreat")
     d = tempfile.mkdtemp(prefix="bgr_cpu_")
+    TEMP_DIRS.add(d)
     try:
         syn.write_unitigs(os.path.join(d, "u.fa"))
         syn.write_reads(os.path.join(d, "r.fa"), 0, nc, L, args.mismatch, seed_reads)
