@@ -73,6 +73,7 @@ def parse_args():
     ap.add_argument("--anchors", action="store_true", help="-G: greedy mapping from k-mer anchors (diagnostic; not the headline metric)")
     ap.add_argument("--gamma", type=float, default=0.0, help="overlap key table slots per key (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--prepass", action="store_true", help="greedy: 2-bit planes by a pre-pass kernel (rounds 2-4) instead of staging from the characters inside the mapping kernels (diagnostic, A/B)")
     ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the eight-reads-per-wave passes (diagnostic)")
     ap.add_argument("--exh-first-pass-off", action="store_true", help="exhaustive: skip the eight-reads-per-wave pass, every read goes through the search kernels (diagnostic)")
     ap.add_argument("--anc-first-pass-off", action="store_true", help="anchors: skip the several-reads-per-wave pass (diagnostic)")
@@ -138,7 +139,7 @@ def run_pmc_passes(args):
            "--genome", str(args.genome), "--site-spacing", str(args.site_spacing), "--alleles", str(args.alleles), "--lds-mphf", str(args.lds_mphf),
            "--waves", str(args.waves), "--blocks-per-cu", str(args.blocks_per_cu), "--gamma", str(args.gamma), "--cpu-threads", str(args.cpu_threads),
            "--debug-stop", str(args.debug_stop)]
-    for flag in ("exhaustive", "anchors", "general_kernel_only", "exh_first_pass_off", "anc_first_pass_off", "sorted_reads"):
+    for flag in ("exhaustive", "anchors", "general_kernel_only", "exh_first_pass_off", "anc_first_pass_off", "sorted_reads", "prepass"):
         if getattr(args, flag):
             fwd.append("--" + flag.replace("_", "-"))
     fwd += ["--exh-search", str(args.exh_search), "--exh-frame-cap", str(args.exh_frame_cap)]
@@ -252,6 +253,8 @@ def main():
     al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
     if args.general_kernel_only:
         al.set_knob(B.KNOB_GREEDY_FAST, 1)
+    if args.prepass:
+        al.set_knob(B.KNOB_GREEDY_PREPASS, 1)
     if args.debug_stop:
         al.set_knob(B.KNOB_DEBUG_STOP, args.debug_stop)
     if args.exh_first_pass_off:

@@ -34,6 +34,9 @@ struct BatchIO {
     const uint64_t* nmw;         // N-mask plane, same addressing; valid only for reads whose bit is set in hasn
     const uint32_t* hasn;        // bitmap: read holds an N
     const uint64_t* read_offs;   // n+1 base offsets of the reads (lengths; packed-plane addressing)
+    const uint8_t* ascii;        // greedy mode: the reads' characters in HBM -- the mapping kernels stage from them (no pre-pass, no planes); else nullptr
+    const uint32_t* ascii_src;   //   where read r's characters start when the reads lie scattered in a text (text route), else nullptr: at read_offs[r]
+    uint64_t ascii_bytes;        //   bytes of that buffer (a 32-byte load never reaches beyond it)
     uint2* results;              // n: x = path offset in the arena, y = path length | status << 24
     int32_t* arena;
     uint32_t* cursor;            // [0] ints used, [1] overflow flag; counters (5 x u64) start at cursor + 16

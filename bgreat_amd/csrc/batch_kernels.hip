@@ -13,56 +13,6 @@ namespace bgr {
 // the N mask for the few reads that hold an N (their bit is set in `hasn`, which the caller zeroes).  `lpr` lanes per
 // read (the batch's mean words per read, rounded up), 32 bases per lane and step.  ~150 B in + 40 B out per 150 bp read.
 
-// 4 ASCII bases (one dword, first base in the low byte; a zero byte = past the end) -> their 2-bit codes, one per byte.
-// On the alphabet the parser admits (ACGTN, aligner.cpp:56-61; either case): high bit = bit 2 of the character (G T N),
-// low bit = bit 4 (T) | bit 3 (N) | bit 1 & ~bit 2 (C): A0 C1 G2 T3 N3, and 0 for a zero byte.
-__device__ __forceinline__ uint32_t codes4(uint32_t x) {
-    const uint32_t lo = ((x >> 4) | (x >> 3) | ((x >> 1) & ~(x >> 2))) & 0x01010101u;
-    return ((x >> 1) & 0x02020202u) | lo;
-}
-// the four 2-bit fields of c (bytes 0..3, values 0..3) as one byte in bits 24..31, first base in the top two bits: the
-// partial products c << 30, c << 20, c << 10, c put b0 b1 b2 b3 at bits 30 28 26 24 and nothing else at or above bit 24
-__device__ __forceinline__ uint32_t gather4(uint32_t c) { return c * 0x40100401u; }
-// top bytes of four such products -> one dword, p0's first
-__device__ __forceinline__ uint32_t top_bytes(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
-    const uint32_t a = __builtin_amdgcn_perm(p0, p1, 0x07030000u);  // [p0.b3, p1.b3, -, -]
-    const uint32_t b = __builtin_amdgcn_perm(p2, p3, 0x07030000u);
-    return __builtin_amdgcn_perm(a, b, 0x07060302u);                // [a.b3, a.b2, b.b3, b.b2]
-}
-
-// 32 bases [32j, 32j+32) of a read as 8 dwords of ASCII (first base in the low byte of xs[0]), zero beyond the read's end
-__device__ __forceinline__ void load32(const uint8_t* rd, uint32_t L, uint32_t j, bool whole_in_buffer, uint32_t xs[8]) {
-    const uint32_t valid = L - 32 * j;  // >= 1
-    if (whole_in_buffer) {  // all 32 bytes lie inside the batch buffer: two (unaligned) 16-byte loads, bytes past the read masked off
-        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
-        const u32x4_unaligned v0 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j);
-        const u32x4_unaligned v1 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j + 16);
-        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
-        if (valid < 32) {
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const uint32_t lo = 4u * d;
-                if (valid <= lo) xs[d] = 0;
-                else if (valid < lo + 4) xs[d] &= 0xFFFFFFFFu >> (8 * (lo + 4 - valid));
-            }
-        }
-    } else {  // the batch's last bytes: never touch a byte past the buffer
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4u * d + e < valid) x |= (uint32_t)rd[32 * j + 4 * d + e] << (8 * e);
-            xs[d] = x;
-        }
-    }
-}
-__device__ __forceinline__ u64 pack_codes(const uint32_t c[8]) {
-    const uint32_t hi = top_bytes(gather4(c[0]), gather4(c[1]), gather4(c[2]), gather4(c[3]));
-    const uint32_t lo = top_bytes(gather4(c[4]), gather4(c[5]), gather4(c[6]), gather4(c[7]));
-    return (u64)hi << 32 | lo;
-}
-
 // (src_off: null = read r's characters start at reads + read_offs[r], the reads of a batch end to end; else at reads + src_off[r]:
 // reads scattered in a FASTA text, text_kernels.hip -- read_offs still numbers the bases of the batch and addresses the planes)
 __global__ void __launch_bounds__(256) bgr_pack_reads_kernel(const uint8_t* reads, const uint32_t* src_off, const u64* read_offs, uint32_t n, u64 total_bytes, u64* fw3,

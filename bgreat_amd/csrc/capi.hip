@@ -127,7 +127,7 @@ struct bgr_aligner {
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
     bool exh_filter = bgr::opt("exh_filter") != 0;  // exhaustive mode through the minimizer filter too (option exh_filter = 0: without)
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
-    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0, knob_memo_cap = 0;
+    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0, knob_memo_cap = 0, knob_prepass = 0;
     uint64_t knob_split_limit = 0;
     uint32_t knob_overlap = 0;      // BGR_KNOB_BATCH_OVERLAP
     bgr_aligner* twin = nullptr;    // second stream + buffers for the overlapped form of bgr_align_batch (created on first use)
@@ -537,6 +537,7 @@ int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
         case BGR_KNOB_GREEDY_FAST: if (value > 1) break; a->knob_greedy_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_EXH_FAST: if (value > 1) break; a->knob_exh_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_ANCHORS_FAST: if (value > 1) break; a->knob_anc_fast = (uint32_t)value; return BGR_OK;
+        case BGR_KNOB_GREEDY_PREPASS: if (value > 1) break; a->knob_prepass = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_EXH_MEMO_CAP: a->knob_memo_cap = (uint32_t)std::min<uint64_t>(value, 1u << 24); return BGR_OK;
         default: break;
     }
@@ -592,8 +593,9 @@ extern "C" int bgr_plan_launch(const bgr_plan_input* in, bgr_plan_output* out) {
 // The mapping launch of one batch: the geometry comes from plan_launch (launch_plan.h, a pure function of numbers), this function sizes the
 // buffers and enqueues.  planes_ready: the aligner's 2-bit planes (pk_fw3 / pk_nm / pk_hasn) already hold the batch
 // (bgr_align_batch_packed copied them in); else they are made from the ASCII reads at d_reads by the pre-pass.
+// d_src_off (may be null): where each read's characters start in d_reads when they lie scattered in a text (text route); reads_bytes: bytes of d_reads.
 static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
-                             uint64_t total_bases, uint32_t max_read_len, bool planes_ready) {
+                             uint64_t total_bases, uint32_t max_read_len, bool planes_ready, const void* d_src_off = nullptr, uint64_t reads_bytes = 0) {
     if (!a || !p) return fail(BGR_E_ARG, "bgr_align_device: null argument");
     if (p->mode > BGR_MODE_ANCHORS) return fail(BGR_E_ARG, "bgr_align_device: unknown mode");
     if (p->mode == BGR_MODE_ANCHORS && !a->graph->header.anc_n)
@@ -630,11 +632,20 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (x4_pass) { a->last_launch[0] = cfg_x4.blocks; a->last_launch[1] = cfg_x4.waves_per_block * 64; a->last_launch[2] = cfg_x4.lds_bytes; a->last_launch[3] = cfg_x4.stage_mphf | (level_search ? 2u : 0u) | 4u; }
     if (fast_pass) { a->last_launch[0] = cfg_fast.blocks; a->last_launch[1] = cfg_fast.waves_per_block * 64; a->last_launch[2] = cfg_fast.lds_bytes; a->last_launch[3] = cfg_fast.stage_mphf | 4u; }
 
-    // the reads as 2-bit planes (streaming pre-pass over the ASCII bytes; the mapping kernels only see the planes)
-    HIP_TRY(a->pk_fw3.ensure(P.plane_words * 8));
-    HIP_TRY(a->pk_nm.ensure(P.plane_words * 8));
-    HIP_TRY(a->pk_hasn.ensure((n_reads + 31) / 32 * 4 + 4));
+    // The reads as 2-bit planes: a streaming pre-pass over the ASCII bytes, the mapping kernels see the planes -- except in greedy mode behind its
+    // sixteen-reads-per-wave pass, where the mapping kernels stage their reads straight from the characters (round 5: the pre-pass was 11 % of a
+    // launch and existed only to write 40 B per read that the next kernel read back; BGR_KNOB_GREEDY_PREPASS 1 = the pre-pass as before)
+    const bool inline_pack = fast_pass && !planes_ready && d_reads && !a->knob_prepass;
+    if (!reads_bytes) reads_bytes = total_bases;  // (reads end to end: the buffer holds exactly their bases)
+    if (!inline_pack) {
+        HIP_TRY(a->pk_fw3.ensure(P.plane_words * 8));
+        HIP_TRY(a->pk_nm.ensure(P.plane_words * 8));
+        HIP_TRY(a->pk_hasn.ensure((n_reads + 31) / 32 * 4 + 4));
+    }
     bgr::BatchIO io;
+    io.ascii = inline_pack ? static_cast<const uint8_t*>(d_reads) : nullptr;
+    io.ascii_src = inline_pack ? static_cast<const uint32_t*>(d_src_off) : nullptr;
+    io.ascii_bytes = reads_bytes;
     io.fw3 = static_cast<const uint64_t*>(a->pk_fw3.p);
     io.nmw = static_cast<const uint64_t*>(a->pk_nm.p);
     io.hasn = static_cast<const uint32_t*>(a->pk_hasn.p);
@@ -711,10 +722,12 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     };
     HIP_TRY(hipEventRecord(a->ev[a->ev_used][0], a->stream));
     hipError_t e = hipSuccess;
-    if (!planes_ready) {
+    if (!planes_ready && !inline_pack) {
         HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, (n_reads + 31) / 32 * 4, a->stream));
-        e = bgr::launch_pack_reads(static_cast<const uint8_t*>(d_reads), io.read_offs, io.n_reads, total_bases, static_cast<uint64_t*>(a->pk_fw3.p),
-                                   static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
+        e = d_src_off ? bgr::launch_pack_reads_at(static_cast<const uint8_t*>(d_reads), static_cast<const uint32_t*>(d_src_off), io.read_offs, io.n_reads, reads_bytes, total_bases,
+                                                  static_cast<uint64_t*>(a->pk_fw3.p), static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream)
+                      : bgr::launch_pack_reads(static_cast<const uint8_t*>(d_reads), io.read_offs, io.n_reads, total_bases, static_cast<uint64_t*>(a->pk_fw3.p),
+                                               static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
         if (e != hipSuccess) return fail(BGR_E_HIP, std::string("pre-pass launch: ") + hipGetErrorString(e));
         HIP_TRY(mark("bgr_pack_reads_kernel"));
     }
@@ -1128,16 +1141,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         if (b->record_info_out) memset(b->record_info_out, 0, (size_t)R * 4);  // (nothing kept: every record a dropped one)
         return BGR_OK;
     }
-    // 3. planes, mapping launch
-    const uint64_t plane_words = (bases >> 5) + (uint64_t)n_acc + 4;
-    HIP_TRY(a->pk_fw3.ensure(plane_words * 8));
-    HIP_TRY(a->pk_nm.ensure(plane_words * 8));
-    HIP_TRY(a->pk_hasn.ensure(((uint64_t)n_acc + 31) / 32 * 4 + 4));
-    HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, ((uint64_t)n_acc + 31) / 32 * 4, a->stream));
-    e = bgr::launch_pack_reads_at(text, static_cast<const uint32_t*>(a->tx_accsrc.p), static_cast<const uint64_t*>(a->tx_offs.p), n_acc, nbytes, bases,
-                                  static_cast<uint64_t*>(a->pk_fw3.p), static_cast<uint64_t*>(a->pk_nm.p), static_cast<uint32_t*>(a->pk_hasn.p), a->stream);
-    if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text pack launch: ") + hipGetErrorString(e));
-    int rc = align_device_impl(a, p, nullptr, a->tx_offs.p, n_acc, bases, max_len, true);
+    // 3. the mapping launch, its reads where they lie in the text (planes by the pre-pass, or -- greedy mode -- staged by the mapping kernels themselves)
+    int rc = align_device_impl(a, p, text, a->tx_offs.p, n_acc, bases, max_len, false, a->tx_accsrc.p, nbytes);
     if (rc != BGR_OK) return rc;
     if (a->deep.open) {  // exhaustive mode: what is enqueued below reads the FINAL results (reads the last pass handed back are mapped first)
         rc = settle_launch_sync(a);
@@ -1300,7 +1305,7 @@ static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const cha
         bgr_aligner* tw = prev->twin;
         tw->cfg_waves = a->cfg_waves; tw->cfg_blocks_per_cu = a->cfg_blocks_per_cu; tw->cfg_lds_mphf = a->cfg_lds_mphf;
         tw->knob_frame_cap = a->knob_frame_cap; tw->knob_search = a->knob_search; tw->knob_debug_stop = a->knob_debug_stop;
-        tw->knob_greedy_fast = a->knob_greedy_fast; tw->knob_exh_fast = a->knob_exh_fast; tw->knob_anc_fast = a->knob_anc_fast;
+        tw->knob_greedy_fast = a->knob_greedy_fast; tw->knob_exh_fast = a->knob_exh_fast; tw->knob_anc_fast = a->knob_anc_fast; tw->knob_memo_cap = a->knob_memo_cap; tw->knob_prepass = a->knob_prepass;
         al[t] = tw;
     }
     uint64_t cut[kOverlapMaxPieces + 1];

@@ -224,6 +224,80 @@ __device__ __forceinline__ uint32_t half_handle(const BgrDeviceGraph& g, uint32_
     return canon == left ? h.y : h.x;
 }
 
+// ---- ASCII -> 2-bit codes (the pre-pass bgr_pack_reads_kernel, and -- greedy mode -- the mapping kernels themselves, which stage their reads
+// straight from the characters: no planes written and read back) --------------------------------------------------------------------------
+// 4 ASCII bases (one dword, first base in the low byte; a zero byte = past the end) -> their 2-bit codes, one per byte.
+// On the alphabet the parser admits (ACGTN, aligner.cpp:56-61; either case): high bit = bit 2 of the character (G T N),
+// low bit = bit 4 (T) | bit 3 (N) | bit 1 & ~bit 2 (C): A0 C1 G2 T3 N3, and 0 for a zero byte.
+// (round 5: as a table lookup -- bits 1..3 of a character number it 0..7 (A 0, C 1, T 2, G 3, N 7, either case) and v_perm_b32 picks the four codes out
+// of an 8-byte table in one instruction: 3 instructions per dword instead of 7 of bit logic; a zero byte picks entry 0 = code 0, as before)
+__device__ __forceinline__ uint32_t codes4(uint32_t x) {
+    const uint32_t sel = (x >> 1) & 0x07070707u;
+    return __builtin_amdgcn_perm(0x03030303u, 0x02030100u, sel);  // bytes 0..3 of the second operand = entries 0..3 (A C T G), 4..7 of the first (3: N and the rest)
+}
+// the four 2-bit fields of c (bytes 0..3, values 0..3) as one byte in bits 24..31, first base in the top two bits: the
+// partial products c << 30, c << 20, c << 10, c put b0 b1 b2 b3 at bits 30 28 26 24 and nothing else at or above bit 24
+__device__ __forceinline__ uint32_t gather4(uint32_t c) { return c * 0x40100401u; }
+// top bytes of four such products -> one dword, p0's first
+__device__ __forceinline__ uint32_t top_bytes(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+    const uint32_t a = __builtin_amdgcn_perm(p0, p1, 0x07030000u);  // [p0.b3, p1.b3, -, -]
+    const uint32_t b = __builtin_amdgcn_perm(p2, p3, 0x07030000u);
+    return __builtin_amdgcn_perm(a, b, 0x07060302u);                // [a.b3, a.b2, b.b3, b.b2]
+}
+
+// 32 bases [32j, 32j+32) of a read as 8 dwords of ASCII (first base in the low byte of xs[0]), zero beyond the read's end
+__device__ __forceinline__ void load32(const uint8_t* rd, uint32_t L, uint32_t j, bool whole_in_buffer, uint32_t xs[8]) {
+    const uint32_t valid = L - 32 * j;  // >= 1
+    if (whole_in_buffer) {  // all 32 bytes lie inside the batch buffer: two (unaligned) 16-byte loads, bytes past the read masked off
+        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
+        const u32x4_unaligned v0 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j);
+        const u32x4_unaligned v1 = *reinterpret_cast<const u32x4_unaligned*>(rd + 32 * j + 16);
+        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+        if (valid < 32) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t lo = 4u * d;
+                if (valid <= lo) xs[d] = 0;
+                else if (valid < lo + 4) xs[d] &= 0xFFFFFFFFu >> (8 * (lo + 4 - valid));
+            }
+        }
+    } else {  // the batch's last bytes: never touch a byte past the buffer
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4u * d + e < valid) x |= (uint32_t)rd[32 * j + 4 * d + e] << (8 * e);
+            xs[d] = x;
+        }
+    }
+}
+__device__ __forceinline__ u64 pack_codes(const uint32_t c[8]) {
+    const uint32_t hi = top_bytes(gather4(c[0]), gather4(c[1]), gather4(c[2]), gather4(c[3]));
+    const uint32_t lo = top_bytes(gather4(c[4]), gather4(c[5]), gather4(c[6]), gather4(c[7]));
+    return (u64)hi << 32 | lo;
+}
+
+// 32 bases from byte `start` of the batch's characters (`valid` <= 32 of them belong to the read) as one word, first base most significant, zero
+// beyond `valid`; *chars |= every character seen (bit 3 of a character is set for N only, of the alphabet getReads admits)
+__device__ __forceinline__ u64 ascii_word(const uint8_t* reads, u64 start, uint32_t valid, u64 total_bytes, uint32_t* chars) {
+    uint32_t xs[8], c[8];
+    load32(reads + start, valid, 0, start + 32 <= total_bytes, xs);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { c[d] = codes4(xs[d]); *chars |= xs[d]; }
+    return pack_codes(c);
+}
+// ... and their N mask (3 on every N)
+__device__ __forceinline__ u64 ascii_nmask_word(const uint8_t* reads, u64 start, uint32_t valid, u64 total_bytes) {
+    uint32_t xs[8], c[8];
+    load32(reads + start, valid, 0, start + 32 <= total_bytes, xs);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) c[d] = ((xs[d] >> 3) & 0x01010101u) * 3u;
+    return pack_codes(c);
+}
+// where read r's characters start: the reads of a batch lie end to end (read_offs), or scattered in a FASTA text (ascii_src, text_kernels.hip)
+__device__ __forceinline__ u64 ascii_start(const BatchIO& io, uint32_t r, u64 off) { return io.ascii_src ? (u64)io.ascii_src[r] : off; }
+
 // ---- stage A: the read's 2-bit words, from the planes the pre-pass (bgr_pack_reads_kernel) or the host packer wrote ----
 // FW3: str2num codes (N->3).  NM: 3 on every N.  RCW: reverseComplements(read) (utils.cpp:66-73, non-ACG -> 'A').
 // FWQ: what the rolling `num` of getNOverlap/getListOverlap holds: str2num codes inside the first window,
@@ -234,6 +308,16 @@ __device__ __forceinline__ uint32_t half_handle(const BgrDeviceGraph& g, uint32_
 __device__ __forceinline__ uint32_t packed_word_offset(u64 off, uint32_t r) { return (uint32_t)(off >> 5) + r; }
 
 __device__ __forceinline__ bool load_packed(const BatchIO& io, uint32_t r, u64 off, uint32_t L, uint32_t W, u64* FW3, u64* NM, int lane) {
+    if (io.ascii) {  // no planes: the words straight from the read's characters (greedy mode: the launch has no pre-pass)
+        const uint32_t Wr = (L + 31) >> 5;
+        const u64 s0 = ascii_start(io, r, off);
+        uint32_t chars = 0;
+        for (uint32_t j = lane; j < W; j += 64) FW3[j] = j < Wr ? ascii_word(io.ascii, s0 + 32ull * j, L - 32 * j, io.ascii_bytes, &chars) : 0;
+        const bool hasN = wave_any((chars & 0x08080808u) != 0);
+        for (uint32_t j = lane; j < W; j += 64) NM[j] = (hasN && j < Wr) ? ascii_nmask_word(io.ascii, s0 + 32ull * j, L - 32 * j, io.ascii_bytes) : 0;
+        wave_sync();
+        return hasN;
+    }
     const uint32_t woff = packed_word_offset(off, r), Wr = (L + 31) >> 5;
     const bool hasN = (io.hasn[r >> 5] >> (r & 31)) & 1u;
     for (uint32_t j = lane; j < W; j += 64) {

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #define G4_ST_POS_MASK 0xFFFFFu
 
 // GL = lanes per read (kG4GroupLanes, align_kernels.h): 16 = four reads per wave, 8 = eight, 4 = sixteen.
-template <bool STAGE, int GL>
+template <bool STAGE, int GL, bool ASCII>
 __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kernel(BgrDeviceGraph g, BatchIO io, KernelParams prm) {
     constexpr uint32_t RPW = 64 / GL;  // reads per wave
     extern __shared__ u64 lds[];
@@ -235,18 +235,30 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         {   // stage the item's 2-bit words: the lanes of a group bring the words of its read -- or of reverseComplements(read)
             // (utils.cpp:66-73), word j of which is the reversed complement of bases [L - 32 (j + 1), L - 32 j)
             const u64* src = io.fw3;
+            u64 a0 = 0;  // (ASCII staging: where the read's characters start)
             if (r != BGR_NONE) {
                 const u64 off = io.read_offs[r];
                 L = (uint32_t)(io.read_offs[r + 1] - off);
-                act = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
+                act = ASCII ? 1u : ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;  // a read with an N goes to the general kernel
                 if (((L + 31) >> 5) >= W) act = 0;               // so does a read too long for one lane per word (a batch of mixed lengths)
-                src += packed_word_offset(off, r);
+                if (ASCII) a0 = ascii_start(io, r, off);
+                else src += packed_word_offset(off, r);
             }
             const uint32_t Wr = (L + 31) >> 5;
+            uint32_t chars = 0;
             for (uint32_t j = sub; j < W; j += GL) {
                 u64 f = 0;
                 if (act && j < Wr) {
-                    if (!(st >> 31)) f = src[j];
+                    if (ASCII) {
+                        // no pre-pass, no planes: the words straight from the characters (a launch handed ASCII reads: 150 B in instead of 40 B of planes
+                        // that a pre-pass wrote and this kernel read back; ~11 vector instructions per read)
+                        if (!(st >> 31)) f = ascii_word(io.ascii, a0 + 32ull * j, L - 32 * j, io.ascii_bytes, &chars);
+                        else {
+                            const int32_t p = (int32_t)L - 32 * ((int32_t)j + 1);
+                            if (p >= 0) f = ~rev2_fast(ascii_word(io.ascii, a0 + (uint32_t)p, 32, io.ascii_bytes, &chars));
+                            else { const uint32_t v = (uint32_t)(32 + p); f = (~rev2_fast(ascii_word(io.ascii, a0, v, io.ascii_bytes, &chars) >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
+                        }
+                    } else if (!(st >> 31)) f = src[j];
                     else {
                         const int32_t p = (int32_t)L - 32 * ((int32_t)j + 1);
                         if (p >= 0) f = ~rev2_fast(win32(src, (u64)(uint32_t)p));
@@ -254,6 +266,14 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                     }
                 }
                 F[j] = f;
+            }
+            if (ASCII) {  // an N anywhere in the read (bit 3 of a character): the general kernel
+                uint32_t n8 = chars & 0x08080808u;
+                n8 |= quad_xor1(n8);
+                if (GL >= 4) n8 |= quad_xor2(n8);
+                if (GL >= 8) n8 |= half_row_mirror(n8);
+                if (GL == 16) n8 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)n8, 0x140, 0xF, 0xF, true);  // row_mirror
+                if (n8) act = 0;
             }
         }
         wave_sync();
@@ -438,13 +458,17 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
 
 hipError_t launch_greedy(const BgrDeviceGraph& g, const BatchIO& io, const KernelParams& p, const LaunchCfg& cfg, hipStream_t stream) {
     constexpr int GL = (int)kG4GroupLanes;
-    if (io.greedy_multi) return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, GL>, g, io, p, cfg, stream)
-                                               : launch_one(bgr_align_greedy_multi_kernel<false, GL>, g, io, p, cfg, stream);
+    if (io.greedy_multi) {
+        if (io.ascii) return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, GL, true>, g, io, p, cfg, stream)
+                                            : launch_one(bgr_align_greedy_multi_kernel<false, GL, true>, g, io, p, cfg, stream);
+        return cfg.stage_mphf ? launch_one(bgr_align_greedy_multi_kernel<true, GL, false>, g, io, p, cfg, stream)
+                              : launch_one(bgr_align_greedy_multi_kernel<false, GL, false>, g, io, p, cfg, stream);
+    }
     return cfg.stage_mphf ? launch_one(bgr_align_greedy_kernel<true>, g, io, p, cfg, stream)
                           : launch_one(bgr_align_greedy_kernel<false>, g, io, p, cfg, stream);
 }
 const void* greedy_kernel_fn(bool many_reads) {
-    return many_reads ? reinterpret_cast<const void*>(&bgr_align_greedy_multi_kernel<true, (int)kG4GroupLanes>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
+    return many_reads ? reinterpret_cast<const void*>(&bgr_align_greedy_multi_kernel<true, (int)kG4GroupLanes, true>) : reinterpret_cast<const void*>(&bgr_align_greedy_kernel<true>);
 }
 
 }  // namespace bgr
