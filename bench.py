@@ -96,6 +96,9 @@ def parse_args():
                                                                 "and 2 M reads of configs[4] through bin/bgreat and through the compiled reference (-t cpu-threads); sorted record "
                                                                 "multisets + counters; the report goes to gpurun_out/full_parity.txt, the verdict into the line (full_parity, config.full_parity_*)")
     ap.add_argument("--full-parity-scale", type=float, default=1.0, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true", help="no device: the launcher / rendezvous / collective / line-assembly path of an N-rank run on stand-in devices (gloo; the index is "
+                                                            "built for real on rank 0 and broadcast, a step sleeps): `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --dry-run` "
+                                                            "walks exactly the argument path the driver uses for --gpus 8 on a box without eight GPUs; the line says dry_run and carries no value")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--debug-stop", type=int, default=0, help="diagnostic builds of the library only (-DBGR_PHASE_TIMING, loaded through BGR_LIB_PATH): "
                                                               "1 = the mapping kernel stops behind the staging of the reads, 2 = behind the anchor scan")
@@ -183,6 +186,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if args.dry_run:
+        return dry_run(args, mode, world, rank, local_rank)
     pmc = None
     if not args.pmc_child and not args.no_pmc and world == 1:
         # child processes; this process has not initialised the GPU yet.  Never nested inside another profiler run.
@@ -243,11 +248,39 @@ def main():
         dist.all_reduce(ones)                 # (also brings the communicator up before the broadcast is timed)
         torch.cuda.synchronize()
         tb0 = time.perf_counter()
-        g, _blob_keepalive = D.broadcast_graph(g, dist, device=coll_dev)  # C1: the only data-path collective; reads never move
-        torch.cuda.synchronize()
+        # C1: the only data-path collective; reads never move.  First contact with RCCL between real devices happens HERE: if the broadcast raises, every
+        # rank builds the index itself from the same seed (the blob does not depend on the thread count: same bytes) and the line says so.
+        bc_form, bc_err = "torch.distributed broadcast over %s, adopted in place" % ("gloo (rehearsal)" if rehearsal else "RCCL"), None
+        try:
+            g, _blob_keepalive = D.broadcast_graph(g, dist, device=coll_dev)
+            torch.cuda.synchronize()
+        except Exception as ex:
+            bc_err = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+            log("bench.py rank %d: graph broadcast failed (%s): building the index on this rank" % (rank, bc_err))
+            if rank != 0:
+                seqs, offs = syn.unitigs()
+                g = B.Graph.build(args.k, seqs, offs, args.gamma, anchors=(mode == 2))
+            bc_form = "FAILED (%s): every rank built the index itself from the same unitigs" % bc_err
         bc_ms = (time.perf_counter() - tb0) * 1e3
-        multi = {"backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "ranks_seen": int(ones.item()), "graph_broadcast_bytes": int(g.info()["blob_bytes"]),
+        # who took part: device, bus id and host of every rank; the RCCL the process group runs on
+        who = None
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            mine = {"rank": rank, "local_rank": local_rank, "device": dev, "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None), "host": os.uname().nodename,
+                    "blob_bytes": int(g.info()["blob_bytes"])}
+            who = [None] * world
+            dist.all_gather_object(who, mine)
+        except Exception as ex:
+            who = "all_gather_object failed: %s" % type(ex).__name__
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if not rehearsal else None
+        except Exception:
+            rccl_version = None
+        multi = {"backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "rccl_version": rccl_version, "ranks_seen": int(ones.item()),
+                 "graph_broadcast_form": bc_form, "graph_broadcast_bytes": int(g.info()["blob_bytes"]),
                  "graph_broadcast_ms": round(bc_ms, 2), "graph_broadcast_GB_per_s": round(g.info()["blob_bytes"] / max(bc_ms, 1e-6) / 1e6, 2),
+                 "ranks": who,
+                 "blob_bytes_equal_on_all_ranks": (len({w["blob_bytes"] for w in who}) == 1) if isinstance(who, list) and all(isinstance(w, dict) for w in who) else None,
                  "what": "one process per GPU (torch.distributed): all-reduce of ones = ranks that took part; C1 = rank 0's blob to every rank's HBM, adopted in place"}
     al = B.Aligner(g, dev)
     al.configure(args.waves, args.blocks_per_cu, args.lds_mphf)
@@ -499,6 +532,69 @@ def main():
     guard.finish(line, dist)
 
 
+def dry_run(args, mode, world, rank, local_rank):
+    """bench.py --dry-run: everything around the device work of an N-rank run, on stand-in devices -- environment of torch.distributed.run, process group
+    (gloo), the all-reduce of ones, C1 (the real blob of the real index, through bgreat_amd.dist.broadcast_graph's CPU form), barriers around a timed region
+    whose steps sleep, max over ranks, C2, the LineGuard, one JSON line on rank 0 (value null: nothing was mapped)."""
+    import torch
+    import torch.distributed as dist
+    import bgreat_amd as B
+    from bgreat_amd import dist as D
+    from tools.synth import Synth
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    K, W, R, L = args.steps, args.warmup, args.reads_per_step, args.read_len
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    syn = Synth(min(args.genome, 300_000), args.site_spacing, args.alleles, args.k, 20261003)
+    g = None
+    if rank == 0:
+        seqs, offs = syn.unitigs()
+        g = B.Graph.build(args.k, seqs, offs, args.gamma)
+    multi = None
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(ones)
+        tb0 = time.perf_counter()
+        g, _keep = D.broadcast_graph(g, dist, device=None)
+        bc_ms = (time.perf_counter() - tb0) * 1e3
+        who = [None] * world
+        dist.all_gather_object(who, {"rank": rank, "local_rank": local_rank, "host": os.uname().nodename, "blob_bytes": int(g.info()["blob_bytes"])})
+        multi = {"backend": "gloo (dry run, stand-in devices)", "ranks_seen": int(ones.item()), "graph_broadcast_form": "torch.distributed broadcast over gloo (CPU tensors), re-wrapped with bgr_graph_from_blob",
+                 "graph_broadcast_bytes": int(g.info()["blob_bytes"]), "graph_broadcast_ms": round(bc_ms, 2), "ranks": who, "blob_bytes_equal_on_all_ranks": len({w["blob_bytes"] for w in who}) == 1}
+    guard = LineGuard(rank, float(os.environ.get("BGR_BENCH_DEADLINE", "120")))
+    for _ in range(W):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t_start = time.perf_counter()
+    for _ in range(K):
+        time.sleep(0.001 * (1 + rank % 2))   # (ranks differ: the line must carry the MAX over ranks)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        elapsed = D.max_over_ranks(elapsed, dist, device=None)
+        counters = D.reduce_counters({"reads": K * R}, dist, device=None)
+    else:
+        counters = {"reads": K * R}
+    line = None
+    if rank == 0:
+        line = {"metric": "Mreads/s aligned (k=%d, %dbp, m=%d)" % (args.k, L, args.mismatch), "value": None, "unit": "Mreads/s", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": round(elapsed / max(1, K) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "dry_run": "no device was used: launcher, rendezvous, collectives and line assembly of a %d-rank run on stand-in devices; steps slept" % world,
+                "config": {"workload": "dry run", "reads_per_step_per_gpu": R, "read_len": L, "parallelism": "reads sharded over %d rank(s); graph blob broadcast once" % world},
+                "roofline": None, "cpu_baseline": None, "multi_gpu": multi, "counters": counters}
+    guard.arm(line)
+    if rank != 0:
+        guard.leave(dist if world > 1 else None)
+        return
+    guard.finish(line, dist if world > 1 else None)
+
+
 TEMP_DIRS = set()   # scratch directories of the legs in flight (tens of GB at default sizes): removed on every way out, the deadline's os._exit included
 
 
@@ -530,9 +626,12 @@ def scalar_copies(line):
         if isinstance(one, dict) and one.get("value") is not None:
             cfg["one_process_all_gpus_mreads"] = one.get("value")
             cfg["one_process_fanout_method"] = one.get("fanout_method")
+            cfg["one_process_fanout_ms"] = one.get("fanout_ms")
+            for nm, rec in (one.get("fanout_both_ways") or {}).items():
+                cfg["one_process_fanout_%s_ms" % nm] = rec.get("ms") if isinstance(rec, dict) else None
         mg = line.get("multi_gpu") or {}
         if isinstance(mg, dict):
-            for k in ("backend", "ranks_seen", "broadcast_bytes", "broadcast_ms", "broadcast_gbps", "rccl_version", "broadcast_form"):
+            for k in ("backend", "ranks_seen", "rccl_version", "graph_broadcast_form", "graph_broadcast_bytes", "graph_broadcast_ms", "graph_broadcast_GB_per_s", "blob_bytes_equal_on_all_ranks"):
                 if mg.get(k) is not None and isinstance(mg.get(k), (bool, int, float, str)):
                     cfg["multi_gpu_%s" % k] = mg[k]
     if isinstance(roof, dict):
@@ -966,6 +1065,22 @@ def run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, reh
             time.sleep(1e6)
         n_dev = max(1, min(world, B.device_count(), torch.cuda.device_count()))
         K, W, R, L = min(args.steps, 4), 1, args.reads_per_step, args.read_len
+        # C1 of the one-process form, BOTH ways on graphs of their own (the same blob bytes): one RCCL broadcast through ncclCommInitAll
+        # communicators, and xGMI peer copies in a doubling schedule; then the measured run on whatever BGR_FANOUT_AUTO picks (RCCL, else peer copies)
+        fan_both = {}
+        if n_dev > 1:
+            for name, how_id in (("rccl_broadcast", 1), ("peer_copies", 2)):
+                try:
+                    g2 = B.Graph.from_blob(np.array(g.blob())) if g.blob() is not None and len(g.blob()) else None
+                    if g2 is None:
+                        fan_both[name] = {"error": "this rank's graph has no host blob (adopted from a device blob)"}
+                        continue
+                    tq = time.perf_counter()
+                    g2.devices_init(0, n_dev, how_id)
+                    fan_both[name] = {"ms": round((time.perf_counter() - tq) * 1e3, 2), "includes": "host -> first device upload, allocation on every device, the copies"}
+                    g2.close()
+                except Exception as ex:
+                    fan_both[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
         t0 = time.perf_counter()
         how = g.devices_init(0, n_dev, 0)
         fan_ms = (time.perf_counter() - t0) * 1e3
@@ -1025,7 +1140,7 @@ def run_one_process_all_gpus(args, B, g, syn, world, mode, seed_reads, ncpu, reh
             return {"error": "; ".join(errs) or "barrier broken"}
         return {"value": round(n_dev * K * R / wall / 1e6, 3), "unit": "Mreads/s", "n_gpus": n_dev, "steps": K, "reads_per_step_per_gpu": R, "ms_per_step": round(wall / K * 1e3, 4),
                 "fanout_method": {0: "none (one device)", 1: "rccl broadcast (ncclCommInitAll)", 2: "peer copies, doubling schedule"}.get(how, str(how)),
-                "fanout_ms": round(fan_ms, 2), "graph_blob_bytes": int(g.info()["blob_bytes"]), "rehearsal_devices_shared": bool(rehearsal),
+                "fanout_ms": round(fan_ms, 2), "fanout_both_ways": fan_both, "graph_blob_bytes": int(g.info()["blob_bytes"]), "rehearsal_devices_shared": bool(rehearsal),
                 "reads_mapped_per_device": [c["reads"] for c in counters],
                 "what": "bgr_devices_init + one bgr_aligner and one host thread per device in ONE process, batches resident in each device's HBM (bgr_device_alloc), "
                         "wall time from a common start barrier to the last device's sync"}

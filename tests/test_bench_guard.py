@@ -46,3 +46,23 @@ def test_a_finished_line_is_printed_once():
     assert p.returncode == 0
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["e2e"] == {"value": 2.0} and "incomplete" not in lines[0]
+
+
+def test_dry_run_of_the_eight_rank_command_line_the_driver_uses():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`
+    with --dry-run: no device, stand-in ranks over gloo -- rendezvous, the all-reduce of ones, C1 with the real blob (every rank ends up with the
+    same bytes), barriers, max over ranks, C2, the guard, ONE line on rank 0."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--dry-run"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] is None and "dry_run" in d
+    m = d["multi_gpu"]
+    assert m["ranks_seen"] == 8 and m["blob_bytes_equal_on_all_ranks"] is True and sorted(r["rank"] for r in m["ranks"]) == list(range(8))
+    assert d["counters"]["reads"] == 8 * 4 * d["config"]["reads_per_step_per_gpu"]
+    assert d["config"]["multi_gpu_ranks_seen"] == 8      # (the scalar copies the driver's record keeps)
