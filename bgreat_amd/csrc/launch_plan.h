@@ -76,6 +76,8 @@ struct PlanGeometry {
         bool stage = false;
         if (allow_tuning && (t.cfg_waves || t.cfg_blocks_per_cu)) {  // explicit tuning through bgr_aligner_configure
             stage = allow_stage && mode != BGR_MODE_ANCHORS && (t.cfg_lds_mphf == 2 || (t.cfg_lds_mphf == 0 && fits(1, 1, true, pw)));
+            if (stage && !fits(1, 1, true, pw)) stage = false;  // (staging asked for a table no CU can hold next to one wave: probed in L2, at the waves asked for -- the
+                                                                // loops below would otherwise shrink the workgroup to one wave first: 0.06 of the rate, tools/geometry_sweep.py)
             waves = t.cfg_waves ? t.cfg_waves : (stage ? 12 : 4);
             bpc = t.cfg_blocks_per_cu ? t.cfg_blocks_per_cu : std::max<uint32_t>(1, cap / waves);
             while (bpc > 1 && !fits(bpc, waves, stage, pw)) --bpc;

@@ -71,6 +71,9 @@ def test_explicit_tuning_is_honoured_or_shrunk_to_fit():
                 check(p, table_bytes)
                 if stage == 1 or mode == B.MODE_ANCHORS or table_bytes > LDS:
                     assert not any(v["table_staged"] for v in p.values() if isinstance(v, dict))
+                if table_bytes > LDS and waves:   # staging asked for a table no CU can hold: the workgroup keeps the waves asked for (it used to shrink to one wave)
+                    q = p["greedy16"] if mode == B.MODE_GREEDY else p["exhaustive8"] if mode == B.MODE_EXHAUSTIVE else p["anchors4"]
+                    assert q["waves_per_block"] == min(waves, 16) or q["lds_bytes"] > LDS // 2, (waves, bpc, stage, table_bytes, q)
 
 
 def test_smaller_devices():
