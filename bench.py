@@ -387,11 +387,12 @@ def main():
         path_ints = float(len(p1)) / ns                     # per read, from the parity sample's paths
         items = float(pass_counts[0]) / R if mode == 0 else 0.0
         words = (L + 31) // 32
+        has_prepass = any(nm.startswith("bgr_pack_reads_kernel") for nm, _ in slots)   # (greedy mode since round 5: the mapping kernels stage from the characters themselves)
         own = {
-            "bgr_pack_reads_kernel": {"ascii_in": L, "offsets_in": 8, "planes_out": 8 * words, "hasn_out": 0.125},
-            "mapping": {"planes_in": 8 * words * (1.0 + items), "offsets_in": 8 * (1.0 + items), "hasn_in": 0.125, "results_out": 8, "path_ints_out": 4 * path_ints,
-                        "retry_queue_rw": 16 * items, "graph_blob_once_per_launch": blob_bytes / R},
+            "bgr_pack_reads_kernel": {"ascii_in": L, "offsets_in": 8, "planes_out": 8 * words, "hasn_out": 0.125} if has_prepass else {},
+            "mapping": ({"planes_in": 8 * words * (1.0 + items), "hasn_in": 0.125} if has_prepass else {"ascii_in": L * (1.0 + items)}),
         }
+        own["mapping"].update({"offsets_in": 8 * (1.0 + items), "results_out": 8, "path_ints_out": 4 * path_ints, "retry_queue_rw": 16 * items, "graph_blob_once_per_launch": blob_bytes / R})
         own_pack = sum(own["bgr_pack_reads_kernel"].values())
         own_map = sum(own["mapping"].values())
         dom_own = own_pack if (dom_short or "").startswith("bgr_pack") else own_map

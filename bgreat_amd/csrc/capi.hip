@@ -1111,7 +1111,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     // text (a sequencing read with its header is several times that): a piece with more record starts goes to the host parser.
     const uint32_t R_cap = nbytes / 24 + 1024;
     // (scratch: the marking kernel's tile sums, then room for the scans)
-    HIP_TRY(a->tx_sums.ensure(((uint64_t)bgr::text_tiles(nbytes) + bgr::scan_tiles(R_cap) + 16) * 4));
+    HIP_TRY(a->tx_sums.ensure(((uint64_t)bgr::text_tiles(nbytes) + 2 * bgr::scan_tiles(R_cap) + 16) * 4));
     for (DevBuf* d : {&a->tx_start, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff})
         HIP_TRY(d->ensure(((uint64_t)R_cap + 4) * 4));
     HIP_TRY(a->tx_rec.ensure(((uint64_t)R_cap + 1) * 16));
@@ -1120,8 +1120,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     hipError_t e = bgr::launch_text_mark(text, nbytes, rec_lines, static_cast<uint32_t*>(a->tx_sums.p), static_cast<uint32_t*>(a->tx_start.p), R_cap, info + TXT_INFO_N_REC, a->stream);
     if (e == hipSuccess) e = bgr::launch_text_records(text, nbytes, b->fastq != 0, static_cast<const uint32_t*>(a->tx_start.p), info + TXT_INFO_N_REC, R_cap, a->dg.k, static_cast<uint4*>(a->tx_rec.p),
                                                       static_cast<uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_len.p), info, a->stream);
-    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_idx.p), R_cap, sums2, info + TXT_INFO_N_ACC, a->stream);
-    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_len.p), static_cast<uint32_t*>(a->tx_boff.p), R_cap, sums2, info + TXT_INFO_BASES, a->stream);
+    if (e == hipSuccess) e = bgr::launch_scan2_u32(static_cast<const uint32_t*>(a->tx_flag.p), static_cast<const uint32_t*>(a->tx_len.p), static_cast<uint32_t*>(a->tx_idx.p),
+                                                   static_cast<uint32_t*>(a->tx_boff.p), R_cap, info + TXT_INFO_N_REC, sums2, info + TXT_INFO_N_ACC, info + TXT_INFO_BASES, a->stream);
     if (e == hipSuccess) e = bgr::launch_text_compact(static_cast<const uint4*>(a->tx_rec.p), info + TXT_INFO_N_REC, R_cap, static_cast<const uint32_t*>(a->tx_idx.p),
                                                       static_cast<const uint32_t*>(a->tx_boff.p), static_cast<uint32_t*>(a->tx_accrec.p), static_cast<uint32_t*>(a->tx_accsrc.p),
                                                       static_cast<uint64_t*>(a->tx_offs.p), info + TXT_INFO_N_ACC, info + TXT_INFO_BASES, a->stream);
@@ -1172,8 +1172,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     } else
     e = bgr::launch_text_sizes(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
                                static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, static_cast<uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_nsz.p), a->stream);
-    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_poff.p), n_acc, sums2, info + TXT_INFO_PBYTES, a->stream);
-    if (e == hipSuccess) e = bgr::launch_scan_u32(static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_noff.p), n_acc, sums2, info + TXT_INFO_NBYTES, a->stream);
+    if (e == hipSuccess) e = bgr::launch_scan2_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_poff.p),
+                                                   static_cast<uint32_t*>(a->tx_noff.p), n_acc, nullptr, sums2, info + TXT_INFO_PBYTES, info + TXT_INFO_NBYTES, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text size launches: ") + hipGetErrorString(e));
     uint32_t h2[16];
     HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));

@@ -22,6 +22,9 @@ namespace bgr {
 
 // exclusive scan of n u32 (out may alias in); sums: scan_tiles(n) words of scratch; *total_out = the sum
 hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, uint32_t* total_out, hipStream_t stream);
+// ... of two arrays of equal length at once, over their first min(n, *n_dev) entries (n_dev: a count on the device, or null); sums: 2 * scan_tiles(n) words
+hipError_t launch_scan2_u32(const uint32_t* inA, const uint32_t* inB, uint32_t* outA, uint32_t* outB, uint32_t n, const uint32_t* n_dev, uint32_t* sums, uint32_t* totalA,
+                            uint32_t* totalB, hipStream_t stream);
 uint32_t scan_tiles(uint32_t n);
 uint32_t text_tiles(uint32_t bytes);
 // record starts: *n_rec_out and rec_start[0 .. min(*n_rec_out, rec_cap)) (sums: text_tiles(n) words of scratch)

@@ -84,6 +84,62 @@ __global__ void __launch_bounds__(kTxtThreads) bgr_scan_apply(const uint32_t* in
     }
 }
 
+// ---- the same for TWO arrays of equal length in one go, over the first min(n, *n_dev) entries (n_dev may be null) -------------------------
+// (round 5: the text form scanned four arrays per piece with three launches each, over all rec_cap entries of arrays of which a sixth is used --
+// the record count is only known on the device; now two pairs, and workgroups beyond the count leave at once)
+__global__ void __launch_bounds__(kTxtThreads) bgr_scan2_block_sums(const uint32_t* inA, const uint32_t* inB, uint32_t n, const uint32_t* n_dev, uint32_t* sums, uint32_t nb) {
+    __shared__ uint32_t lw[16];
+    if (n_dev && *n_dev < n) n = *n_dev;
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    if (blockIdx.x * kScanTile >= n) { if (threadIdx.x == 0) { sums[blockIdx.x] = 0; sums[nb + blockIdx.x] = 0; } return; }
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanItems; ++j) if (base + j < n) { a += inA[base + j]; b += inB[base + j]; }
+    uint32_t ta, tb;
+    (void)block_exclusive_scan32(a, lw, &ta);
+    (void)block_exclusive_scan32(b, lw, &tb);
+    if (threadIdx.x == 0) { sums[blockIdx.x] = ta; sums[nb + blockIdx.x] = tb; }
+}
+__global__ void __launch_bounds__(kTxtThreads) bgr_scan2_sums(uint32_t* sums, uint32_t nb, uint32_t* totalA, uint32_t* totalB) {
+    __shared__ uint32_t lw[16];
+    __shared__ uint32_t carry_s[2];
+    if (threadIdx.x < 2) carry_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t half = 0; half < 2; ++half) {
+        uint32_t* S = sums + half * nb;
+        for (uint32_t b0 = 0; b0 < nb; b0 += kTxtThreads) {
+            const uint32_t i = b0 + threadIdx.x;
+            const uint32_t v = i < nb ? S[i] : 0;
+            uint32_t total;
+            const uint32_t ex = block_exclusive_scan32(v, lw, &total);
+            const uint32_t carry = carry_s[half];
+            if (i < nb) S[i] = carry + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) carry_s[half] = carry + total;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) { *totalA = carry_s[0]; *totalB = carry_s[1]; }
+}
+__global__ void __launch_bounds__(kTxtThreads) bgr_scan2_apply(const uint32_t* inA, const uint32_t* inB, uint32_t n, const uint32_t* n_dev, const uint32_t* sums, uint32_t nb,
+                                                               uint32_t* outA, uint32_t* outB) {
+    __shared__ uint32_t lw[16];
+    if (n_dev && *n_dev < n) n = *n_dev;
+    if (blockIdx.x * kScanTile >= n) return;
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t va[kScanItems], vb[kScanItems], a = 0, b = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanItems; ++j) { va[j] = base + j < n ? inA[base + j] : 0; vb[j] = base + j < n ? inB[base + j] : 0; a += va[j]; b += vb[j]; }
+    uint32_t total;
+    uint32_t wa = sums[blockIdx.x] + block_exclusive_scan32(a, lw, &total);
+    uint32_t wb = sums[nb + blockIdx.x] + block_exclusive_scan32(b, lw, &total);
+#pragma unroll
+    for (uint32_t j = 0; j < kScanItems; ++j) {
+        if (base + j < n) { outA[base + j] = wa; outB[base + j] = wb; }
+        wa += va[j]; wb += vb[j];
+    }
+}
+
 // ---- record starts: a '>' at the start of a line ---------------------------------------------------------------------------
 // bit 7 of every byte of x that equals the byte replicated in `pat`
 __device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t pat) { return bgr_zero_bytes(x ^ pat); }
@@ -189,13 +245,12 @@ template <bool FASTQ>
 __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* text, uint32_t n, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t k,
                                                                uint4* rec, uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, uint32_t rec_cap) {
     const uint32_t R = *n_rec_p;
-    const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-    // (more record starts than rec_start holds: the caller hands the piece to the host once it has read the count -- but the scans and the
-    // compaction behind this kernel are already enqueued and run over all rec_cap entries: they must find zeroes, not whatever the buffers held)
-    if (j >= R || R > rec_cap) {
-        if (sub == 0 && j < rec_cap) { acc_flag[j] = 0; acc_len[j] = 0; }
-        return;
-    }
+    const uint32_t sub = threadIdx.x & 15;
+    // (more record starts than rec_start holds: the caller hands the piece to the host once it has read the count; the scans behind this kernel
+    // stop at min(count, rec_cap) and the compaction leaves at once -- nothing reads what this kernel did not write.  Round 4 launched one group
+    // per rec_cap entry, five in six of them only to write zeroes for scans that ran over all of them: 111 us per 44 MB piece, 0.40 TB/s)
+    if (R > rec_cap) return;
+    for (uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; j < R; j += (gridDim.x * blockDim.x) >> 4) {
     const uint32_t p = rec_start[j], q = j + 1 < R ? rec_start[j + 1] : n;
     // pass 1: the first two newlines and the number of newlines
     uint32_t first = 0xFFFFFFFFu, second = 0xFFFFFFFFu, count = 0;
@@ -246,6 +301,7 @@ __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* te
         acc_len[j] = ok ? L : 0u;
         // (one atomic per record on one word would cap the kernel near 90 M records/s: only a read longer than what the word holds adds)
         if (ok && L > __hip_atomic_load(&info[TXT_INFO_MAX_LEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&info[TXT_INFO_MAX_LEN], L);
+    }
     }
 }
 
@@ -493,6 +549,14 @@ hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32
     hipLaunchKernelGGL(bgr_scan_apply, dim3(nb), dim3(kTxtThreads), 0, stream, in, n, sums, out);
     return hipGetLastError();
 }
+hipError_t launch_scan2_u32(const uint32_t* inA, const uint32_t* inB, uint32_t* outA, uint32_t* outB, uint32_t n, const uint32_t* n_dev, uint32_t* sums, uint32_t* totalA,
+                            uint32_t* totalB, hipStream_t stream) {
+    const uint32_t nb = std::max<uint32_t>(1, (n + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL(bgr_scan2_block_sums, dim3(nb), dim3(kTxtThreads), 0, stream, inA, inB, n, n_dev, sums, nb);
+    hipLaunchKernelGGL(bgr_scan2_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, totalA, totalB);
+    hipLaunchKernelGGL(bgr_scan2_apply, dim3(nb), dim3(kTxtThreads), 0, stream, inA, inB, n, n_dev, sums, nb, outA, outB);
+    return hipGetLastError();
+}
 uint32_t scan_tiles(uint32_t n) { return std::max<uint32_t>(1, (n + kScanTile - 1) / kScanTile); }
 uint32_t text_tiles(uint32_t bytes) { return std::max<uint32_t>(1, (bytes + kTxtTile - 1) / kTxtTile); }
 
@@ -516,8 +580,10 @@ hipError_t launch_text_mark(const uint8_t* text, uint32_t n, uint32_t fastq_line
 hipError_t launch_text_records(const uint8_t* text, uint32_t n, bool fastq, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t max_rec, uint32_t k, uint4* rec,
                                uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, hipStream_t stream) {
     if (max_rec == 0) return hipSuccess;
-    if (fastq) hipLaunchKernelGGL(bgr_text_records_kernel<true>, dim3((max_rec + 15) / 16), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
-    else hipLaunchKernelGGL(bgr_text_records_kernel<false>, dim3((max_rec + 15) / 16), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
+    // (the record count lives on the device: a grid of the device's size, 16-lane groups striding over the records; ~110 bytes of text per record at least)
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((max_rec + 15) / 16, std::min<uint32_t>(256 * 16, n / (16 * 110) + 1)));
+    if (fastq) hipLaunchKernelGGL(bgr_text_records_kernel<true>, dim3(blocks), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
+    else hipLaunchKernelGGL(bgr_text_records_kernel<false>, dim3(blocks), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
     return hipGetLastError();
 }
 

@@ -4,7 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
-O=gpurun_out/r04_e2e
+O=gpurun_out/r05_e2e
 mkdir -p $O
 run() { tag=$1; shift; python tools/e2e.py --reads 100000000 --check 200000 "$@" > $O/$tag.json 2> $O/$tag.err || { tail -20 $O/$tag.err; exit 1; }; python3 -c "
 import json; d=json.load(open('$O/$tag.json')); print('%-22s run0 %7.1f  run1 %7.1f Mreads/s   cpu user %5.1f s sys %5.1f s   %s' % ('$tag', d['run0']['mreads_per_s'], d['run1']['mreads_per_s'], d['run1']['cpu_user_s'], d['run1']['cpu_sys_s'], d.get('check')))"; }
