@@ -632,10 +632,12 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (x4_pass) { a->last_launch[0] = cfg_x4.blocks; a->last_launch[1] = cfg_x4.waves_per_block * 64; a->last_launch[2] = cfg_x4.lds_bytes; a->last_launch[3] = cfg_x4.stage_mphf | (level_search ? 2u : 0u) | 4u; }
     if (fast_pass) { a->last_launch[0] = cfg_fast.blocks; a->last_launch[1] = cfg_fast.waves_per_block * 64; a->last_launch[2] = cfg_fast.lds_bytes; a->last_launch[3] = cfg_fast.stage_mphf | 4u; }
 
-    // The reads as 2-bit planes: a streaming pre-pass over the ASCII bytes, the mapping kernels see the planes -- except in greedy mode behind its
-    // sixteen-reads-per-wave pass, where the mapping kernels stage their reads straight from the characters (round 5: the pre-pass was 11 % of a
-    // launch and existed only to write 40 B per read that the next kernel read back; BGR_KNOB_GREEDY_PREPASS 1 = the pre-pass as before)
-    const bool inline_pack = fast_pass && !planes_ready && d_reads && !a->knob_prepass;
+    // A launch handed ASCII reads maps them straight from the characters: the mapping kernels stage each read's 2-bit words themselves (round 5:
+    // the pre-pass was 4-11 % of a launch and existed only to write 40 B per read that the next kernel read back).  BGR_KNOB_GREEDY_PREPASS 1 = the
+    // pre-pass over the ASCII bytes and 2-bit planes as in rounds 2-4 (what bgr_align_batch_packed's host-packed planes still use)
+    // (greedy and exhaustive mode: their several-reads-per-wave kernels stage their groups, the one-read-per-wave kernels go through load_packed.  Anchors
+    // mode keeps the pre-pass: its four-reads-per-wave kernel -- BooPHF arithmetic at 96 VGPRs -- lost more inside than the pre-pass cost: 934 vs 965-1 000 Mreads/s)
+    const bool inline_pack = p->mode != BGR_MODE_ANCHORS && !planes_ready && d_reads && !a->knob_prepass;
     if (!reads_bytes) reads_bytes = total_bases;  // (reads end to end: the buffer holds exactly their bases)
     if (!inline_pack) {
         HIP_TRY(a->pk_fw3.ensure(P.plane_words * 8));

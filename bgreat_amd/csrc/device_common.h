@@ -280,12 +280,19 @@ __device__ __forceinline__ u64 pack_codes(const uint32_t c[8]) {
 
 // 32 bases from byte `start` of the batch's characters (`valid` <= 32 of them belong to the read) as one word, first base most significant, zero
 // beyond `valid`; *chars |= every character seen (bit 3 of a character is set for N only, of the alphabet getReads admits)
+// loose: the characters behind the read's end are not masked off one by one -- the word is cut to `valid` bases after packing, and *chars may see
+// up to 31 characters that follow the read.  Good enough where those are the next read's bases (reads end to end: an N there sends THIS read to the
+// general kernel too, which maps any read); not in a FASTA text, where a newline and a header follow (bit 3 of '\n' is set).
+template <bool LOOSE = false>
 __device__ __forceinline__ u64 ascii_word(const uint8_t* reads, u64 start, uint32_t valid, u64 total_bytes, uint32_t* chars) {
     uint32_t xs[8], c[8];
-    load32(reads + start, valid, 0, start + 32 <= total_bytes, xs);
+    const bool whole = start + 32 <= total_bytes;
+    load32(reads + start, (LOOSE && whole) ? 32u : valid, 0, whole, xs);
 #pragma unroll
     for (int d = 0; d < 8; ++d) { c[d] = codes4(xs[d]); *chars |= xs[d]; }
-    return pack_codes(c);
+    u64 f = pack_codes(c);
+    if (LOOSE && valid < 32) f &= ~0ULL << (64 - 2 * valid);
+    return f;
 }
 // ... and their N mask (3 on every N)
 __device__ __forceinline__ u64 ascii_nmask_word(const uint8_t* reads, u64 start, uint32_t valid, u64 total_bytes) {
@@ -328,6 +335,31 @@ __device__ __forceinline__ bool load_packed(const BatchIO& io, uint32_t r, u64 o
     }
     wave_sync();
     return hasN;
+}
+
+// The GL lanes of a read's group stage its words straight from the characters (several-reads-per-wave kernels; `on`: the group has a read it maps);
+// -> nonzero in every lane of the group when the read holds an N (bit 3 of a character: such a read goes to the one-read-per-wave kernels)
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t x);
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t x);
+__device__ __forceinline__ uint32_t half_row_mirror(uint32_t x);
+template <int GL>
+__device__ __forceinline__ uint32_t stage_group_ascii(const BatchIO& io, u64 a0, uint32_t L, uint32_t W, uint32_t on, u64* F, uint32_t sub) {
+    uint32_t chars = 0;
+    const uint32_t Wr = (L + 31) >> 5;
+    for (uint32_t j = sub; j < W; j += GL) {
+        u64 f = 0;
+        if (on && j < Wr) {
+            if (io.ascii_src) f = ascii_word<false>(io.ascii, a0 + 32ull * j, L - 32 * j, io.ascii_bytes, &chars);
+            else f = ascii_word<true>(io.ascii, a0 + 32ull * j, L - 32 * j, io.ascii_bytes, &chars);
+        }
+        F[j] = f;
+    }
+    uint32_t n8 = chars & 0x08080808u;
+    n8 |= quad_xor1(n8);
+    n8 |= quad_xor2(n8);
+    if (GL >= 8) n8 |= half_row_mirror(n8);
+    if (GL == 16) n8 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)n8, 0x140, 0xF, 0xF, true);  // row_mirror
+    return n8;
 }
 
 // RCW (reverse-complement stream) and FWQ (rolling-update quirk stream) from FW3/NM.  Only needed when the read

@@ -906,10 +906,13 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         if (have) {
             off = io.read_offs[r];
             L = (uint32_t)(io.read_offs[r + 1] - off);
-            fast = ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;
+            fast = io.ascii ? 1u : ((io.hasn[r >> 5] >> (r & 31)) & 1u) ^ 1u;
             if (L <= K1) fast = 0;  // (a read of k-1 bases or fewer: the general kernel)
             if (((L + 31) >> 5) >= W) fast = 0;  // (or too long for one lane per word)
         }
+        if (io.ascii) {  // no pre-pass, no planes (round 5): the words straight from the read's characters; a read with an N goes on the list
+            if (stage_group_ascii<GL>(io, have ? ascii_start(io, r, off) : 0, L, W, fast, F, sub)) fast = 0;
+        } else
         for (uint32_t j = sub; j < W; j += GL) {
             u64 f = 0;
             if (fast && j < ((L + 31) >> 5)) f = io.fw3[packed_word_offset(off, r) + j];

@@ -252,12 +252,17 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                     if (ASCII) {
                         // no pre-pass, no planes: the words straight from the characters (a launch handed ASCII reads: 150 B in instead of 40 B of planes
                         // that a pre-pass wrote and this kernel read back; ~11 vector instructions per read)
-                        if (!(st >> 31)) f = ascii_word(io.ascii, a0 + 32ull * j, L - 32 * j, io.ascii_bytes, &chars);
-                        else {
-                            const int32_t p = (int32_t)L - 32 * ((int32_t)j + 1);
-                            if (p >= 0) f = ~rev2_fast(ascii_word(io.ascii, a0 + (uint32_t)p, 32, io.ascii_bytes, &chars));
-                            else { const uint32_t v = (uint32_t)(32 + p); f = (~rev2_fast(ascii_word(io.ascii, a0, v, io.ascii_bytes, &chars) >> (64 - 2 * v))) & (~0ULL << (64 - 2 * v)); }
-                        }
+                        // (reads end to end: what follows a read in its last 32-byte window are the next read's bases -- no character is masked;
+                        // reads scattered in a text: a newline and a header follow, masked off precisely)
+                        u64 fw;
+                        const int32_t p = (st >> 31) ? (int32_t)L - 32 * ((int32_t)j + 1) : 0;
+                        const u64 at = (st >> 31) ? a0 + (uint32_t)(p > 0 ? p : 0) : a0 + 32ull * j;
+                        const uint32_t vv = (st >> 31) ? (p >= 0 ? 32u : (uint32_t)(32 + p)) : L - 32 * j;
+                        if (io.ascii_src) fw = ascii_word<false>(io.ascii, at, vv, io.ascii_bytes, &chars);
+                        else fw = ascii_word<true>(io.ascii, at, vv, io.ascii_bytes, &chars);
+                        if (!(st >> 31)) f = fw;
+                        else if (p >= 0) f = ~rev2_fast(fw);
+                        else f = (~rev2_fast(fw >> (64 - 2 * vv))) & (~0ULL << (64 - 2 * vv));
                     } else if (!(st >> 31)) f = src[j];
                     else {
                         const int32_t p = (int32_t)L - 32 * ((int32_t)j + 1);

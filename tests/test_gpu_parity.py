@@ -1170,3 +1170,34 @@ def test_exhaustive_where_the_reference_is_exponential(m):
         assert all(np.array_equal(a, b) for a, b in zip(got_s, exp_short)), knobs
         assert all(np.array_equal(a, b) for a, b in zip(got_l, exp_long)), knobs
         al.close()
+
+
+@pytest.mark.parametrize("mode", ["greedy", "exhaustive", "anchors"])
+def test_staging_from_the_characters_equals_the_pre_pass_and_the_oracle(mode):
+    """Round 5: a launch handed ASCII reads stages them inside the mapping kernels (ascii_word: v_perm table lookup, no planes); KNOB_GREEDY_PREPASS = 1
+    keeps the pre-pass + planes of rounds 2-4.  Both against the oracle, in every mode, on reads with N (one-read-per-wave kernels through load_packed's
+    ASCII form), mixed lengths (partial last words, a read too long for the several-reads-per-wave kernels) and the batch's last read (no byte behind it)."""
+    k = 31
+    s = Synth(200000, 70, 3, k, 515)
+    seqs, offs = s.unitigs()
+    rng = np.random.default_rng(5)
+    base, _ = s.reads(0, 6000, 300, 3, 616)
+    lens = rng.choice([32, 33, 63, 64, 65, 100, 128, 150, 151, 250, 300], size=6000)
+    lens[-1] = 150
+    lens[17] = 300
+    reads = np.concatenate([base[i * 300: i * 300 + int(l)] for i, l in enumerate(lens)])
+    roffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    reads = _inject_n(reads, rng, 0.0008)
+    anchors = mode == "anchors"
+    g = B.Graph.build(k, seqs, offs, anchors=anchors)
+    o = oracle_py.Oracle(k, seqs, offs, anchors=anchors)
+    gm, om = {"greedy": (B.MODE_GREEDY, 0), "exhaustive": (B.MODE_EXHAUSTIVE, 1), "anchors": (B.MODE_ANCHORS, 2)}[mode]
+    exp = o.align(reads, roffs, m=3, effort=2, mode=om)
+    for prepass in (0, 1):
+        al = B.Aligner(g, 0)
+        al.set_knob(B.KNOB_GREEDY_PREPASS, prepass)
+        got = al.align(reads, roffs, m=3, effort=2, mode=gm)
+        names = [n for n, _ in al.kernel_times()[1]]
+        assert any(n.startswith("bgr_pack_reads_kernel") for n in names) == bool(prepass or mode == "anchors"), names   # (anchors mode keeps its pre-pass: measured faster)
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp)), (mode, prepass)
+        al.close()
