@@ -1457,10 +1457,12 @@ int bgr_aligner_counters(bgr_aligner* a, uint64_t out[5]) {
     if (!a || !out) return fail(BGR_E_ARG, "bgr_aligner_counters: null argument");
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(hipStreamSynchronize(a->stream));
+    { const int src = settle_launch_sync(a); if (src != BGR_OK) return src; }  // (exhaustive mode: reads the last pass handed back are mapped -- and counted -- first)
     HIP_TRY(hipMemcpy(out, static_cast<char*>(a->small.p) + 64, 40, hipMemcpyDeviceToHost));
     for (bgr_aligner* tw = a->twin; tw; tw = tw->twin) {  // the pieces of overlapped batches its other streams mapped
         uint64_t t[5];
         HIP_TRY(hipStreamSynchronize(tw->stream));
+        { const int src = settle_launch_sync(tw); if (src != BGR_OK) return src; }
         HIP_TRY(hipMemcpy(t, static_cast<char*>(tw->small.p) + 64, 40, hipMemcpyDeviceToHost));
         for (int i = 0; i < 5; ++i) out[i] += t[i];
     }

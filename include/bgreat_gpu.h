@@ -260,6 +260,9 @@ int bgr_aligner_fetch_text(bgr_aligner* a, bgr_text_batch* b);
  * Read characters must be from ACGTN (what getReads lets through).                                      */
 int bgr_align_device(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
                      uint64_t total_bases, uint32_t max_read_len);
+/* Waits for the aligner's stream.  In exhaustive mode it also SETTLES the launch: reads whose search outgrew the last pass's table of remembered calls
+ * are mapped again with a larger one (BGR_KNOB_EXH_MEMO_CAP) before the results count as final -- every fetch / counters call does the same; a caller
+ * that reads the device results below by itself calls this first. */
 int bgr_aligner_sync(bgr_aligner* a);
 /* Device pointers of the last bgr_align_device results: results uint32[n][2] = {path offset in the arena,
  * path length | status << 24}, arena int32[], cursor u32[1] (ints used in the arena).
