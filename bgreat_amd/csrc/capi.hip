@@ -1146,12 +1146,13 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     // 3. the mapping launch, its reads where they lie in the text (planes by the pre-pass, or -- greedy mode -- staged by the mapping kernels themselves)
     int rc = align_device_impl(a, p, text, a->tx_offs.p, n_acc, bases, max_len, false, a->tx_accsrc.p, nbytes);
     if (rc != BGR_OK) return rc;
-    if (a->deep.open) {  // exhaustive mode: what is enqueued below reads the FINAL results (reads the last pass handed back are mapped first)
-        rc = settle_launch_sync(a);
-        if (rc != BGR_OK) return rc;
-    }
     a->last_n = 0;  // (bgr_aligner_fetch has no host read_offsets to pair its rows with: the text form hands out text)
     a->tx_n_acc = n_acc;
+    // Everything behind the mapping launch reads its results.  In exhaustive mode those are final only once the launch is settled (reads the last pass
+    // handed back for a larger table are mapped again: settle_launch) -- which hardly ever happens: so the kernels below are enqueued at once, the
+    // cursor comes back with the wait this call makes anyway, and only a launch that did hand reads back is settled and the kernels enqueued AGAIN
+    // (a wait between the mapping launch and them cost -b a fifth of its end-to-end rate)
+    for (int again = 0; again < 2; ++again) {
     if (b->record_info_out) {  // what became of every record (the -b progress blocks of the caller), on its way to the host behind the mapping launch
         HIP_TRY(a->tx_info.ensure((uint64_t)R * 4));
         e = bgr::launch_text_record_info(static_cast<const uint4*>(a->tx_rec.p), static_cast<const uint32_t*>(a->tx_idx.p), static_cast<const uint2*>(a->results.p), R,
@@ -1163,7 +1164,10 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         uint32_t cur[16];
         HIP_TRY(hipMemcpyAsync(cur, a->small.p, sizeof(cur), hipMemcpyDeviceToHost, a->stream));
         HIP_TRY(wait_stream(a));
-        return settle_launch(a, cur);
+        const bool handed_back = a->deep.open && cur[kRetryCtr] != 0;
+        rc = settle_launch(a, cur);
+        if (rc != BGR_OK || !handed_back || !b->record_info_out) return rc;
+        continue;  // (the record info was made from results that were not final)
     }
     // 4. sizes of the records, stream offsets, the bytes
     if (b->want_output == 2) {  // (tx_idx is free again behind the compaction: it takes the corrected reads' lengths)
@@ -1183,6 +1187,14 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     HIP_TRY(wait_stream(a));
     lap(2);
     if (h2[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
+    if (a->deep.open) {
+        const bool handed_back = h2[kRetryCtr] != 0;
+        rc = settle_launch(a, h2);
+        if (rc != BGR_OK) return rc;
+        if (handed_back) continue;  // sizes and offsets once more, from the final results
+    }
+    break;
+    }
     if (b->want_output == 2 && h[TXT_INFO_BUG] != 0xFFFFFFFFu) {  // a path that does not spell a walk: the reference prints "bug compaction" and exits
         b->irregular = 2;                                          // (aligner.cpp:280-283); the caller reproduces that on the host
         a->tx_n_acc = 0;

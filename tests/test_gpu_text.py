@@ -354,3 +354,28 @@ def test_pieces_of_tiny_records_beyond_the_record_table_go_to_the_host(fastq, tm
         s.write_unitigs(str(u))
         a = _cli_pair(["-r", str(f), "-k", "15", "-g", str(u), "-t", "4"] + (["-q"] if fastq else []), [], ["--host-route"])
         assert a[0][1:] == a[1][1:]
+
+
+@pytest.mark.parametrize("memo_cap", [0, 8])
+def test_text_form_in_exhaustive_mode_when_the_last_pass_hands_reads_back(memo_cap, tmp_path):
+    """Exhaustive mode on a unitig set where the reference's recursion is exponential (tests/util.py homopolymer_soup), through the TEXT form: the kernels behind
+    the mapping launch (record info, sizes, formatting) are enqueued before the host knows whether the last pass handed reads back for a larger table of
+    remembered calls (BGR_KNOB_EXH_MEMO_CAP 8: it does); then the launch is settled and they are enqueued again -- same record bytes and the same record info
+    as the host route (parser + bgr_align_batch + the reference's record format), with and without the formatted streams."""
+    from util import homopolymer_soup
+    k, (seqs, offs), (sr, so), (lr, lo) = homopolymer_soup()
+    reads = [bytes(sr[int(so[i]):int(so[i + 1])]) for i in range(len(so) - 1)] + [bytes(lr[int(lo[i]):int(lo[i + 1])]) for i in range(len(lo) - 1)]
+    text = b"".join(b">q%d\n%s\n" % (i, r) for i, r in enumerate(reads))
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    al.set_knob(B.KNOB_EXH_MEMO_CAP, memo_cap)
+    pb, nb, n = _host_route(al, text, k, tmp_path, m=2, mode=B.MODE_EXHAUSTIVE)
+    assert n == len(reads) and len(pb) > 0 and len(nb) > 0
+    p1, n1, info = al.align_fasta_text(text, m=2, mode=B.MODE_EXHAUSTIVE, want_output=True, record_info=True)
+    assert not info["irregular"] and p1 == pb and n1 == nb
+    if memo_cap:
+        assert al.last_pass_runs()[0] >= 2    # (reads were handed back: the kernels behind the launch ran twice)
+    mapped = int(((info["records"] >> 30) & 1).sum())
+    assert mapped == pb.count(b"\n") // 2
+    _, _, info0 = al.align_fasta_text(text, m=2, mode=B.MODE_EXHAUSTIVE, want_output=False, record_info=True)
+    assert np.array_equal(info0["records"], info["records"])
