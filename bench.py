@@ -405,7 +405,7 @@ def main():
                              "x reads per launch / that kernel's mean duration; `traffic` next to it is what the memory side saw (rocprofv3 PMC)"}
         roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
                     "dominant_kernel": dominant, "dominant_kernel_ms": round(dom_ms, 4), "hbm": hbm,
-                    "launch": "pre-pass + mapping kernels of one batch, enqueued back to back on one stream (HIP events around every kernel, on the aligner's stream)",
+                    "launch": "the kernels of one batch (mapping kernels; a pre-pass in anchors mode), enqueued back to back on one stream (HIP events around every kernel, on the aligner's stream)",
                     "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "kernels_ms": kernels_ms, "reads_per_launch": R,
                     # SURVEY 8d's figure describes the REFERENCE's control flow (gamma-10 BooPHF probes, rank words, 24-B records): kept for the
                     # record under its own keys, never as a fraction of this implementation's roofline
