@@ -146,6 +146,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #ifndef BGR_G4_OCC
 #define BGR_G4_OCC 8
 #endif
+#ifndef BGR_G4_RESTART_IN_LOOP
+#define BGR_G4_RESTART_IN_LOOP 0
+#endif
 
 // where an item stands: which strand (the reference maps the reverse complement once every forward anchor has failed,
 // alignerGreedy.cpp:54), how many anchors of that strand have been tried (getNOverlap hands out the first `effort` of them)
@@ -362,11 +365,18 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
             if (on != 0) {
                 if (!(w1 & G4_FOUND)) {
                     st += 1u << G4_ST_TRIED_SHIFT;
+#if BGR_G4_RESTART_IN_LOOP
                     if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
                         a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
                         nl = 0; nr = 0; budget = m;
                         phase = 1; pos = a_pos; rec = take_anchor(a_rec);
                     } else phase = 5;
+#else
+                    // (the next anchor of getNOverlap's list, when the scan saw it, is taken up by a follow-up item that resumes AT it -- a restart
+                    // in this loop keeps all sixteen groups' loop going for one walk)
+                    if (b_rec != BGR_NONE) { a_pos = b_pos - 1; b_rec = BGR_NONE; }
+                    phase = 5;
+#endif
                 } else if (phase == 1) {
                     if (sub == 0) PT[PH - 1 - nl] = sid;
                     ++nl;
