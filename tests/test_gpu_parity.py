@@ -935,7 +935,8 @@ def test_bench_line_contract():
     import subprocess
     import sys
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads-per-step", "200000", "--e2e-reads", "200000",
-           "--pcie-steps", "1", "--cpu-sample", "20000", "--cpu-sample-all", "30000", "--alg-sample", "4000", "--no-pmc", "--no-sub", "--genome", "400000"]
+           "--pcie-steps", "1", "--cpu-sample", "20000", "--cpu-sample-all", "30000", "--alg-sample", "4000", "--no-pmc", "--no-sub", "--genome", "400000",
+           "--full-parity", "--full-parity-scale", "0.002"]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -967,6 +968,12 @@ def test_bench_line_contract():
     assert len(runs) == 3 and min(runs) - 0.1 <= d["e2e"]["value"] <= max(runs) + 0.1 and d["e2e"]["worst"] <= d["e2e"]["value"] <= d["e2e"]["best"]
     if c.get("all_cores"):   # (only on hosts with more visible CPUs than --cpu-threads)
         assert c["all_cores"]["value"] > 0 and c["all_cores"]["cores"] > c["cores"]
+    # round 5: the scalar copies the driver's record keeps (it drops nested objects), and --full-parity (tools/full_parity.py at 1/500 of the configs' sizes:
+    # bin/bgreat against the compiled reference, sorted record multisets + counters)
+    assert d["config"]["value_e2e"] == d["value_e2e"] and d["config"]["value_pcie_inclusive"] == d["value_pcie_inclusive"] and d["config"]["parity_sample_ok"] is True
+    assert d["cpu_baseline"]["t1_value"] == c["t1"]["value"] and "hbm_compulsory_frac" in r
+    fp = d["full_parity"]
+    assert fp["equal"] is True and fp["c1_equal"] and fp["c2_equal"] and fp["c4_equal"] and fp["c2_reads"] == 100000 and d["config"]["full_parity_equal"] is True
 
 
 def test_bench_sub_record_of_the_exhaustive_config():
