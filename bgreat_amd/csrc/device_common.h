@@ -777,10 +777,16 @@ __device__ __forceinline__ void wg_counts_flush(const BatchIO& io, unsigned long
 // first ones end after 55 % of the launch and nothing takes their place (profiles/r04_wave_times_static_split_*.txt: a wave of the
 // E. coli-scale launch lives 0.74 of its duration, 0.64 at configs[1], 0.83 at chr1 scale).  So a wave CLAIMS its next task: from its
 // workgroup's stock in LDS (one 64-bit word {end, next}, one LDS atomic per task), which the wave that finds it used up refills with
-// up to kTaskRefill tasks from the launch's counter in HBM (one global atomic per refill: ~10-20 k per launch).  The end of a launch
+// up to kTaskRefill tasks from the launch's counter in HBM (one global atomic per refill: ~20-40 k per launch).  The end of a launch
 // is then ragged by one task per wave, not by a third of the batch.
-constexpr uint32_t kTaskRefill = 32;          // tasks a workgroup takes from the launch's counter at a time, at most
-constexpr uint32_t kTaskRefillMin = 4;        // ... and at least
+#ifndef BGR_TASK_REFILL
+#define BGR_TASK_REFILL 16
+#endif
+#ifndef BGR_TASK_REFILL_MIN
+#define BGR_TASK_REFILL_MIN 1
+#endif
+constexpr uint32_t kTaskRefill = BGR_TASK_REFILL;        // tasks a workgroup takes from the launch's counter at a time, at most (round 4: 32; same box, interleaved, round 5:
+constexpr uint32_t kTaskRefillMin = BGR_TASK_REFILL_MIN;  // ... and at least (4)        16 / 1 gives the default line +0.5 %, configs[1] +3 %; 64 / 2 and 8 / 1 lose)
 constexpr uint32_t kTaskDone = 0xC0000000u;   // `next` of a stock whose launch has no task left
 constexpr uint32_t kLdsTaskWord = 8;          // the stock: u64 number 8 of the workgroup's reserved LDS header (bytes 64 .. 71)
 // A workgroup starts with one task per wave, its own by number (tasks [b W, (b + 1) W) for workgroup b of W waves): no atomic at the start of a
