@@ -779,6 +779,9 @@ __device__ __forceinline__ void wg_counts_flush(const BatchIO& io, unsigned long
 // workgroup's stock in LDS (one 64-bit word {end, next}, one LDS atomic per task), which the wave that finds it used up refills with
 // up to kTaskRefill tasks from the launch's counter in HBM (one global atomic per refill: ~20-40 k per launch).  The end of a launch
 // is then ragged by one task per wave, not by a third of the batch.
+#ifndef BGR_TASK_SHARE_DIV
+#define BGR_TASK_SHARE_DIV 2u
+#endif
 #ifndef BGR_TASK_REFILL
 #define BGR_TASK_REFILL 16
 #endif
@@ -813,7 +816,7 @@ __device__ __forceinline__ uint32_t claim_task(u64* lds, uint32_t* ctr, uint32_t
             // (guided: what is left of the batch -- judged by where the stock just used up ended -- shared out twice over all workgroups, at most
             // kTaskRefill and at least kTaskRefillMin tasks: towards the end of a launch the workgroups take small bites)
             const uint32_t seen = end > base ? end : base;  // (tasks known to be handed out: the static first ones, and what this workgroup took last)
-            const uint32_t left = n_tasks > seen ? n_tasks - seen : 0u, share = left / (2u * gridDim.x);
+            const uint32_t left = n_tasks > seen ? n_tasks - seen : 0u, share = left / (BGR_TASK_SHARE_DIV * gridDim.x);
             const uint32_t want = share > kTaskRefill ? kTaskRefill : share < kTaskRefillMin ? kTaskRefillMin : share;
             uint32_t g = 0;
             if (lane == 0) g = atomicAdd(ctr, want);
