@@ -146,6 +146,9 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #ifndef BGR_G4_OCC
 #define BGR_G4_OCC 8
 #endif
+#ifndef BGR_G4_HANDLES_WITH_KEY
+#define BGR_G4_HANDLES_WITH_KEY 0
+#endif
 #ifndef BGR_G4_RESTART_IN_LOOP
 #define BGR_G4_RESTART_IN_LOOP 0
 #endif
@@ -289,6 +292,9 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each item from where its scan stands and,
         // when it lies in the same 64 positions, the one after it; record | canonical << 28
         uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
+#if BGR_G4_HANDLES_WITH_KEY
+        uint2 a_handles = make_uint2(0, 0);  // (table in LDS: the anchor's handles came with its key compare)
+#endif
         for (uint32_t q = 0; q < RPW; ++q) {
             if (!rl32(act, (int)(GL * q))) continue;
 #ifdef BGR_PHASE_TIMING
@@ -307,7 +313,12 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                 if (valid) num = win >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
                 const uint32_t mblock = (!STAGE && mmx_w) ? scan_mblock(g, win, i + BGR_MMX_BASES <= Lq, mmx_w) : 0u;
+#if BGR_G4_HANDLES_WITH_KEY
+                uint2 kh = make_uint2(0, 0);
+                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid, mblock, STAGE ? &kh : nullptr);
+#else
                 uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid, mblock);
+#endif
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {
                     if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
@@ -320,7 +331,12 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                         h2 = rl32(idx, s2);
                         p2 = base + (uint32_t)s2;
                     }
+#if BGR_G4_HANDLES_WITH_KEY
+                    const uint32_t hl = rl32(kh.x, s1), hr = rl32(kh.y, s1);
+                    if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; a_handles = make_uint2(hl, hr); }
+#else
                     if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
+#endif
                     break;
                 }
             }
@@ -343,7 +359,11 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         uint32_t a_right = G4_REC_MASK;
         auto take_anchor = [&](uint32_t anchor) -> uint32_t {  // -> the left start; sets a_right
             const uint32_t cn = (anchor >> 28) & 1u;
+#if BGR_G4_HANDLES_WITH_KEY
+            const uint2 h = STAGE ? a_handles : *reinterpret_cast<const uint2*>(&g.keys[anchor & G4_REC_MASK].hL);
+#else
             const uint2 h = *reinterpret_cast<const uint2*>(&g.keys[anchor & G4_REC_MASK].hL);
+#endif
             a_right = (cn ? h.x : h.y) | (cn ? G4_CANON : 0u);
             return (cn ? h.y : h.x) | (cn ? G4_CANON : 0u);
         };
