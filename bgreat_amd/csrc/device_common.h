@@ -101,10 +101,8 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 // 1.2 instead of 2 requests per position (chr1-scale graph: 749 -> 930 Mreads/s).
 // (mblock: the key's block of the minimizer filter, from the caller -- the scans work it out across lanes, wave_window_max below;
 // callers that cannot pass a graph without filter)
-// hout (may be null; table staged in LDS only): the matching entry's two handles -- the key compare then loads the whole 16-byte entry, and a walk that starts
-// from this key needs no second load
 template <bool LAZY2 = false, typename TP>
-__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u64 key, bool active, uint32_t mblock = 0, uint2* hout = nullptr) {
+__device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u64 key, bool active, uint32_t mblock = 0) {
     const u64 m = bgr_mix64(key);
     const uint32_t b1 = __umulhi((uint32_t)m, g.n_buckets), b2 = __umulhi((uint32_t)(m >> 32), g.n_buckets);
     uint32_t res = BGR_NONE;
@@ -156,13 +154,7 @@ __device__ __forceinline__ uint32_t find_key(const BgrDeviceGraph& g, TP tab, u6
                 const bool first = c1 != 0;
                 const uint32_t c = first ? c1 : c2;
                 const uint32_t idx = (first ? b1 : b2) * 4 + ((uint32_t)(__ffs((int)c) - 1) >> 3);
-                bool same;
-                if (hout) {
-                    const uint4 e = *reinterpret_cast<const uint4*>(&g.keys[idx]);
-                    same = (((u64)e.y << 32) | e.x) == key;
-                    if (same) *hout = make_uint2(e.z, e.w);
-                } else same = g.keys[idx].key == key;
-                if (same) { res = idx; c1 = 0; c2 = 0; }
+                if (g.keys[idx].key == key) { res = idx; c1 = 0; c2 = 0; }
                 else if (first) c1 &= c1 - 1;
                 else c2 &= c2 - 1;
             }

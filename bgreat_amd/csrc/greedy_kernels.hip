@@ -146,12 +146,6 @@ __global__ void __launch_bounds__(1024, BGR_GREEDY_OCC) bgr_align_greedy_kernel(
 #ifndef BGR_G4_OCC
 #define BGR_G4_OCC 8
 #endif
-#ifndef BGR_G4_HANDLES_WITH_KEY
-#define BGR_G4_HANDLES_WITH_KEY 0
-#endif
-#ifndef BGR_G4_RESTART_IN_LOOP
-#define BGR_G4_RESTART_IN_LOOP 0
-#endif
 
 // where an item stands: which strand (the reference maps the reverse complement once every forward anchor has failed,
 // alignerGreedy.cpp:54), how many anchors of that strand have been tried (getNOverlap hands out the first `effort` of them)
@@ -291,10 +285,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
 
         // ---- anchors (getNOverlap, aligner.cpp:345-378): the next overlap (k-1)-mer of each item from where its scan stands and,
         // when it lies in the same 64 positions, the one after it; record | canonical << 28
-        uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0, b_rec = BGR_NONE;
-#if BGR_G4_HANDLES_WITH_KEY
-        uint2 a_handles = make_uint2(0, 0);  // (table in LDS: the anchor's handles came with its key compare)
-#endif
+        uint32_t a_pos = 0, a_rec = BGR_NONE, b_pos = 0;  // (b_pos: the hit after a_pos when the scan's step saw one, else 0)
         for (uint32_t q = 0; q < RPW; ++q) {
             if (!rl32(act, (int)(GL * q))) continue;
 #ifdef BGR_PHASE_TIMING
@@ -313,30 +304,16 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                 if (valid) num = win >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
                 const uint32_t mblock = (!STAGE && mmx_w) ? scan_mblock(g, win, i + BGR_MMX_BASES <= Lq, mmx_w) : 0u;
-#if BGR_G4_HANDLES_WITH_KEY
-                uint2 kh = make_uint2(0, 0);
-                uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid, mblock, STAGE ? &kh : nullptr);
-#else
                 uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid, mblock);
-#endif
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {
                     if (idx != BGR_NONE && num <= rcn) idx |= G4_CANON;
                     const int s1 = __ffsll((long long)mask) - 1;
                     const u64 mask2 = mask & (mask - 1);
                     const uint32_t h1 = rl32(idx, s1);
-                    uint32_t h2 = BGR_NONE, p2 = 0;
-                    if (mask2 && left_q >= 2) {  // a second anchor is tried when the first fails
-                        const int s2 = __ffsll((long long)mask2) - 1;
-                        h2 = rl32(idx, s2);
-                        p2 = base + (uint32_t)s2;
-                    }
-#if BGR_G4_HANDLES_WITH_KEY
-                    const uint32_t hl = rl32(kh.x, s1), hr = rl32(kh.y, s1);
-                    if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; a_handles = make_uint2(hl, hr); }
-#else
-                    if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; b_rec = h2; }
-#endif
+                    uint32_t p2 = 0;
+                    if (mask2 && left_q >= 2) p2 = base + (uint32_t)(__ffsll((long long)mask2) - 1);  // a second anchor is tried when the first fails: where a follow-up item resumes
+                    if (grp == q) { a_pos = base + (uint32_t)s1; a_rec = h1; b_pos = p2; }
                     break;
                 }
             }
@@ -359,11 +336,7 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
         uint32_t a_right = G4_REC_MASK;
         auto take_anchor = [&](uint32_t anchor) -> uint32_t {  // -> the left start; sets a_right
             const uint32_t cn = (anchor >> 28) & 1u;
-#if BGR_G4_HANDLES_WITH_KEY
-            const uint2 h = STAGE ? a_handles : *reinterpret_cast<const uint2*>(&g.keys[anchor & G4_REC_MASK].hL);
-#else
             const uint2 h = *reinterpret_cast<const uint2*>(&g.keys[anchor & G4_REC_MASK].hL);
-#endif
             a_right = (cn ? h.x : h.y) | (cn ? G4_CANON : 0u);
             return (cn ? h.y : h.x) | (cn ? G4_CANON : 0u);
         };
@@ -385,18 +358,10 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
             if (on != 0) {
                 if (!(w1 & G4_FOUND)) {
                     st += 1u << G4_ST_TRIED_SHIFT;
-#if BGR_G4_RESTART_IN_LOOP
-                    if (b_rec != BGR_NONE) {  // next anchor of getNOverlap's list, from scratch
-                        a_pos = b_pos; a_rec = b_rec; b_rec = BGR_NONE;
-                        nl = 0; nr = 0; budget = m;
-                        phase = 1; pos = a_pos; rec = take_anchor(a_rec);
-                    } else phase = 5;
-#else
-                    // (the next anchor of getNOverlap's list, when the scan saw it, is taken up by a follow-up item that resumes AT it -- a restart
-                    // in this loop keeps all sixteen groups' loop going for one walk)
-                    if (b_rec != BGR_NONE) { a_pos = b_pos - 1; b_rec = BGR_NONE; }
+                    // (the next anchor of getNOverlap's list, when the scan saw it, is taken up by a follow-up item that resumes AT it -- rounds 3-4
+                    // restarted the walk in this loop, which kept all sixteen groups' loop going for one walk: profiles/r05_scan_schemes.txt)
+                    if (b_pos) { a_pos = b_pos - 1; b_pos = 0; }
                     phase = 5;
-#endif
                 } else if (phase == 1) {
                     if (sub == 0) PT[PH - 1 - nl] = sid;
                     ++nl;
