@@ -66,3 +66,35 @@ def test_dry_run_of_the_eight_rank_command_line_the_driver_uses():
     assert m["ranks_seen"] == 8 and m["blob_bytes_equal_on_all_ranks"] is True and sorted(r["rank"] for r in m["ranks"]) == list(range(8))
     assert d["counters"]["reads"] == 8 * 4 * d["config"]["reads_per_step_per_gpu"]
     assert d["config"]["multi_gpu_ranks_seen"] == 8      # (the scalar copies the driver's record keeps)
+
+
+def test_scalar_copies_put_every_number_where_the_driver_keeps_it():
+    """The driver's record keeps scalar members of config / roofline / cpu_baseline only: bench.scalar_copies mirrors the nested numbers there."""
+    sys.path.insert(0, ROOT)
+    import bench
+    line = {"value": 2800.0, "value_e2e": 210.0, "value_pcie_inclusive": 290.0, "config": {"workload": "w"}, "parity_sample": {"gpu_equals_oracle": True},
+            "e2e": {"value": 210.0, "host_route": {"value": 100.0, "identical_bytes_to_the_text_route": True}},
+            "roofline": {"frac": 0.85, "hbm": {"frac": 0.07}, "valu_issue": {"valu_insts_per_read": 235.0, "salu_insts_per_read": 98.0, "frac": 0.85}},
+            "cpu_baseline": {"value": 0.6, "all_cores": {"value": 0.1, "cores": 255}, "t1": {"value": 0.08}},
+            "other_configs": {"small": {"value": 2600.0, "ms_per_step": 0.38, "parity_sample": {"gpu_equals_oracle": True}, "roofline": {"frac": 0.75, "bound": "valu_issue"},
+                                        "hbm": {"traffic_over_compulsory": 1.7, "traffic_frac": 0.09}, "l2_hit_rate": 0.88, "valu_insts_per_read": 215.0, "dominant_kernel_ms": 0.37},
+                              "chr1": {"error": "timeout"},
+                              "branchy": {"value": 1000.0, "ms_per_step": 2.0, "parity_sample": {"gpu_equals_oracle": True}, "roofline": {"frac": 0.75, "bound": "valu_issue"}, "hbm": {},
+                                          "cpu_baseline": {"value": 0.08, "cores": 16, "sample": "s"}}},
+            "full_parity": {"equal": True, "c2_reads": 50000000, "c2_equal": True},
+            "multi_gpu": {"backend": "nccl (RCCL)", "ranks_seen": 8, "rccl_version": "2.22.3", "graph_broadcast_ms": 3.1, "ranks": [{"rank": 0}]},
+            "one_process_all_gpus": {"value": 20000.0, "fanout_method": "rccl broadcast (ncclCommInitAll)", "fanout_ms": 12.0, "fanout_both_ways": {"rccl_broadcast": {"ms": 10.0}, "peer_copies": {"error": "x"}}}}
+    d = bench.scalar_copies(line)
+    c, r, b = d["config"], d["roofline"], d["cpu_baseline"]
+    assert c["value_e2e"] == 210.0 and c["value_pcie_inclusive"] == 290.0 and c["e2e_host_route_mreads"] == 100.0 and c["e2e_routes_identical_bytes"] is True
+    assert c["small_mreads"] == 2600.0 and c["branchy_mreads"] == 1000.0 and c["chr1_error"] == "timeout" and c["small_parity_ok"] is True and c["parity_sample_ok"] is True
+    assert c["full_parity_equal"] is True and c["full_parity_c2_reads"] == 50000000
+    assert c["multi_gpu_ranks_seen"] == 8 and c["multi_gpu_rccl_version"] == "2.22.3" and c["one_process_all_gpus_mreads"] == 20000.0
+    assert c["one_process_fanout_rccl_broadcast_ms"] == 10.0 and c["one_process_fanout_peer_copies_ms"] is None
+    assert r["valu_insts_per_read"] == 235.0 and r["hbm_compulsory_frac"] == 0.07 and r["small_frac"] == 0.75 and r["small_traffic_over_compulsory"] == 1.7 and r["branchy_bound"] == "valu_issue"
+    assert b["all_cores_value"] == 0.1 and b["t1_value"] == 0.08 and b["exhaustive_value"] == 0.08 and b["exhaustive_cores"] == 16
+    for obj in (c, r, b):   # (what the copies add are scalars)
+        for k, v in obj.items():
+            if k not in ("hbm", "valu_issue", "all_cores", "t1"):
+                assert isinstance(v, (bool, int, float, str)) or v is None, (k, v)
+    json.dumps(d)
