@@ -637,7 +637,9 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     // pre-pass over the ASCII bytes and 2-bit planes as in rounds 2-4 (what bgr_align_batch_packed's host-packed planes still use)
     // (greedy and exhaustive mode: their several-reads-per-wave kernels stage their groups, the one-read-per-wave kernels go through load_packed.  Anchors
     // mode keeps the pre-pass: its four-reads-per-wave kernel -- BooPHF arithmetic at 96 VGPRs -- lost more inside than the pre-pass cost: 934 vs 965-1 000 Mreads/s)
-    const bool inline_pack = p->mode != BGR_MODE_ANCHORS && !planes_ready && d_reads && !a->knob_prepass;
+    // ... and so do launches without a several-reads-per-wave pass (-i, budgets beyond 254, exception planes, the knobs): the one-read-per-wave kernels alone are
+    // faster from planes (depth-first 11.8 vs 12.8 ms per 5 M reads, level search 14.0 vs 14.3 per 2 M)
+    const bool inline_pack = (fast_pass || x4_pass) && !planes_ready && d_reads && !a->knob_prepass;
     if (!reads_bytes) reads_bytes = total_bases;  // (reads end to end: the buffer holds exactly their bases)
     if (!inline_pack) {
         HIP_TRY(a->pk_fw3.ensure(P.plane_words * 8));

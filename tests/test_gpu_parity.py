@@ -1208,3 +1208,22 @@ def test_staging_from_the_characters_equals_the_pre_pass_and_the_oracle(mode):
         assert any(n.startswith("bgr_pack_reads_kernel") for n in names) == bool(prepass or mode == "anchors"), names   # (anchors mode keeps its pre-pass: measured faster)
         assert all(np.array_equal(a, b) for a, b in zip(got, exp)), (mode, prepass)
         al.close()
+
+
+def test_launches_without_a_several_reads_per_wave_pass_keep_the_pre_pass():
+    """Staging from the characters pays behind the several-reads-per-wave passes; the one-read-per-wave kernels ALONE (knobs; -i; budgets beyond 254) are faster
+    from planes, so such launches keep bgr_pack_reads_kernel -- same rows either way."""
+    s = Synth(150000, 75, 2, 31, 717)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, 4000, 150, 2, 718)
+    g = B.Graph.build(31, seqs, offs)
+    o = oracle_py.Oracle(31, seqs, offs)
+    for gm, om, knob, kw in ((B.MODE_GREEDY, 0, B.KNOB_GREEDY_FAST, {}), (B.MODE_EXHAUSTIVE, 1, B.KNOB_EXH_FAST, {}), (B.MODE_EXHAUSTIVE, 1, None, {"partial": True})):
+        exp = o.align(reads, roffs, m=2, effort=2, mode=om, **kw)
+        al = B.Aligner(g, 0)
+        if knob is not None:
+            al.set_knob(knob, 1)
+        got = al.align(reads, roffs, m=2, effort=2, mode=gm, **kw)
+        assert any(n.startswith("bgr_pack_reads_kernel") for n, _ in al.kernel_times()[1])
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+        al.close()
