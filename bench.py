@@ -1158,6 +1158,25 @@ def cpu_quota():
         return None
 
 
+REFERENCE_RERUNS = [0]
+
+
+def run_reference(cmd, wd):
+    """The compiled reference's stdout.  Its progress block divides by the reads counted so far (alignerExhaustive.cpp:314 `overlaps/(alignedRead+notAligned)`,
+    unsigned integers shared by the workers): a worker that comes through with an empty batch before another one has counted its first read dies of SIGFPE -- a race of
+    the reference itself at -t N on small inputs.  Such a run is started again (at most three times; counted in cpu_baseline.reference_reruns); any other failure raises."""
+    for attempt in range(4):
+        p = subprocess.run(cmd, cwd=wd, stdout=subprocess.PIPE, text=True)
+        if p.returncode == 0:
+            return p.stdout
+        if p.returncode != -8 or attempt == 3:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        REFERENCE_RERUNS[0] += 1
+        for fn in os.listdir(wd):
+            os.unlink(os.path.join(wd, fn))
+    raise AssertionError("unreachable")
+
+
 def run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads):
     """Exhaustive mode on the host: the compiled reference with -b (alignerExhaustive.cpp:262-318) on a bounded sample.  It writes
     nothing in that mode (alignerExhaustive.cpp:285: the fwrite is commented out), so what is compared with the GPU is the count it
@@ -1179,7 +1198,7 @@ def run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads):
             os.makedirs(wd)
             cmd = [exe, "-r", os.path.join(d, reads_file), "-k", str(args.k), "-g", os.path.join(d, "u.fa"), "-m", str(args.mismatch), "-e", str(args.effort), "-t", str(cores), "-b"]
             t1 = time.perf_counter()
-            out = subprocess.run(cmd, cwd=wd, check=True, stdout=subprocess.PIPE, text=True).stdout
+            out = run_reference(cmd, wd)
             return time.perf_counter() - t1, out
 
         wall, out = timed("r.fa", "tN")
@@ -1197,7 +1216,7 @@ def run_cpu_baseline_exhaustive(args, al, syn, first_host, ncpu, seed_reads):
         gp, gpo, gst = al.align(c_reads, c_offs, m=args.mismatch, effort=args.effort, mode=1)
         gpu_aligned = int((gpo[1:] > gpo[:-1]).sum())
         return {"value": round(nc / map_s / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "host_cores_visible": len(os.sched_getaffinity(0)),
-                "cpu_quota": cpu_quota(),
+                "cpu_quota": cpu_quota(), "reference_reruns": REFERENCE_RERUNS[0],
                 "sample": "first %d reads of step 0 of this workload, %s -b -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(exe), cores, wall, wall_idx),
                 "reference_reads": ref_reads, "reference_aligned": ref_aligned, "gpu_aligned": gpu_aligned,
                 "gpu_matches_cpu_counters": bool(ref_aligned == gpu_aligned and ref_reads == nc)}
@@ -1246,7 +1265,7 @@ def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
             os.makedirs(wd)
             cmd = [exe, "-r", os.path.join(d, reads_file), "-k", str(args.k), "-g", os.path.join(d, "u.fa"), "-m", str(args.mismatch), "-e", str(args.effort), "-t", str(threads)]
             t1 = time.perf_counter()
-            out = subprocess.run(cmd, cwd=wd, check=True, stdout=subprocess.PIPE, text=True).stdout
+            out = run_reference(cmd, wd)
             wall = time.perf_counter() - t1
             own = None
             for line in out.splitlines():  # "Reads/seconds : N" = reads / (whole mapping seconds + 1), integer arithmetic (aligner.cpp:595)
@@ -1292,7 +1311,7 @@ def run_cpu_baseline(args, al, syn, first_host, ncpu, seed_reads):
                     break
         return {"value": round(nc / map_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "host_cores_visible": len(os.sched_getaffinity(0)),
                 "sample": "first %d reads of step 0 of this workload, %s -t %d, wall %.2fs minus %.2fs index-only run" % (nc, os.path.basename(exe), cores, wall, wall_idx),
-                "reference_stdout_reads_per_second": own_line, "cpu_quota": cpu_quota(), "all_cores": all_cores,
+                "reference_stdout_reads_per_second": own_line, "cpu_quota": cpu_quota(), "reference_reruns": REFERENCE_RERUNS[0], "all_cores": all_cores,
                 "t1": {"value": round(n1 / map_s1 / 1e6, 4), "unit": "Mreads/s", "cores": 1,
                        "sample": "first %d reads, %s -t 1, wall %.2fs minus %.2fs index-only run" % (n1, os.path.basename(exe), wall1, wall_idx1),
                        "reference_stdout_reads_per_second": own_line1},

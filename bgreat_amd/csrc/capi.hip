@@ -98,11 +98,14 @@ struct bgr_aligner {
     hipStream_t stream = nullptr;
     BgrDeviceGraph dg;
     // the text route (bgr_align_fasta_text): the piece, its records, the formatted streams
-    DevBuf tx_in, tx_sums, tx_start, tx_rec, tx_flag, tx_len, tx_idx, tx_boff, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout, tx_info;
+    DevBuf tx_in, tx_sums, tx_state, tx_rec, tx_idx, tx_accrec, tx_accsrc, tx_offs, tx_psz, tx_nsz, tx_poff, tx_noff, tx_pout, tx_nout, tx_info;
     uint64_t tx_n_acc = 0, tx_pbytes = 0, tx_nbytes = 0;
     bool blocking_sync = bgr::opt("blocking_sync") != 0;
     hipEvent_t ev_wait = nullptr;
     const uint8_t* tx_text = nullptr;  // where the last call's piece lies in HBM (tx_in, or the caller's stage)
+    uint32_t tx_flip = 0;              // which of the two info blocks the current piece uses
+    uint32_t tx_epoch = 0, tx_ticket[2] = {0, 0};   // the one-launch kernels' chains: epoch of the last launch; tickets earlier launches took (parse, format)
+    bool tx_written = false;           // the streams lie in tx_pout / tx_nout (the format launch wrote them: every stretch ended below the capacities)
     uint32_t tx_want = 0;              // its want_output (2 = correction mode: mapped reads as spelled by their paths)
     double tx_phase_s[5] = {0, 0, 0, 0, 0};  // BGREAT_TIMING: host wall seconds to the call's four waits (mark, records, mapping + sizes, streams) + calls
 
@@ -509,7 +512,7 @@ void bgr_aligner_destroy(bgr_aligner* a) {
         if (a->stream) (void)hipStreamSynchronize(a->stream);
         a->in_reads.release(); a->in_offs.release(); a->pk_fw3.release(); a->pk_nm.release(); a->pk_hasn.release(); a->results.release(); a->arena.release(); a->ovf.release(); a->ovf2.release(); a->lst.release(); a->deepbuf.release(); a->retry.release(); a->retry2.release(); a->small.release();
         a->csr_sums.release(); a->csr_poffs.release(); a->csr_status.release(); a->csr_paths.release(); a->wave_times.release();
-        for (DevBuf* b : {&a->tx_in, &a->tx_sums, &a->tx_start, &a->tx_rec, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_offs,
+        for (DevBuf* b : {&a->tx_in, &a->tx_sums, &a->tx_state, &a->tx_rec, &a->tx_idx, &a->tx_accrec, &a->tx_accsrc, &a->tx_offs,
                           &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff, &a->tx_pout, &a->tx_nout, &a->tx_info}) b->release();
         for (int i = 0; i < kTimerRing; ++i) for (int j = 0; j <= kTimerSlots; ++j) (void)hipEventDestroy(a->ev[i][j]);
         if (a->ev_wait) (void)hipEventDestroy(a->ev_wait);
@@ -595,7 +598,8 @@ extern "C" int bgr_plan_launch(const bgr_plan_input* in, bgr_plan_output* out) {
 // (bgr_align_batch_packed copied them in); else they are made from the ASCII reads at d_reads by the pre-pass.
 // d_src_off (may be null): where each read's characters start in d_reads when they lie scattered in a text (text route); reads_bytes: bytes of d_reads.
 static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_reads, const void* d_read_offsets, uint64_t n_reads,
-                             uint64_t total_bases, uint32_t max_read_len, bool planes_ready, const void* d_src_off = nullptr, uint64_t reads_bytes = 0) {
+                             uint64_t total_bases, uint32_t max_read_len, bool planes_ready, const void* d_src_off = nullptr, uint64_t reads_bytes = 0,
+                             bool cursor_is_zero = false) {
     if (!a || !p) return fail(BGR_E_ARG, "bgr_align_device: null argument");
     if (p->mode > BGR_MODE_ANCHORS) return fail(BGR_E_ARG, "bgr_align_device: unknown mode");
     if (p->mode == BGR_MODE_ANCHORS && !a->graph->header.anc_n)
@@ -710,7 +714,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     BgrDeviceGraph dgl = a->dg;
     if (p->mode == BGR_MODE_EXHAUSTIVE && !(dgl.filter_kind == BGR_FILTER_MINIMIZER && a->exh_filter)) dgl.bloom = nullptr;
 
-    HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters
+    if (!cursor_is_zero) HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters (the text form: the parse launch cleared them)
     {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: the cursor starts behind
         const uint64_t own = fast_pass ? P.fast_rows
                            : x4_pass   ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * P.arena_chunk
@@ -979,6 +983,7 @@ static int fetch_text_impl(bgr_aligner* a, bgr_text_batch* b) {
     if (!b->want_output || a->tx_n_acc == 0) return BGR_OK;
     if (a->tx_pbytes > b->paths_cap || a->tx_nbytes > b->notaligned_cap || (a->tx_pbytes && !b->paths_out) || (a->tx_nbytes && !b->notaligned_out))
         return fail(BGR_E_CAPACITY, "bgr_align_fasta_text: output buffer too small (paths_bytes / notaligned_bytes say what is needed; bgr_aligner_fetch_text)");
+    if (!a->tx_written) {   // (correction mode; streams larger than the buffers the format launch wrote into; a second fetch)
     HIP_TRY(a->tx_pout.ensure(a->tx_pbytes + 64));
     HIP_TRY(a->tx_nout.ensure(a->tx_nbytes + 64));
     hipError_t e = a->tx_want == 2
@@ -991,6 +996,8 @@ static int fetch_text_impl(bgr_aligner* a, bgr_text_batch* b) {
                                  static_cast<const uint32_t*>(a->tx_poff.p), static_cast<const uint32_t*>(a->tx_noff.p), static_cast<uint8_t*>(a->tx_pout.p),
                                  static_cast<uint8_t*>(a->tx_nout.p), a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text write launch: ") + hipGetErrorString(e));
+    a->tx_written = true;
+    }
     if (a->tx_pbytes) HIP_TRY(hipMemcpyAsync(b->paths_out, a->tx_pout.p, a->tx_pbytes, hipMemcpyDeviceToHost, a->stream));
     if (a->tx_nbytes) HIP_TRY(hipMemcpyAsync(b->notaligned_out, a->tx_nout.p, a->tx_nbytes, hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(wait_stream(a));
@@ -1038,9 +1045,9 @@ int bgr_text_stage_upload(bgr_text_stage* s, const char* text, uint64_t bytes) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));  // (a piece still on its way: the buffer may grow, i.e. move)
     s->settle();
-    HIP_TRY(s->buf.ensure(bytes + 64));
+    HIP_TRY(s->buf.ensure(bytes + 128));
     if (s->timing) { HIP_TRY(hipEventRecord(s->ev0, s->stream)); s->pending = true; }
-    HIP_TRY(hipMemsetAsync(static_cast<char*>(s->buf.p) + bytes, 0, 64, s->stream));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(s->buf.p) + (bytes & ~63ull), 0, 128, s->stream));   // (from an aligned address: one fill; the copies below lay the text over its start)
     if (bytes) HIP_TRY(hipMemcpyAsync(s->buf.p, text, bytes, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev, s->stream));
     s->bytes = bytes;
@@ -1055,9 +1062,9 @@ int bgr_text_stage_upload_parts(bgr_text_stage* s, uint32_t n_parts, const char*
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));  // (a piece still on its way: the buffer may grow, i.e. move)
     s->settle();
-    HIP_TRY(s->buf.ensure(bytes + 64));
+    HIP_TRY(s->buf.ensure(bytes + 128));
     if (s->timing) { HIP_TRY(hipEventRecord(s->ev0, s->stream)); s->pending = true; }
-    HIP_TRY(hipMemsetAsync(static_cast<char*>(s->buf.p) + bytes, 0, 64, s->stream));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(s->buf.p) + (bytes & ~63ull), 0, 128, s->stream));   // (from an aligned address: one fill; the copies below lay the text over its start)
     uint64_t at = 0;
     for (uint32_t i = 0; i < n_parts; ++i) {
         if (part_bytes[i]) HIP_TRY(hipMemcpyAsync(static_cast<char*>(s->buf.p) + at, parts[i], part_bytes[i], hipMemcpyHostToDevice, s->stream));
@@ -1095,9 +1102,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (b->text_bytes == 0) return BGR_OK;
     HIP_TRY(hipSetDevice(a->device));
     const uint32_t nbytes = (uint32_t)b->text_bytes;
-    uint32_t* info = reinterpret_cast<uint32_t*>(static_cast<char*>(a->small.p) + 192);  // TXT_INFO_WORDS u32 behind cursor / counters / CSR total
     const uint8_t* text = nullptr;
-    HIP_TRY(hipMemsetAsync(info, 0, TXT_INFO_WORDS * 4, a->stream));
     // 1. the piece in HBM (zero padded): uploaded ahead of this call by a stage (bgr_text_stage_upload, a copy stream of its own), or copied now
     if (b->stage) {
         if (b->stage->device != a->device || b->stage->bytes != b->text_bytes) return fail(BGR_E_ARG, "bgr_align_fasta_text: the stage holds another piece / lives on another device");
@@ -1105,30 +1110,44 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         text = static_cast<const uint8_t*>(b->stage->buf.p);
     } else {
         if (!b->text) return fail(BGR_E_ARG, "bgr_align_fasta_text: null text");
-        HIP_TRY(a->tx_in.ensure((uint64_t)nbytes + 64));
+        HIP_TRY(a->tx_in.ensure((uint64_t)nbytes + 128));
         text = static_cast<const uint8_t*>(a->tx_in.p);
-        HIP_TRY(hipMemsetAsync(static_cast<char*>(a->tx_in.p) + nbytes, 0, 64, a->stream));
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(a->tx_in.p) + (nbytes & ~63ull), 0, 128, a->stream));   // (64 zero bytes behind the piece at least; from an aligned address: ONE fill, and the copy below lays the text over its start)
         HIP_TRY(hipMemcpyAsync(a->tx_in.p, b->text, nbytes, hipMemcpyHostToDevice, a->stream));
     }
     a->tx_text = text;
     // 2. records: starts, extents, shape, accept test; accepted records compacted in input order.  Room for one record per 24 bytes of
     // text (a sequencing read with its header is several times that): a piece with more record starts goes to the host parser.
     const uint32_t R_cap = nbytes / 24 + 1024;
-    // (scratch: the marking kernel's tile sums, then room for the scans)
-    HIP_TRY(a->tx_sums.ensure(((uint64_t)bgr::text_tiles(nbytes) + 2 * bgr::scan_tiles(R_cap) + 16) * 4));
-    for (DevBuf* d : {&a->tx_start, &a->tx_flag, &a->tx_len, &a->tx_idx, &a->tx_boff, &a->tx_accrec, &a->tx_accsrc, &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff})
+    // (tickets and chains of the two one-launch kernels, text_kernels.hip: never cleared between launches -- every launch gets a fresh epoch)
+    {
+        const uint64_t chain_words = std::max<uint64_t>(3ull * bgr::text_tiles(nbytes), 2ull * bgr::format_tiles(R_cap));
+        const size_t had = a->tx_state.cap;
+        HIP_TRY(a->tx_state.ensure(64 + chain_words * 8));
+        if (a->tx_state.cap != had || a->tx_epoch + 2 > BGR_TEXT_EPOCH_MAX) {
+            HIP_TRY(hipMemsetAsync(a->tx_state.p, 0, a->tx_state.cap, a->stream));
+            a->tx_epoch = 0;
+            a->tx_ticket[0] = a->tx_ticket[1] = 0;
+        }
+    }
+    uint32_t* tickets = static_cast<uint32_t*>(a->tx_state.p);
+    uint64_t* chains = reinterpret_cast<uint64_t*>(static_cast<char*>(a->tx_state.p) + 64);
+    HIP_TRY(a->tx_sums.ensure((2ull * bgr::scan_tiles(R_cap) + 16) * 4));   // (correction mode's scans)
+    for (DevBuf* d : {&a->tx_idx, &a->tx_accrec, &a->tx_accsrc, &a->tx_psz, &a->tx_nsz, &a->tx_poff, &a->tx_noff})
         HIP_TRY(d->ensure(((uint64_t)R_cap + 4) * 4));
     HIP_TRY(a->tx_rec.ensure(((uint64_t)R_cap + 1) * 16));
     HIP_TRY(a->tx_offs.ensure(((uint64_t)R_cap + 2) * 8));
-    uint32_t* sums2 = static_cast<uint32_t*>(a->tx_sums.p) + bgr::text_tiles(nbytes);
-    hipError_t e = bgr::launch_text_mark(text, nbytes, rec_lines, static_cast<uint32_t*>(a->tx_sums.p), static_cast<uint32_t*>(a->tx_start.p), R_cap, info + TXT_INFO_N_REC, a->stream);
-    if (e == hipSuccess) e = bgr::launch_text_records(text, nbytes, b->fastq != 0, static_cast<const uint32_t*>(a->tx_start.p), info + TXT_INFO_N_REC, R_cap, a->dg.k, static_cast<uint4*>(a->tx_rec.p),
-                                                      static_cast<uint32_t*>(a->tx_flag.p), static_cast<uint32_t*>(a->tx_len.p), info, a->stream);
-    if (e == hipSuccess) e = bgr::launch_scan2_u32(static_cast<const uint32_t*>(a->tx_flag.p), static_cast<const uint32_t*>(a->tx_len.p), static_cast<uint32_t*>(a->tx_idx.p),
-                                                   static_cast<uint32_t*>(a->tx_boff.p), R_cap, info + TXT_INFO_N_REC, sums2, info + TXT_INFO_N_ACC, info + TXT_INFO_BASES, a->stream);
-    if (e == hipSuccess) e = bgr::launch_text_compact(static_cast<const uint4*>(a->tx_rec.p), info + TXT_INFO_N_REC, R_cap, static_cast<const uint32_t*>(a->tx_idx.p),
-                                                      static_cast<const uint32_t*>(a->tx_boff.p), static_cast<uint32_t*>(a->tx_accrec.p), static_cast<uint32_t*>(a->tx_accsrc.p),
-                                                      static_cast<uint64_t*>(a->tx_offs.p), info + TXT_INFO_N_ACC, info + TXT_INFO_BASES, a->stream);
+    uint32_t* sums2 = static_cast<uint32_t*>(a->tx_sums.p);
+    // TXT_INFO_WORDS u32 behind cursor / counters / CSR total -- two such blocks, taken in turn: a piece's parse launch clears the block of the NEXT piece (and the
+    // mapping launch's cursor), so that no fill stands in front of either (the blocks start zero: bgr_aligner_create)
+    a->tx_flip ^= 1u;   // (here, behind everything that can fail before the launch: a block is cleared by the launch in front of the one that uses it)
+    uint32_t* info = reinterpret_cast<uint32_t*>(static_cast<char*>(a->small.p) + 192 + 32 * a->tx_flip);
+    uint32_t* info_next = reinterpret_cast<uint32_t*>(static_cast<char*>(a->small.p) + 192 + 32 * (a->tx_flip ^ 1u));
+    static_assert(TXT_INFO_WORDS * 4 == 32, "two info blocks of 32 bytes at small + 192");
+    hipError_t e = bgr::launch_text_parse(text, nbytes, rec_lines, a->dg.k, tickets, a->tx_ticket[0], ++a->tx_epoch, chains, static_cast<uint4*>(a->tx_rec.p),
+                                          static_cast<uint32_t*>(a->tx_idx.p), static_cast<uint32_t*>(a->tx_accrec.p), static_cast<uint32_t*>(a->tx_accsrc.p),
+                                          static_cast<uint64_t*>(a->tx_offs.p), info, R_cap, static_cast<uint32_t*>(a->small.p), 16, info_next, TXT_INFO_WORDS, a->stream);
+    a->tx_ticket[0] += bgr::text_tiles(nbytes);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text record launches: ") + hipGetErrorString(e));
     uint32_t h[TXT_INFO_WORDS];
     HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
@@ -1146,7 +1165,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         return BGR_OK;
     }
     // 3. the mapping launch, its reads where they lie in the text (planes by the pre-pass, or -- greedy mode -- staged by the mapping kernels themselves)
-    int rc = align_device_impl(a, p, text, a->tx_offs.p, n_acc, bases, max_len, false, a->tx_accsrc.p, nbytes);
+    int rc = align_device_impl(a, p, text, a->tx_offs.p, n_acc, bases, max_len, false, a->tx_accsrc.p, nbytes, true);
     if (rc != BGR_OK) return rc;
     a->last_n = 0;  // (bgr_aligner_fetch has no host read_offsets to pair its rows with: the text form hands out text)
     a->tx_n_acc = n_acc;
@@ -1154,6 +1173,8 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     // handed back for a larger table are mapped again: settle_launch) -- which hardly ever happens: so the kernels below are enqueued at once, the
     // cursor comes back with the wait this call makes anyway, and only a launch that did hand reads back is settled and the kernels enqueued AGAIN
     // (a wait between the mapping launch and them cost -b a fifth of its end-to-end rate)
+    uint64_t pcap_dev = 0, ncap_dev = 0;
+    a->tx_written = false;
     for (int again = 0; again < 2; ++again) {
     if (b->record_info_out) {  // what became of every record (the -b progress blocks of the caller), on its way to the host behind the mapping launch
         HIP_TRY(a->tx_info.ensure((uint64_t)R * 4));
@@ -1177,10 +1198,19 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         e = bgr::launch_text_correct_sizes(a->dg, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
                                            static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, static_cast<uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_nsz.p),
                                            static_cast<uint32_t*>(a->tx_idx.p), info + TXT_INFO_BUG, a->stream);
-    } else
-    e = bgr::launch_text_sizes(static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
-                               static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, static_cast<uint32_t*>(a->tx_psz.p), static_cast<uint32_t*>(a->tx_nsz.p), a->stream);
-    if (e == hipSuccess) e = bgr::launch_scan2_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_poff.p),
+    } else {
+        // sizes, offsets and bytes in one launch, into device buffers of the caller's capacities (at most twice the piece + 1 MB each: a piece whose
+        // streams need more -- paths of very many unitigs -- is written by bgr_text_write_kernel from the offsets once the totals are known)
+        pcap_dev = b->paths_out ? std::min<uint64_t>(b->paths_cap, 2ull * nbytes + (1ull << 20)) : 0;
+        ncap_dev = b->notaligned_out ? std::min<uint64_t>(b->notaligned_cap, 2ull * nbytes + (1ull << 20)) : 0;
+        HIP_TRY(a->tx_pout.ensure(pcap_dev + 64));
+        HIP_TRY(a->tx_nout.ensure(ncap_dev + 64));
+        e = bgr::launch_text_format(text, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
+                                    static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, tickets + 1, a->tx_ticket[1], ++a->tx_epoch, chains, static_cast<uint32_t*>(a->tx_poff.p),
+                                    static_cast<uint32_t*>(a->tx_noff.p), static_cast<uint8_t*>(a->tx_pout.p), static_cast<uint8_t*>(a->tx_nout.p), pcap_dev, ncap_dev, info, a->stream);
+        a->tx_ticket[1] += bgr::format_tiles(n_acc);
+    }
+    if (e == hipSuccess && b->want_output == 2) e = bgr::launch_scan2_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_poff.p),
                                                    static_cast<uint32_t*>(a->tx_noff.p), n_acc, nullptr, sums2, info + TXT_INFO_PBYTES, info + TXT_INFO_NBYTES, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text size launches: ") + hipGetErrorString(e));
     uint32_t h2[16];
@@ -1204,6 +1234,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     }
     a->tx_pbytes = h[TXT_INFO_PBYTES];
     a->tx_nbytes = h[TXT_INFO_NBYTES];
+    a->tx_written = b->want_output == 1 && a->tx_pbytes <= pcap_dev && a->tx_nbytes <= ncap_dev;   // (every workgroup's stretch ended below the capacities)
     const int frc = fetch_text_impl(a, b);
     lap(3);
     a->tx_phase_s[4] += 1;

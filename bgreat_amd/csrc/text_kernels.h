@@ -17,24 +17,29 @@
 #define TXT_INFO_NBYTES 6     /* bytes of the notAligned stream */
 #define TXT_INFO_BUG 7        /* correction mode: the first accepted read whose path does not spell a walk ("bug compaction"), else ~0 */
 #define TXT_INFO_WORDS 8
+#define BGR_TEXT_EPOCH_MAX 0x3FFFFFu /* epochs of the chains: 22 bits, 0 = never written */
 
 namespace bgr {
 
-// exclusive scan of n u32 (out may alias in); sums: scan_tiles(n) words of scratch; *total_out = the sum
-hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, uint32_t* total_out, hipStream_t stream);
-// ... of two arrays of equal length at once, over their first min(n, *n_dev) entries (n_dev: a count on the device, or null); sums: 2 * scan_tiles(n) words
+// exclusive scan of two u32 arrays of equal length at once, over their first min(n, *n_dev) entries (n_dev: a count on the device, or null); sums: 2 * scan_tiles(n) words
 hipError_t launch_scan2_u32(const uint32_t* inA, const uint32_t* inB, uint32_t* outA, uint32_t* outB, uint32_t n, const uint32_t* n_dev, uint32_t* sums, uint32_t* totalA,
                             uint32_t* totalB, hipStream_t stream);
 uint32_t scan_tiles(uint32_t n);
-uint32_t text_tiles(uint32_t bytes);
-// record starts: *n_rec_out and rec_start[0 .. min(*n_rec_out, rec_cap)) (sums: text_tiles(n) words of scratch)
-hipError_t launch_text_mark(const uint8_t* text, uint32_t n, uint32_t fastq_lines, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream);
-hipError_t launch_text_records(const uint8_t* text, uint32_t n, bool fastq, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t max_rec, uint32_t k, uint4* rec,
-                               uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, hipStream_t stream);
-hipError_t launch_text_compact(const uint4* rec, const uint32_t* n_rec_p, uint32_t max_rec, const uint32_t* acc_idx, const uint32_t* base_off, uint32_t* acc_rec,
-                               uint32_t* acc_src, uint64_t* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p, hipStream_t stream);
-hipError_t launch_text_sizes(const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* psz, uint32_t* nsz,
-                             hipStream_t stream);
+uint32_t text_tiles(uint32_t bytes);     // workgroups (= chain entries) of the parse launch
+uint32_t format_tiles(uint32_t n_acc);   // ... of the format launch
+// The piece in one launch: info[N_REC, N_ACC, BASES, MAX_LEN, IRREGULAR]; rec[0 .. min(N_REC, rec_cap)); the accepted records compacted in input order: acc_rec (which
+// record), acc_src (where its read starts in the text), read_offs (base offsets, N_ACC + 1 of them); acc_idx[j] = a for accepted record j.
+// fastq_lines: 0 FASTA, else lines per FASTQ record (4, 2).  Running totals pass between the launch's workgroups through `chains` (3 * text_tiles(n) u64), tagged
+// with `epoch` (1 .. kTextEpochMax, a fresh one per launch; the chains are zero before epoch 1 is used), the workgroups numbered by *ticket - ticket_base (*ticket
+// grows by text_tiles(n) per launch).  words_a words at zero_a and words_b at zero_b (at most 1024 each) are cleared: words only later launches read.
+hipError_t launch_text_parse(const uint8_t* text, uint32_t n, uint32_t fastq_lines, uint32_t k, uint32_t* ticket, uint32_t ticket_base, uint32_t epoch, uint64_t* chains,
+                             uint4* rec, uint32_t* acc_idx, uint32_t* acc_rec, uint32_t* acc_src, uint64_t* read_offs, uint32_t* info, uint32_t rec_cap, uint32_t* zero_a,
+                             uint32_t words_a, uint32_t* zero_b, uint32_t words_b, hipStream_t stream);
+// Sizes, stream offsets and the bytes of the records in one launch: info[PBYTES, NBYTES] (saturating at 2^32 - 1); poff/noff as launch_text_write takes them; the bytes
+// where a workgroup's whole stretch ends below pcap / ncap.  chains: 2 * format_tiles(n_acc) u64; ticket / epoch as above.
+hipError_t launch_text_format(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* ticket,
+                              uint32_t ticket_base, uint32_t epoch, uint64_t* chains, uint32_t* poff, uint32_t* noff, uint8_t* pout, uint8_t* nout, uint64_t pcap, uint64_t ncap,
+                              uint32_t* info, hipStream_t stream);
 hipError_t launch_text_write(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc,
                              const uint32_t* poff, const uint32_t* noff, uint8_t* pout, uint8_t* nout, hipStream_t stream);
 // one word per record, record order: kept << 31 | mapped << 30 | read length (bgr_text_batch.record_info_out)

@@ -11,80 +11,57 @@
 #include "device_common.h"
 #include "text_kernels.h"
 
+#ifdef BGR_X_TIMES
+__device__ unsigned long long bgr_x_times[4 * 16];
+extern "C" int bgr_x_times_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bgr_x_times), sizeof(bgr_x_times)); }
+#define BGR_XT(slot, ph) do { if (threadIdx.x == 0 && (vt == 0 || vt == ntiles / 2)) bgr_x_times[((slot) * 2 + (vt ? 1 : 0)) * 16 + (ph)] = wall_clock64(); } while (0)
+#else
+#define BGR_XT(slot, ph) do {} while (0)
+#endif
+
 namespace bgr {
 namespace {
 
 typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
 
-constexpr uint32_t kTxtThreads = 1024, kTxtTile = kTxtThreads * 16;  // bytes per workgroup of the marking kernel
+constexpr uint32_t kTxtThreads = 1024;
+
+// inclusive scan over the 64 lanes of a wave without LDS: four row_shr steps scan each row of 16, row_bcast:15 carries row 0 into row 1 and row 2 into row 3,
+// row_bcast:31 carries rows 0..1 into rows 2..3 (a lane whose source lies outside its row, or whose row is masked out, adds the 0 given as `old`)
+#define BGR_DPP0(x, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xF, false))
+__device__ __forceinline__ uint32_t wave_inclusive_scan32(uint32_t x) {
+    x += BGR_DPP0(x, 0x111, 0xF); x += BGR_DPP0(x, 0x112, 0xF); x += BGR_DPP0(x, 0x114, 0xF); x += BGR_DPP0(x, 0x118, 0xF);
+    x += BGR_DPP0(x, 0x142, 0xA);
+    x += BGR_DPP0(x, 0x143, 0xC);
+    return x;
+}
+#define BGR_DPP0_64(x, ctrl, rows) (((u64)BGR_DPP0((uint32_t)((x) >> 32), ctrl, rows) << 32) | BGR_DPP0((uint32_t)(x), ctrl, rows))
+__device__ __forceinline__ u64 wave_inclusive_scan64(u64 x) {
+    x += BGR_DPP0_64(x, 0x111, 0xF); x += BGR_DPP0_64(x, 0x112, 0xF); x += BGR_DPP0_64(x, 0x114, 0xF); x += BGR_DPP0_64(x, 0x118, 0xF);
+    x += BGR_DPP0_64(x, 0x142, 0xA);
+    x += BGR_DPP0_64(x, 0x143, 0xC);
+    return x;
+}
 
 __device__ __forceinline__ uint32_t block_exclusive_scan32(uint32_t v, uint32_t* lds_waves, uint32_t* block_total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += up;
-    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;   // (up to 16 waves)
+    const uint32_t inc = wave_inclusive_scan32(v);
     if (lane == 63) lds_waves[wave] = inc;
     __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
-        const uint32_t t = lds_waves[w];
-        if (w < (uint32_t)wave) before += t;
-        total += t;
-    }
+    // every wave scans the (at most 16) wave totals itself: one LDS read, four shuffles (a loop over them waits for LDS sixteen times)
+    const uint32_t t = lane < nw ? lds_waves[lane] : 0u;
+    uint32_t ti = t;
+    ti += BGR_DPP0(ti, 0x111, 0xF); ti += BGR_DPP0(ti, 0x112, 0xF); ti += BGR_DPP0(ti, 0x114, 0xF); ti += BGR_DPP0(ti, 0x118, 0xF);   // (row 0 holds them)
+    const uint32_t before = (uint32_t)__shfl((int)(ti - t), wave, 64);
+    *block_total = (uint32_t)__shfl((int)ti, 15, 64);
     __syncthreads();
-    *block_total = total;
     return before + inc - v;
 }
 
-// ---- device-wide exclusive scan of a u32 array (4096 items per workgroup; sums, one-workgroup scan of the sums, apply) ----------
 constexpr uint32_t kScanItems = 4, kScanTile = kTxtThreads * kScanItems;
-__global__ void __launch_bounds__(kTxtThreads) bgr_scan_block_sums(const uint32_t* in, uint32_t n, uint32_t* sums) {
-    __shared__ uint32_t lw[16];
-    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t s = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kScanItems; ++j) if (base + j < n) s += in[base + j];
-    uint32_t total;
-    (void)block_exclusive_scan32(s, lw, &total);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-__global__ void __launch_bounds__(kTxtThreads) bgr_scan_sums(uint32_t* sums, uint32_t nb, uint32_t* total_out) {
-    __shared__ uint32_t lw[16];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < nb; b0 += kTxtThreads) {
-        const uint32_t i = b0 + threadIdx.x;
-        const uint32_t v = i < nb ? sums[i] : 0;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan32(v, lw, &total);
-        const uint32_t carry = carry_s;
-        if (i < nb) sums[i] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total_out = carry_s;
-}
-__global__ void __launch_bounds__(kTxtThreads) bgr_scan_apply(const uint32_t* in, uint32_t n, const uint32_t* sums, uint32_t* out) {
-    __shared__ uint32_t lw[16];
-    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t v[kScanItems], s = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kScanItems; ++j) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
-    uint32_t total;
-    uint32_t w = sums[blockIdx.x] + block_exclusive_scan32(s, lw, &total);
-#pragma unroll
-    for (uint32_t j = 0; j < kScanItems; ++j) {
-        if (base + j < n) out[base + j] = w;
-        w += v[j];
-    }
-}
 
-// ---- the same for TWO arrays of equal length in one go, over the first min(n, *n_dev) entries (n_dev may be null) -------------------------
+// ---- device-wide exclusive scan of TWO u32 arrays of equal length in one go (4096 items per workgroup; sums, one-workgroup scan of the sums, apply),
+// over the first min(n, *n_dev) entries (n_dev may be null).  Correction mode's sizes; the default route's totals run down chains inside its two kernels.
 // (round 5: the text form scanned four arrays per piece with three launches each, over all rec_cap entries of arrays of which a sixth is used --
 // the record count is only known on the device; now two pairs, and workgroups beyond the count leave at once)
 __global__ void __launch_bounds__(kTxtThreads) bgr_scan2_block_sums(const uint32_t* inA, const uint32_t* inB, uint32_t n, const uint32_t* n_dev, uint32_t* sums, uint32_t nb) {
@@ -140,67 +117,11 @@ __global__ void __launch_bounds__(kTxtThreads) bgr_scan2_apply(const uint32_t* i
     }
 }
 
-// ---- record starts: a '>' at the start of a line ---------------------------------------------------------------------------
 // bit 7 of every byte of x that equals the byte replicated in `pat`
 __device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t pat) { return bgr_zero_bytes(x ^ pat); }
+// bits 7, 15, 23, 31 of h -> bits 0..3 (one multiply: the four shifted copies do not meet)
+__device__ __forceinline__ uint32_t nibble_of(uint32_t h) { return (((h >> 7) * 0x00204081u) >> 21) & 0xFu; }
 
-// phase 0: record starts per 16 KB tile -> sums[tile]; phase 1: rec_start[] (byte offsets, ascending) from the scanned sums
-// (rec_cap: room in rec_start; a piece with more record starts than that is left to the host, the caller sees it from the count)
-// FASTQ (-q): record j is lines 4j .. 4j+3 whatever they contain (aligner.cpp:51-68), so the marks are the NEWLINES; the byte behind
-// every fourth one starts a record (the piece holds whole records and starts at one: the caller cuts it so)
-// (FASTQ = lines per record: 4, or 2 when the caller has left the '+' and quality lines on the host; 0 = FASTA)
-template <int PHASE, int FASTQ>
-__global__ void __launch_bounds__(kTxtThreads) bgr_text_mark_kernel(const uint8_t* text, uint32_t n, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap) {
-    __shared__ uint32_t lw[16];
-    constexpr uint32_t LN = FASTQ ? (uint32_t)FASTQ : 1u;  // lines per FASTQ record (a power of two)
-    const uint32_t pos = blockIdx.x * kTxtTile + threadIdx.x * 16;
-    uint32_t rs = 0;  // bit i: byte pos + i starts a record (FASTQ: is a newline)
-    if (FASTQ) {
-        if (pos < n) {
-            const uint4 v = *reinterpret_cast<const uint4*>(text + pos);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t nl = eq_bytes(w[d], 0x0A0A0A0Au) >> 7;
-                rs |= (((nl & 1u) | ((nl >> 7) & 2u) | ((nl >> 14) & 4u) | ((nl >> 21) & 8u)) << (4 * d));
-            }
-            if (pos + 16 > n) rs &= (1u << (n - pos)) - 1u;
-        }
-    } else if (pos < n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(text + pos);  // (the buffer is zero padded: a zero byte is neither '>' nor '\n')
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t prev_nl = pos == 0 ? 1u : (text[pos - 1] == '\n' ? 1u : 0u);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const uint32_t gt = eq_bytes(w[d], 0x3E3E3E3Eu) >> 7, nl = eq_bytes(w[d], 0x0A0A0A0Au) >> 7;  // bit 0 of each byte
-            const uint32_t after_nl = (nl << 8) | prev_nl;   // byte i follows a newline
-            const uint32_t hit = gt & after_nl;
-            rs |= (((hit & 1u) | ((hit >> 7) & 2u) | ((hit >> 14) & 4u) | ((hit >> 21) & 8u)) << (4 * d));
-            prev_nl = nl >> 24;
-        }
-        if (pos + 16 > n) rs &= (1u << (n - pos)) - 1u;
-    }
-    const uint32_t cnt = (uint32_t)__popc(rs);
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan32(cnt, lw, &total);
-    if (PHASE == 0) {
-        if (threadIdx.x == 0) sums[blockIdx.x] = total;
-    } else {
-        uint32_t at = sums[blockIdx.x] + ex;
-        if (FASTQ && blockIdx.x == 0 && threadIdx.x == 0 && n) rec_start[0] = 0;
-        while (rs) {
-            const uint32_t i = (uint32_t)__ffs((int)rs) - 1;
-            rs &= rs - 1;
-            if (!FASTQ) { if (at < rec_cap) rec_start[at] = pos + i; }
-            else if (((at + 1) & (LN - 1u)) == 0 && ((at + 1) / LN) < rec_cap && pos + i + 1 < n) rec_start[(at + 1) / LN] = pos + i + 1;  // behind the 4th, 8th ... (2nd, 4th ...) newline
-            ++at;
-        }
-    }
-}
-// FASTQ: newlines counted -> records (a piece of whole records ends with a newline: 4 per record)
-__global__ void bgr_text_fastq_count_kernel(uint32_t* n_rec, uint32_t lines) { *n_rec = *n_rec / lines; }
-
-// ---- records: header / sequence extents, shape check, accept test ------------------------------------------------------------
 // min over the 16 lanes of a row, result in every lane
 __device__ __forceinline__ uint32_t row16_min(uint32_t x) {
     uint32_t o = quad_xor1(x); x = o < x ? o : x;
@@ -229,55 +150,166 @@ __device__ __forceinline__ void load16(const uint8_t* text, uint32_t p, uint32_t
 __device__ __forceinline__ uint32_t mask16(const uint32_t w[4], uint32_t pat) {
     uint32_t m = 0;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const uint32_t h = eq_bytes(w[d], pat) >> 7;
-        m |= ((h & 1u) | ((h >> 7) & 2u) | ((h >> 14) & 4u) | ((h >> 21) & 8u)) << (4 * d);
-    }
+    for (int d = 0; d < 4; ++d) m |= nibble_of(eq_bytes(w[d], pat)) << (4 * d);
     return m;
 }
 
-// One 16-lane group per record j: bytes [rec_start[j], rec_start[j+1] or n).  The shape this route takes: exactly two
-// newlines, the second one the record's last byte (header line + one sequence line).  Anything else sets *irregular.
+// ---- a running total handed from tile to tile inside ONE launch (decoupled look-back) ----------------------------------------------------------
+// st[t]: bits 63..62 = 1 tile t's own sum, 2 the sum of tiles 0..t; bits 61..40 the EPOCH of the launch that wrote the word (a word of another
+// epoch counts as "nothing yet": the chains are never cleared between launches -- the host hands every launch a fresh epoch and clears them when the
+// 22 bits wrap); bits 39..0 the value.  Tiles are numbered by a ticket taken at run time (ticket word - what the host knows earlier launches took), so
+// every tile a workgroup waits for has already started.  Called by ALL 64 lanes of one wave; -> the sum of the tiles in front of vt.  The words are
+// read and written whole (64-bit, device scope): no fence needed, and nothing else passes between workgroups.
+constexpr u64 kChainValue = (1ull << 40) - 1;
+__device__ __forceinline__ u64 chain_word(uint32_t flag, uint32_t epoch, u64 value) { return ((u64)flag << 62) | ((u64)epoch << 40) | (value & kChainValue); }
+// (in two halves, so that a workgroup can publish its own sum, do other work, and walk the chain when the tiles in front have had time to publish theirs)
+__device__ __forceinline__ void chain_publish(u64* st, uint32_t vt, uint32_t epoch, u64 own) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&st[vt], chain_word(vt ? 1 : 2, epoch, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 chain_walk(u64* st, uint32_t vt, uint32_t epoch, u64 own) {
+    const int lane = threadIdx.x & 63;
+    if (vt == 0) return 0;
+    u64 before = 0;
+    int64_t base = (int64_t)vt - 1;
+    // Four windows of 64 tiles per round trip, lane l at tiles base - l, base - 64 - l, ...: 64 consecutive words per load instruction (8 sectors).  All the tiles
+    // of a launch start at about the same time, so the tile that knows its running total is far back and every tile reads most of the chain: the number of
+    // sector requests on these few cache lines (device-scope loads go past the L2) is what the walk costs -- with lane l at four neighbouring tiles it was
+    // four times as many and the chains took 18 us of a 48 us launch.
+    for (bool done = false; !done;) {
+        u64 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t idx = base - 64 * q - lane;
+            v[q] = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : chain_word(2, epoch, 0);
+        }
+        u64 sum = 0;
+        int taken = 0;   // windows of this round trip that were complete up to a tile that knows its running total / to their end
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (done || taken != q) continue;
+            const uint32_t flag = ((uint32_t)(v[q] >> 40) & 0x3FFFFFu) == epoch ? (uint32_t)(v[q] >> 62) : 0u;
+            const u64 m_none = __ballot(flag == 0), m_full = __ballot(flag == 2);
+            const int stop = m_full ? __ffsll((long long)m_full) - 1 : 63;
+            const u64 need = stop == 63 ? ~0ull : ((2ull << stop) - 1ull);
+            if (m_none & need) continue;                                      // a tile in it has not published yet: read again from this window on
+            sum += lane <= stop ? (v[q] & kChainValue) : 0ull;
+            taken = q + 1;
+            if (m_full) done = true;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)sum, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(sum >> 32), d, 64);
+            sum += ((u64)hi << 32) | lo;
+        }
+        before += sum;
+        base -= 64 * taken;
+        if (!done && taken < 4) __builtin_amdgcn_s_sleep(20);   // ~0.5 us: whoever is missing is busy publishing; polling faster only adds traffic
+    }
+    if (lane == 0) __hip_atomic_store(&st[vt], chain_word(2, epoch, before + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return before;
+}
+__device__ __forceinline__ u64 chain_lookback(u64* st, uint32_t vt, uint32_t epoch, u64 own) {
+    chain_publish(st, vt, epoch, own);
+    return chain_walk(st, vt, epoch, own);
+}
+
+__device__ __forceinline__ u64 shfl64(u64 x, int l) { return ((u64)(uint32_t)__shfl((int)(uint32_t)(x >> 32), l, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)x, l, 64); }
+// exclusive scans of N 64-bit values per thread over the workgroup, array after array (value n of thread t comes behind value n - 1 of every thread): one pair
+// of barriers for all of them.  ex[n] = what lies in front of v[n]; *total = everything.  (fields packed in a value must not carry into each other)
+template <int N>
+__device__ __forceinline__ void block_exclusive_scan64xN(const u64 (&v)[N], u64* lds_waves /* N * 16 */, u64 (&ex)[N], u64* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    u64 inc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        inc[n] = wave_inclusive_scan64(v[n]);
+        if (lane == 63) lds_waves[n * 16 + wave] = inc[n];
+    }
+    __syncthreads();
+    u64 run = 0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const u64 t = lane < nw ? lds_waves[n * 16 + lane] : 0ull;
+        u64 ti = t;
+        ti += BGR_DPP0_64(ti, 0x111, 0xF); ti += BGR_DPP0_64(ti, 0x112, 0xF); ti += BGR_DPP0_64(ti, 0x114, 0xF); ti += BGR_DPP0_64(ti, 0x118, 0xF);
+        ex[n] = run + shfl64(ti - t, wave) + inc[n] - v[n];
+        run += shfl64(ti, 15);
+    }
+    *total = run;
+    __syncthreads();
+}
+
+// ---- the piece in ONE pass: record starts, extents, shape, accept test, accepted records compacted in input order --------------------------------
+// (round 4/5: eight launches -- two marking passes and a scan for the record starts, a 16-lane group per record reading the text a third time,
+//  three launches of scans, a compaction; 230 us per 44 MB piece.)  A workgroup takes 96 KB of text as three stretches of 32 KB, 32 bytes per thread
+// and stretch, and turns each stretch into three bit masks in LDS (newline, '>', "not one of ACGTN"), with the 1 KB behind it seen through the same
+// masks.  A record start is a '>' behind a newline (FASTA) or the byte behind every LN-th newline (FASTQ: record j is lines LN*j .. whatever they
+// hold, aligner.cpp:51-68; the newline count in front of the tile comes down a chain).  One THREAD per record then reads the record's shape off the
+// masks: first newline f, second newline s; the shape this route takes is header line + ONE sequence line, i.e. the byte behind s starts the next
+// record or ends the piece (FASTA), anything else raises `irregular` and the caller parses the piece on the host with the exact state machine
+// (fastx.cpp).  Accepted: size > 2, ACGTN only, FASTA: size > k (aligner.cpp:54-66, :78-88).  Records that leave the window (long reads) go to
+// 16-lane groups that scan the text itself.  Running totals down three chains: record starts / newlines, accepted records, their bases.
 // rec[j] = {header offset, header length, sequence offset, sequence length | accepted << 31}
-// FASTQ: a record is four lines; header = the first, read = the second; accepted when size > 2 and ACGTN only (aligner.cpp:54-66: no
-// size > k test), and there is no "other shape" -- record j is lines 4j .. 4j+3 whatever they hold.
-template <bool FASTQ>
-__global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* text, uint32_t n, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t k,
-                                                               uint4* rec, uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, uint32_t rec_cap) {
-    const uint32_t R = *n_rec_p;
-    const uint32_t sub = threadIdx.x & 15;
-    // (more record starts than rec_start holds: the caller hands the piece to the host once it has read the count; the scans behind this kernel
-    // stop at min(count, rec_cap) and the compaction leaves at once -- nothing reads what this kernel did not write.  Round 4 launched one group
-    // per rec_cap entry, five in six of them only to write zeroes for scans that ran over all of them: 111 us per 44 MB piece, 0.40 TB/s)
-    if (R > rec_cap) return;
-    for (uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; j < R; j += (gridDim.x * blockDim.x) >> 4) {
-    const uint32_t p = rec_start[j], q = j + 1 < R ? rec_start[j + 1] : n;
-    // pass 1: the first two newlines and the number of newlines
-    uint32_t first = 0xFFFFFFFFu, second = 0xFFFFFFFFu, count = 0;
-    for (uint32_t base = p; base < q; base += 256) {
+constexpr uint32_t kParseThreads = 1024, kParseStretch = kParseThreads * 32, kParseStretches = 3, kParseTile = kParseStretch * kParseStretches;
+constexpr uint32_t kParseHaloWords = 32, kParseWords = kParseThreads + kParseHaloWords, kParseWindow = kParseWords * 32;
+constexpr uint32_t kParseMaxLocal = kParseThreads;   // record starts per stretch (a record of 32 bytes is hardly a read: such a piece goes to the host)
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t next_set(const uint32_t* bits, uint32_t from) {   // first set bit at or behind `from` in the window, or kNone
+    if (from >= kParseWindow) return kNone;
+    uint32_t w = from >> 5, x = bits[w] & (0xFFFFFFFFu << (from & 31));
+    while (!x) { if (++w >= kParseWords) return kNone; x = bits[w]; }
+    return (w << 5) + (uint32_t)__ffs((int)x) - 1;
+}
+__device__ __forceinline__ bool any_set(const uint32_t* bits, uint32_t lo, uint32_t hi) {   // a set bit in [lo, hi), hi inside the window
+    if (lo >= hi) return false;
+    uint32_t w = lo >> 5;
+    const uint32_t wl = (hi - 1) >> 5;
+    uint32_t x = bits[w] & (0xFFFFFFFFu << (lo & 31));
+    while (w < wl) { if (x) return true; x = bits[++w]; }
+    if (hi & 31) x &= (1u << (hi & 31)) - 1u;
+    return x != 0;
+}
+// 32 bytes at pos (a multiple of 32) as masks, bit i = byte pos + i; bytes at or behind n read as "nothing"
+__device__ __forceinline__ void masks32(const uint8_t* text, uint32_t pos, uint32_t n, uint32_t& nl, uint32_t& gt, uint32_t& bad) {
+    nl = gt = bad = 0;
+    if (pos >= n) return;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(text + pos), v1 = *reinterpret_cast<const uint4*>(text + pos + 16);  // (the buffer is padded by 64 bytes)
+    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint32_t good = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const uint32_t x = w[d];
+        nl |= nibble_of(eq_bytes(x, 0x0A0A0A0Au)) << (4 * d);
+        gt |= nibble_of(eq_bytes(x, 0x3E3E3E3Eu)) << (4 * d);
+        // one of ACGTN: bits 1..3 of a character number it 0..7 (A 0, C 1, T 2, G 3, N 7) -- the character it has to be then, out of an 8-byte table by v_perm_b32
+        const uint32_t must_be = __builtin_amdgcn_perm(0x4EFFFFFFu, 0x47544341u, (x >> 1) & 0x07070707u);
+        good |= nibble_of(bgr_zero_bytes(x ^ must_be)) << (4 * d);
+    }
+    const uint32_t valid = n - pos >= 32 ? 0xFFFFFFFFu : (1u << (n - pos)) - 1u;
+    nl &= valid; gt &= valid;
+    bad = ~good & valid;
+}
+// a record that leaves the window, by the 16 lanes of a group from the text itself: its first two newlines, and whether a character between them
+// is not one of ACGTN
+__device__ __forceinline__ void record_from_text(const uint8_t* text, uint32_t p, uint32_t n, uint32_t sub, uint32_t& first, uint32_t& second, bool& bad_char) {
+    first = second = kNone;
+    for (uint32_t base = p; base < n; base += 256) {
         uint32_t w[4];
         const uint32_t at = base + 16 * sub;
-        load16(text, at, q, w);
+        load16(text, at, n, w);
         uint32_t m = mask16(w, 0x0A0A0A0Au);
-        count += row16_sum((uint32_t)__popc(m));
-        if (first == 0xFFFFFFFFu) {
-            const uint32_t mine = m ? at + (uint32_t)__ffs((int)m) - 1 : 0xFFFFFFFFu;
+        if (first == kNone) {
+            const uint32_t mine = m ? at + (uint32_t)__ffs((int)m) - 1 : kNone;
             first = row16_min(mine);
             if (m && mine == first) m &= m - 1;  // the lane that holds it looks past it; every other newline lies behind it anyway
         }
-        if (first != 0xFFFFFFFFu && second == 0xFFFFFFFFu) second = row16_min(m ? at + (uint32_t)__ffs((int)m) - 1 : 0xFFFFFFFFu);
-        if (count > 2 || (FASTQ && count >= 2)) break;
+        if (first != kNone) second = row16_min(m ? at + (uint32_t)__ffs((int)m) - 1 : kNone);
+        if (second != kNone) break;
     }
-    const bool regular = FASTQ ? (first != 0xFFFFFFFFu && second != 0xFFFFFFFFu)
-                               : (count == 2 && second == q - 1 && (j != 0 || p == 0));  // (bytes in front of the piece's first record start: not this route's shape)
-    uint32_t hl = 0, so = 0, L = 0, ok = 0;
-    if (regular) {
-        hl = first - p;
-        so = first + 1;
-        L = second - so;
-        // pass 2: every character of the read in ACGTN (aligner.cpp:79-84)
-        uint32_t bad = 0;
-        for (uint32_t base = so; base < second; base += 256) {
+    uint32_t bad = 0;
+    if (second != kNone) {
+        for (uint32_t base = first + 1; base < second; base += 256) {
             uint32_t w[4];
             const uint32_t at = base + 16 * sub;
             load16(text, at, second, w);
@@ -291,17 +323,196 @@ __global__ void __launch_bounds__(256) bgr_text_records_kernel(const uint8_t* te
                 bad |= (good ^ 0x80808080u) & in_read;
             }
         }
-        bad = row16_sum(bad ? 1u : 0u);
-        ok = (L > 2 && bad == 0 && (FASTQ || L > k)) ? 1u : 0u;  // aligner.cpp:78-88: size > 2, alphabet, size > k (FASTA only)
     }
-    if (sub == 0) {
-        if (!regular && !__hip_atomic_load(&info[TXT_INFO_IRREGULAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&info[TXT_INFO_IRREGULAR], 1u);
-        rec[j] = make_uint4(p, hl, so, L | (ok << 31));
-        acc_flag[j] = ok;
-        acc_len[j] = ok ? L : 0u;
-        // (one atomic per record on one word would cap the kernel near 90 M records/s: only a read longer than what the word holds adds)
-        if (ok && L > __hip_atomic_load(&info[TXT_INFO_MAX_LEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&info[TXT_INFO_MAX_LEN], L);
+    bad_char = row16_sum(bad ? 1u : 0u) != 0;
+}
+
+template <int LN>   // lines per record of a FASTQ piece (4; 2 when the caller has left the '+' and quality lines on the host); 0 = FASTA
+__global__ void __launch_bounds__(kParseThreads, 8) bgr_text_parse_kernel(const uint8_t* text, uint32_t n, uint32_t k, uint32_t ntiles, uint32_t* ticket, uint32_t ticket_base,
+                                                                       uint32_t epoch, u64* chainA, u64* chainB, u64* chainC, uint4* rec, uint32_t* acc_idx, uint32_t* acc_rec,
+                                                                       uint32_t* acc_src, u64* read_offs, uint32_t* info, uint32_t rec_cap, uint32_t* zero_a, uint32_t words_a, uint32_t* zero_b, uint32_t words_b) {
+    __shared__ uint32_t s_nl[kParseWords], s_gt[kParseWords], s_bad[kParseWords];
+    __shared__ uint32_t s_pos[kParseStretches][kParseMaxLocal], s_hl[kParseStretches][kParseMaxLocal], s_len[kParseStretches][kParseMaxLocal];
+    __shared__ uint16_t s_left[kParseStretches * kParseMaxLocal];
+    __shared__ u64 lw64[kParseStretches * 16];
+    __shared__ uint32_t lw[16];
+    __shared__ uint32_t s_vt, s_nleft, s_jfirst, s_have_first, s_maxlen, s_carry;
+    __shared__ u64 s_exA, s_exB, s_exC;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) {
+        s_vt = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
+        s_nleft = 0; s_jfirst = 0; s_have_first = 0; s_maxlen = 0; s_exA = 0; s_exB = 0; s_exC = 0;
     }
+    __syncthreads();
+    const uint32_t vt = s_vt, T0 = vt * kParseTile;
+    BGR_XT(0, 0);
+    if (vt == 0) {   // (words only LATER launches use: the mapping launch's cursor, the next piece's info block)
+        if (tid < words_a) zero_a[tid] = 0;
+        if (tid < words_b) zero_b[tid] = 0;
+    }
+    // 1. the masks of the three stretches (all loads in flight together) and of the 1 KB behind the tile
+    uint32_t nl[kParseStretches], gt[kParseStretches], bad[kParseStretches], hnl = 0, hgt = 0, hbad = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < kParseStretches; ++s) masks32(text, T0 + s * kParseStretch + tid * 32, n, nl[s], gt[s], bad[s]);
+    if (tid < kParseHaloWords) masks32(text, T0 + kParseTile + tid * 32, n, hnl, hgt, hbad);
+    uint32_t front_nl = 1;   // the byte in front of the tile is a newline (or the piece starts here)
+    if (tid == 0 && T0) front_nl = text[T0 - 1] == '\n' ? 1u : 0u;
+    BGR_XT(0, 1);
+    uint32_t lines_before = 0, tile_lines = 0;   // FASTQ: newlines in front of the current stretch; of the tile
+    if (LN) {
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kParseStretches; ++s) c += (uint32_t)__popc(nl[s]);
+        (void)block_exclusive_scan32(c, lw, &tile_lines);
+        if (wave == 0) { const u64 b4 = chain_lookback(chainA, vt, epoch, tile_lines); if (tid == 0) s_exA = b4; }
+        __syncthreads();
+        lines_before = (uint32_t)s_exA;
+    }
+    uint32_t total[kParseStretches];   // record starts per stretch
+    BGR_XT(0, 2);
+    bool irregular = false, over = false;
+    if (!LN && vt == 0 && tid == 0 && n && !((gt[0] & 1u))) irregular = true;   // bytes in front of the piece's first record start: not this route's shape
+#pragma unroll
+    for (uint32_t s = 0; s < kParseStretches; ++s) {
+        const uint32_t t0 = T0 + s * kParseStretch, pos = t0 + tid * 32;
+        __syncthreads();   // (the masks of the stretch before this one are no longer read)
+        s_nl[tid] = nl[s]; s_gt[tid] = gt[s]; s_bad[tid] = bad[s];
+        if (tid < kParseHaloWords) {
+            s_nl[kParseThreads + tid] = s + 1 < kParseStretches ? nl[s + 1 < kParseStretches ? s + 1 : s] : hnl;
+            s_gt[kParseThreads + tid] = s + 1 < kParseStretches ? gt[s + 1 < kParseStretches ? s + 1 : s] : hgt;
+            s_bad[kParseThreads + tid] = s + 1 < kParseStretches ? bad[s + 1 < kParseStretches ? s + 1 : s] : hbad;
+        }
+        const uint32_t carry = s ? s_carry : front_nl;   // (tid 0 reads it; written behind the barriers of the stretch before)
+        __syncthreads();
+        const uint32_t valid = pos < n ? (n - pos >= 32 ? 0xFFFFFFFFu : (1u << (n - pos)) - 1u) : 0u;
+        const uint32_t after_nl = ((nl[s] << 1) | (tid ? s_nl[tid - 1] >> 31 : carry)) & valid;   // bit i: byte pos + i follows a newline
+        uint32_t rs, j_mine = 0;   // rs: bit i = byte pos + i starts a record
+        if (LN) {
+            uint32_t stretch_lines;
+            const uint32_t before = lines_before + block_exclusive_scan32((uint32_t)__popc(nl[s]), lw, &stretch_lines);   // newlines in front of this thread's bytes
+            lines_before += stretch_lines;
+            rs = 0;
+            for (uint32_t m = after_nl; m; m &= m - 1) {
+                const uint32_t i = (uint32_t)__ffs((int)m) - 1;
+                const uint32_t c = before + (uint32_t)__popc(nl[s] & ((1u << i) - 1u));   // newlines in front of byte pos + i
+                if ((c & (LN - 1)) == 0) { if (!rs) j_mine = c / (LN ? LN : 1); rs |= 1u << i; }
+            }
+        } else {
+            rs = gt[s] & after_nl;
+        }
+        const uint32_t ex = block_exclusive_scan32((uint32_t)__popc(rs), lw, &total[s]);
+        const bool over_s = total[s] > kParseMaxLocal;
+        if (!over_s) {
+            uint32_t at = ex;
+            for (uint32_t m = rs; m; m &= m - 1) s_pos[s][at++] = pos + (uint32_t)__ffs((int)m) - 1;
+        } else over = true;
+        if (LN && rs && ex == 0 && !s_have_first) { s_jfirst = j_mine; s_have_first = 1; }   // (one thread per stretch can be here, stretches in turn: barriers in between)
+        if (tid == kParseThreads - 1) s_carry = nl[s] >> 31;
+        __syncthreads();
+        BGR_XT(0, 3 + 2 * s);
+        // 2. one thread per record of the stretch, from the masks
+        if (!over_s && tid < total[s]) {
+            const uint32_t l = tid, pr = s_pos[s][l] - t0;
+            const uint32_t f = next_set(s_nl, pr);
+            const uint32_t e = f != kNone ? next_set(s_nl, f + 1) : kNone;
+            if (e == kNone || (!LN && e + 1 >= kParseWindow && t0 + e + 1 < n)) s_left[atomicAdd(&s_nleft, 1u)] = (uint16_t)((s << 10) | l);
+            else {
+                const bool regular = LN ? true : (t0 + e + 1 == n || ((s_gt[(e + 1) >> 5] >> ((e + 1) & 31)) & 1u));
+                const uint32_t L = e - f - 1;
+                const uint32_t ok = (regular && L > 2 && (LN || L > k) && !any_set(s_bad, f + 1, e)) ? 1u : 0u;   // aligner.cpp:78-88: size > 2, alphabet, size > k (FASTA only)
+                s_hl[s][l] = regular ? f - pr : kNone;
+                s_len[s][l] = regular ? (L | (ok << 31)) : 0u;
+                if (!regular) irregular = true;
+            }
+        }
+        BGR_XT(0, 4 + 2 * s);
+    }
+    __syncthreads();
+    // 3. records that leave their window: a 16-lane group each, from the text
+    BGR_XT(0, 9);
+    {
+        const uint32_t nleft = s_nleft, sub = tid & 15;
+        for (uint32_t e = tid >> 4; e < nleft; e += kParseThreads / 16) {
+            const uint32_t s = s_left[e] >> 10, l = s_left[e] & 1023u, p = s_pos[s][l];
+            uint32_t first, second;
+            bool bad_char;
+            record_from_text(text, p, n, sub, first, second, bad_char);
+            bool regular = second != kNone;
+            if (!LN && regular && second + 1 != n) regular = text[second + 1] == '>';
+            if (sub == 0) {
+                const uint32_t L = regular ? second - first - 1 : 0u;
+                const uint32_t ok = (regular && L > 2 && (LN || L > k) && !bad_char) ? 1u : 0u;
+                s_hl[s][l] = regular ? first - p : kNone;
+                s_len[s][l] = regular ? (L | (ok << 31)) : 0u;
+                if (!regular) irregular = true;
+            }
+        }
+    }
+    if ((irregular || over) && !__hip_atomic_load(&info[TXT_INFO_IRREGULAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&info[TXT_INFO_IRREGULAR], 1u);
+    __syncthreads();
+    // 4. accepted records and their bases in front of each record of the tile (accepted << 40 | bases in one scan); the running totals
+    BGR_XT(0, 10);
+    uint32_t v[kParseStretches];
+    u64 pk[kParseStretches], exs[kParseStretches], t_all;
+    uint32_t starts = 0, mx = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < kParseStretches; ++s) {
+        v[s] = (!over && tid < total[s]) ? s_len[s][tid] : 0u;
+        const uint32_t L = (v[s] >> 31) ? v[s] & 0x7FFFFFFFu : 0u;
+        pk[s] = ((u64)(v[s] >> 31) << 40) | L;
+        starts += total[s];
+        mx = L > mx ? L : mx;
+    }
+    block_exclusive_scan64xN<kParseStretches>(pk, lw64, exs, &t_all);
+    if (mx) atomicMax(&s_maxlen, mx);
+    BGR_XT(0, 11);
+    const uint32_t t_acc = (uint32_t)(t_all >> 40);
+    const u64 t_bases = t_all & ((1ull << 40) - 1);
+    if (!LN && wave == 0) { const u64 b4 = chain_lookback(chainA, vt, epoch, starts); if (tid == 0) s_exA = b4; }
+    if (wave == 1) { const u64 b4 = chain_lookback(chainB, vt, epoch, t_acc); if ((tid & 63) == 0) s_exB = b4; }
+    if (wave == 2) { const u64 b4 = chain_lookback(chainC, vt, epoch, t_bases); if ((tid & 63) == 0) s_exC = b4; }
+    __syncthreads();
+    const uint32_t a0 = (uint32_t)s_exB;
+    const u64 b0 = s_exC;
+    BGR_XT(0, 12);
+    // 5. the records; the accepted ones compacted
+    if (!over) {
+        uint32_t j0 = LN ? s_jfirst : (uint32_t)s_exA;
+#pragma unroll
+        for (uint32_t s = 0; s < kParseStretches; ++s) {
+            const uint32_t j = j0 + tid;
+            if (tid < total[s] && j < rec_cap) {
+                const uint32_t p = s_pos[s][tid], hl = s_hl[s][tid];
+                rec[j] = hl == kNone ? make_uint4(p, 0, 0, 0) : make_uint4(p, hl, p + hl + 1, v[s]);
+                if (v[s] >> 31) {
+                    const uint32_t a = a0 + (uint32_t)(exs[s] >> 40);
+                    acc_idx[j] = a;
+                    acc_rec[a] = j;
+                    acc_src[a] = p + hl + 1;
+                    read_offs[a] = b0 + (exs[s] & ((1ull << 40) - 1));
+                }
+            }
+            j0 += total[s];
+        }
+    }
+    BGR_XT(0, 13);
+    if (tid == 0) {
+        // (one atomic per record on one word would cap the kernel near 90 M records/s: one per tile, and only when it raises the word)
+        if (s_maxlen > __hip_atomic_load(&info[TXT_INFO_MAX_LEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&info[TXT_INFO_MAX_LEN], s_maxlen);
+        if (vt == ntiles - 1) {   // the piece's last tile: the totals
+            const uint32_t n_acc = a0 + t_acc;
+            const u64 bases = b0 + t_bases;
+            uint32_t n_rec;
+            if (LN) {
+                const uint32_t lines = (uint32_t)s_exA + tile_lines;
+                n_rec = lines / (LN ? LN : 1);   // a piece of whole records ends with a newline: LN per record
+                if (n && ((lines & (LN - 1)) || text[n - 1] != '\n')) atomicOr(&info[TXT_INFO_IRREGULAR], 1u);   // (it does not: the host parser decides)
+            } else n_rec = (uint32_t)s_exA + starts;
+            info[TXT_INFO_N_REC] = n_rec;
+            info[TXT_INFO_N_ACC] = n_acc;
+            info[TXT_INFO_BASES] = (uint32_t)bases;
+            if (n_acc <= rec_cap) read_offs[n_acc] = bases;
+        }
     }
 }
 
@@ -341,45 +552,26 @@ __device__ __forceinline__ uint32_t dec_len(int32_t v) {  // characters of to_st
     len += u < 10 ? 1 : u < 100 ? 2 : u < 1000 ? 3 : u < 10000 ? 4 : u < 100000 ? 5 : u < 1000000 ? 6 : u < 10000000 ? 7 : u < 100000000 ? 8 : u < 1000000000 ? 9 : 10;
     return len;
 }
-__global__ void __launch_bounds__(256) bgr_text_sizes_kernel(const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc,
-                                                             uint32_t* psz, uint32_t* nsz) {
-    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n_acc) return;
-    const uint2 res = results[a];
-    const uint4 r = rec[acc_rec[a]];
-    const uint32_t np = res.y & 0xFFFFFFu;
-    uint32_t ps = 0, ns = 0;
-    if (np) {
-        ps = r.y + 2;
-        for (uint32_t i = 0; i < np; ++i) ps += dec_len(arena[res.x + i]);
-    } else {
-        ns = r.y + (r.w & 0x7FFFFFFFu) + 2;
-    }
-    psz[a] = ps;
-    nsz[a] = ns;
+// the first min(m, 16) bytes of v to dst (any alignment)
+__device__ __forceinline__ void store_upto16(uint8_t* dst, const u32x4_unaligned v, uint32_t m) {
+    if (m >= 16) { *reinterpret_cast<u32x4_unaligned*>(dst) = v; return; }
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};   // (the last bytes: byte stores out of registers -- a loop of byte loads and stores waits for memory once per byte)
+#pragma unroll
+    for (uint32_t i = 0; i < 15; ++i) if (i < m) dst[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
 }
-
-// n bytes from src to dst by the 16 lanes of a group (any alignment on both sides)
+// n bytes from src to dst by the 16 lanes of a group (any alignment on both sides; the SOURCE may be read up to 15 bytes past its end: the text is padded)
 __device__ __forceinline__ void group_copy(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t sub) {
     for (uint32_t b = 16 * sub; b < n; b += 256) {
-        if (b + 16 <= n) {
-            *reinterpret_cast<u32x4_unaligned*>(dst + b) = *reinterpret_cast<const u32x4_unaligned*>(src + b);
-        } else {
-            for (uint32_t i = b; i < n; ++i) dst[i] = src[i];
-        }
+        store_upto16(dst + b, *reinterpret_cast<const u32x4_unaligned*>(src + b), n - b);
     }
 }
 
-// one 16-lane group per accepted read: its record into the paths stream or the notAligned stream
-__global__ void __launch_bounds__(256) bgr_text_write_kernel(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec,
-                                                             uint32_t n_acc, const uint32_t* poff, const uint32_t* noff, uint8_t* pout, uint8_t* nout) {
-    const uint32_t a = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-    if (a >= n_acc) return;
-    const uint2 res = results[a];
-    const uint4 r = rec[acc_rec[a]];
+// one accepted read's record by the 16 lanes of a group: into the paths stream (d_p) or the notAligned stream (d_n), whichever is not null
+__device__ __forceinline__ void write_record(const uint8_t* text, const uint2 res, const uint4 r, const int32_t* arena, uint8_t* d_p, uint8_t* d_n, uint32_t sub) {
     const uint32_t np = res.y & 0xFFFFFFu, hl = r.y;
     if (np) {  // alignerGreedy.cpp:406-411: header + '\n' + printPath
-        uint8_t* d = pout + poff[a];
+        if (!d_p) return;
+        uint8_t* d = d_p;
         group_copy(d, text + r.x, hl, sub);
         if (sub == 0) d[hl] = '\n';
         uint32_t cur = hl + 1;
@@ -404,13 +596,185 @@ __global__ void __launch_bounds__(256) bgr_text_write_kernel(const uint8_t* text
             cur += (uint32_t)__shfl((int)inc, 15, 16);
         }
         if (sub == 0) d[cur] = '\n';
-    } else {   // alignerGreedy.cpp:421-427: header + '\n' + read + '\n'
-        uint8_t* d = nout + noff[a];
+    } else if (d_n) {   // alignerGreedy.cpp:421-427: header + '\n' + read + '\n'
+        uint8_t* d = d_n;
         const uint32_t L = r.w & 0x7FFFFFFFu;
-        group_copy(d, text + r.x, hl, sub);
-        if (sub == 0) d[hl] = '\n';
-        group_copy(d + hl + 1, text + r.z, L, sub);
-        if (sub == 0) d[hl + 1 + L] = '\n';
+        // (the first 256 bytes of both, loaded before either is stored: one wait for memory instead of two)
+        const uint32_t b = 16 * sub;
+        u32x4_unaligned vh = {0, 0, 0, 0}, vr = {0, 0, 0, 0};
+        if (b < hl) vh = *reinterpret_cast<const u32x4_unaligned*>(text + r.x + b);
+        if (b < L) vr = *reinterpret_cast<const u32x4_unaligned*>(text + r.z + b);
+        if (b < hl) store_upto16(d + b, vh, hl - b);
+        if (b < L) store_upto16(d + hl + 1 + b, vr, L - b);
+        if (hl > 256) group_copy(d + 256, text + r.x + 256, hl - 256, sub);
+        if (L > 256) group_copy(d + hl + 1 + 256, text + r.z + 256, L - 256, sub);
+        if (sub == 0) { d[hl] = '\n'; d[hl + 1 + L] = '\n'; }
+    }
+}
+
+// one 16-lane group per accepted read, offsets from arrays (bgr_aligner_fetch_text into larger buffers: the format kernel below has left them)
+__global__ void __launch_bounds__(256) bgr_text_write_kernel(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec,
+                                                             uint32_t n_acc, const uint32_t* poff, const uint32_t* noff, uint8_t* pout, uint8_t* nout) {
+    const uint32_t a = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (a >= n_acc) return;
+    write_record(text, results[a], rec[acc_rec[a]], arena, pout + poff[a], nout + noff[a], sub);
+}
+
+// ---- out in ONE launch: sizes, stream offsets (running totals down two chains), the bytes -------------------------------------------------------
+// (round 4/5: sizes, three launches of scans, a write kernel of 79 us per 274 k reads whose path digits went out as single-byte stores.)
+// A workgroup takes 1024 accepted reads, one thread each for the sizes; its stretch of the paths stream (~30 bytes per mapped read) is put together
+// in LDS -- header bytes by 16-byte loads, digits as LDS byte stores -- and leaves as aligned 16-byte stores; a stretch that does not fit (long
+// headers, long paths) and the notAligned records (header + read: 16-byte copies as they are) go out by 16-lane groups.  Bytes are written only
+// where the whole stretch fits below pcap / ncap; the totals say what is needed.  poff/noff are kept for bgr_aligner_fetch_text.
+constexpr uint32_t kFmtThreads = 1024, kFmtChunk = 49152, kFmtInts = 6;
+__global__ void __launch_bounds__(kFmtThreads, 8) bgr_text_format_kernel(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec,
+                                                                      uint32_t n_acc, uint32_t ntiles, uint32_t* ticket, uint32_t ticket_base, uint32_t epoch, u64* chainP, u64* chainN,
+                                                                      uint32_t* poff, uint32_t* noff, uint8_t* pout, uint8_t* nout, u64 pcap, u64 ncap, uint32_t* info) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_chunk[kFmtChunk + 16];
+    __shared__ uint32_t lw[16];
+    __shared__ uint32_t s_rel[kFmtThreads];   // where each read's record starts in the workgroup's stretch of ITS stream
+    __shared__ uint16_t s_un[kFmtThreads];    // the reads without a path
+    __shared__ uint4 s_unrec[kFmtThreads];    // ... and their records
+    __shared__ uint32_t s_vt, s_nun;
+    __shared__ u64 s_exP, s_exN;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, sub = tid & 15, grp = tid >> 4;
+    if (tid == 0) { s_vt = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base; s_exP = 0; s_exN = 0; s_nun = 0; }
+    __syncthreads();
+    const uint32_t vt = s_vt, a0 = vt * kFmtThreads, a = a0 + tid;
+    BGR_XT(1, 0);
+    uint2 res = make_uint2(0, 0);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    uint32_t ps = 0, ns = 0, np = 0;
+    int32_t pv[kFmtInts];   // the first ints of the path, loaded together (a path is its offset + a handful of unitigs)
+    if (a < n_acc) {
+        res = results[a];
+        const uint32_t j = acc_rec[a];
+        np = res.y & 0xFFFFFFu;
+#pragma unroll
+        for (uint32_t i = 0; i < kFmtInts; ++i) pv[i] = i < np ? arena[res.x + i] : 0;
+        r = rec[j];
+        if (np) {
+            ps = r.y + 2;
+#pragma unroll
+            for (uint32_t i = 0; i < kFmtInts; ++i) if (i < np) ps += dec_len(pv[i]);
+            for (uint32_t i = kFmtInts; i < np; ++i) ps += dec_len(arena[res.x + i]);
+        } else {
+            ns = r.y + (r.w & 0x7FFFFFFFu) + 2;
+            const uint32_t e = atomicAdd(&s_nun, 1u);
+            s_un[e] = (uint16_t)tid;
+            s_unrec[e] = r;
+        }
+    }
+    uint32_t tp, tn;
+    BGR_XT(1, 1);
+    const uint32_t exp_ = block_exclusive_scan32(ps, lw, &tp);
+    const uint32_t exn = block_exclusive_scan32(ns, lw, &tn);
+    s_rel[tid] = ps ? exp_ : exn;
+    BGR_XT(1, 2);
+    if (wave == 0) chain_publish(chainP, vt, epoch, tp);
+    if (wave == 1) chain_publish(chainN, vt, epoch, tn);
+    // (the totals are out; before anyone walks the chains the paths stretch is put together -- it does not need to know where it goes: it is laid down at 0 and
+    // shifted to the destination's 16-byte units on the way out)
+    const bool in_lds = tp && tp <= kFmtChunk;
+    BGR_XT(1, 3);
+    if (in_lds && ps) {
+        uint32_t o = exp_;
+        const uint32_t hl = r.y;
+        for (uint32_t b = 0; b < hl; b += 16) {   // the header, 16 bytes per load
+            const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned*>(text + r.x + b);  // (the text is padded: reading past the header is reading the read)
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t m = hl - b < 16 ? hl - b : 16u;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; ++i) if (i < m) s_chunk[o + b + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        }
+        o += hl;
+        s_chunk[o++] = '\n';
+        for (uint32_t i = 0; i < np; ++i) {   // to_string(v) + '.', written back to front (aligner.cpp:600-609)
+            int32_t v = 0;
+            if (i < kFmtInts) {
+#pragma unroll
+                for (uint32_t q = 0; q < kFmtInts; ++q) if (q == i) v = pv[q];
+            } else v = arena[res.x + i];
+            const uint32_t len = dec_len(v);
+            uint32_t e = o + len;
+            s_chunk[--e] = '.';
+            uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+            do { const uint32_t qd = u / 10; s_chunk[--e] = (uint8_t)('0' + (u - qd * 10)); u = qd; } while (u);
+            if (v < 0) s_chunk[--e] = '-';
+            o += len;
+        }
+        s_chunk[o] = '\n';
+    }
+    if (wave == 0) { const u64 b4 = chain_walk(chainP, vt, epoch, tp); if (tid == 0) s_exP = b4; }
+    if (wave == 1) { const u64 b4 = chain_walk(chainN, vt, epoch, tn); if ((tid & 63) == 0) s_exN = b4; }
+    __syncthreads();
+    const u64 P0 = s_exP, N0 = s_exN;
+    BGR_XT(1, 4);
+    if (a < n_acc) {
+        const u64 po = P0 + exp_, no = N0 + exn;
+        poff[a] = po > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)po;
+        noff[a] = no > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)no;
+    }
+    const bool p_fits = P0 + tp <= pcap, n_fits = N0 + tn <= ncap;
+    if (tp && p_fits) {
+        if (in_lds) {
+            // byte i of the stretch lies at s_chunk[i] and goes to pout[P0 + i]: 16-byte units of the DESTINATION, each put together from two LDS reads
+            const uint32_t shift = (uint32_t)(P0 & 15);
+            uint8_t* base = pout + (P0 - shift);   // 16-byte aligned (pout is); unit u covers stretch bytes [16 u - shift, 16 u - shift + 16)
+            const uint32_t end = shift + tp;
+            for (uint32_t u = tid * 16; u < end; u += kFmtThreads * 16) {
+                if (u >= shift && u + 16 <= end) {
+                    const uint32_t from = u - shift;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const uint32_t at = from + 4 * d, al = at & ~3u, sh = 8 * (at & 3);
+                        const uint32_t lo = *reinterpret_cast<const uint32_t*>(s_chunk + al), hi = *reinterpret_cast<const uint32_t*>(s_chunk + al + 4);
+                        w[d] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+                    }
+                    *reinterpret_cast<uint4*>(base + u) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else for (uint32_t i = u < shift ? shift : u; i < u + 16 && i < end; ++i) base[i] = s_chunk[i - shift];
+            }
+        } else {
+            for (uint32_t t = grp; t < kFmtThreads; t += kFmtThreads / 16) {
+                const uint32_t b = a0 + t;
+                if (b >= n_acc) break;
+                const uint2 rs = results[b];
+                if (rs.y & 0xFFFFFFu) write_record(text, rs, rec[acc_rec[b]], arena, pout + P0 + s_rel[t], nullptr, sub);
+            }
+        }
+    }
+    BGR_XT(1, 5);
+    if (tn && n_fits) {   // header + '\n' + read + '\n' of the reads without a path: 16-byte copies by 16-lane groups, straight from the text
+        const uint32_t nun = s_nun, b = 16 * sub;
+        for (uint32_t e = grp; e < nun; e += 2 * (kFmtThreads / 16)) {   // two records per turn, their (first 256) bytes loaded before any is stored: one wait for memory
+            const uint32_t e2 = e + kFmtThreads / 16;
+            const bool two = e2 < nun;
+            const uint4 r1 = s_unrec[e], r2 = two ? s_unrec[e2] : make_uint4(0, 0, 0, 0);
+            const uint32_t L1 = r1.w & 0x7FFFFFFFu, L2 = r2.w & 0x7FFFFFFFu;
+            uint8_t* d1 = nout + N0 + s_rel[s_un[e]];
+            uint8_t* d2 = nout + N0 + s_rel[s_un[two ? e2 : e]];
+            u32x4_unaligned h1 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0}, h2 = {0, 0, 0, 0}, q2 = {0, 0, 0, 0};
+            if (b < r1.y) h1 = *reinterpret_cast<const u32x4_unaligned*>(text + r1.x + b);
+            if (b < L1) q1 = *reinterpret_cast<const u32x4_unaligned*>(text + r1.z + b);
+            if (b < r2.y) h2 = *reinterpret_cast<const u32x4_unaligned*>(text + r2.x + b);
+            if (b < L2) q2 = *reinterpret_cast<const u32x4_unaligned*>(text + r2.z + b);
+            if (b < r1.y) store_upto16(d1 + b, h1, r1.y - b);
+            if (b < L1) store_upto16(d1 + r1.y + 1 + b, q1, L1 - b);
+            if (b < r2.y) store_upto16(d2 + b, h2, r2.y - b);
+            if (b < L2) store_upto16(d2 + r2.y + 1 + b, q2, L2 - b);
+            if (r1.y > 256) group_copy(d1 + 256, text + r1.x + 256, r1.y - 256, sub);
+            if (L1 > 256) group_copy(d1 + r1.y + 1 + 256, text + r1.z + 256, L1 - 256, sub);
+            if (r2.y > 256) group_copy(d2 + 256, text + r2.x + 256, r2.y - 256, sub);
+            if (L2 > 256) group_copy(d2 + r2.y + 1 + 256, text + r2.z + 256, L2 - 256, sub);
+            if (sub == 0) { d1[r1.y] = '\n'; d1[r1.y + 1 + L1] = '\n'; if (two) { d2[r2.y] = '\n'; d2[r2.y + 1 + L2] = '\n'; } }
+        }
+    }
+    BGR_XT(1, 6);
+    if (tid == 0 && vt == ntiles - 1) {
+        const u64 P = P0 + tp, N = N0 + tn;
+        info[TXT_INFO_PBYTES] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+        info[TXT_INFO_NBYTES] = N > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)N;
     }
 }
 
@@ -542,13 +906,6 @@ __global__ void __launch_bounds__(256) bgr_text_correct_write_kernel(BgrDeviceGr
 
 }  // namespace
 
-hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, uint32_t* total_out, hipStream_t stream) {
-    const uint32_t nb = std::max<uint32_t>(1, (n + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(bgr_scan_block_sums, dim3(nb), dim3(kTxtThreads), 0, stream, in, n, sums);
-    hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, total_out);
-    hipLaunchKernelGGL(bgr_scan_apply, dim3(nb), dim3(kTxtThreads), 0, stream, in, n, sums, out);
-    return hipGetLastError();
-}
 hipError_t launch_scan2_u32(const uint32_t* inA, const uint32_t* inB, uint32_t* outA, uint32_t* outB, uint32_t n, const uint32_t* n_dev, uint32_t* sums, uint32_t* totalA,
                             uint32_t* totalB, hipStream_t stream) {
     const uint32_t nb = std::max<uint32_t>(1, (n + kScanTile - 1) / kScanTile);
@@ -558,52 +915,39 @@ hipError_t launch_scan2_u32(const uint32_t* inA, const uint32_t* inB, uint32_t* 
     return hipGetLastError();
 }
 uint32_t scan_tiles(uint32_t n) { return std::max<uint32_t>(1, (n + kScanTile - 1) / kScanTile); }
-uint32_t text_tiles(uint32_t bytes) { return std::max<uint32_t>(1, (bytes + kTxtTile - 1) / kTxtTile); }
+uint32_t text_tiles(uint32_t bytes) { return std::max<uint32_t>(1, (bytes + kParseTile - 1) / kParseTile); }
+uint32_t format_tiles(uint32_t n_acc) { return std::max<uint32_t>(1, (n_acc + kFmtThreads - 1) / kFmtThreads); }
 
-hipError_t launch_text_mark(const uint8_t* text, uint32_t n, uint32_t fastq_lines, uint32_t* sums, uint32_t* rec_start, uint32_t rec_cap, uint32_t* n_rec_out, hipStream_t stream) {
-    const uint32_t nb = text_tiles(n);
-    if (fastq_lines) {
-        if (fastq_lines == 2) hipLaunchKernelGGL((bgr_text_mark_kernel<0, 2>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-        else hipLaunchKernelGGL((bgr_text_mark_kernel<0, 4>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-        hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, n_rec_out);
-        if (fastq_lines == 2) hipLaunchKernelGGL((bgr_text_mark_kernel<1, 2>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-        else hipLaunchKernelGGL((bgr_text_mark_kernel<1, 4>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-        hipLaunchKernelGGL(bgr_text_fastq_count_kernel, dim3(1), dim3(1), 0, stream, n_rec_out, fastq_lines);
-    } else {
-        hipLaunchKernelGGL((bgr_text_mark_kernel<0, 0>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-        hipLaunchKernelGGL(bgr_scan_sums, dim3(1), dim3(kTxtThreads), 0, stream, sums, nb, n_rec_out);
-        hipLaunchKernelGGL((bgr_text_mark_kernel<1, 0>), dim3(nb), dim3(kTxtThreads), 0, stream, text, n, sums, rec_start, rec_cap);
-    }
+hipError_t launch_text_parse(const uint8_t* text, uint32_t n, uint32_t fastq_lines, uint32_t k, uint32_t* ticket, uint32_t ticket_base, uint32_t epoch, uint64_t* chains,
+                             uint4* rec, uint32_t* acc_idx, uint32_t* acc_rec, uint32_t* acc_src, uint64_t* read_offs, uint32_t* info, uint32_t rec_cap, uint32_t* zero_a,
+                             uint32_t words_a, uint32_t* zero_b, uint32_t words_b, hipStream_t stream) {
+    const uint32_t nt = text_tiles(n);
+    u64* cA = reinterpret_cast<u64*>(chains);
+    u64* cB = cA + nt;
+    u64* cC = cB + nt;
+    u64* offs = reinterpret_cast<u64*>(read_offs);
+#define BGR_PARSE_ARGS text, n, k, nt, ticket, ticket_base, epoch, cA, cB, cC, rec, acc_idx, acc_rec, acc_src, offs, info, rec_cap, zero_a, words_a, zero_b, words_b
+    if (fastq_lines == 4) hipLaunchKernelGGL(bgr_text_parse_kernel<4>, dim3(nt), dim3(kParseThreads), 0, stream, BGR_PARSE_ARGS);
+    else if (fastq_lines == 2) hipLaunchKernelGGL(bgr_text_parse_kernel<2>, dim3(nt), dim3(kParseThreads), 0, stream, BGR_PARSE_ARGS);
+    else hipLaunchKernelGGL(bgr_text_parse_kernel<0>, dim3(nt), dim3(kParseThreads), 0, stream, BGR_PARSE_ARGS);
+#undef BGR_PARSE_ARGS
     return hipGetLastError();
 }
 
-hipError_t launch_text_records(const uint8_t* text, uint32_t n, bool fastq, const uint32_t* rec_start, const uint32_t* n_rec_p, uint32_t max_rec, uint32_t k, uint4* rec,
-                               uint32_t* acc_flag, uint32_t* acc_len, uint32_t* info, hipStream_t stream) {
-    if (max_rec == 0) return hipSuccess;
-    // (the record count lives on the device: a grid of the device's size, 16-lane groups striding over the records; ~110 bytes of text per record at least)
-    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((max_rec + 15) / 16, std::min<uint32_t>(256 * 16, n / (16 * 110) + 1)));
-    if (fastq) hipLaunchKernelGGL(bgr_text_records_kernel<true>, dim3(blocks), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
-    else hipLaunchKernelGGL(bgr_text_records_kernel<false>, dim3(blocks), dim3(256), 0, stream, text, n, rec_start, n_rec_p, k, rec, acc_flag, acc_len, info, max_rec);
-    return hipGetLastError();
-}
-
-hipError_t launch_text_compact(const uint4* rec, const uint32_t* n_rec_p, uint32_t max_rec, const uint32_t* acc_idx, const uint32_t* base_off, uint32_t* acc_rec,
-                               uint32_t* acc_src, uint64_t* read_offs, const uint32_t* n_acc_p, const uint32_t* bases_p, hipStream_t stream) {
-    hipLaunchKernelGGL(bgr_text_compact_kernel, dim3(std::max<uint32_t>(1, (max_rec + 255) / 256)), dim3(256), 0, stream, rec, n_rec_p, acc_idx, base_off, acc_rec, acc_src,
-                       reinterpret_cast<u64*>(read_offs), n_acc_p, bases_p, max_rec);
+hipError_t launch_text_format(const uint8_t* text, const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* ticket,
+                              uint32_t ticket_base, uint32_t epoch, uint64_t* chains, uint32_t* poff, uint32_t* noff, uint8_t* pout, uint8_t* nout, uint64_t pcap, uint64_t ncap,
+                              uint32_t* info, hipStream_t stream) {
+    if (n_acc == 0) return hipSuccess;
+    const uint32_t nt = format_tiles(n_acc);
+    u64* cP = reinterpret_cast<u64*>(chains);
+    hipLaunchKernelGGL(bgr_text_format_kernel, dim3(nt), dim3(kFmtThreads), 0, stream, text, results, arena, rec, acc_rec, n_acc, nt, ticket, ticket_base, epoch, cP, cP + nt, poff, noff,
+                       pout, nout, (u64)pcap, (u64)ncap, info);
     return hipGetLastError();
 }
 
 hipError_t launch_text_record_info(const uint4* rec, const uint32_t* acc_idx, const uint2* results, uint32_t n_rec, uint32_t* out, hipStream_t stream) {
     if (n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(bgr_text_record_info_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, stream, rec, acc_idx, results, n_rec, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_text_sizes(const uint2* results, const int32_t* arena, const uint4* rec, const uint32_t* acc_rec, uint32_t n_acc, uint32_t* psz, uint32_t* nsz,
-                             hipStream_t stream) {
-    if (n_acc == 0) return hipSuccess;
-    hipLaunchKernelGGL(bgr_text_sizes_kernel, dim3((n_acc + 255) / 256), dim3(256), 0, stream, results, arena, rec, acc_rec, n_acc, psz, nsz);
     return hipGetLastError();
 }
 

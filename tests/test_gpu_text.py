@@ -379,3 +379,46 @@ def test_text_form_in_exhaustive_mode_when_the_last_pass_hands_reads_back(memo_c
     assert mapped == pb.count(b"\n") // 2
     _, _, info0 = al.align_fasta_text(text, m=2, mode=B.MODE_EXHAUSTIVE, want_output=False, record_info=True)
     assert np.array_equal(info0["records"], info["records"])
+
+
+@pytest.mark.parametrize("L,hdr,fastq", [(1500, 0, False), (5000, 0, False), (25000, 3000, False), (700, 2500, False), (150, 400, False), (3000, 0, True), (24000, 1200, True), (150, 300, 2)])
+def test_records_that_leave_a_tile_and_its_window(L, hdr, fastq, tmp_path):
+    """The parse launch reads a record's shape off bit masks of 32 KB of text + 1 KB behind it; a record that leaves that window (long reads, long
+    headers) is scanned from the text by a 16-lane group, and a workgroup's stretch of the paths stream that is larger than its LDS buffer (long
+    headers) goes out record by record: same bytes as the host parser + formatter; a dropped record, an N, and the tile borders anywhere."""
+    n = max(40, min(4000, 6_000_000 // (L + hdr + 10)))
+    s = Synth(300000, 110, 2, 31, 9100 + L)
+    seqs, offs = s.unitigs()
+    reads, roffs = s.reads(0, n, L, 3, 9200 + L)
+    rng = np.random.default_rng(L + hdr)
+    recs = []
+    for i in range(n):
+        r = reads[i * L:(i + 1) * L].tobytes()
+        x = rng.random()
+        if x < 0.03:
+            b = bytearray(r); b[int(rng.integers(0, L))] = ord("x"); r = bytes(b)     # dropped: a character that is not one of ACGTN, anywhere in a long read
+        elif x < 0.06:
+            b = bytearray(r); b[int(rng.integers(0, L))] = ord("N"); r = bytes(b)
+        h = b">r%d" % i + (   # (FASTQ: the header is line 0 whatever it holds -- a '>' here, so that the expected bytes come from the FASTA host parser
+                             # on the header and read lines; the reference's FASTQ reader adds a phantom record at the end of a FILE, tests above)
+                           b" " + bytes(rng.integers(97, 123, int(rng.integers(hdr // 2, hdr + 1))).astype(np.uint8)) if hdr else b"")
+        if fastq == 1:
+            recs.append(h + b"\n" + r + b"\n+\n" + bytes(rng.integers(33, 74, len(r)).astype(np.uint8)) + b"\n")
+        else:
+            recs.append(h + b"\n" + r + b"\n")
+    text = b"".join(recs)
+    al = B.Aligner(B.Graph.build(31, seqs, offs), 0)
+    host_text = text if fastq != 1 else b"".join(b"\n".join(rec.split(b"\n")[:2]) + b"\n" for rec in recs)
+    want_p, want_n, n_acc = _host_route(al, host_text, 31, tmp_path, m=3)
+    c0 = al.counters()
+    for kw in ({}, {"staged": True}):
+        al.reset_counters()
+        got_p, got_n, info = al.align_fasta_text(text, m=3, fastq=fastq, **kw)
+        assert not info["irregular"] and info["n_records"] == n and info["n_accepted"] == n_acc and n_acc < n
+        assert got_p == want_p and got_n == want_n and len(want_p) > 0
+        assert al.counters() == c0
+    # a last record that leaves the window AND lacks its newline / its sequence line: another shape
+    if not fastq:
+        for cut in (text[:-1], text[: len(text) - L - 1], text + b">tail with no newline"):
+            p, nn, info = al.align_fasta_text(cut, m=3)
+            assert info["irregular"] and p == b"" and nn == b""

@@ -5,7 +5,9 @@ import numpy as np
 
 def make_file(rng, path, s, k, n, fastq, irr, mixed, hdr_style):
     """n records drawn from the genome into `path` (the file is the test case) -> the longest read length drawn"""
-    L = int(rng.choice([8, 12, k + 3, 60, 100, 150, 150, 250, 400]))   # (8, 12: more than one record per 24 bytes -- pieces beyond the device's record table)
+    L = int(rng.choice([8, 12, k + 3, 60, 100, 150, 150, 250, 400, 1200, 3000]))   # (8, 12: more than one record per 24 bytes -- pieces beyond the device's record table;
+    if L >= 1200:                                                                    #  1200, 3000: records that leave the 1 KB window behind a tile of the parse launch)
+        n = min(n, 12000)
     if L <= k and not (fastq or rng.random() < 0.3):
         L = k + 3
     reads, roffs = s.reads(int(rng.integers(0, 1 << 30)), n, L, 3, int(rng.integers(1, 1 << 30)))
@@ -23,6 +25,8 @@ def make_file(rng, path, s, k, n, fastq, irr, mixed, hdr_style):
             h = b"read_%d length=%d some description with spaces" % (i, lens[i])
         else:
             h = b"" if i % 97 == 0 else b"x%d" % i
+        if hdr_style == 2 and i % 41 == 7:
+            h = h + b" " + b"long header text " * int(rng.integers(20, 90))   # (a workgroup's stretch of the paths stream beyond its LDS buffer)
         qual = b"I" * len(seq)
         if kinds[i]:
             kind = int(rng.integers(0, 12))

@@ -43,3 +43,14 @@ for i in range(reps):
     dt = time.perf_counter() - t0
     print("rep %d: %.2f ms  %.1f Mreads/s  (%d records, %d accepted, %d + %d bytes out, irregular %d)" % (i, dt * 1e3, n / dt / 1e6, b.n_records, b.n_accepted, b.paths_bytes, b.notaligned_bytes, b.irregular), flush=True)
 print(al.kernel_times())
+
+if hasattr(lib, "bgr_x_times_read") or True:
+    try:
+        t = (C.c_ulonglong * 64)()
+        lib.bgr_x_times_read.restype = C.c_int
+        if lib.bgr_x_times_read(t) == 0:
+            for slot, name in ((0, "parse tile 0"), (1, "parse tile mid"), (2, "format tile 0"), (3, "format tile mid")):
+                v = [t[slot * 16 + i] for i in range(16)]
+                print(name, " ".join("%d:%.1f" % (i, (v[i] - v[0]) / 100.0) for i in range(1, 16) if v[i]), "(us, 100 MHz clock assumed)")
+    except AttributeError:
+        pass
