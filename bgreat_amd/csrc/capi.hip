@@ -671,6 +671,7 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     io.level_search = level_search ? 1u : 0u;
     io.search_iters = P.search_iters;
     io.deep_memo_cap = P.memo_cap;
+    io.wide_scan = P.wide_scan ? 1u : 0u;
     io.greedy_multi = 0;
     io.queue = nullptr;
     io.q_cap = 0;

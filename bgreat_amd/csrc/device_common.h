@@ -215,6 +215,24 @@ __device__ __forceinline__ uint32_t scan_mblock(const BgrDeviceGraph& g, u64 win
     const uint32_t h = has16 ? bgr_mmx_hash((uint32_t)(win >> 32)) : 0u;
     return bgr_mmx_block(wave_window_max(h, W), g.bloom_mask);
 }
+// ... in ALL 64 lanes for W = 15 / 16 (k = 31 / 32), so that a scan step covers 64 positions instead of 65 - W = 50 / 49 (a 150-base read: two steps instead of
+// three).  Lanes 65 - W .. 63 lack the 16-mers that start at positions 64 .. 62 + W of the step -- which lie in the LOW halves of the windows of lanes 48 .. 46 + W:
+// their hashes, a running maximum from lane 48 upwards (row_shr 1, 2, 4, 8 inside row 3) and lane i takes the one of lane i - (17 - W).
+// has16_hi = a 16-mer starts 16 bases behind the lane's position.
+__device__ __forceinline__ bool scan_mblock_is_wide(uint32_t W) { return W == 15 || W == 16; }
+__device__ __forceinline__ uint32_t scan_mblock_wide(const BgrDeviceGraph& g, u64 win, bool has16, bool has16_hi, uint32_t W) {
+    const uint32_t h = has16 ? bgr_mmx_hash((uint32_t)(win >> 32)) : 0u;
+    uint32_t r = wave_window_max(h, W);
+    uint32_t q = has16_hi ? bgr_mmx_hash((uint32_t)win) : 0u;
+    q = umax(q, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x111, 0xF, 0xF, false));   // row_shr:1 (a lane without a source inside its row takes the 0)
+    q = umax(q, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x112, 0xF, 0xF, false));
+    q = umax(q, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x114, 0xF, 0xF, false));
+    q = umax(q, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x118, 0xF, 0xF, false));
+    const uint32_t up = W == 15 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x112, 0x8, 0xF, false)    // row 3 only: the other rows take the 0
+                                : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x111, 0x8, 0xF, false);
+    r = umax(r, up);
+    return bgr_mmx_block(r, g.bloom_mask);
+}
 
 // The half of key entry `idx` a walk step reads (graph_layout.h: handles): getEnd(bin) -- a step to the LEFT -- reads the right table
 // when bin is canonical, else the left one; getBegin(bin) -- a step to the right -- the other way round (aligner.cpp:147-267).

@@ -185,7 +185,8 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
     const uint32_t eff = prm.effort ? prm.effort : 1;  // getNOverlap(read, 0) still takes a hit at position 0 (aligner.cpp:349-368)
     // (minimizer filter in front of a key table that is not staged: a scan step covers 65 - w positions, device_common.h)
     const uint32_t mmx_w = (!STAGE && g.bloom && g.filter_kind == BGR_FILTER_MINIMIZER) ? K1 + 1 - BGR_MMX_BASES : 0u;
-    const uint32_t scan_step = mmx_w ? 65 - mmx_w : 64;
+    const bool wide_scan = io.wide_scan && mmx_w && scan_mblock_is_wide(mmx_w);   // (k = 31 / 32: the filter block in all 64 lanes, scan_mblock_wide)
+    const uint32_t scan_step = (mmx_w && !wide_scan) ? 65 - mmx_w : 64;
 
     // Path ints go straight into the arena: read r owns the row arena[r * kG4PathInts ...] (the host keeps n_reads rows in front of the
     // chunks the cursor serves to the other kernels).  Left int number i (near -> far, offset last) at row[PH - 1 - i], right int number
@@ -303,7 +304,9 @@ __global__ void __launch_bounds__(1024, BGR_G4_OCC) bgr_align_greedy_multi_kerne
                 if (valid || (mmx_w && i + BGR_MMX_BASES <= Lq)) win = lds_win32(A, i);
                 if (valid) num = win >> (64 - 2 * K1);
                 const u64 rcn = rcb_fast(num, K1);  // no N in the read: the rolling reverse k-mer is rcb of the forward one
-                const uint32_t mblock = (!STAGE && mmx_w) ? scan_mblock(g, win, i + BGR_MMX_BASES <= Lq, mmx_w) : 0u;
+                const uint32_t mblock = (STAGE || !mmx_w) ? 0u
+                                      : wide_scan ? scan_mblock_wide(g, win, i + BGR_MMX_BASES <= Lq, i + 2 * BGR_MMX_BASES <= Lq, mmx_w)
+                                                  : scan_mblock(g, win, i + BGR_MMX_BASES <= Lq, mmx_w);
                 uint32_t idx = find_key<!STAGE>(g, ktab, num < rcn ? num : rcn, valid, mblock);
                 const u64 mask = __ballot(idx != BGR_NONE);
                 if (mask) {

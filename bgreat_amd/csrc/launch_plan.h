@@ -43,7 +43,7 @@ struct PlanBatch {
 struct LaunchPlan {
     const char* error = nullptr;  // the batch cannot be mapped (read too long, batch too large): what to tell the caller
     LaunchCfg cfg, cfg_deep, cfg_mid, cfg_fast, cfg_x4, cfg_a4;
-    bool level_search = false, two_pass = false, deep_only = false, mid_pass = false, fast_pass = false, x4_pass = false, a4_pass = false;
+    bool level_search = false, two_pass = false, deep_only = false, mid_pass = false, fast_pass = false, x4_pass = false, a4_pass = false, wide_scan = false;
     uint32_t words = 0, wfast = 0, path_cap = 0, frames = 0, frames_deep = 0, frames_mid = 0, x4_levels = 16, a4_lanes = 16;
     uint32_t arena_chunk = 0, q_cap = 0, search_iters = 0, memo_cap = 0;
     uint64_t deep_stride = 0;     // u32 words of one wave's region of the last pass's scratch
@@ -147,8 +147,12 @@ inline LaunchPlan plan_launch(const PlanGraph& g, const PlanDevice& d, const Pla
     // Which one is faster depends on how much the walks branch within the mismatch budget: the depth-first search wins
     // on a graph with an occasional 2-way bubble (about 1.2x), the level search where a read crosses many multi-way
     // sites (3.6x at 4 alleles every ~36 bp, m=5).  Estimate: (extra candidates per record) x (m+1) x (unitigs per read).
+    const double mean_ext = std::max(1.0, (double)g.total_bases / (2.0 * (double)std::max<uint64_t>(1, g.n_unitigs)) - (double)(g.k - 1));
+    // Scans behind the minimizer filter (large key tables): 64 positions per step for k = 31 / 32 (scan_mblock_wide: ~15 instructions more per step) where a
+    // read's next overlap usually lies beyond the step's 50 positions -- unitigs longer than a step (chr1-scale graph, 150 bp reads: 3 -> 2 steps, 1 760 ->
+    // 1 873 Mreads/s); on a graph that branches every ~36 bp the first step nearly always holds a hit and the narrow step is the cheaper one (1 004 vs 980).
+    P.wide_scan = mean_ext >= 64.0;
     if (exhaustive) {
-        const double mean_ext = std::max(1.0, (double)g.total_bases / (2.0 * (double)std::max<uint64_t>(1, g.n_unitigs)) - (double)(g.k - 1));
         const double branching = (g.slot_fill_x100 / 100.0 - 1.0) * (double)(b.max_mismatch + 1) * ((double)max_read_len / mean_ext);
         P.level_search = t.search ? t.search == 2 : branching >= 15.0;
         // short walks (E. coli-scale graph, 150 bp: 2-3 unitigs per side): half the table, twice the waves per CU (1 200 vs 1 440 Mreads/s)

@@ -1227,3 +1227,25 @@ def test_launches_without_a_several_reads_per_wave_pass_keep_the_pre_pass():
         assert any(n.startswith("bgr_pack_reads_kernel") for n, _ in al.kernel_times()[1])
         assert all(np.array_equal(a, b) for a, b in zip(got, exp))
         al.close()
+
+
+@pytest.mark.parametrize("k,L", [(31, 150), (32, 250), (31, 100), (27, 150)])
+def test_minimizer_filter_scan_steps_of_64_positions(k, L):
+    """k = 31 / 32: a scan step behind the minimizer filter covers 64 positions -- lanes 50.. take the 16-mers of positions 64.. out of the low halves of the
+    windows of lanes 48.. (scan_mblock_wide); k = 27 keeps 65 - (k - 16) positions per step.  Long unitigs, so that a read's first overlap lies anywhere
+    (also in the lanes that lack their right neighbours, and in the second and third step): the oracle's rows, and the rows of the same graph without filter."""
+    B.set_option("build_filter", 2)   # (put back by conftest.py's fixture)
+    s = Synth(600000, 230, 2, k, 9900 + k + L)
+    seqs, offs = s.unitigs()
+    n = 30000
+    reads, roffs = s.reads(0, n, L, 2, 9950 + k)
+    g = B.Graph.build(k, seqs, offs)
+    al = B.Aligner(g, 0)
+    al.configure(lds_mphf=1)   # table not staged in LDS: the filter is in use
+    o = oracle_py.Oracle(k, seqs, offs)
+    exp = o.align(reads, roffs, m=2, effort=3)
+    got = al.align(reads, roffs, m=2, effort=3)
+    assert not al.launch_info()["mphf_in_lds"] and al.launch_info()["four_reads_per_wave"]
+    assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+    assert ((exp[2] & 3) == B.ST_ALIGNED).sum() > n // 10
+    al.close()
