@@ -925,6 +925,9 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         uint32_t a_pos = 0, a_rec = BGR_NONE;
         for (uint32_t qq = 0; qq < RPW; ++qq) {
             if (!rl32(fast, (int)(GL * qq))) continue;
+#ifdef BGR_PHASE_TIMING
+            if (prm.debug_stop == 1) continue;  // 1 = stops behind the staging of the reads
+#endif
             const uint32_t Lq = rl32(L, (int)(GL * qq));
             const u64* A = WV + qq * grp_words;
             const uint32_t npos = Lq - K1 + 1;
@@ -950,6 +953,9 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
             }
         }
         const uint32_t npos_g = L >= K1 ? L - K1 + 1 : 0;
+#ifdef BGR_PHASE_TIMING
+        if (prm.debug_stop == 2) a_rec = BGR_NONE;  // 2 = stops behind the anchor scan (every read "without anchor")
+#endif
         const uint32_t anchored = (fast && a_rec != BGR_NONE) ? 1u : 0u;
         // left side: [0] at position 0 (no search), else the search with the whole budget
         uint32_t eb = 0, nl = 0, fbl = 0;
