@@ -3,6 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 
+cp gpurun_out/prof_r05_ecoli/summary.txt profiles/r05_ecoli_greedy_5Mx150_summary.txt
 cp gpurun_out/prof_r05_chr1/summary.txt profiles/r05_chr1_greedy_5Mx150_summary.txt
 cp gpurun_out/prof_r05_branchy/summary.txt profiles/r05_branchy_exhaustive_2Mx250_summary.txt
 cp gpurun_out/prof_r05_small/summary.txt profiles/r05_small_greedy_1Mx100_summary.txt

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "bgreat_amd", "csrc")
 print("# per-kernel resource usage of the shipped code objects (hipcc -O3 -S --offload-arch=gfx950)")
 print("# kernel | vgpr_count | sgpr_count | vgpr_spill_count | sgpr_spill_count | scratch bytes per lane")
-for f in ("greedy_kernels.hip", "exhaustive_kernels.hip", "anchors_kernel.hip", "batch_kernels.hip"):
+for f in ("greedy_kernels.hip", "exhaustive_kernels.hip", "anchors_kernel.hip", "batch_kernels.hip", "text_kernels.hip"):
     with tempfile.NamedTemporaryFile(suffix=".s") as t:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-S", "--cuda-device-only",
                                os.path.join(SRC, f), "-o", t.name])
