@@ -1126,8 +1126,9 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         const size_t had = a->tx_state.cap;
         HIP_TRY(a->tx_state.ensure(64 + chain_words * 8));
         if (a->tx_state.cap != had || a->tx_epoch + 2 > BGR_TEXT_EPOCH_MAX) {
+            const bool fresh = a->tx_state.cap != had;
             HIP_TRY(hipMemsetAsync(a->tx_state.p, 0, a->tx_state.cap, a->stream));
-            a->tx_epoch = 0;
+            a->tx_epoch = fresh ? (uint32_t)bgr::opt("test.text_epoch") : 0u;   // (0 but for the test hook)
             a->tx_ticket[0] = a->tx_ticket[1] = 0;
         }
     }

@@ -33,6 +33,7 @@ inline Option* option_table(size_t* n) {
         {"poison_device_buffers", {0}, 0, 1, "diagnostic: every new device buffer is filled with a pattern (a kernel that reads what nothing wrote shows in any run)"},
         {"test.bases_cap", {0}, 0, INT64_MAX, "test hook: bases per batch of bgr_align_all (walks the cut of large batches with small inputs)"},
         {"test.lanes_on_one_device", {0}, 0, 1, "test hook: every lane of a split run / every device of --gpus N is device 0 (a one-GPU box walks the N-device code)"},
+        {"test.text_epoch", {0}, 0, 0x3FFFFF, "test hook: the epoch the text form's chains start from when their state is (re)allocated (walks the 22-bit wrap with a few pieces)"},
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

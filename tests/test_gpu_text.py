@@ -422,3 +422,24 @@ def test_records_that_leave_a_tile_and_its_window(L, hdr, fastq, tmp_path):
         for cut in (text[:-1], text[: len(text) - L - 1], text + b">tail with no newline"):
             p, nn, info = al.align_fasta_text(cut, m=3)
             assert info["irregular"] and p == b"" and nn == b""
+
+
+def test_the_chains_of_the_text_kernels_across_the_wrap_of_their_epoch(tmp_path):
+    """The parse and format launches pass running totals between workgroups through chain words tagged with a 22-bit epoch, never cleared between launches; when
+    the epochs run out the host clears the chains and starts over.  With the test hook the wrap comes after three pieces: same bytes before, at and behind it, on
+    pieces of several tiles each (so that stale words of the piece before would be read)."""
+    s, seqs, offs, text = _mixed_piece(1, 30000, 150, 31)
+    g = B.Graph.build(31, seqs, offs)
+    with B.options(**{"test.text_epoch": 0x3FFFFF - 6}):
+        al = B.Aligner(g, 0)
+        want_p, want_n, n_acc = _host_route(al, text, 31, tmp_path, m=2)
+        half = text[: text.index(b">r15000\n")]
+        for i in range(8):   # (two epochs per piece: parse, format)
+            piece = text if i % 2 == 0 else half
+            got_p, got_n, info = al.align_fasta_text(piece, m=2)
+            assert not info["irregular"]
+            if i % 2 == 0:
+                assert info["n_accepted"] == n_acc and got_p == want_p and got_n == want_n, i
+            else:
+                assert want_p.startswith(got_p) and want_n.startswith(got_n) and 0 < len(got_p) < len(want_p), i
+        al.close()
