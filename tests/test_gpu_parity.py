@@ -1249,3 +1249,29 @@ def test_minimizer_filter_scan_steps_of_64_positions(k, L):
     assert all(np.array_equal(a, b) for a, b in zip(got, exp))
     assert ((exp[2] & 3) == B.ST_ALIGNED).sum() > n // 10
     al.close()
+
+
+@pytest.mark.parametrize("extra", [[], ["--host-route"], ["-c"]])
+def test_cli_paths_into_a_fifo_and_into_a_file(extra, tmp_path):
+    """Regular output files are written at known offsets by several workers (pwrite); a FIFO (or a pipe) gets the same bytes through ONE fwrite per stream,
+    in order: `-f FIFO` read by another thread = the file of the plain run; 120 000 reads x 3 host threads, several pieces and slices."""
+    import subprocess
+    import threading
+    s = Synth(150000, 90, 2, 31, 41)
+    ufa, rfa = str(tmp_path / "u.fa"), str(tmp_path / "r.fa")
+    s.write_unitigs(ufa)
+    s.write_reads(rfa, 0, 120000, 120, 2, 42)
+    args = ["-r", rfa, "-g", ufa, "-k", "31", "-m", "2", "-t", "3", "--batch", "20000"] + extra
+    o1, p1, n1 = run_cli(B.CLI_PATH, args)
+    assert len(p1) > 1_000_000
+    fifo = str(tmp_path / "paths.fifo")
+    os.mkfifo(fifo)
+    got = []
+    t = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    t.start()
+    wd = tmp_path / "wd"
+    wd.mkdir()
+    p = subprocess.run([B.CLI_PATH] + args + ["-f", fifo], cwd=str(wd), capture_output=True, text=True, timeout=600)
+    t.join()
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert got[0] == p1 and open(wd / "notAligned.fa", "rb").read() == n1
