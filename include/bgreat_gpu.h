@@ -204,7 +204,8 @@ int bgr_align_batch_wait(const bgr_ticket* ticket, int32_t* paths_out, uint64_t 
  * Aligner::alignPartGreedy (alignerGreedy.cpp:367-431: getReads, alignReadGreedy per read, the fwrite of a record) on the device,
  * so a batch crosses PCIe as the file's own bytes (text_kernels.hip).  The piece must start at a header line and end behind the
  * newline of a sequence line (or at the end of the file).  The device takes the shape nearly every piece has (header line, ONE
- * sequence line, next header ...); for any other piece (multi-line sequences, blank lines, a last record without its newline)
+ * sequence line, next header ...); for any other piece (multi-line sequences, blank lines, a last record without its newline;
+ * records of fewer than 32 bytes on average over 32 KB of the piece -- reads of two dozen bases: more than the device's tables hold)
  * the call returns BGR_OK with `irregular` = 1 and NOTHING mapped: the caller then parses that piece on the host (the exact
  * getReads state machine) and uses bgr_align_batch*, so the records are the reference's either way.
  * BGR_E_CAPACITY: an output buffer is too small; paths_bytes / notaligned_bytes say what is needed, the mapping is done, and

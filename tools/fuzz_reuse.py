@@ -79,7 +79,9 @@ for it in range(NCALL):
         rr = reads.reshape(n, L)
         text = b"".join(h + b"\n" + rr[i].tobytes() + b"\n" for i, h in enumerate(headers))
         pt, nt, info = al.align_fasta_text(text, m=m, effort=effort, mode=gm, staged=bool(rng.integers(0, 2)))
-        if L > k:
+        if info["irregular"] and len(text) < 34 * n:
+            ok = pt == b"" and nt == b""   # (records of fewer than 32 bytes on average: more record starts per 32 KB than the parse launch lists -- the host parser's piece)
+        elif L > k:
             ep, en = records(headers, reads, roffs, p2, po2)
             ok = (not info["irregular"]) and pt == ep and nt == en
         else:
