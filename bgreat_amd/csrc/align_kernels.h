@@ -53,6 +53,8 @@ struct BatchIO {
     uint32_t level_search;       // exhaustive pass 1: level-by-level search (exh_dp), frames_per_wave = its level cap
     uint32_t search_iters;       // exhaustive, depth-first passes with their stack in LDS: loop iterations one search may take before its read is handed to the
                                  //   last pass (0 = no bound): the recursion is exponential where unitigs duplicate each other's k-mers
+    uint32_t arena_own;          // ints at the start of the arena that waves own by their number: what the cursor hands out lies behind them (the cursor itself starts at 0:
+                                 // one fill less per launch than starting it at this value)
     uint32_t wide_scan;          // scans behind the minimizer filter: 64 positions per step where k allows (launch_plan.h)
     uint32_t deep_memo_cap;      // exhaustive, last pass: entries (a power of two) of a wave's table of remembered calls in deep_scratch (exh_memo); a read that
                                  //   fills it is put on ovf_list and run again by the host with a larger table

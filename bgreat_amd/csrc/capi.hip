@@ -716,11 +716,11 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     if (p->mode == BGR_MODE_EXHAUSTIVE && !(dgl.filter_kind == BGR_FILTER_MINIMIZER && a->exh_filter)) dgl.bloom = nullptr;
 
     if (!cursor_is_zero) HIP_TRY(hipMemsetAsync(a->small.p, 0, 64, a->stream));  // cursor[0..15]: arena cursor, overflow flag, list counters (the text form: the parse launch cleared them)
-    {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: the cursor starts behind
+    {   // the waves of a several-reads-per-wave kernel own the first grid x chunk ints of the arena by their number: what the cursor hands out lies behind
         const uint64_t own = fast_pass ? P.fast_rows
                            : x4_pass   ? (uint64_t)cfg_x4.blocks * cfg_x4.waves_per_block * P.arena_chunk
                            : a4_pass   ? n_reads * bgr::kA4PathInts : 0;
-        if (own) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->small.p), (int)own, 1, a->stream));
+        io.arena_own = (uint32_t)own;   // (< 2^32: plan_launch refuses a launch whose arena is larger)
     }
     // HIP events on the aligner's stream: one in front of the launch, one behind every kernel of it (bgr_aligner_kernel_times)
     int marks = 0;

@@ -855,7 +855,7 @@ __device__ __forceinline__ uint32_t publish_path(const BatchIO& io, const int32_
     if (p_n > *chunk_end - *chunk_pos) {
         const uint32_t want = p_n > io.arena_chunk ? p_n : io.arena_chunk;
         uint32_t got = 0;
-        if (lane == 0) got = atomicAdd(io.cursor, want);
+        if (lane == 0) got = io.arena_own + atomicAdd(io.cursor, want);
         *chunk_pos = rl32(got, 0);
         *chunk_end = *chunk_pos + want;
     }

@@ -990,7 +990,7 @@ __global__ void __launch_bounds__(1024, BGR_X4_OCC) bgr_align_exhaustive4_kernel
         if (tot > chunk_end - chunk_pos) {
             const uint32_t want = tot > io.arena_chunk ? tot : io.arena_chunk;
             uint32_t got = 0;
-            if (lane == 0) got = atomicAdd(io.cursor, want);
+            if (lane == 0) got = io.arena_own + atomicAdd(io.cursor, want);
             chunk_pos = rl32(got, 0);
             chunk_end = chunk_pos + want;
         }
