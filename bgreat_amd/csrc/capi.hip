@@ -1215,10 +1215,11 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     if (e == hipSuccess && b->want_output == 2) e = bgr::launch_scan2_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_poff.p),
                                                    static_cast<uint32_t*>(a->tx_noff.p), n_acc, nullptr, sums2, info + TXT_INFO_PBYTES, info + TXT_INFO_NBYTES, a->stream);
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text size launches: ") + hipGetErrorString(e));
-    uint32_t h2[16];
-    HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
-    HIP_TRY(hipMemcpyAsync(h2, a->small.p, sizeof(h2), hipMemcpyDeviceToHost, a->stream));  // cursor[1]: arena overflow flag
+    uint32_t all[64], h2[16];   // the cursor words (cursor[1]: arena overflow flag) and the info block lie in the same 256 bytes: one copy
+    HIP_TRY(hipMemcpyAsync(all, a->small.p, sizeof(all), hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(wait_stream(a));
+    memcpy(h2, all, sizeof(h2));
+    memcpy(h, all + (info - static_cast<const uint32_t*>(a->small.p)), sizeof(h));
     lap(2);
     if (h2[1]) return fail(BGR_E_INTERNAL, "path arena overflow (internal sizing error)");
     if (a->deep.open) {
