@@ -1149,7 +1149,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
     hipError_t e = bgr::launch_text_parse(text, nbytes, rec_lines, a->dg.k, tickets, a->tx_ticket[0], ++a->tx_epoch, chains, static_cast<uint4*>(a->tx_rec.p),
                                           static_cast<uint32_t*>(a->tx_idx.p), static_cast<uint32_t*>(a->tx_accrec.p), static_cast<uint32_t*>(a->tx_accsrc.p),
                                           static_cast<uint64_t*>(a->tx_offs.p), info, R_cap, static_cast<uint32_t*>(a->small.p), 16, info_next, TXT_INFO_WORDS, a->stream);
-    a->tx_ticket[0] += bgr::text_tiles(nbytes);
+    if (e == hipSuccess) a->tx_ticket[0] += bgr::text_tiles(nbytes);   // (as many tickets as workgroups will take)
     if (e != hipSuccess) return fail(BGR_E_HIP, std::string("text record launches: ") + hipGetErrorString(e));
     uint32_t h[TXT_INFO_WORDS];
     HIP_TRY(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, a->stream));
@@ -1210,7 +1210,7 @@ int bgr_align_fasta_text(bgr_aligner* a, const bgr_params* p, bgr_text_batch* b)
         e = bgr::launch_text_format(text, static_cast<const uint2*>(a->results.p), static_cast<const int32_t*>(a->arena.p), static_cast<const uint4*>(a->tx_rec.p),
                                     static_cast<const uint32_t*>(a->tx_accrec.p), n_acc, tickets + 1, a->tx_ticket[1], ++a->tx_epoch, chains, static_cast<uint32_t*>(a->tx_poff.p),
                                     static_cast<uint32_t*>(a->tx_noff.p), static_cast<uint8_t*>(a->tx_pout.p), static_cast<uint8_t*>(a->tx_nout.p), pcap_dev, ncap_dev, info, a->stream);
-        a->tx_ticket[1] += bgr::format_tiles(n_acc);
+        if (n_acc && e == hipSuccess) a->tx_ticket[1] += bgr::format_tiles(n_acc);   // (as many tickets as workgroups ran: launch_text_format launches nothing for zero reads)
     }
     if (e == hipSuccess && b->want_output == 2) e = bgr::launch_scan2_u32(static_cast<const uint32_t*>(a->tx_psz.p), static_cast<const uint32_t*>(a->tx_nsz.p), static_cast<uint32_t*>(a->tx_poff.p),
                                                    static_cast<uint32_t*>(a->tx_noff.p), n_acc, nullptr, sums2, info + TXT_INFO_PBYTES, info + TXT_INFO_NBYTES, a->stream);
