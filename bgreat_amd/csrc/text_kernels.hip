@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(kParseThreads, 8) bgr_text_parse_kernel(const 
     }
     __syncthreads();
     const uint32_t vt = s_vt, T0 = vt * kParseTile;
+    if (vt >= ntiles) return;   // (cannot happen while the host's ticket base matches the ticket word: no access outside the chains if it ever does not)
     BGR_XT(0, 0);
     if (vt == 0) {   // (words only LATER launches use: the mapping launch's cursor, the next piece's info block)
         if (tid < words_a) zero_a[tid] = 0;
@@ -641,6 +642,7 @@ __global__ void __launch_bounds__(kFmtThreads, 8) bgr_text_format_kernel(const u
     if (tid == 0) { s_vt = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base; s_exP = 0; s_exN = 0; s_nun = 0; }
     __syncthreads();
     const uint32_t vt = s_vt, a0 = vt * kFmtThreads, a = a0 + tid;
+    if (vt >= ntiles) return;   // (see bgr_text_parse_kernel)
     BGR_XT(1, 0);
     uint2 res = make_uint2(0, 0);
     uint4 r = make_uint4(0, 0, 0, 0);
