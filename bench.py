@@ -73,6 +73,7 @@ def parse_args():
     ap.add_argument("--anchors", action="store_true", help="-G: greedy mapping from k-mer anchors (diagnostic; not the headline metric)")
     ap.add_argument("--gamma", type=float, default=0.0, help="overlap key table slots per key (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels of a mapping launch (BGR_KNOB_KERNEL_EVENTS 0): what they cost a small launch; the roofline's per-kernel durations are then missing")
     ap.add_argument("--prepass", action="store_true", help="greedy: 2-bit planes by a pre-pass kernel (rounds 2-4) instead of staging from the characters inside the mapping kernels (diagnostic, A/B)")
     ap.add_argument("--general-kernel-only", action="store_true", help="greedy: skip the eight-reads-per-wave passes (diagnostic)")
     ap.add_argument("--exh-first-pass-off", action="store_true", help="exhaustive: skip the eight-reads-per-wave pass, every read goes through the search kernels (diagnostic)")
@@ -288,6 +289,8 @@ def main():
         al.set_knob(B.KNOB_GREEDY_FAST, 1)
     if args.prepass:
         al.set_knob(B.KNOB_GREEDY_PREPASS, 1)
+    if args.no_kernel_events:
+        al.set_knob(B.KNOB_KERNEL_EVENTS, 0)
     if args.debug_stop:
         al.set_knob(B.KNOB_DEBUG_STOP, args.debug_stop)
     if args.exh_first_pass_off:

@@ -36,7 +36,7 @@ SYMBOLS = [
     "bgr_align_batch_begin", "bgr_align_batch_test", "bgr_align_batch_wait", "bgr_text_stage_device", "bgr_text_stage_upload_parts",
     "bgr_device_alloc", "bgr_device_free", "bgr_device_upload", "bgr_device_download",
 ]
-KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP, KNOB_EXH_MEMO_CAP, KNOB_GREEDY_PREPASS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+KNOB_EXH_FRAME_CAP, KNOB_EXH_SEARCH, KNOB_BATCH_SPLIT_LIMIT, KNOB_DEBUG_STOP, KNOB_GREEDY_FAST, KNOB_EXH_FAST, KNOB_ANCHORS_FAST, KNOB_BATCH_OVERLAP, KNOB_EXH_MEMO_CAP, KNOB_GREEDY_PREPASS, KNOB_KERNEL_EVENTS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 SEARCH_AUTO, SEARCH_DEPTH_FIRST, SEARCH_BY_LEVEL = 0, 1, 2
 
 

@@ -130,7 +130,7 @@ struct bgr_aligner {
     uint32_t cfg_waves = 0, cfg_blocks_per_cu = 0, cfg_lds_mphf = 0;
     bool exh_filter = bgr::opt("exh_filter") != 0;  // exhaustive mode through the minimizer filter too (option exh_filter = 0: without)
     // bgr_aligner_set_knob (test / diagnostic hooks, read here instead of from the environment on every launch)
-    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0, knob_memo_cap = 0, knob_prepass = 0;
+    uint32_t knob_frame_cap = 0, knob_search = 0, knob_debug_stop = 0, knob_greedy_fast = 0, knob_exh_fast = 0, knob_anc_fast = 0, knob_memo_cap = 0, knob_prepass = 0, knob_no_events = 0;
     uint64_t knob_split_limit = 0;
     uint32_t knob_overlap = 0;      // BGR_KNOB_BATCH_OVERLAP
     bgr_aligner* twin = nullptr;    // second stream + buffers for the overlapped form of bgr_align_batch (created on first use)
@@ -541,6 +541,7 @@ int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value) {
         case BGR_KNOB_EXH_FAST: if (value > 1) break; a->knob_exh_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_ANCHORS_FAST: if (value > 1) break; a->knob_anc_fast = (uint32_t)value; return BGR_OK;
         case BGR_KNOB_GREEDY_PREPASS: if (value > 1) break; a->knob_prepass = (uint32_t)value; return BGR_OK;
+        case BGR_KNOB_KERNEL_EVENTS: if (value > 1) break; a->knob_no_events = value ? 0u : 1u; return BGR_OK;
         case BGR_KNOB_EXH_MEMO_CAP: a->knob_memo_cap = (uint32_t)std::min<uint64_t>(value, 1u << 24); return BGR_OK;
         default: break;
     }
@@ -724,12 +725,16 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
     }
     // HIP events on the aligner's stream: one in front of the launch, one behind every kernel of it (bgr_aligner_kernel_times)
     int marks = 0;
+    // (timing a kernel is not free: the events make the runtime dispatch with completion stamps and keep the kernels of a launch apart -- three events around two
+    // kernels cost a 262 144-read launch 16 of its 167 us, 1 730 -> 1 560 Mreads/s, and stamps taken by the dispatch packets themselves (hipExtLaunchKernelGGL)
+    // cost the same, profiles/r05_mode_by_batch_size.txt; BGR_KNOB_KERNEL_EVENTS 0: none -- bgr_align_all without its timing option)
+    const bool timed = !a->knob_no_events;
     auto mark = [&](const char* name) -> hipError_t {
-        if (marks >= kTimerSlots) return hipSuccess;
+        if (!timed || marks >= kTimerSlots) return hipSuccess;
         a->t_slot_name[marks] = name;
         return hipEventRecord(a->ev[a->ev_used][++marks], a->stream);
     };
-    HIP_TRY(hipEventRecord(a->ev[a->ev_used][0], a->stream));
+    if (timed) HIP_TRY(hipEventRecord(a->ev[a->ev_used][0], a->stream));
     hipError_t e = hipSuccess;
     if (!planes_ready && !inline_pack) {
         HIP_TRY(hipMemsetAsync(a->pk_hasn.p, 0, (n_reads + 31) / 32 * 4, a->stream));
@@ -838,8 +843,10 @@ static int align_device_impl(bgr_aligner* a, const bgr_params* p, const void* d_
         a->deep.path_cap = P.path_cap; a->deep.frames = P.frames_deep; a->deep.memo_cap = P.memo_cap;
         a->deep.runs = 1;
     }
-    a->ev_marks[a->ev_used] = marks;
-    ++a->ev_used;
+    if (timed) {
+        a->ev_marks[a->ev_used] = marks;
+        ++a->ev_used;
+    }
     return BGR_OK;
 }
 
@@ -1355,7 +1362,7 @@ static int align_batch_overlapped(bgr_aligner* a, const bgr_params* p, const cha
         bgr_aligner* tw = prev->twin;
         tw->cfg_waves = a->cfg_waves; tw->cfg_blocks_per_cu = a->cfg_blocks_per_cu; tw->cfg_lds_mphf = a->cfg_lds_mphf;
         tw->knob_frame_cap = a->knob_frame_cap; tw->knob_search = a->knob_search; tw->knob_debug_stop = a->knob_debug_stop;
-        tw->knob_greedy_fast = a->knob_greedy_fast; tw->knob_exh_fast = a->knob_exh_fast; tw->knob_anc_fast = a->knob_anc_fast; tw->knob_memo_cap = a->knob_memo_cap; tw->knob_prepass = a->knob_prepass;
+        tw->knob_greedy_fast = a->knob_greedy_fast; tw->knob_exh_fast = a->knob_exh_fast; tw->knob_anc_fast = a->knob_anc_fast; tw->knob_memo_cap = a->knob_memo_cap; tw->knob_prepass = a->knob_prepass; tw->knob_no_events = a->knob_no_events;
         al[t] = tw;
     }
     uint64_t cut[kOverlapMaxPieces + 1];

@@ -545,6 +545,8 @@ int align_all_impl(bgr_graph* graph, const bgr_params* prm, const bgr_run_option
                 fclose(pathF); fclose(notF);
                 return rc;
             }
+            // (nobody reads bgr_aligner_kernel_times here: no events around the kernels -- they cost a 262 144-read piece's mapping launch a tenth of its time)
+            (void)bgr_aligner_set_knob(a, BGR_KNOB_KERNEL_EVENTS, 0);
             aligners.push_back(a);
         }
     }

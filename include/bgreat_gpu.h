@@ -318,6 +318,7 @@ int bgr_aligner_configure(bgr_aligner* a, uint32_t waves_per_block, uint32_t blo
                                    its table of remembered calls in the FIRST run, 0 = from the read length (>= 1024).  A read whose search fills the table is run again with a table
                                    16 times as large, until it fits (bgr_aligner_last_pass_runs); tests set 8 to walk that path with small inputs */
 #define BGR_KNOB_GREEDY_PREPASS 10u /* a launch handed ASCII reads, greedy / exhaustive mode: 0 = the mapping kernels stage their reads straight from the characters (default), 1 = a pre-pass writes 2-bit planes first (rounds 2-4; what anchors mode does) */
+#define BGR_KNOB_KERNEL_EVENTS 11u /* 1 = a HIP event in front of a mapping launch and behind each of its kernels (default: bgr_aligner_kernel_times reports them), 0 = none (a caller that never asks for the times: bgr_align_all without its timing option) */
 #define BGR_KNOB_GREEDY_FAST 5u /* greedy mode: 0 = sixteen-reads-per-wave pass + general kernel for the rest (default), 1 = general kernel only */
 int bgr_aligner_set_knob(bgr_aligner* a, uint32_t knob, uint64_t value);
 /* The launch geometry by itself (bgreat_amd/csrc/launch_plan.h: a pure function of these numbers; no device, no graph object needed -- CPU tests sweep
